@@ -1,0 +1,604 @@
+"""
+oracle/builders.py -- TEST INFRASTRUCTURE, not product code.
+
+numpy / plain-Python restatement of the reference's host-side "code generators":
+everything that turns a medium / geometry / spectrum description into the float
+constants the OpenCL kernel is compiled with.  The product has its own C++
+implementation of the same steps (clsim_amd/csrc/*.cpp); tests compare the two
+table by table.
+
+Each function cites the reference file:line it follows (paths relative to the
+reference root).  All arithmetic is IEEE binary64 in the reference's operation
+order; values reach the kernel through `float_literal` = what an OpenCL compiler
+makes of the "%.10e" text the reference prints
+(private/clsim/I3CLSimHelperToFloatString.h:36-59).
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+
+_libc = ctypes.CDLL(None)
+_libc.strtof.restype = ctypes.c_float
+_libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+
+# I3Units / I3Constants (icetray): m = ns = 1
+NANOMETER = 1e-9
+MICROMETER = 1e-6
+DEG = math.pi / 180.0
+C_LIGHT = 0.299792458
+
+
+def float_literal(v):
+    """binary32 value of the literal ToFloatString(v) (ToFloatString.h:36-59):
+    scientific notation, precision digits10+4 = 10, parsed by the compiler
+    with correct rounding (strtof)."""
+    return np.float32(_libc.strtof(("%.10e" % float(v)).encode(), None))
+
+
+def float_literals(vs):
+    return np.array([float_literal(v) for v in np.asarray(vs, dtype=np.float64).ravel()],
+                    dtype=np.float32).reshape(np.shape(vs))
+
+
+# --------------------------------------------------------------------------
+# DOM acceptance, wavelength generator
+# --------------------------------------------------------------------------
+
+# python/GetIceCubeDOMAcceptance.py:62-105 (photonics efficiency.h table, m^2)
+DOM2007A_EFF_AREA = [
+    0.0000064522, 0.0000064522, 0.0000064522, 0.0000064522, 0.0000021980, 0.0001339040,
+    0.0005556810, 0.0016953000, 0.0035997000, 0.0061340900, 0.0074592700, 0.0090579800,
+    0.0099246700, 0.0105769000, 0.0110961000, 0.0114214000, 0.0114425000, 0.0111527000,
+    0.0108086000, 0.0104458000, 0.0099763100, 0.0093102500, 0.0087516600, 0.0083225800,
+    0.0079767200, 0.0075625100, 0.0066377000, 0.0053335800, 0.0043789400, 0.0037583500,
+    0.0033279800, 0.0029212500, 0.0025334900, 0.0021115400, 0.0017363300, 0.0013552700,
+    0.0010546600, 0.0007201020, 0.0004843820, 0.0002911110, 0.0001782310, 0.0001144300,
+    0.0000509155]
+
+
+def icecube_dom_acceptance(dom_radius=0.16510, efficiency=1.0):
+    """python/GetIceCubeDOMAcceptance.py:35-115 (highQE=False).  Returns the
+    FunctionFromTable description (start, step, values) in doubles."""
+    area = np.array(DOM2007A_EFF_AREA, dtype=np.float64) * 1.0
+    dom_area = math.pi * dom_radius ** 2.0
+    eff = efficiency * (area / dom_area)
+    return dict(kind="table", start=260.0 * NANOMETER, step=10.0 * NANOMETER, values=eff)
+
+
+REFINDEX_N = (1.55749, -1.57988, 3.99993, -4.68271, 2.09354)       # RefIndexIceCube.cxx:36-40
+REFINDEX_G = (1.227106, -0.954648, 1.42568, -0.711832, 0.0)        # RefIndexIceCube.cxx:43-47
+
+
+def phase_ref_index_host(wlen, n=REFINDEX_N):
+    """I3CLSimFunctionRefIndexIceCube::GetValue, mode 'phase' (RefIndexIceCube.cxx:84-101)."""
+    x = wlen / MICROMETER
+    return n[0] + x * (n[1] + x * (n[2] + x * (n[3] + x * n[4])))
+
+
+def from_table_host(tab, wlen):
+    """I3CLSimFunctionFromTable::GetValue, equal spacing (FromTable.cxx:105-122)."""
+    q = (wlen - tab["start"]) / tab["step"]
+    fraction, fbin = math.modf(q)
+    ibin = int(fbin)
+    n = len(tab["values"])
+    if ibin < 0 or (ibin == 0 and fraction < 0):
+        ibin, fraction = 0, 0.0
+    elif ibin >= n - 1:
+        ibin, fraction = n - 2, 1.0
+    v = tab["values"]
+    return v[ibin] + (v[ibin + 1] - v[ibin]) * fraction
+
+
+def cherenkov_wlen_generator(bias, medium, beta=1.0):
+    """I3CLSimModuleHelper::makeCherenkovWavelengthGenerator with a tabulated
+    bias and dispersion on (I3CLSimModuleHelper.cxx:175-263, 52-63).  Returns an
+    InterpolatedDistribution description (first, spacing, y)."""
+    assert bias["kind"] == "table"
+    n = len(bias["values"])
+    y = np.empty(n, dtype=np.float64)
+    for i in range(n):
+        wl = bias["start"] + float(i) * bias["step"]          # FromTable.cxx:88-90
+        nphase = phase_ref_index_host(wl, medium["n"])
+        y[i] = bias["values"][i] * ((2.0 * math.pi / (137.0 * (wl * wl))) * (1.0 - 1.0 / (math.pow(beta * nphase, 2.0))))
+    return dict(kind="interp", first=bias["start"], spacing=bias["step"], y=y)
+
+
+def interp_dist_tables(gen):
+    """I3CLSimRandomValueInterpolatedDistribution::InitTables + WriteTableCode
+    (InterpolatedDistribution.cxx:134-175, 177-234): -> (yv, ycum) literals."""
+    y = np.asarray(gen["y"], dtype=np.float64)
+    n = len(y)
+    acu = np.zeros(n, dtype=np.float64)
+    for j in range(1, n):
+        acu[j] = acu[j - 1] + (gen["spacing"]) * (y[j] + y[j - 1]) / 2.0
+    total = acu[n - 1]
+    beta = np.empty(n)
+    for j in range(n):
+        beta[j] = y[j] / total
+        acu[j] = acu[j] / total
+    return float_literals(beta), float_literals(acu)
+
+
+# --------------------------------------------------------------------------
+# ice model loader (PPC tables)
+# --------------------------------------------------------------------------
+
+def _loadtxt(path):
+    rows = []
+    with open(path) as f:
+        for line in f:
+            line = line.split("#")[0].strip()
+            if line:
+                rows.append([float(t) for t in line.split()])
+    return rows
+
+
+def load_ppc_ice(directory, detector_center_depth=1948.07, use_tilt_if_available=True):
+    """python/MakeIceCubeMediumProperties.py:49-256 (+ util/GetIceTiltZShift.py:40-62,
+    util/GetSpiceLeaAnisotropyTransforms.py:39-101).  Returns a medium description
+    in doubles (the values the reference hands to its C++ function objects)."""
+    use_tilt = False
+    if use_tilt_if_available:
+        has_par = os.path.isfile(os.path.join(directory, "tilt.par"))
+        has_dat = os.path.isfile(os.path.join(directory, "tilt.dat"))
+        if has_par != has_dat:
+            raise RuntimeError("tilt.par / tilt.dat: one of the two is missing")
+        use_tilt = has_par and has_dat
+    dat = np.array(_loadtxt(os.path.join(directory, "icemodel.dat")), dtype=np.float64).T
+    par = np.array(_loadtxt(os.path.join(directory, "icemodel.par")), dtype=np.float64)
+    cfg = np.array([r[0] for r in _loadtxt(os.path.join(directory, "cfg.txt"))], dtype=np.float64)
+    if len(par) == 6:
+        alpha, kappa, A, B, D, E = (par[i][0] for i in range(6))
+    elif len(par) == 4:
+        alpha, kappa, A, B = (par[i][0] for i in range(4))
+        D = 400.0 ** kappa
+        E = 0.0
+    else:
+        raise RuntimeError("icemodel.par needs 4 or 6 rows")
+    if len(cfg) < 4:
+        raise RuntimeError("cfg.txt needs at least 4 lines")
+    liu_fraction = cfg[2]
+    mean_cos = cfg[3]
+    has_aniso = False
+    if 4 < len(cfg) < 7:
+        raise RuntimeError("cfg.txt: anisotropy needs 7 lines")
+    elif len(cfg) > 4:
+        has_aniso = True
+        an_az = cfg[4] * DEG
+        an_k1 = cfg[5]
+        an_k2 = cfg[6]
+    depth = dat[0] * 1.0
+    b_e400, a_dust400, delta_tau = dat[1], dat[2], dat[3]
+    layer_height = depth[1] - depth[0]
+    if layer_height <= 0:
+        raise RuntimeError("ice layer depths are not in increasing order")
+    for i in range(len(depth) - 1):
+        if abs((depth[i + 1] - depth[i]) - layer_height) > 1e-5:
+            raise RuntimeError("ice layers are not spaced evenly")
+    depth = depth[::-1]
+    b_e400 = b_e400[::-1]
+    a_dust400 = a_dust400[::-1]
+    delta_tau = delta_tau[::-1]
+    b_400 = b_e400 / (1.0 - mean_cos)
+    depth = depth - layer_height / 2.0
+    depth_bottom = depth + layer_height
+    layer_z_start = detector_center_depth - depth_bottom
+    med = dict(
+        num_layers=len(layer_z_start), layers_z_start=float(layer_z_start[0]), layers_height=float(layer_height),
+        min_wlen=265.0 * NANOMETER, max_wlen=675.0 * NANOMETER,
+        len_mode="icecube", alpha=alpha, kappa=kappa, A=A, B=B, D=D, E=E,
+        aDust400=np.array(a_dust400), deltaTau=np.array(delta_tau), b400=np.array(b_400),
+        n=REFINDEX_N, g=REFINDEX_G,
+        scat=dict(kind="mixed", fraction=float(liu_fraction), mean_cos=float(mean_cos)),
+    )
+    if has_aniso:
+        med["aniso"] = dict(azimuth=an_az, k1=an_k1, k2=an_k2)
+        k1 = np.exp(an_k1); k2 = np.exp(an_k2); kz = 1.0 / (k1 * k2)
+        Am = np.array([[k1, 0., 0.], [0., k2, 0.], [0., 0., kz]])
+        sa = np.sin(an_az); ca = np.cos(an_az)
+        T = np.array([[ca, sa, 0.], [-sa, ca, 0.], [0., 0., 1.]])
+        med["pre"] = dict(matrix=np.dot(np.dot(T.T, Am), T), renormalize=True)
+        med["post"] = dict(matrix=np.dot(np.dot(T.T, np.linalg.inv(Am)), T), renormalize=True)
+    if use_tilt:
+        tpar = np.array(_loadtxt(os.path.join(directory, "tilt.par")), dtype=np.float64).T
+        tdat = np.array(_loadtxt(os.path.join(directory, "tilt.dat")), dtype=np.float64).T
+        dist = tpar[1] * 1.0
+        zcoords = (detector_center_depth - tdat[0])[::-1]
+        zshift = np.array([tdat[i + 1][::-1] for i in range(len(dist))])
+        med["tilt"] = dict(distances=dist, zcoords=zcoords, zcorr=zshift, azimuth=225.0 * DEG)
+    return med
+
+
+def homogeneous_medium(abs_len=100.0, sca_len=25.0, z_start=-1000.0, height=2000.0, mean_cos=0.9, liu_fraction=0.45):
+    """BASELINE config C1 (SURVEY.md 9.7 option i): one layer, FunctionConstant
+    absorption / scattering length, IceCube refractive index, Mixed(Liu,HG)."""
+    return dict(num_layers=1, layers_z_start=z_start, layers_height=height,
+                min_wlen=265.0 * NANOMETER, max_wlen=675.0 * NANOMETER,
+                len_mode="constant", abs_const=np.array([abs_len]), sca_const=np.array([sca_len]),
+                n=REFINDEX_N, g=REFINDEX_G,
+                scat=dict(kind="mixed", fraction=liu_fraction, mean_cos=mean_cos))
+
+
+def tilt_spacing(zcoords):
+    """ScalarFieldIceTiltZShift.cxx:62-89: mean z spacing and first coordinate."""
+    z = np.asarray(zcoords, dtype=np.float64)
+    mean = 0.0
+    for i in range(len(z) - 1):
+        mean += z[i + 1] - z[i]
+    mean /= float(len(z) - 1)
+    return float(z[0]), mean
+
+
+def aniso_constants(an):
+    """ScalarFieldAnisotropyAbsLenScaling.cxx:96-108: host constants."""
+    azx = math.cos(an["azimuth"]); azy = math.sin(an["azimuth"])
+    k1 = math.exp(an["k1"]); k2 = math.exp(an["k2"]); kz = 1.0 / (k1 * k2)
+    l1 = k1 * k1; l2 = k2 * k2; l3 = kz * kz
+    B2 = 1.0 / l1 + 1.0 / l2 + 1.0 / l3
+    return dict(azx=azx, azy=azy, l=(l1, l2, l3), rl=(1.0 / l1, 1.0 / l2, 1.0 / l3), B2=B2)
+
+
+# --------------------------------------------------------------------------
+# geometry
+# --------------------------------------------------------------------------
+
+def _cell_contains(lo, hi, cmin, cmax):
+    c = False
+    if lo <= cmin and hi >= cmin: c = True
+    if lo <= cmax and hi >= cmax: c = True
+    if lo >= cmin and hi <= cmax: c = True
+    return c
+
+
+def _divide_into_cells(strings, sd, n):
+    """GeometrySource.cxx:135-271."""
+    sel = [s for s in strings if s["sd"] == sd]
+    min_x = min_y = max_x = max_y = float("nan")
+    for s in sel:
+        if (s["meanX"] - s["maxR"] < min_x) or math.isnan(min_x): min_x = s["meanX"] - s["maxR"]
+        if (s["meanY"] - s["maxR"] < min_y) or math.isnan(min_y): min_y = s["meanY"] - s["maxR"]
+        if (s["meanX"] + s["maxR"] > max_x) or math.isnan(max_x): max_x = s["meanX"] + s["maxR"]
+        if (s["meanY"] + s["maxR"] > max_y) or math.isnan(max_y): max_y = s["meanY"] + s["maxR"]
+    start_x, start_y = min_x, min_y
+    wx = (max_x - min_x) / float(n)
+    wy = (max_y - min_y) / float(n)
+    cells = [0xFFFF] * (n * n)
+    for i in range(n):
+        cx0 = start_x + float(i) * wx
+        cx1 = start_x + float(i + 1) * wx
+        xs = [(k, s) for k, s in enumerate(strings) if s["sd"] == sd and
+              _cell_contains(s["meanX"] - s["maxR"], s["meanX"] + s["maxR"], cx0, cx1)]
+        for j in range(n):
+            cy0 = start_y + float(j) * wy
+            cy1 = start_y + float(j + 1) * wy
+            found = 0xFFFF
+            for k, s in xs:
+                if _cell_contains(s["meanY"] - s["maxR"], s["meanY"] + s["maxR"], cy0, cy1):
+                    if found != 0xFFFF:
+                        return None
+                    found = k
+            cells[j * n + i] = found
+    return start_x, start_y, wx, wy, cells
+
+
+def _layer_contains(z, r, zmin, zmax):
+    return _cell_contains(z - r, z + r, zmin, zmax)
+
+
+def _divide_into_layers(s, n, r, min_hint, max_hint):
+    """GeometrySource.cxx:375-446."""
+    if n == 0 or r < 0: return None
+    table = [0xFFFF] * n
+    min_z, max_z = min_hint, max_hint
+    if (s["minZ"] - r < min_z) or math.isnan(min_z): min_z = s["minZ"] - r
+    if (s["maxZ"] + r > max_z) or math.isnan(max_z): max_z = s["maxZ"] + r
+    start = min_z
+    height = (max_z - min_z) / float(n)
+    for i in range(n):
+        z0 = start + float(i) * height
+        z1 = start + float(i + 1) * height
+        for d, dom in enumerate(s["doms"]):
+            if _layer_contains(dom[3], r, z0, z1):
+                if table[i] != 0xFFFF:
+                    return None
+                table[i] = d
+    return start, height, table
+
+
+def _does_match_layering(s, start, height, n, r, table):
+    """GeometrySource.cxx:273-342."""
+    if n == 0 or r < 0: return False
+    assigned = 0
+    for i in range(n):
+        z0 = start + float(i) * height
+        z1 = start + float(i + 1) * height
+        should = 0xFFFF
+        for d, dom in enumerate(s["doms"]):
+            if _layer_contains(dom[3], r, z0, z1):
+                if should != 0xFFFF:
+                    return False
+                should = d
+                assigned += 1
+        if table[i] != should:
+            return False
+    return assigned == len(s["doms"])
+
+
+def _c_short(v):
+    """static_cast<short>(double) as x86-64 gcc does it: truncate toward zero;
+    NaN (0/0 for perfectly straight strings) -> 0."""
+    if math.isnan(v):
+        return 0
+    return int(v)        # python int() truncates toward zero
+
+
+def build_geometry(string_ids, dom_ids, pos_x, pos_y, pos_z, subdetectors, om_radius):
+    """I3CLSimHelper::write_geometry_code_and_fill_buffer + generate_get_dom_position_code
+    (GeometrySource.cxx:712-1275, 499-709).  Returns every constant the kernel
+    sees as numpy arrays of the kernel's types plus the index->ID maps."""
+    n = len(string_ids)
+    assert n > 0 and om_radius >= 0
+    keys = sorted(set((int(string_ids[i]), str(subdetectors[i])) for i in range(n)))
+    subdet_names = sorted(set(str(s) for s in subdetectors))
+    subdet_id = {name: i for i, name in enumerate(subdet_names)}
+    by_key = {}
+    for i in range(n):
+        by_key.setdefault((int(string_ids[i]), str(subdetectors[i])), []).append(i)
+    strings = []
+    string_max_r = float("nan")
+    for sid, sname in keys:
+        s = dict(id=sid, sd=subdet_id[sname], doms=[], maxZ=float("nan"), minZ=float("nan"),
+                 meanX=0.0, meanY=0.0, maxR=float("nan"))
+        last_z = last_dz = float("nan")
+        numdz = 0
+        meandz = 0.0
+        for i in by_key[(sid, sname)]:
+            s["meanX"] += float(pos_x[i]); s["meanY"] += float(pos_y[i])
+            z = float(pos_z[i])
+            if (z > s["maxZ"]) or math.isnan(s["maxZ"]): s["maxZ"] = z
+            if (z < s["minZ"]) or math.isnan(s["minZ"]): s["minZ"] = z
+            if math.isnan(last_z):
+                last_z = z
+            else:
+                dz = abs(last_z - z)
+                last_z = z
+                if not math.isnan(last_dz):
+                    if dz < 1.75 * meandz / float(numdz):
+                        meandz += dz; numdz += 1; last_dz = dz
+                else:
+                    last_dz = dz; meandz += dz; numdz += 1
+            s["doms"].append((int(dom_ids[i]), float(pos_x[i]), float(pos_y[i]), z))
+        nd = len(s["doms"])
+        s["meanX"] /= float(nd); s["meanY"] /= float(nd)
+        s["meandZ"] = meandz / float(numdz) if numdz else float("nan")
+        for (_, x, y, _z) in s["doms"]:
+            dx = s["meanX"] - x; dy = s["meanY"] - y
+            r = math.sqrt(dx * dx + dy * dy) + om_radius
+            if (r > s["maxR"]) or math.isnan(s["maxR"]): s["maxR"] = r
+            if (r > string_max_r) or math.isnan(string_max_r): string_max_r = r
+        strings.append(s)
+    ns = len(strings)
+    assert ns < 0xFFFF - 1
+
+    # xy cells per subdetector (GeometrySource.cxx:913-949)
+    cells = []
+    for sd in range(len(subdet_names)):
+        g = 1
+        while True:
+            res = _divide_into_cells(strings, sd, g)
+            if res is not None:
+                break
+            g += 1
+            if g >= 1000:
+                raise RuntimeError("no x-y cell division")
+        sx, sy, wx, wy, idx = res
+        cells.append(dict(nx=g, ny=g, start_x=float_literal(sx), start_y=float_literal(sy),
+                          width_x=float_literal(wx), width_y=float_literal(wy),
+                          index=np.array(idx, dtype=np.uint16)))
+
+    # z layers / string sets (GeometrySource.cxx:956-1091)
+    set_n, set_start, set_height, set_table, in_set = [], [], [], [], []
+    max_layers = 0
+    for s in strings:
+        match = None
+        for k in range(len(set_n)):
+            if _does_match_layering(s, set_start[k], set_height[k], set_n[k], om_radius, set_table[k]):
+                match = k
+                break
+        if match is not None:
+            in_set.append(match)
+            continue
+        in_set.append(len(set_n))
+        if len(set_n) + 1 >= 0xFF:
+            raise RuntimeError("more than 255 string sets")
+        lo_hint = s["minZ"] - s["meandZ"] / 2.0
+        hi_hint = s["maxZ"] + s["meandZ"] / 2.0
+        n0 = int((s["maxZ"] - s["minZ"] + s["meandZ"]) / s["meandZ"])
+        res = _divide_into_layers(s, n0, om_radius, lo_hint, hi_hint)
+        nl = n0
+        if res is None:
+            nl = n0 + 1
+            res = _divide_into_layers(s, nl, om_radius, lo_hint, hi_hint)
+        if res is None:
+            nl = 1
+            while True:
+                res = _divide_into_layers(s, nl, om_radius, lo_hint, hi_hint)
+                if res is not None:
+                    break
+                nl += 1
+                if nl >= 1000:
+                    raise RuntimeError("no layer division for string")
+        set_n.append(nl); set_start.append(res[0]); set_height.append(res[1]); set_table.append(res[2])
+        if nl > max_layers: max_layers = nl
+    nsets = len(set_n)
+    flat = [0xFFFF] * (max_layers * nsets)
+    for j in range(nsets):
+        for i in range(set_n[j]):
+            flat[j * max_layers + i] = set_table[j][i]
+    bufsize = ((nsets * max_layers) // 64 + 1) * 64
+    layer_to_om = np.full(bufsize, 0xFFFF, dtype=np.uint16)
+    layer_to_om[:nsets * max_layers] = flat
+
+    # DOM position templates (GeometrySource.cxx:499-709)
+    mean_x = []; mean_y = []
+    for s in strings:
+        sx = sy = 0.0
+        for (_, x, y, _z) in s["doms"]:
+            sx += x; sy += y
+        mean_x.append(sx / float(len(s["doms"]))); mean_y.append(sy / float(len(s["doms"])))
+    eps = 1e-1 * 1e-3
+    templates = []
+    in_template = []
+    for i, s in enumerate(strings):
+        found = None
+        for t, tpl in enumerate(templates):
+            if len(tpl) != len(s["doms"]):
+                continue
+            ok = True
+            for j, (_, x, y, z) in enumerate(s["doms"]):
+                if abs(tpl[j][0] - (x - mean_x[i])) > eps: ok = False; break
+                if abs(tpl[j][1] - (y - mean_y[i])) > eps: ok = False; break
+                if abs(tpl[j][2] - z) > eps: ok = False; break
+            if ok:
+                found = t
+                break
+        if found is None:
+            templates.append([(x - mean_x[i], y - mean_y[i], z) for (_, x, y, z) in s["doms"]])
+            found = len(templates) - 1
+        in_template.append(found)
+    max_abs_x = max_abs_y = float("nan")
+    flat_x, flat_y, flat_z, tpl_start = [], [], [], []
+    for tpl in templates:
+        tpl_start.append(len(flat_x))
+        for (x, y, z) in tpl:
+            flat_x.append(x); flat_y.append(y); flat_z.append(z)
+            if (abs(x) > max_abs_x) or math.isnan(max_abs_x): max_abs_x = abs(x)
+            if (abs(y) > max_abs_y) or math.isnan(max_abs_y): max_abs_y = abs(y)
+
+    def _q(v, m):
+        d = m / 32767.0
+        return _c_short(v / d if d != 0.0 else float("nan"))
+
+    geo = dict(
+        num_strings=ns, om_radius=float_literal(om_radius), string_max_radius=float_literal(string_max_r),
+        str_x=float_literals([s["meanX"] for s in strings]), str_y=float_literals([s["meanY"] for s in strings]),
+        str_radius=float_literals([s["maxR"] for s in strings]),
+        str_minz=float_literals([s["minZ"] for s in strings]), str_maxz=float_literals([s["maxZ"] for s in strings]),
+        str_set=np.array(in_set, dtype=np.uint8),
+        num_sets=nsets, max_layers=max_layers, set_nlayers=np.array(set_n, dtype=np.uint16),
+        set_startz=float_literals(set_start), set_height=float_literals(set_height),
+        layer_to_om=layer_to_om, cells=cells, subdetectors=subdet_names,
+        max_dom_index=max(len(s["doms"]) for s in strings),
+        dom_mul_x=float_literal(max_abs_x / 32767.0), dom_mul_y=float_literal(max_abs_y / 32767.0),
+        dom_tx=np.array([_q(v, max_abs_x) for v in flat_x], dtype=np.int16),
+        dom_ty=np.array([_q(v, max_abs_y) for v in flat_y], dtype=np.int16),
+        dom_tz=float_literals(flat_z),
+        dom_start=np.array([tpl_start[t] for t in in_template], dtype=np.uint32),
+        dom_meanx=float_literals(mean_x), dom_meany=float_literals(mean_y),
+        string_index_to_id=np.array([s["id"] for s in strings], dtype=np.int32),
+        dom_index_to_id=[np.array([d[0] for d in s["doms"]], dtype=np.uint32) for s in strings],
+    )
+    return geo
+
+
+# --------------------------------------------------------------------------
+# RNG: safeprime multipliers + stream seeding
+# --------------------------------------------------------------------------
+
+_MR_BASES = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+
+
+def _is_prime(n):
+    """Deterministic Miller-Rabin for n < 3.3e24 (the reference uses GMP's
+    mpz_probab_prime_p, private/make_safeprimes/main.cxx:13-29)."""
+    if n < 2:
+        return False
+    for p in _MR_BASES:
+        if n % p == 0:
+            return n == p
+    d = n - 1
+    r = 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in _MR_BASES:
+        x = pow(a, d, n)
+        if x == 1 or x == n - 1:
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _small_primes(limit):
+    sieve = np.ones(limit + 1, dtype=bool)
+    sieve[:2] = False
+    for p in range(2, int(limit ** 0.5) + 1):
+        if sieve[p]:
+            sieve[p * p::p] = False
+    return np.nonzero(sieve)[0]
+
+
+def mwc_multipliers(count, start=4294967118):
+    """private/make_safeprimes/main.cxx:31-104: multipliers a, descending from
+    4294967118, with a*2^32-1 and (a*2^32-2)/2 both prime."""
+    out = []
+    primes = [int(p) for p in _small_primes(20000) if p > 2]
+    # residues of a that make n2 = a*2^32-1 or n1 = a*2^31-1 divisible by p
+    bad = []
+    for p in primes:
+        bad.append((p, pow(pow(2, 32, p), -1, p), pow(pow(2, 31, p), -1, p)))
+    hi = start
+    seg = 1 << 20
+    while len(out) < count:
+        lo = hi - seg + 1
+        alive = np.ones(seg, dtype=bool)         # index k <-> a = hi - k
+        for p, r2, r1 in bad:
+            for r in (r2, r1):
+                k0 = (hi - r) % p                 # smallest k with (hi-k) % p == r
+                alive[k0::p] = False
+        for k in np.nonzero(alive)[0]:
+            a = hi - int(k)
+            n2 = (a << 32) - 1
+            if not _is_prime(n2):
+                continue
+            if not _is_prime((n2 - 1) >> 1):
+                continue
+            out.append(a)
+            if len(out) >= count:
+                break
+        hi = lo - 1
+    return np.array(out, dtype=np.uint32)
+
+
+def splitmix64(state):
+    state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return state, z ^ (z >> 31)
+
+
+def seed_streams(a, seed=12345):
+    """init_MWC_RNG's state loop (private/opencl/mwcrng_init.h:105-113) with
+    I3RandomService::Integer(0xffffffff) replaced by splitmix64: each call is
+    (next() >> 32) % 0xffffffff (the random service is external to clsim)."""
+    st = seed & 0xFFFFFFFFFFFFFFFF
+    x = np.zeros(len(a), dtype=np.uint64)
+    for i in range(len(a)):
+        xi = 0
+        ai = int(a[i])
+        while (xi == 0) or ((xi >> 32) >= (ai - 1)) or ((xi & 0xFFFFFFFF) >= 0xFFFFFFFF):
+            st, v = splitmix64(st)
+            h = (v >> 32) % 0xFFFFFFFF
+            st, v = splitmix64(st)
+            l = (v >> 32) % 0xFFFFFFFF
+            xi = (h << 32) + l
+        x[i] = xi
+    return x

@@ -1,0 +1,331 @@
+"""
+oracle/capi.py -- TEST INFRASTRUCTURE, not product code.
+
+ctypes front end of liboracle.so (oracle/clsim_oracle.c): packs the constants
+made by oracle/builders.py into `struct oracle_tables` and runs the CPU
+restatement of propKernel.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import builders as B
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+STEP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<f4"),
+                       ("theta", "<f4"), ("phi", "<f4"), ("length", "<f4"), ("beta", "<f4"),
+                       ("num", "<u4"), ("weight", "<f4"), ("id", "<u4"),
+                       ("sourceType", "u1"), ("dummy1", "u1"), ("dummy2", "<u2")])
+PHOTON_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<f4"),
+                         ("theta", "<f4"), ("phi", "<f4"), ("wavelength", "<f4"), ("cherenkovDist", "<f4"),
+                         ("numScatters", "<u4"), ("weight", "<f4"), ("id", "<u4"),
+                         ("stringID", "<i2"), ("omID", "<u2"),
+                         ("sx", "<f4"), ("sy", "<f4"), ("sz", "<f4"), ("st", "<f4"),
+                         ("stheta", "<f4"), ("sphi", "<f4"), ("groupVelocity", "<f4"), ("distInAbsLens", "<f4")])
+assert STEP_DTYPE.itemsize == 48 and PHOTON_DTYPE.itemsize == 80
+
+MAX_GEN = 8
+MAX_SUBDET = 9
+FP = C.POINTER(C.c_float)
+
+
+class WlenGen(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("first", C.c_float), ("spacing", C.c_float),
+                ("yv", FP), ("ycum", FP), ("value", C.c_float)]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("stop_detected", C.c_int32), ("has_pancake", C.c_int32), ("pancake", C.c_float),
+        ("num_layers", C.c_int32), ("layer_bottom", C.c_float), ("layer_thickness", C.c_float),
+        ("len_mode", C.c_int32), ("abs_const", FP), ("sca_const", FP),
+        ("aDust400", FP), ("deltaTau", FP), ("b400", FP),
+        ("kappa", C.c_float), ("A", C.c_float), ("B", C.c_float), ("D", C.c_float), ("E", C.c_float),
+        ("alpha", C.c_float), ("ref_wlen_recip", C.c_float), ("nanometer", C.c_float),
+        ("n", C.c_float * 5), ("g", C.c_float * 5), ("micrometer", C.c_float), ("c_light", C.c_float),
+        ("scat_kind", C.c_int32), ("mix_frac", C.c_float), ("mix_frac_rest", C.c_float),
+        ("liu_beta", C.c_float), ("hg_g", C.c_float), ("hg_g2", C.c_float),
+        ("has_abs_corr", C.c_int32), ("abs_corr_const", C.c_float),
+        ("an_l", C.c_float * 3), ("an_rl", C.c_float * 3), ("an_azx", C.c_float), ("an_azy", C.c_float),
+        ("an_mazy", C.c_float), ("an_B2", C.c_float),
+        ("has_pre", C.c_int32), ("pre_renorm", C.c_int32), ("has_post", C.c_int32), ("post_renorm", C.c_int32),
+        ("pre", C.c_float * 9), ("post", C.c_float * 9),
+        ("has_tilt", C.c_int32), ("tilt_const", C.c_float), ("tilt_nd", C.c_int32), ("tilt_nz", C.c_int32),
+        ("tilt_first_z", C.c_float), ("tilt_dz", C.c_float), ("tilt_lnx", C.c_float), ("tilt_lny", C.c_float),
+        ("tilt_dist", FP), ("tilt_zcorr", FP),
+        ("num_gen", C.c_int32), ("gen", WlenGen * MAX_GEN),
+        ("bias_kind", C.c_int32), ("bias_n", C.c_int32), ("bias_start", C.c_float), ("bias_step", C.c_float),
+        ("bias_value", C.c_float), ("bias_data", FP),
+        ("num_strings", C.c_int32), ("om_radius", C.c_float), ("string_max_radius", C.c_float),
+        ("str_x", FP), ("str_y", FP), ("str_minz", FP), ("str_maxz", FP),
+        ("str_set", C.POINTER(C.c_uint8)),
+        ("num_sets", C.c_int32), ("max_layers", C.c_int32),
+        ("set_nlayers", C.POINTER(C.c_uint16)), ("set_startz", FP), ("set_height", FP),
+        ("layer_to_om", C.POINTER(C.c_uint16)),
+        ("num_subdet", C.c_int32),
+        ("cell_nx", C.c_int32 * MAX_SUBDET), ("cell_ny", C.c_int32 * MAX_SUBDET),
+        ("cell_wx", C.c_float * MAX_SUBDET), ("cell_wy", C.c_float * MAX_SUBDET),
+        ("cell_sx", C.c_float * MAX_SUBDET), ("cell_sy", C.c_float * MAX_SUBDET),
+        ("cell_index", C.POINTER(C.c_uint16) * MAX_SUBDET),
+        ("dom_mul_x", C.c_float), ("dom_mul_y", C.c_float),
+        ("dom_tx", C.POINTER(C.c_int16)), ("dom_ty", C.POINTER(C.c_int16)), ("dom_tz", FP),
+        ("dom_start", C.POINTER(C.c_uint32)), ("dom_meanx", FP), ("dom_meany", FP),
+    ]
+
+
+_lib = None
+
+
+def build():
+    """Compile liboracle.so (gcc).  Building the checker is not using it."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.oracle_sizeof_tables.restype = C.c_size_t
+        assert _lib.oracle_sizeof_tables() == C.sizeof(Tables), "oracle_tables layout mismatch"
+        _lib.oracle_propagate.restype = C.c_uint32
+        _lib.oracle_propagate_mt.restype = C.c_uint32
+    return _lib
+
+
+class OracleTables:
+    """Owns the ctypes struct and the numpy arrays it points into."""
+
+    def __init__(self):
+        self.t = Tables()
+        self._keep = []
+        self.arrays = {}
+
+    def _ptr(self, name, arr, ctype):
+        arr = np.ascontiguousarray(arr)
+        self._keep.append(arr)
+        self.arrays[name] = arr
+        return arr.ctypes.data_as(C.POINTER(ctype))
+
+    def scalars(self):
+        out = {}
+        for name, ctype in Tables._fields_:
+            v = getattr(self.t, name)
+            if isinstance(v, (int, float)):
+                out[name] = v
+            elif hasattr(v, "_length_") and ctype._type_ in (C.c_float, C.c_int32):
+                out[name] = list(v)
+        return out
+
+
+def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=True):
+    """The oracle's counterpart of Compile() (OpenCL.cxx:485-533): converts the
+    descriptions (doubles) into the literals of the generated OpenCL program."""
+    fl = B.float_literal
+    fls = B.float_literals
+    O = OracleTables()
+    t = O.t
+    t.stop_detected = 1 if stop_detected else 0
+    t.has_pancake = 1 if pancake != 1.0 else 0          # OpenCL.cxx:432
+    t.pancake = fl(pancake)
+    m = medium
+    t.num_layers = m["num_layers"]
+    t.layer_bottom = fl(m["layers_z_start"])
+    t.layer_thickness = fl(m["layers_height"])
+    if m["len_mode"] == "constant":
+        t.len_mode = 0
+        t.abs_const = O._ptr("abs_const", fls(m["abs_const"]), C.c_float)
+        t.sca_const = O._ptr("sca_const", fls(m["sca_const"]), C.c_float)
+    else:
+        t.len_mode = 1
+        t.aDust400 = O._ptr("aDust400", fls(m["aDust400"]), C.c_float)
+        t.deltaTau = O._ptr("deltaTau", fls(m["deltaTau"]), C.c_float)
+        t.b400 = O._ptr("b400", fls(m["b400"]), C.c_float)
+        t.kappa, t.A, t.B, t.D, t.E = fl(m["kappa"]), fl(m["A"]), fl(m["B"]), fl(m["D"]), fl(m["E"])
+        t.alpha = fl(m["alpha"])
+        t.ref_wlen_recip = fl(1.0 / (400.0 * B.NANOMETER))
+    t.nanometer = fl(B.NANOMETER)
+    t.micrometer = fl(B.MICROMETER)
+    t.c_light = fl(B.C_LIGHT)
+    for i in range(5):
+        t.n[i] = fl(m["n"][i])
+        t.g[i] = fl(m["g"][i])
+    sc = m["scat"]
+    g = sc["mean_cos"]
+    t.liu_beta = fl((1.0 - g) / (1.0 + g))
+    t.hg_g = fl(g)
+    t.hg_g2 = fl(g * g)
+    if sc["kind"] == "mixed":
+        t.scat_kind = 2
+        t.mix_frac = fl(sc["fraction"])
+        t.mix_frac_rest = fl(1.0 - sc["fraction"])
+    elif sc["kind"] == "hg":
+        t.scat_kind = 0
+    else:
+        t.scat_kind = 1
+    if "aniso" in m:
+        c = B.aniso_constants(m["aniso"])
+        t.has_abs_corr = 1
+        for i in range(3):
+            t.an_l[i] = fl(c["l"][i])
+            t.an_rl[i] = fl(c["rl"][i])
+        t.an_azx, t.an_azy, t.an_mazy, t.an_B2 = fl(c["azx"]), fl(c["azy"]), fl(-c["azy"]), fl(c["B2"])
+    else:
+        t.has_abs_corr = 0
+        t.abs_corr_const = fl(1.0)
+    for key in ("pre", "post"):
+        if key in m:
+            setattr(t, "has_" + key, 1)
+            setattr(t, key + "_renorm", 1 if m[key]["renormalize"] else 0)
+            arr = getattr(t, key)
+            mat = np.asarray(m[key]["matrix"], dtype=np.float64)
+            for i in range(3):
+                for j in range(3):
+                    arr[3 * i + j] = fl(mat[i, j])
+    if "tilt" in m:
+        tl = m["tilt"]
+        first_z, dz = B.tilt_spacing(tl["zcoords"])
+        t.has_tilt = 1
+        t.tilt_nd = len(tl["distances"])
+        t.tilt_nz = len(tl["zcoords"])
+        t.tilt_first_z = fl(first_z)
+        t.tilt_dz = fl(dz)
+        t.tilt_lnx = fl(np.cos(tl["azimuth"]))
+        t.tilt_lny = fl(np.sin(tl["azimuth"]))
+        t.tilt_dist = O._ptr("tilt_dist", fls(tl["distances"]), C.c_float)
+        t.tilt_zcorr = O._ptr("tilt_zcorr", fls(np.asarray(tl["zcorr"]).ravel()), C.c_float)
+    else:
+        t.has_tilt = 0
+        t.tilt_const = fl(0.0)
+    assert len(generators) <= MAX_GEN
+    t.num_gen = len(generators)
+    for k, gdesc in enumerate(generators):
+        if gdesc["kind"] == "interp":
+            yv, ycum = B.interp_dist_tables(gdesc)
+            t.gen[k].kind = 0
+            t.gen[k].n = len(yv)
+            t.gen[k].first = fl(gdesc["first"])
+            t.gen[k].spacing = fl(gdesc["spacing"])
+            t.gen[k].yv = O._ptr("gen%d_yv" % k, yv, C.c_float)
+            t.gen[k].ycum = O._ptr("gen%d_ycum" % k, ycum, C.c_float)
+        else:
+            t.gen[k].kind = 1
+            t.gen[k].value = fl(gdesc["value"])
+    if bias["kind"] == "table":
+        t.bias_kind = 0
+        t.bias_n = len(bias["values"])
+        t.bias_start = fl(bias["start"])
+        t.bias_step = fl(bias["step"])
+        t.bias_data = O._ptr("bias_data", fls(bias["values"]), C.c_float)
+    else:
+        t.bias_kind = 1
+        t.bias_value = fl(bias["value"])
+    geo = geometry
+    O.geo = geo
+    t.num_strings = geo["num_strings"]
+    t.om_radius = geo["om_radius"]
+    t.string_max_radius = geo["string_max_radius"]
+    for name in ("str_x", "str_y", "str_minz", "str_maxz", "set_startz", "set_height", "dom_tz", "dom_meanx", "dom_meany"):
+        setattr(t, name, O._ptr(name, geo[name], C.c_float))
+    t.str_set = O._ptr("str_set", geo["str_set"], C.c_uint8)
+    t.num_sets = geo["num_sets"]
+    t.max_layers = geo["max_layers"]
+    t.set_nlayers = O._ptr("set_nlayers", geo["set_nlayers"], C.c_uint16)
+    t.layer_to_om = O._ptr("layer_to_om", geo["layer_to_om"], C.c_uint16)
+    assert len(geo["cells"]) <= MAX_SUBDET
+    t.num_subdet = len(geo["cells"])
+    for k, cell in enumerate(geo["cells"]):
+        t.cell_nx[k], t.cell_ny[k] = cell["nx"], cell["ny"]
+        t.cell_wx[k], t.cell_wy[k] = cell["width_x"], cell["width_y"]
+        t.cell_sx[k], t.cell_sy[k] = cell["start_x"], cell["start_y"]
+        t.cell_index[k] = O._ptr("cell_index_%d" % k, cell["index"], C.c_uint16)
+    t.dom_mul_x, t.dom_mul_y = geo["dom_mul_x"], geo["dom_mul_y"]
+    t.dom_tx = O._ptr("dom_tx", geo["dom_tx"], C.c_int16)
+    t.dom_ty = O._ptr("dom_ty", geo["dom_ty"], C.c_int16)
+    t.dom_start = O._ptr("dom_start", geo["dom_start"], C.c_uint32)
+    return O
+
+
+def propagate(tables, steps, x, a, max_hits=None, threads=1):
+    """Runs the restated propKernel on steps (STEP_DTYPE) with RNG streams (x,a).
+    Returns (photons[:min(count,max_hits)], count, x_after, iterations).
+    String / DOM fields hold INDICES, like the kernel's raw output."""
+    L = lib()
+    steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+    n = len(steps)
+    x = np.array(x[:n], dtype=np.uint64, copy=True)
+    a = np.ascontiguousarray(a[:n], dtype=np.uint32)
+    if max_hits is None:
+        max_hits = int(steps["num"].sum()) + 1
+    out = np.zeros(max_hits, dtype=PHOTON_DTYPE)
+    it = C.c_uint64(0)
+    args = [C.byref(tables.t), steps.ctypes.data_as(C.c_void_p), C.c_uint32(n), x.ctypes.data_as(C.c_void_p),
+            a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(max_hits)]
+    if threads == 1:
+        cnt = L.oracle_propagate(*args, C.byref(it))
+    else:
+        cnt = L.oracle_propagate_mt(*args, C.c_int(threads), C.byref(it))
+    return out[:min(cnt, max_hits)], cnt, x, it.value
+
+
+def replace_indices_with_ids(photons, geo):
+    """ReplaceStringDOMIndexWithStringDOMIDs (OpenCL.cxx:1565-1600)."""
+    out = photons.copy()
+    for k in range(len(out)):
+        s = int(out["stringID"][k])
+        d = int(out["omID"][k])
+        out["stringID"][k] = geo["string_index_to_id"][s]
+        out["omID"][k] = geo["dom_index_to_id"][s][d]
+    return out
+
+
+def sort_photons(ph):
+    """Canonical order for multiset comparison."""
+    raw = np.ascontiguousarray(ph).view(np.uint32).reshape(len(ph), 20)
+    keys = [raw[:, c] for c in range(19, -1, -1)]
+    keys += [ph["numScatters"], ph["omID"], ph["stringID"], ph["id"]]
+    return ph[np.lexsort(keys)]
+
+
+def eval_math(what, xs, ys=None):
+    L = lib()
+    xs = np.ascontiguousarray(xs, dtype=np.float32)
+    out = np.empty_like(xs)
+    yp = None
+    if ys is not None:
+        ys = np.ascontiguousarray(ys, dtype=np.float32)
+        yp = ys.ctypes.data_as(C.c_void_p)
+    L.oracle_eval_math(C.c_int(what), xs.ctypes.data_as(C.c_void_p), yp, C.c_int(len(xs)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def eval_medium(tables, what, wlens, layer=0):
+    L = lib()
+    w = np.ascontiguousarray(wlens, dtype=np.float32)
+    out = np.empty_like(w)
+    L.oracle_eval_medium(C.byref(tables.t), C.c_int(what), w.ctypes.data_as(C.c_void_p), C.c_int(len(w)),
+                         C.c_int(layer), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def eval_field(tables, what, xyz):
+    L = lib()
+    v = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(len(v) * (3 if what >= 2 else 1), dtype=np.float32)
+    L.oracle_eval_field(C.byref(tables.t), C.c_int(what), v.ctypes.data_as(C.c_void_p), C.c_int(len(v)),
+                        out.ctypes.data_as(C.c_void_p))
+    return out.reshape(-1, 3) if what >= 2 else out
+
+
+def eval_rng(x, a, n):
+    L = lib()
+    xs = C.c_uint64(int(x))
+    out = np.empty(n, dtype=np.float32)
+    L.oracle_eval_rng(C.byref(xs), C.c_uint32(int(a)), C.c_int(n), out.ctypes.data_as(C.c_void_p))
+    return out, xs.value

@@ -1,0 +1,785 @@
+/*
+ * clsim_oracle.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * CPU restatement of clsim's photon propagator `propKernel`
+ * (resources/kernels/propagation_kernel.c.cl:406-913) together with the DOM
+ * collision search (resources/kernels/sparse_collision_kernel.c.cl:27-587), the
+ * MWC random number generator (resources/kernels/mwcrng_kernel.cl:12-28) and
+ * the run-time generated medium / spectrum / geometry functions, which the
+ * reference emits as OpenCL text (private/opencl/I3CLSimHelperGenerate*.cxx and
+ * the GetOpenCLFunction() bodies under private/clsim/function, random_value);
+ * here they are evaluated from tables (struct oracle_tables) that
+ * oracle/builders.py fills with the float literals the reference would print.
+ *
+ * Every function cites the reference file:line it follows.  The arithmetic is
+ * the reference's single precision expression order with NO implicit fma
+ * contraction (build with -ffp-contract=off) and the math library of
+ * oracle_math.h in place of the OpenCL runtime builtins.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this file.  PARITY STATUS: the reference holds no golden vector for
+ * propKernel output and cannot be built here (needs
+ * IceTray, boost, an OpenCL CPU runtime and run-time generated code), so the
+ * whole-kernel output of this oracle is UNPINNED by the reference; the
+ * sub-functions that the reference's tests and data files do pin (safeprime
+ * multipliers, anisotropy scaling, SPICE-Lea transforms, ice loader tables)
+ * are pinned in tests/ against fixtures generated from those files.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_math.h"
+
+/* ---- wire structs: public/clsim/I3CLSimStep.h:141-155, I3CLSimPhoton.h:194-213;
+ *      propagation_kernel.h.cl:52-81 ---- */
+typedef struct __attribute__((packed)) {
+    float pos[4];               /* x,y,z,time */
+    float dir[4];               /* theta,phi,length,beta */
+    uint32_t numPhotons;
+    float weight;
+    uint32_t identifier;
+    uint8_t sourceType;
+    uint8_t dummy1;
+    uint16_t dummy2;
+} oracle_step;                  /* 48 bytes */
+
+typedef struct __attribute__((packed)) {
+    float pos[4];
+    float dir[2];
+    float wavelength;
+    float cherenkovDist;
+    uint32_t numScatters;
+    float weight;
+    uint32_t identifier;
+    int16_t stringID;
+    uint16_t omID;
+    float startPos[4];
+    float startDir[2];
+    float groupVelocity;
+    float distInAbsLens;
+} oracle_photon;                /* 80 bytes */
+
+_Static_assert(sizeof(oracle_step) == 48, "step size");
+_Static_assert(sizeof(oracle_photon) == 80, "photon size");
+
+#define ORACLE_MAX_GEN 8
+#define ORACLE_MAX_SUBDET 9
+
+typedef struct {
+    int32_t kind;               /* 0 interpolated (const spacing), 1 constant */
+    int32_t n;
+    float first, spacing;       /* literals of InterpolatedDistribution.cxx:250-266 */
+    const float *yv;            /* _distYValues */
+    const float *ycum;          /* _distYCumulativeValues */
+    float value;                /* RandomValueConstant */
+} oracle_wlen_gen;
+
+typedef struct {
+    /* ---- compile-time switches of the reference (OpenCL.cxx:390-442) ---- */
+    int32_t stop_detected;      /* STOP_PHOTONS_ON_DETECTION (only 1 is restated) */
+    int32_t has_pancake;        /* PANCAKE_FACTOR defined (pancakeFactor != 1) */
+    float pancake;
+    /* ---- medium (MediumPropertiesSource.cxx:207-389) ---- */
+    int32_t num_layers;
+    float layer_bottom, layer_thickness;
+    int32_t len_mode;           /* 0: per-layer FunctionConstant, 1: IceCube abs/scat */
+    const float *abs_const, *sca_const;
+    const float *aDust400, *deltaTau, *b400;
+    float kappa, A, B, D, E, alpha, ref_wlen_recip, nanometer;
+    float n[5], g[5], micrometer, c_light;
+    int32_t scat_kind;          /* 0 HG, 1 SimplifiedLiu, 2 Mixed(Liu,HG) */
+    float mix_frac, mix_frac_rest, liu_beta, hg_g, hg_g2;
+    int32_t has_abs_corr;       /* ScalarFieldAnisotropyAbsLenScaling vs constant */
+    float abs_corr_const;
+    float an_l[3], an_rl[3], an_azx, an_azy, an_mazy, an_B2;
+    int32_t has_pre, pre_renorm, has_post, post_renorm;
+    float pre[9], post[9];
+    int32_t has_tilt;           /* ScalarFieldIceTiltZShift vs constant */
+    float tilt_const;
+    int32_t tilt_nd, tilt_nz;
+    float tilt_first_z, tilt_dz, tilt_lnx, tilt_lny;
+    const float *tilt_dist, *tilt_zcorr;
+    /* ---- spectra ---- */
+    int32_t num_gen;
+    oracle_wlen_gen gen[ORACLE_MAX_GEN];
+    int32_t bias_kind;          /* 0 FromTable, 1 Constant */
+    int32_t bias_n;
+    float bias_start, bias_step, bias_value;
+    const float *bias_data;
+    /* ---- geometry (GeometrySource.cxx:1153-1269, 619-700) ---- */
+    int32_t num_strings;
+    float om_radius, string_max_radius;
+    const float *str_x, *str_y, *str_minz, *str_maxz;
+    const uint8_t *str_set;
+    int32_t num_sets, max_layers;
+    const uint16_t *set_nlayers;
+    const float *set_startz, *set_height;
+    const uint16_t *layer_to_om;        /* geoLayerToOMNumIndexPerStringSet */
+    int32_t num_subdet;
+    int32_t cell_nx[ORACLE_MAX_SUBDET], cell_ny[ORACLE_MAX_SUBDET];
+    float cell_wx[ORACLE_MAX_SUBDET], cell_wy[ORACLE_MAX_SUBDET];
+    float cell_sx[ORACLE_MAX_SUBDET], cell_sy[ORACLE_MAX_SUBDET];
+    const uint16_t *cell_index[ORACLE_MAX_SUBDET];
+    float dom_mul_x, dom_mul_y;
+    const int16_t *dom_tx, *dom_ty;
+    const float *dom_tz;
+    const uint32_t *dom_start;
+    const float *dom_meanx, *dom_meany;
+} oracle_tables;
+
+typedef struct { uint64_t x; uint32_t a; } rng_t;
+
+/* mwcrng_kernel.cl:12-20 */
+static inline float rand_co(rng_t *r)
+{
+    r->x = (r->x & 0xffffffffull) * (uint64_t)r->a + (r->x >> 32);
+    const uint32_t lo = (uint32_t)(r->x & 0xffffffffull);
+    /* convert_float_rtz(uint): keep the top 24 significant bits */
+    float f;
+    if (lo == 0) f = 0.0f;
+    else {
+        const int lz = __builtin_clz(lo);
+        const int drop = 8 - lz;
+        const uint32_t t = (drop > 0) ? ((lo >> drop) << drop) : lo;
+        f = (float)t;                              /* exact */
+    }
+    return f / 4294967296.0f;
+}
+/* mwcrng_kernel.cl:25-28 */
+static inline float rand_oc(rng_t *r) { return 1.0f - rand_co(r); }
+
+static inline float sqr(float a) { return a * a; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+static inline float clampf(float v, float lo, float hi) { return fminf_(fmaxf_(v, lo), hi); }
+
+/* ---------------- generated medium functions ---------------- */
+
+/* RefIndexIceCube.cxx:128-180 */
+static inline float getPhaseRefIndex(const oracle_tables *T, float wlen)
+{
+    const float x = wlen / T->micrometer;
+    return T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
+}
+static inline float getGroupRefIndex(const oracle_tables *T, float wlen)
+{
+    const float x = wlen / T->micrometer;
+    const float np = T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
+    const float np_corr = T->g[0] + x * (T->g[1] + x * (T->g[2] + x * (T->g[3] + x * T->g[4])));
+    return np * np_corr;
+}
+/* MediumPropertiesSource.cxx:255-272 (group index override path) */
+static inline float getGroupVelocity(const oracle_tables *T, float wlen)
+{
+    return T->c_light / getGroupRefIndex(T, wlen);
+}
+/* _Optimizers.cxx:195-250 / FunctionConstant.cxx:81-100 */
+static inline float getScatteringLength(const oracle_tables *T, int layer, float wlen)
+{
+    if (T->len_mode == 0) return T->sca_const[layer];
+    return 1.0f / (T->b400[layer] * om_powr(wlen * T->ref_wlen_recip, -T->alpha));
+}
+/* _Optimizers.cxx:123-190 */
+static inline float getAbsorptionLength(const oracle_tables *T, int layer, float wlen)
+{
+    if (T->len_mode == 0) return T->abs_const[layer];
+    const float x = wlen / T->nanometer;
+    return 1.0f / ((T->D * T->aDust400[layer] + T->E) * om_powr(x, -T->kappa)
+                   + T->A * om_exp(-T->B / x) * (1.0f + 0.01f * T->deltaTau[layer]));
+}
+/* HenyeyGreenstein.cxx:69-92 */
+static inline float hg_cos(const oracle_tables *T, float rnd_co)
+{
+    const float s = 2.0f * rnd_co - 1.0f;
+    const float ii = ((1.0f - T->hg_g2) / (1.0f + T->hg_g * s));
+    return clampf((1.0f + T->hg_g2 - ii * ii) / (2.0f * T->hg_g), -1.0f, 1.0f);
+}
+/* SimplifiedLiu.cxx:64-88 */
+static inline float liu_cos(const oracle_tables *T, float rnd_co)
+{
+    return clampf(2.0f * om_powr(rnd_co, T->liu_beta) - 1.0f, -1.0f, 1.0f);
+}
+/* Mixed.cxx:115-157 (single random number form) */
+static inline float makeScatteringCosAngle(const oracle_tables *T, rng_t *rng)
+{
+    if (T->scat_kind == 0) return hg_cos(T, rand_co(rng));
+    if (T->scat_kind == 1) return liu_cos(T, rand_co(rng));
+    const float rr = rand_co(rng);
+    if (rr < T->mix_frac) return liu_cos(T, rr / T->mix_frac);
+    return hg_cos(T, (1.0f - rr) / T->mix_frac_rest);
+}
+/* ScalarFieldAnisotropyAbsLenScaling.cxx:92-140 / ScalarFieldConstant.cxx:61-80 */
+static inline float getDirectionalAbsLenCorrFactor(const oracle_tables *T, const float d[4])
+{
+    if (!T->has_abs_corr) return T->abs_corr_const;
+    const float n0 = (T->an_azx * d[0]) + (T->an_azy * d[1]);
+    const float n1 = (T->an_mazy * d[0]) + (T->an_azx * d[1]);
+    const float n2 = d[2];
+    const float s0 = n0 * n0, s1 = n1 * n1, s2 = n2 * n2, s3 = 0.0f * 0.0f;
+    /* dot(float4,float4): fixed as ((x+y)+z)+w */
+    const float nB = ((s0 * T->an_rl[0] + s1 * T->an_rl[1]) + s2 * T->an_rl[2]) + s3 * 0.0f;
+    const float An = ((s0 * T->an_l[0] + s1 * T->an_l[1]) + s2 * T->an_l[2]) + s3 * 0.0f;
+    return 2.0f / ((T->an_B2 - nB) * An);
+}
+/* VectorTransformMatrix.cxx:101-135 / VectorTransformConstant.cxx:58-74 */
+static inline void transformDirection(int has, int renorm, const float m[9], float d[4])
+{
+    if (!has) return;
+    const float x = (m[0] * d[0]) + (m[1] * d[1]) + (m[2] * d[2]);
+    const float y = (m[3] * d[0]) + (m[4] * d[1]) + (m[5] * d[2]);
+    const float z = (m[6] * d[0]) + (m[7] * d[1]) + (m[8] * d[2]);
+    d[0] = x; d[1] = y; d[2] = z;
+    if (renorm) {
+        const float norm = om_rsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] = d[0] * norm; d[1] = d[1] * norm; d[2] = d[2] * norm;
+    }
+}
+/* ScalarFieldIceTiltZShift.cxx:145-213 */
+static inline float getTiltZShift(const oracle_tables *T, const float p[4])
+{
+    const float z_rescaled = (p[2] - T->tilt_first_z) / T->tilt_dz;
+    const int k = imin(imax((int)__builtin_floorf(z_rescaled), 0), T->tilt_nz - 2);
+    const float fraction_z_above = z_rescaled - (float)k;
+    const float fraction_z_below = 1.0f - fraction_z_above;
+    const float nr = T->tilt_lnx * p[0] + T->tilt_lny * p[1];
+    for (int j = 1; j < T->tilt_nd; j++) {
+        const float thisDist = T->tilt_dist[j];
+        if ((nr < thisDist) || (j == T->tilt_nd - 1)) {
+            const float previousDist = T->tilt_dist[j - 1];
+            const float thisDistanceBinWidth = thisDist - previousDist;
+            const float frac_at_lower = (thisDist - nr) / thisDistanceBinWidth;
+            const float frac_at_upper = 1.0f - frac_at_lower;
+            const float val_at_lower = (T->tilt_zcorr[(j - 1) * T->tilt_nz + k + 1] * fraction_z_above
+                                        + T->tilt_zcorr[(j - 1) * T->tilt_nz + k] * fraction_z_below);
+            const float val_at_upper = (T->tilt_zcorr[j * T->tilt_nz + k + 1] * fraction_z_above
+                                        + T->tilt_zcorr[j * T->tilt_nz + k] * fraction_z_below);
+            return (val_at_upper * frac_at_upper + val_at_lower * frac_at_lower);
+        }
+    }
+    return 0.0f;
+}
+/* InterpolatedDistribution.cxx:236-336 / RandomValueConstant.cxx */
+static inline float generateWavelength_k(const oracle_tables *T, int kgen, rng_t *rng)
+{
+    const oracle_wlen_gen *G = &T->gen[kgen];
+    if (G->kind == 1) return G->value;
+    const float randomNumber = rand_oc(rng);
+    unsigned int k = 0;
+    float this_acu = 0.0f;
+    for (;;) {
+        float next_acu = G->ycum[k + 1];
+        if (next_acu >= randomNumber) break;
+        this_acu = next_acu;
+        ++k;
+    }
+    const float b = G->yv[k];
+    const float x0 = (float)k * (G->spacing) + (G->first);
+    const float slope = (G->yv[k + 1] - b) / (G->spacing);
+    const float dy = randomNumber - this_acu;
+    if ((b == 0.0f) && (slope == 0.0f)) return x0;
+    else if (b == 0.0f) return x0 + om_sqrt(2.0f * dy / slope);
+    else if (slope == 0.0f) return x0 + dy / b;
+    else return x0 + (om_sqrt(dy * (2.0f * slope) / (b * b) + 1.0f) - 1.0f) * b / slope;
+}
+/* MediumPropertiesSource.cxx:392-432 */
+static inline float generateWavelength(const oracle_tables *T, uint32_t number, rng_t *rng)
+{
+    if (T->num_gen == 0) return 0.0f;
+    if (T->num_gen == 1) return generateWavelength_k(T, 0, rng);
+    if (number < (uint32_t)T->num_gen) return generateWavelength_k(T, (int)number, rng);
+    return 0.0f;
+}
+/* FunctionFromTable.cxx:167-300 / FunctionConstant.cxx */
+static inline float getWavelengthBias(const oracle_tables *T, float wavelength)
+{
+    if (T->bias_kind == 1) return T->bias_value;
+    const float q = (wavelength - T->bias_start) / T->bias_step;
+    const float fbin = __builtin_truncf(q);
+    float fraction = q - fbin;                      /* modf */
+    int ibin = (int)fbin;
+    if ((ibin < 0) || ((ibin == 0) && (fraction < 0))) { ibin = 0; fraction = 0.0f; }
+    else if (ibin >= T->bias_n - 1) { ibin = T->bias_n - 2; fraction = 1.0f; }
+    const float a = T->bias_data[ibin], b = T->bias_data[ibin + 1];
+    return a + (b - a) * fraction;                  /* mix */
+}
+/* GeometrySource.cxx:685-700 */
+static inline void geometryGetDomPosition(const oracle_tables *T, unsigned s, unsigned d,
+                                          float *x, float *y, float *z)
+{
+    const unsigned int index = T->dom_start[s] + d;
+    *x = (float)T->dom_tx[index] * T->dom_mul_x + T->dom_meanx[s];
+    *y = (float)T->dom_ty[index] * T->dom_mul_y + T->dom_meany[s];
+    *z = T->dom_tz[index];
+}
+
+/* ---------------- propagation_kernel.c.cl ---------------- */
+
+#define SPEED_OF_LIGHT 0.299792458f     /* h.cl:148 */
+#define PI_F 3.14159265359f             /* h.cl:150 */
+#define EPSILON 0.00001f                /* c.cl:505 */
+
+/* c.cl:73-81 */
+static inline int findLayerForGivenZPos(const oracle_tables *T, float z)
+{
+    return (int)((z - T->layer_bottom) / T->layer_thickness);
+}
+static inline float mediumLayerBoundary(const oracle_tables *T, int layer)
+{
+    return ((float)layer * T->layer_thickness) + T->layer_bottom;
+}
+
+/* c.cl:83-129 */
+static void scatterDirectionByAngle(float cosa, float sina, float d[4], float randomNumber)
+{
+    const float b = 2.0f * PI_F * randomNumber;
+    float cosb, sinb;
+    om_sincos(b, &sinb, &cosb);
+    const float sinth = om_sqrt(fmaxf_(0.0f, 1.0f - d[2] * d[2]));
+    if (sinth > 0.0f) {
+        const float ox = d[0], oy = d[1], oz = d[2];
+        d[0] = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
+        d[1] = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
+        d[2] = oz * cosa + sina * sinb * sinth;
+    } else {
+        const float sgn = (d[2] > 0.0f) ? 1.0f : ((d[2] < 0.0f) ? -1.0f : d[2]);
+        d[0] = sina * cosb;
+        d[1] = sina * sinb;
+        d[2] = cosa * sgn;
+    }
+    {
+        const float recip_length = om_rsqrt(sqr(d[0]) + sqr(d[1]) + sqr(d[2]));
+        d[0] *= recip_length; d[1] *= recip_length; d[2] *= recip_length;
+    }
+}
+
+/* c.cl:132-184 */
+static void createPhotonFromTrack(const oracle_tables *T, const oracle_step *step, const float stepDir[4],
+                                  rng_t *rng, float pos[4], float dirw[4])
+{
+    const float shiftMultiplied = step->dir[2] * rand_co(rng);
+    const float inverseParticleSpeed = 1.0f / (SPEED_OF_LIGHT * step->dir[3]);
+    pos[0] = step->pos[0] + stepDir[0] * shiftMultiplied;
+    pos[1] = step->pos[1] + stepDir[1] * shiftMultiplied;
+    pos[2] = step->pos[2] + stepDir[2] * shiftMultiplied;
+    pos[3] = step->pos[3] + inverseParticleSpeed * shiftMultiplied;
+    /* NO_FLASHER (OpenCL.cxx:648-650): with <=1 spectrum every step is Cherenkov */
+    if (T->num_gen <= 1 || step->sourceType == 0) {
+        const float wavelength = generateWavelength_k(T, 0, rng);
+        const float cosCherenkov = fminf_(1.0f, 1.0f / (step->dir[3] * getPhaseRefIndex(T, wavelength)));
+        const float sinCherenkov = om_sqrt(1.0f - cosCherenkov * cosCherenkov);
+        dirw[0] = stepDir[0]; dirw[1] = stepDir[1]; dirw[2] = stepDir[2];
+        dirw[3] = wavelength;
+        scatterDirectionByAngle(cosCherenkov, sinCherenkov, dirw, rand_co(rng));
+    } else {
+        const float wavelength = generateWavelength(T, (uint32_t)step->sourceType, rng);
+        dirw[0] = stepDir[0]; dirw[1] = stepDir[1]; dirw[2] = stepDir[2];
+        dirw[3] = wavelength;
+    }
+}
+
+/* c.cl:206-223 */
+static void sphDirFromCar(const float d[4], float out[2])
+{
+    const float r_inv = om_rsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float theta = 0.0f;
+    if (om_fabs(d[2] * r_inv) <= 1.0f) theta = om_acos(d[2] * r_inv);
+    else if (d[2] < 0.0f) theta = PI_F;
+    if (theta < 0.0f) theta += 2.0f * PI_F;
+    float phi = om_atan2(d[1], d[0]);
+    if (phi < 0.0f) phi += 2.0f * PI_F;
+    out[0] = theta; out[1] = phi;
+}
+
+typedef struct {
+    oracle_photon *out;
+    uint32_t max_hits;
+    uint32_t count;             /* keeps counting past max_hits (c.cl:329-330) */
+} hit_sink;
+
+/* c.cl:307-404 */
+static void saveHit(const oracle_tables *T, const float pos[4], const float dirw[4], float thisStepLength,
+                    float inv_groupvel, float totalPath, uint32_t numScatters, float distAbsLens,
+                    const float startPos[4], const float startDirw[4], const oracle_step *step,
+                    unsigned hitOnString, unsigned hitOnDom, hit_sink *sink)
+{
+    const uint32_t myIndex = sink->count++;
+    if (myIndex >= sink->max_hits) return;
+    oracle_photon *o = &sink->out[myIndex];
+    float domPosX, domPosY, domPosZ;
+    geometryGetDomPosition(T, hitOnString, hitOnDom, &domPosX, &domPosY, &domPosZ);
+    if (T->has_pancake) {
+        const float px = pos[0] - domPosX, py = pos[1] - domPosY, pz = pos[2] - domPosZ;
+        const float parallel = px * dirw[0] + py * dirw[1] + pz * dirw[2];
+        const float nx = px - parallel * dirw[0];
+        const float ny = py - parallel * dirw[1];
+        const float nz = pz - parallel * dirw[2];
+        const float f = (T->pancake - 1.0f) / T->pancake;
+        domPosX += f * nx; domPosY += f * ny; domPosZ += f * nz;
+    }
+    o->pos[0] = pos[0] + thisStepLength * dirw[0] - domPosX;
+    o->pos[1] = pos[1] + thisStepLength * dirw[1] - domPosY;
+    o->pos[2] = pos[2] + thisStepLength * dirw[2] - domPosZ;
+    o->pos[3] = pos[3] + thisStepLength * inv_groupvel;
+    sphDirFromCar(dirw, o->dir);
+    o->wavelength = dirw[3];
+    o->cherenkovDist = totalPath + thisStepLength;
+    o->numScatters = numScatters;
+    o->weight = step->weight / getWavelengthBias(T, dirw[3]);
+    o->identifier = step->identifier;
+    o->stringID = (int16_t)hitOnString;
+    o->omID = (uint16_t)hitOnDom;
+    memcpy(o->startPos, startPos, 16);
+    sphDirFromCar(startDirw, o->startDir);
+    o->groupVelocity = 1.0f / inv_groupvel;
+    o->distInAbsLens = distAbsLens;
+}
+
+/* sparse_collision_kernel.c.cl:27-192 (STOP_PHOTONS_ON_DETECTION branch) */
+static void checkForCollision_OnString(const oracle_tables *T, unsigned stringNum, float dirLenXYSqr,
+                                       const float pos[4], const float dirw[4], float *thisStepLength,
+                                       int *hitRecorded, unsigned *hitOnString, unsigned *hitOnDom)
+{
+    const unsigned stringSet = T->str_set[stringNum];
+    {
+        const float smin = sqr(((pos[0] - T->str_x[stringNum]) * dirw[1]
+                                - (pos[1] - T->str_y[stringNum]) * dirw[0])) / dirLenXYSqr;
+        if (smin > sqr(T->string_max_radius)) return;
+    }
+    {
+        if ((dirw[2] > 0.0f) && (pos[2] > T->str_maxz[stringNum] + T->om_radius)) return;
+        if ((dirw[2] < 0.0f) && (pos[2] < T->str_minz[stringNum] - T->om_radius)) return;
+    }
+    int lowLayerZ = (int)((pos[2] - T->set_startz[stringSet]) / T->set_height[stringSet]);
+    int highLayerZ = (int)((pos[2] + dirw[2] * (*thisStepLength) - T->set_startz[stringSet]) / T->set_height[stringSet]);
+    if (highLayerZ < lowLayerZ) { int tmp = lowLayerZ; lowLayerZ = highLayerZ; highLayerZ = tmp; }
+    lowLayerZ = imin(imax(lowLayerZ, 0), (int)T->set_nlayers[stringSet] - 1);
+    highLayerZ = imin(imax(highLayerZ, 0), (int)T->set_nlayers[stringSet] - 1);
+
+    const uint16_t *geoLayerToOMNumIndex = T->layer_to_om + (stringSet * (unsigned)T->max_layers) + lowLayerZ;
+    for (int layer_z = lowLayerZ; layer_z <= highLayerZ; ++layer_z, ++geoLayerToOMNumIndex) {
+        const unsigned domNum = *geoLayerToOMNumIndex;
+        if (domNum == 0xFFFF) continue;
+        float domPosX, domPosY, domPosZ;
+        geometryGetDomPosition(T, stringNum, domNum, &domPosX, &domPosY, &domPosZ);
+        float urdot, discr;
+        {
+            const float dx = domPosX - pos[0], dy = domPosY - pos[1], dz = domPosZ - pos[2], dw = 0.0f;
+            /* dot(): ((x*x+y*y)+z*z)+w*w */
+            const float dr2 = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+            urdot = ((dx * dirw[0] + dy * dirw[1]) + dz * dirw[2]) + dw * dirw[3];
+            discr = sqr(urdot) - dr2 + T->om_radius * T->om_radius;
+        }
+        if (discr < 0.0f) continue;
+        if (T->has_pancake) discr = om_sqrt(discr) / T->pancake;
+        else discr = om_sqrt(discr);
+        {
+            const float smin2 = urdot + discr;
+            if (smin2 < 0.0f) continue;
+        }
+        const float smin1 = urdot - discr;
+        if (smin1 < 0.0f) continue;
+        if (smin1 < *thisStepLength) {
+            *thisStepLength = smin1;
+            *hitOnString = stringNum;
+            *hitOnDom = domNum;
+            *hitRecorded = 1;
+        }
+    }
+}
+
+/* sparse_collision_kernel.c.cl:194-303 */
+static void checkForCollision_InCell(const oracle_tables *T, int sd, float dirLenXYSqr, const float pos[4],
+                                     const float dirw[4], float *thisStepLength, int *hitRecorded,
+                                     unsigned *hitOnString, unsigned *hitOnDom)
+{
+    const float sx = T->cell_sx[sd], sy = T->cell_sy[sd], wx = T->cell_wx[sd], wy = T->cell_wy[sd];
+    const int nx = T->cell_nx[sd], ny = T->cell_ny[sd];
+    int lowCellX = (int)((pos[0] - sx) / wx);
+    int lowCellY = (int)((pos[1] - sy) / wy);
+    int highCellX = (int)((pos[0] + dirw[0] * (*thisStepLength) - sx) / wx);
+    int highCellY = (int)((pos[1] + dirw[1] * (*thisStepLength) - sy) / wy);
+    if (highCellX < lowCellX) { int tmp = lowCellX; lowCellX = highCellX; highCellX = tmp; }
+    if (highCellY < lowCellY) { int tmp = lowCellY; lowCellY = highCellY; highCellY = tmp; }
+    lowCellX = imin(imax(lowCellX, 0), nx - 1);
+    lowCellY = imin(imax(lowCellY, 0), ny - 1);
+    highCellX = imin(imax(highCellX, 0), nx - 1);
+    highCellY = imin(imax(highCellY, 0), ny - 1);
+    for (int cell_y = lowCellY; cell_y <= highCellY; ++cell_y) {
+        for (int cell_x = lowCellX; cell_x <= highCellX; ++cell_x) {
+            const unsigned stringNum = T->cell_index[sd][cell_y * nx + cell_x];
+            if (stringNum == 0xFFFF) continue;
+            checkForCollision_OnString(T, stringNum, dirLenXYSqr, pos, dirw, thisStepLength,
+                                       hitRecorded, hitOnString, hitOnDom);
+        }
+    }
+}
+
+/* sparse_collision_kernel.c.cl:462-587 */
+static int checkForCollision(const oracle_tables *T, const float pos[4], const float dirw[4], float inv_groupvel,
+                             float totalPath, uint32_t numScatters, float distAbsLens, const float startPos[4],
+                             const float startDirw[4], const oracle_step *step, float *thisStepLength,
+                             hit_sink *sink)
+{
+    const float dirLenXYSqr = sqr(dirw[0]) + sqr(dirw[1]);
+    if (dirLenXYSqr <= 0.0f) return 0;
+    int hitRecorded = 0;
+    unsigned hitOnString = 0, hitOnDom = 0;
+    for (int sd = 0; sd < T->num_subdet; ++sd)
+        checkForCollision_InCell(T, sd, dirLenXYSqr, pos, dirw, thisStepLength, &hitRecorded,
+                                 &hitOnString, &hitOnDom);
+    if (hitRecorded)
+        saveHit(T, pos, dirw, *thisStepLength, inv_groupvel, totalPath, numScatters, distAbsLens, startPos,
+                startDirw, step, hitOnString, hitOnDom, sink);
+    return hitRecorded;
+}
+
+/* c.cl:406-913: one work item */
+static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rng_t *rng, hit_sink *sink,
+                           uint64_t *iterations)
+{
+    oracle_step step = *stepIn;
+    float stepDir[4];
+    {
+        float st, ct, sp, cp;
+        om_sincos(step.dir[0], &st, &ct);
+        om_sincos(step.dir[1], &sp, &cp);
+        const float rho = st;
+        stepDir[0] = rho * cp; stepDir[1] = rho * sp; stepDir[2] = ct; stepDir[3] = 0.0f;
+    }
+    uint32_t photonsLeftToPropagate = step.numPhotons;
+    float abs_lens_left = 0.0f, abs_lens_initial = 0.0f;
+    float startPos[4] = {0, 0, 0, 0}, startDirw[4] = {0, 0, 0, 0}, pos[4] = {0, 0, 0, 0}, dirw[4] = {0, 0, 0, 0};
+    uint32_t numScatters = 0;
+    float totalPath = 0.0f;
+    int carriedLayer = 0;          /* getTiltZShift_IS_CONSTANT: c.cl:521-523 */
+    float inv_groupvel = 0.0f;
+    const float thickness = T->layer_thickness;
+    const float recip_thickness = 1.0f / thickness;
+    uint64_t iters = 0;
+
+    while (photonsLeftToPropagate > 0) {
+        ++iters;
+        if (abs_lens_left < EPSILON) {
+            createPhotonFromTrack(T, &step, stepDir, rng, pos, dirw);
+            memcpy(startPos, pos, 16); memcpy(startDirw, dirw, 16);
+            numScatters = 0; totalPath = 0.0f;
+            if (!T->has_tilt)
+                carriedLayer = imin(imax(findLayerForGivenZPos(T, pos[2]), 0), T->num_layers - 1);
+            inv_groupvel = 1.0f / getGroupVelocity(T, dirw[3]);
+            abs_lens_initial = -om_log(rand_oc(rng));
+            abs_lens_left = abs_lens_initial;
+        }
+        float distancePropagated;
+        {
+            float effective_z; int currentPhotonLayer;
+            if (!T->has_tilt) {
+                effective_z = pos[2] - T->tilt_const;
+                currentPhotonLayer = carriedLayer;
+            } else {
+                effective_z = pos[2] - getTiltZShift(T, pos);
+                currentPhotonLayer = imin(imax(findLayerForGivenZPos(T, effective_z), 0), T->num_layers - 1);
+            }
+            const float photon_dz = dirw[2];
+            const float abs_len_correction_factor = getDirectionalAbsLenCorrFactor(T, dirw);
+            abs_lens_left *= abs_len_correction_factor;
+            float mediumBoundary = (photon_dz < 0.0f) ? (mediumLayerBoundary(T, currentPhotonLayer))
+                                                      : (mediumLayerBoundary(T, currentPhotonLayer) + thickness);
+            float sca_step_left = -om_log(rand_oc(rng));
+            float currentScaLen = getScatteringLength(T, currentPhotonLayer, dirw[3]);
+            float currentAbsLen = getAbsorptionLength(T, currentPhotonLayer, dirw[3]);
+            float ais = (photon_dz * sca_step_left - ((mediumBoundary - effective_z) / currentScaLen)) * recip_thickness;
+            float aia = (photon_dz * abs_lens_left - ((mediumBoundary - effective_z) / currentAbsLen)) * recip_thickness;
+            int j = currentPhotonLayer;
+            if (photon_dz < 0) {
+                for (; (j > 0) && (ais < 0.0f) && (aia < 0.0f);
+                     mediumBoundary -= thickness,
+                     currentScaLen = getScatteringLength(T, j, dirw[3]),
+                     currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
+                     ais += 1.0f / currentScaLen,
+                     aia += 1.0f / currentAbsLen) --j;
+            } else {
+                for (; (j < T->num_layers - 1) && (ais > 0.0f) && (aia > 0.0f);
+                     mediumBoundary += thickness,
+                     currentScaLen = getScatteringLength(T, j, dirw[3]),
+                     currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
+                     ais -= 1.0f / currentScaLen,
+                     aia -= 1.0f / currentAbsLen) ++j;
+            }
+            float distanceToAbsorption;
+            if ((currentPhotonLayer == j) || ((om_fabs(photon_dz)) < EPSILON)) {
+                distancePropagated = sca_step_left * currentScaLen;
+                distanceToAbsorption = abs_lens_left * currentAbsLen;
+            } else {
+                const float recip_photon_dz = 1.0f / photon_dz;
+                distancePropagated = (ais * thickness * currentScaLen + mediumBoundary - effective_z) * recip_photon_dz;
+                distanceToAbsorption = (aia * thickness * currentAbsLen + mediumBoundary - effective_z) * recip_photon_dz;
+            }
+            if (!T->has_tilt) carriedLayer = j;
+            if (distanceToAbsorption < distancePropagated) {
+                distancePropagated = distanceToAbsorption;
+                abs_lens_left = 0.0f;
+            } else {
+                abs_lens_left = (distanceToAbsorption - distancePropagated) / currentAbsLen;
+            }
+            abs_lens_left = abs_lens_left / abs_len_correction_factor;
+        }
+        const int collided = checkForCollision(T, pos, dirw, inv_groupvel, totalPath, numScatters,
+                                               abs_lens_initial - abs_lens_left, startPos, startDirw, &step,
+                                               &distancePropagated, sink);
+        if (collided) abs_lens_left = 0.0f;
+        pos[0] += dirw[0] * distancePropagated;
+        pos[1] += dirw[1] * distancePropagated;
+        pos[2] += dirw[2] * distancePropagated;
+        pos[3] += inv_groupvel * distancePropagated;
+        totalPath += distancePropagated;
+        if (abs_lens_left < EPSILON) {
+            --photonsLeftToPropagate;
+        } else {
+            transformDirection(T->has_pre, T->pre_renorm, T->pre, dirw);
+            const float cosScatAngle = makeScatteringCosAngle(T, rng);
+            const float sinScatAngle = om_sqrt(1.0f - sqr(cosScatAngle));
+            scatterDirectionByAngle(cosScatAngle, sinScatAngle, dirw, rand_co(rng));
+            transformDirection(T->has_post, T->post_renorm, T->post, dirw);
+            ++numScatters;
+        }
+    }
+    if (iterations) *iterations += iters;
+}
+
+/* ---------------- exported entry points (ctypes) ---------------- */
+
+/* Propagates steps[0..n) with streams (x[i], a[i]); appends hits to `out`
+ * (capacity max_hits) in step order.  Returns the hit counter (which may exceed
+ * max_hits, like the reference's atomic counter).  x[] is updated in place
+ * (c.cl:911-912). */
+uint32_t oracle_propagate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
+                          const uint32_t *a, oracle_photon *out, uint32_t max_hits, uint64_t *iterations)
+{
+    hit_sink sink = { out, max_hits, 0 };
+    uint64_t it = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        rng_t r = { x[i], a[i] };
+        propagate_step(T, &steps[i], &r, &sink, &it);
+        x[i] = r.x;
+    }
+    if (iterations) *iterations = it;
+    return sink.count;
+}
+
+/* Multi-threaded variant used as the CPU baseline (bench.py cpu_baseline): one
+ * step per task; hits are concatenated per thread, so their order differs from
+ * oracle_propagate (the reference's order is not deterministic either, H3). */
+uint32_t oracle_propagate_mt(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
+                             const uint32_t *a, oracle_photon *out, uint32_t max_hits, int threads,
+                             uint64_t *iterations)
+{
+#ifdef _OPENMP
+    uint32_t total = 0;
+    uint64_t it_total = 0;
+#pragma omp parallel num_threads(threads)
+    {
+        uint32_t cap = 1024, cnt = 0;
+        oracle_photon *buf = (oracle_photon *)malloc((size_t)cap * sizeof(oracle_photon));
+        uint64_t it = 0;
+#pragma omp for schedule(dynamic, 16)
+        for (uint32_t i = 0; i < n; ++i) {
+            rng_t r = { x[i], a[i] };
+            /* a step of P photons can record at most P hits */
+            const uint32_t need = cnt + steps[i].numPhotons;
+            if (need > cap) {
+                cap = need * 2 + 4096;
+                buf = (oracle_photon *)realloc(buf, (size_t)cap * sizeof(oracle_photon));
+            }
+            hit_sink sink = { buf + cnt, cap - cnt, 0 };
+            propagate_step(T, &steps[i], &r, &sink, &it);
+            cnt += sink.count;
+            x[i] = r.x;
+        }
+#pragma omp critical
+        {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                if (total < max_hits) out[total] = buf[k];
+                ++total;
+            }
+            it_total += it;
+        }
+        free(buf);
+    }
+    if (iterations) *iterations = it_total;
+    return total;
+#else
+    (void)threads;
+    return oracle_propagate(T, steps, n, x, a, out, max_hits, iterations);
+#endif
+}
+
+/* ---- sub-function probes for the unit tests ---- */
+void oracle_eval_medium(const oracle_tables *T, int what, const float *in, int n, int layer, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        switch (what) {
+        case 0: out[i] = getAbsorptionLength(T, layer, in[i]); break;
+        case 1: out[i] = getScatteringLength(T, layer, in[i]); break;
+        case 2: out[i] = getPhaseRefIndex(T, in[i]); break;
+        case 3: out[i] = getGroupVelocity(T, in[i]); break;
+        case 4: out[i] = getWavelengthBias(T, in[i]); break;
+        default: out[i] = 0.0f;
+        }
+    }
+}
+void oracle_eval_field(const oracle_tables *T, int what, const float *xyz, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        float v[4] = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f };
+        switch (what) {
+        case 0: out[i] = getTiltZShift(T, v); break;
+        case 1: out[i] = getDirectionalAbsLenCorrFactor(T, v); break;
+        case 2: transformDirection(T->has_pre, T->pre_renorm, T->pre, v);
+                out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2]; break;
+        case 3: transformDirection(T->has_post, T->post_renorm, T->post, v);
+                out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2]; break;
+        default: out[i] = 0.0f;
+        }
+    }
+}
+void oracle_eval_rng(uint64_t *x, uint32_t a, int n, float *out_co)
+{
+    rng_t r = { *x, a };
+    for (int i = 0; i < n; ++i) out_co[i] = rand_co(&r);
+    *x = r.x;
+}
+void oracle_eval_wlen(const oracle_tables *T, int kgen, uint64_t *x, uint32_t a, int n, float *out)
+{
+    rng_t r = { *x, a };
+    for (int i = 0; i < n; ++i) out[i] = generateWavelength_k(T, kgen, &r);
+    *x = r.x;
+}
+void oracle_eval_scatcos(const oracle_tables *T, uint64_t *x, uint32_t a, int n, float *out)
+{
+    rng_t r = { *x, a };
+    for (int i = 0; i < n; ++i) out[i] = makeScatteringCosAngle(T, &r);
+    *x = r.x;
+}
+/* math probes: what = 0 log,1 exp,2 sin,3 cos,4 powr(x,y),5 acos,6 atan2(x,y),7 rsqrt,8 sqrt,9 div(x,y) */
+void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float x = xs[i], y = ys ? ys[i] : 0.0f;
+        switch (what) {
+        case 0: out[i] = om_log(x); break;
+        case 1: out[i] = om_exp(x); break;
+        case 2: out[i] = om_sin(x); break;
+        case 3: out[i] = om_cos(x); break;
+        case 4: out[i] = om_powr(x, y); break;
+        case 5: out[i] = om_acos(x); break;
+        case 6: out[i] = om_atan2(x, y); break;
+        case 7: out[i] = om_rsqrt(x); break;
+        case 8: out[i] = om_sqrt(x); break;
+        case 9: out[i] = x / y; break;
+        default: out[i] = 0.0f;
+        }
+    }
+}
+size_t oracle_sizeof_tables(void) { return sizeof(oracle_tables); }
