@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: propagated photons per second (BASELINE.json).
+
+One "step" = one pass of the hot path (the HIP propagation kernel behind the C
+ABI) over one bunch of synthetic I3CLSimSteps that is already resident in HBM.
+N=1 workload = BASELINE.json configs[1]: 1M cascade-like steps x 200 photons,
+SPICE-Mie layered ice with tilt, synthetic 86-string detector, DOM oversize 5.
+N>1: one process per GPU (torch.distributed / RCCL), every rank propagates its
+own bunch of the same size (weak scaling: steps are independent units, no
+data-path collective) and the detected photons are gathered on rank 0 with
+point-to-point RCCL transfers inside the timed region (config C4).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the propagation kernel's
+algorithmic HBM bytes against the 8 TB/s peak (the kernel is VALU-bound, so the
+fraction is tiny by construction -- see DESIGN.md); `cpu_baseline` times the CPU
+restatement of the reference kernel (oracle/, all host cores) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
+    ap.add_argument("--photons-per-step", type=int, default=200)
+    ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, steps_np, seconds):
+    """Times oracle/ (CPU restatement of the reference kernel, the stand-in for
+    the reference's UseCPUs=True path) on a bounded sample of the same steps."""
+    from oracle import builders as B
+    from oracle import capi
+    from clsim_amd import synthetic as S
+    capi.build()
+    cores = os.cpu_count() or 1
+    g = S.ic86_geometry()
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
+    bias = B.icecube_dom_acceptance()
+    T = capi.make_tables(med, geo, [B.cherenkov_wlen_generator(bias, med)], bias, pancake=5.0)
+    probe = 64 * cores
+    a = B.mwc_multipliers(min(len(steps_np), 65536))
+    x = B.seed_streams(a)
+    t0 = time.time()
+    capi.propagate(T, steps_np[:probe], x, a, threads=cores)
+    rate = steps_np["num"][:probe].sum() / max(time.time() - t0, 1e-6)
+    n = int(min(len(a), max(probe, seconds * rate / args.photons_per_step)))
+    n = (n // cores) * cores
+    t0 = time.time()
+    _, hits, _, _ = capi.propagate(T, steps_np[:n], x, a, threads=cores)
+    dt = time.time() - t0
+    photons = int(steps_np["num"][:n].sum())
+    return {"value": photons / dt, "unit": "photons/s", "cores": cores, "kind": "port",
+            "sample": "%d steps x %d photons of the same bunch (%d photons, %d hits) in %.1f s, %d threads" %
+                      (n, args.photons_per_step, photons, hits, dt, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from clsim_amd import converter as CV
+    from clsim_amd import synthetic as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the propagator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = (args.bunch // 256) * 256
+    # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
+    bias = CV.GetIceCubeDOMAcceptance()
+    gen = CV.makeCherenkovWavelengthGenerator(bias, medium)
+    geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
+    conv = CV.initializeHIP(local_rank, geom, medium, bias, [gen], pancakeFactor=5.0,
+                            approximateNumberOfWorkItems=n, seed=12345 + rank)
+    steps_np = S.cascade_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step)
+    photons_per_pass = int(steps_np["num"].sum())
+
+    d_steps = torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)
+    capacity = 4 * 1024 * 1024
+    d_photons = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    gathered = torch.empty((capacity if rank == 0 else 1, 80), dtype=torch.uint8, device=dev) if world > 1 else None
+    counts = torch.zeros(world, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    total_hits = 0
+
+    def one_pass():
+        nonlocal total_hits
+        conv.PropagateDevice(d_steps.data_ptr(), n, d_photons.data_ptr(), capacity, d_count.data_ptr(), stream=stream)
+        if world > 1:
+            # gather of detected photons on rank 0: counts, then one point-to-point
+            # transfer per peer (7 peers -> 7 distinct xGMI links, no ring)
+            dist.all_gather_into_tensor(counts, d_count)
+            c = counts.cpu().numpy().astype(np.int64)
+            if rank == 0:
+                off = int(c[0])
+                reqs = []
+                for peer in range(1, world):
+                    if c[peer]:
+                        reqs.append(dist.irecv(gathered[off:off + int(c[peer])], src=peer))
+                    off += int(c[peer])
+                for r in reqs:
+                    r.wait()
+                total_hits += int(c.sum())
+            elif c[rank]:
+                dist.send(d_photons[:int(c[rank])], dst=0)
+        else:
+            total_hits += 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    conv.KernelTimeMs(reset=True)
+    total_hits = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = conv.KernelTimeMs(reset=True)
+    hits_last = int(d_count.cpu().item())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = photons_per_pass * args.steps * world / elapsed
+        avg_ms = kernel_ms / max(launches, 1)
+        # algorithmic HBM bytes per launch: step record + RNG state read and
+        # write per step (48 + 12 + 12 B) plus one 80-byte record per detected photon
+        alg_bytes = n * 72.0 + hits_last * 80.0
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d I3CLSimSteps x %d photons per GPU and pass, %s ice (171 layers%s), synthetic 86-string "
+                                   "detector (5160 DOMs), DOM oversize 5; BASELINE.json configs[%d]" %
+                                   (n, args.photons_per_step, args.ice, " + tilt" if True else "",
+                                    1 if world == 1 else 3),
+                       "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
+                       "hit_gather": "rccl p2p to rank 0" if world > 1 else "none",
+                       "hits_last_pass_rank0": hits_last},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "prop_kernel", "avg_kernel_ms": avg_ms, "launches": int(launches),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
+                                 (photons_per_pass / (avg_ms * 1e-3))},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

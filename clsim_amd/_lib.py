@@ -1,0 +1,129 @@
+"""ctypes binding of libclsimhip.so (include/clsimhip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing this module raises at import time of the symbols, and every
+compute call fails loudly when no GPU is present (status CLSIMHIP_ERR_DEVICE).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libclsimhip.so")
+
+OK, ERR_ARGUMENT, ERR_STATE, ERR_CONFIG, ERR_DEVICE, ERR_IO = 0, -1, -2, -3, -4, -5
+
+DP = C.POINTER(C.c_double)
+
+
+class Function(C.Structure):        # clsimhip_function
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("start", C.c_double), ("step", C.c_double),
+                ("values", DP), ("value", C.c_double)]
+
+
+class RandomValue(C.Structure):     # clsimhip_random_value
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("first", C.c_double), ("spacing", C.c_double),
+                ("y", DP), ("value", C.c_double)]
+
+
+class MediumDesc(C.Structure):      # clsimhip_medium_desc
+    _fields_ = [("num_layers", C.c_int32), ("layers_z_start", C.c_double), ("layers_height", C.c_double),
+                ("min_wavelength", C.c_double), ("max_wavelength", C.c_double),
+                ("lengths_kind", C.c_int32), ("abs_length", DP), ("sca_length", DP),
+                ("alpha", C.c_double), ("kappa", C.c_double), ("A", C.c_double), ("B", C.c_double),
+                ("D", C.c_double), ("E", C.c_double),
+                ("a_dust400", DP), ("delta_tau", DP), ("b400", DP),
+                ("n", C.c_double * 5), ("g", C.c_double * 5),
+                ("scatter_kind", C.c_int32), ("liu_fraction", C.c_double), ("mean_cosine", C.c_double),
+                ("has_anisotropy", C.c_int32), ("aniso_azimuth", C.c_double), ("aniso_k1", C.c_double),
+                ("aniso_k2", C.c_double),
+                ("has_pre_transform", C.c_int32), ("pre_renormalize", C.c_int32), ("pre_matrix", C.c_double * 9),
+                ("has_post_transform", C.c_int32), ("post_renormalize", C.c_int32), ("post_matrix", C.c_double * 9),
+                ("has_tilt", C.c_int32), ("tilt_num_distances", C.c_int32), ("tilt_num_z", C.c_int32),
+                ("tilt_distances", DP), ("tilt_z_coordinates", DP), ("tilt_z_corrections", DP),
+                ("tilt_azimuth", C.c_double)]
+
+
+# every symbol include/clsimhip.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "clsimhip_medium_create", "clsimhip_medium_create_from_ppc", "clsimhip_medium_describe", "clsimhip_medium_destroy",
+    "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
+    "clsimhip_mwc_multipliers", "clsimhip_seed_streams",
+    "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error",
+    "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
+    "clsimhip_set_enable_double_buffering", "clsimhip_set_double_precision", "clsimhip_set_stop_detected_photons",
+    "clsimhip_set_save_all_photons", "clsimhip_set_save_all_photons_prescale",
+    "clsimhip_set_fixed_number_of_absorption_lengths", "clsimhip_set_dom_pancake_factor",
+    "clsimhip_set_photon_history_entries", "clsimhip_set_workgroup_size", "clsimhip_set_max_num_workitems",
+    "clsimhip_compile", "clsimhip_get_max_workgroup_size", "clsimhip_initialize", "clsimhip_initialize_with_streams",
+    "clsimhip_is_initialized", "clsimhip_enqueue_steps", "clsimhip_get_conversion_result", "clsimhip_release_result",
+    "clsimhip_get_workgroup_size", "clsimhip_get_max_num_workitems", "clsimhip_queue_size",
+    "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
+    "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
+    "clsimhip_eval_math", "clsimhip_version",
+]
+
+_lib = None
+
+
+def load():
+    """Loads libclsimhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C clsim_amd/csrc); the HIP propagator has no fallback path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32, dbl = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    sig = {
+        "clsimhip_medium_create": (i32, [C.POINTER(MediumDesc), C.POINTER(vp)]),
+        "clsimhip_medium_create_from_ppc": (i32, [C.c_char_p, dbl, i32, C.POINTER(vp)]),
+        "clsimhip_medium_describe": (i32, [vp, C.POINTER(MediumDesc)]),
+        "clsimhip_medium_destroy": (None, [vp]),
+        "clsimhip_icecube_dom_acceptance": (i32, [dbl, dbl, DP, DP, DP]),
+        "clsimhip_make_cherenkov_wlen_generator": (i32, [C.POINTER(Function), vp, DP, DP, DP]),
+        "clsimhip_mwc_multipliers": (i32, [vp, sz]),
+        "clsimhip_seed_streams": (i32, [vp, sz, u64, vp]),
+        "clsimhip_create": (i32, [i32, C.POINTER(vp)]),
+        "clsimhip_destroy": (None, [vp]),
+        "clsimhip_last_error": (C.c_char_p, [vp]),
+        "clsimhip_set_wlen_generators": (i32, [vp, C.POINTER(RandomValue), sz]),
+        "clsimhip_set_wlen_bias": (i32, [vp, C.POINTER(Function)]),
+        "clsimhip_set_medium_properties": (i32, [vp, vp]),
+        "clsimhip_set_geometry": (i32, [vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_char_p), dbl]),
+        "clsimhip_set_enable_double_buffering": (i32, [vp, i32]),
+        "clsimhip_set_double_precision": (i32, [vp, i32]),
+        "clsimhip_set_stop_detected_photons": (i32, [vp, i32]),
+        "clsimhip_set_save_all_photons": (i32, [vp, i32]),
+        "clsimhip_set_save_all_photons_prescale": (i32, [vp, dbl]),
+        "clsimhip_set_fixed_number_of_absorption_lengths": (i32, [vp, dbl]),
+        "clsimhip_set_dom_pancake_factor": (i32, [vp, dbl]),
+        "clsimhip_set_photon_history_entries": (i32, [vp, u32]),
+        "clsimhip_set_workgroup_size": (i32, [vp, sz]),
+        "clsimhip_set_max_num_workitems": (i32, [vp, sz]),
+        "clsimhip_compile": (i32, [vp]),
+        "clsimhip_get_max_workgroup_size": (i32, [vp, C.POINTER(sz)]),
+        "clsimhip_initialize": (i32, [vp, u64]),
+        "clsimhip_initialize_with_streams": (i32, [vp, vp, vp, sz]),
+        "clsimhip_is_initialized": (i32, [vp]),
+        "clsimhip_enqueue_steps": (i32, [vp, vp, sz, u32]),
+        "clsimhip_get_conversion_result": (i32, [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(sz)]),
+        "clsimhip_release_result": (i32, [vp, vp]),
+        "clsimhip_get_workgroup_size": (i32, [vp, C.POINTER(sz)]),
+        "clsimhip_get_max_num_workitems": (i32, [vp, C.POINTER(sz)]),
+        "clsimhip_queue_size": (i32, [vp, C.POINTER(sz)]),
+        "clsimhip_more_photons_available": (i32, [vp, C.POINTER(i32)]),
+        "clsimhip_get_statistics": (i32, [vp, DP]),
+        "clsimhip_propagate_device": (i32, [vp, vp, sz, sz, vp, sz, vp, vp]),
+        "clsimhip_replace_indices_with_ids": (i32, [vp, vp, sz]),
+        "clsimhip_kernel_time_ms": (i32, [vp, i32, DP, C.POINTER(u64)]),
+        "clsimhip_get_table": (C.c_long, [vp, C.c_char_p, DP, sz]),
+        "clsimhip_get_rng_state": (i32, [vp, vp, sz]),
+        "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
+        "clsimhip_version": (C.c_char_p, []),
+    }
+    for name in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib

@@ -1,0 +1,366 @@
+"""Host-side mirror of the reference's converter interface over the C ABI.
+
+Names, argument meaning and error behaviour follow
+  public/clsim/I3CLSimStepToPhotonConverter.h:67-192 and
+  public/clsim/I3CLSimStepToPhotonConverterOpenCL.h:78-258;
+the helpers follow python/MakeIceCubeMediumProperties.py,
+python/GetIceCubeDOMAcceptance.py and I3CLSimModuleHelper.cxx:175-372.
+Everything numerical happens inside libclsimhip.so (C++/HIP); this module only
+marshals numpy arrays.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .synthetic import PHOTON_DTYPE, STEP_DTYPE
+
+NANOMETER = 1e-9
+
+
+class I3CLSimStepToPhotonConverter_exception(RuntimeError):
+    """public/clsim/I3CLSimStepToPhotonConverter.h:57-65"""
+
+    def __init__(self, msg, code=0):
+        RuntimeError.__init__(self, msg)
+        self.code = code
+
+
+def _check(rc, handle=None):
+    if rc != _lib.OK:
+        msg = _lib.load().clsimhip_last_error(handle)
+        raise I3CLSimStepToPhotonConverter_exception((msg or b"").decode() or ("status %d" % rc), rc)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.DP)
+
+
+class I3CLSimFunctionFromTable:
+    """private/clsim/function/I3CLSimFunctionFromTable.cxx:70-90 (equal spacing)."""
+
+    def __init__(self, startWlen, wlenStep, values):
+        self.startWlen, self.wlenStep = float(startWlen), float(wlenStep)
+        self.values = np.ascontiguousarray(values, dtype=np.float64)
+
+    def _desc(self):
+        return _lib.Function(0, len(self.values), self.startWlen, self.wlenStep, _dp(self.values), 0.0)
+
+
+class I3CLSimFunctionConstant:
+    def __init__(self, value):
+        self.value = float(value)
+
+    def _desc(self):
+        return _lib.Function(1, 0, 0.0, 0.0, None, self.value)
+
+
+class I3CLSimRandomValueInterpolatedDistribution:
+    """...InterpolatedDistribution.cxx:57-74: (xFirst, xSpacing, y)."""
+
+    def __init__(self, xFirst, xSpacing, y):
+        self.first, self.spacing = float(xFirst), float(xSpacing)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+
+    def _desc(self):
+        return _lib.RandomValue(0, len(self.y), self.first, self.spacing, _dp(self.y), 0.0)
+
+
+class I3CLSimRandomValueConstant:
+    def __init__(self, value):
+        self.value = float(value)
+
+    def _desc(self):
+        return _lib.RandomValue(1, 0, 0.0, 0.0, None, self.value)
+
+
+class I3CLSimMediumProperties:
+    """Opaque medium object living in the library (clsimhip_medium)."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().clsimhip_medium_destroy(self._h)
+        except Exception:
+            pass
+
+    def describe(self):
+        d = _lib.MediumDesc()
+        _check(_lib.load().clsimhip_medium_describe(self._h, C.byref(d)))
+        nl = d.num_layers
+
+        def arr(p, n):
+            return np.ctypeslib.as_array(p, shape=(n,)).copy() if (p and n) else np.zeros(0)
+        out = {k: getattr(d, k) for k in ("num_layers", "layers_z_start", "layers_height", "min_wavelength",
+                                          "max_wavelength", "lengths_kind", "alpha", "kappa", "A", "B", "D", "E",
+                                          "scatter_kind", "liu_fraction", "mean_cosine", "has_anisotropy",
+                                          "aniso_azimuth", "aniso_k1", "aniso_k2", "has_pre_transform",
+                                          "pre_renormalize", "has_post_transform", "post_renormalize", "has_tilt",
+                                          "tilt_azimuth")}
+        out["n"] = list(d.n); out["g"] = list(d.g)
+        out["pre_matrix"] = np.array(list(d.pre_matrix)).reshape(3, 3)
+        out["post_matrix"] = np.array(list(d.post_matrix)).reshape(3, 3)
+        if d.lengths_kind == 0:
+            out["abs_length"] = arr(d.abs_length, nl); out["sca_length"] = arr(d.sca_length, nl)
+        else:
+            out["a_dust400"] = arr(d.a_dust400, nl); out["delta_tau"] = arr(d.delta_tau, nl); out["b400"] = arr(d.b400, nl)
+        if d.has_tilt:
+            nd, nz = d.tilt_num_distances, d.tilt_num_z
+            out["tilt_distances"] = arr(d.tilt_distances, nd)
+            out["tilt_z_coordinates"] = arr(d.tilt_z_coordinates, nz)
+            out["tilt_z_corrections"] = arr(d.tilt_z_corrections, nd * nz).reshape(nd, nz)
+        return out
+
+
+def MakeIceCubeMediumProperties(detectorCenterDepth=1948.07, iceDataDirectory=None, useTiltIfAvailable=True):
+    """python/MakeIceCubeMediumProperties.py:49-256 (PPC ice tables -> medium)."""
+    h = C.c_void_p()
+    _check(_lib.load().clsimhip_medium_create_from_ppc(str(iceDataDirectory).encode(), float(detectorCenterDepth),
+                                                        1 if useTiltIfAvailable else 0, C.byref(h)))
+    return I3CLSimMediumProperties(h)
+
+
+def MakeHomogeneousMediumProperties(absLen=100.0, scaLen=25.0, zStart=-1000.0, height=2000.0, meanCosine=0.9,
+                                    liuFraction=0.45):
+    """BASELINE config C1: one layer with I3CLSimFunctionConstant absorption /
+    scattering lengths, IceCube refractive index (SURVEY.md 9.7 option i)."""
+    d = _lib.MediumDesc()
+    d.num_layers = 1
+    d.layers_z_start, d.layers_height = zStart, height
+    d.min_wavelength, d.max_wavelength = 265.0 * NANOMETER, 675.0 * NANOMETER
+    d.lengths_kind = 0
+    a = np.array([absLen], dtype=np.float64); s = np.array([scaLen], dtype=np.float64)
+    d.abs_length, d.sca_length = _dp(a), _dp(s)
+    for i, v in enumerate((1.55749, -1.57988, 3.99993, -4.68271, 2.09354)):
+        d.n[i] = v
+    for i, v in enumerate((1.227106, -0.954648, 1.42568, -0.711832, 0.0)):
+        d.g[i] = v
+    d.scatter_kind = 2
+    d.liu_fraction, d.mean_cosine = liuFraction, meanCosine
+    h = C.c_void_p()
+    _check(_lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)))
+    return I3CLSimMediumProperties(h)
+
+
+def GetIceCubeDOMAcceptance(domRadius=0.16510, efficiency=1.0):
+    """python/GetIceCubeDOMAcceptance.py:35-115."""
+    vals = np.zeros(43, dtype=np.float64)
+    start, step = C.c_double(), C.c_double()
+    _check(_lib.load().clsimhip_icecube_dom_acceptance(domRadius, efficiency, _dp(vals), C.byref(start), C.byref(step)))
+    return I3CLSimFunctionFromTable(start.value, step.value, vals)
+
+
+def makeCherenkovWavelengthGenerator(wavelengthGenerationBias, mediumProperties):
+    """I3CLSimModuleHelper::makeCherenkovWavelengthGenerator (ModuleHelper.cxx:175-263)."""
+    y = np.zeros(len(wavelengthGenerationBias.values), dtype=np.float64)
+    first, spacing = C.c_double(), C.c_double()
+    desc = wavelengthGenerationBias._desc()
+    _check(_lib.load().clsimhip_make_cherenkov_wlen_generator(C.byref(desc), mediumProperties._h, _dp(y),
+                                                               C.byref(first), C.byref(spacing)))
+    return I3CLSimRandomValueInterpolatedDistribution(first.value, spacing.value, y)
+
+
+def mwc_multipliers(count):
+    a = np.zeros(count, dtype=np.uint32)
+    _check(_lib.load().clsimhip_mwc_multipliers(a.ctypes.data_as(C.c_void_p), count))
+    return a
+
+
+def seed_streams(a, seed=12345):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    x = np.zeros(len(a), dtype=np.uint64)
+    _check(_lib.load().clsimhip_seed_streams(a.ctypes.data_as(C.c_void_p), len(a), seed, x.ctypes.data_as(C.c_void_p)))
+    return x
+
+
+class I3CLSimSimpleGeometry:
+    """public/clsim/I3CLSimSimpleGeometry.h: parallel per-DOM arrays."""
+
+    def __init__(self, string_ids, dom_ids, x, y, z, subdetectors, om_radius):
+        self.string_ids = np.ascontiguousarray(string_ids, dtype=np.int32)
+        self.dom_ids = np.ascontiguousarray(dom_ids, dtype=np.uint32)
+        self.x = np.ascontiguousarray(x, dtype=np.float64)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self.z = np.ascontiguousarray(z, dtype=np.float64)
+        self.subdetectors = [str(s) for s in subdetectors]
+        self.om_radius = float(om_radius)
+
+    @classmethod
+    def from_dict(cls, g):
+        return cls(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+
+
+class I3CLSimStepToPhotonConverterHIP:
+    """MI355X implementation of I3CLSimStepToPhotonConverter."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _check(self._lib.clsimhip_create(int(device), C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.clsimhip_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _check(getattr(self._lib, name)(self._h, *args), self._h)
+
+    # ---- configuration ----
+    def SetWlenGenerators(self, wlenGenerators):
+        descs = (_lib.RandomValue * len(wlenGenerators))(*[g._desc() for g in wlenGenerators])
+        self._call("clsimhip_set_wlen_generators", descs, len(wlenGenerators))
+
+    def SetWlenBias(self, wlenBias):
+        d = wlenBias._desc()
+        self._call("clsimhip_set_wlen_bias", C.byref(d))
+
+    def SetMediumProperties(self, mediumProperties):
+        self._call("clsimhip_set_medium_properties", mediumProperties._h)
+
+    def SetGeometry(self, geometry):
+        g = geometry
+        names = (C.c_char_p * len(g.subdetectors))(*[s.encode() for s in g.subdetectors])
+        self._call("clsimhip_set_geometry", len(g.string_ids), g.string_ids.ctypes.data_as(C.c_void_p),
+                   g.dom_ids.ctypes.data_as(C.c_void_p), g.x.ctypes.data_as(C.c_void_p),
+                   g.y.ctypes.data_as(C.c_void_p), g.z.ctypes.data_as(C.c_void_p), names, g.om_radius)
+
+    def SetEnableDoubleBuffering(self, v): self._call("clsimhip_set_enable_double_buffering", int(bool(v)))
+    def SetDoublePrecision(self, v): self._call("clsimhip_set_double_precision", int(bool(v)))
+    def SetStopDetectedPhotons(self, v): self._call("clsimhip_set_stop_detected_photons", int(bool(v)))
+    def SetSaveAllPhotons(self, v): self._call("clsimhip_set_save_all_photons", int(bool(v)))
+    def SetSaveAllPhotonsPrescale(self, v): self._call("clsimhip_set_save_all_photons_prescale", float(v))
+    def SetFixedNumberOfAbsorptionLengths(self, v): self._call("clsimhip_set_fixed_number_of_absorption_lengths", float(v))
+    def SetDOMPancakeFactor(self, v): self._call("clsimhip_set_dom_pancake_factor", float(v))
+    def SetPhotonHistoryEntries(self, v): self._call("clsimhip_set_photon_history_entries", int(v))
+    def SetWorkgroupSize(self, v): self._call("clsimhip_set_workgroup_size", int(v))
+    def SetMaxNumWorkitems(self, v): self._call("clsimhip_set_max_num_workitems", int(v))
+
+    def Compile(self): self._call("clsimhip_compile")
+
+    def GetMaxWorkgroupSize(self):
+        v = C.c_size_t()
+        self._call("clsimhip_get_max_workgroup_size", C.byref(v))
+        return v.value
+
+    def Initialize(self, seed=12345):
+        self._call("clsimhip_initialize", int(seed))
+
+    def InitializeWithStreams(self, x, a):
+        x = np.ascontiguousarray(x, dtype=np.uint64); a = np.ascontiguousarray(a, dtype=np.uint32)
+        self._call("clsimhip_initialize_with_streams", x.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), len(x))
+
+    def IsInitialized(self):
+        return bool(self._lib.clsimhip_is_initialized(self._h))
+
+    # ---- steady state ----
+    def EnqueueSteps(self, steps, identifier):
+        if steps is None:
+            raise I3CLSimStepToPhotonConverter_exception("Steps pointer is (null)!", _lib.ERR_ARGUMENT)
+        steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+        self._call("clsimhip_enqueue_steps", steps.ctypes.data_as(C.c_void_p), len(steps), int(identifier))
+
+    def GetConversionResult(self):
+        ident, ptr, n = C.c_uint32(), C.c_void_p(), C.c_size_t()
+        self._call("clsimhip_get_conversion_result", C.byref(ident), C.byref(ptr), C.byref(n))
+        if n.value:
+            buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
+            photons = np.frombuffer(buf, dtype=PHOTON_DTYPE).copy()
+            self._call("clsimhip_release_result", ptr)
+        else:
+            photons = np.zeros(0, dtype=PHOTON_DTYPE)
+        return ident.value, photons
+
+    def _size(self, name):
+        v = C.c_size_t()
+        self._call(name, C.byref(v))
+        return v.value
+
+    def GetWorkgroupSize(self): return self._size("clsimhip_get_workgroup_size")
+    def GetMaxNumWorkitems(self): return self._size("clsimhip_get_max_num_workitems")
+    def QueueSize(self): return self._size("clsimhip_queue_size")
+
+    def MorePhotonsAvailable(self):
+        v = C.c_int()
+        self._call("clsimhip_more_photons_available", C.byref(v))
+        return bool(v.value)
+
+    def GetStatistics(self):
+        out = (C.c_double * 8)()
+        self._call("clsimhip_get_statistics", out)
+        keys = ["TotalDeviceTime", "TotalHostTime", "NumKernelCalls", "TotalNumPhotonsGenerated",
+                "TotalNumPhotonsAtDOMs", "AverageDeviceTimePerPhoton", "AverageHostTimePerPhoton", "DeviceUtilization"]
+        return dict(zip(keys, list(out)))
+
+    # ---- device-resident path / introspection ----
+    def PropagateDevice(self, d_steps, n, d_photons, capacity, d_hit_count, stream=0, rng_offset=0):
+        self._call("clsimhip_propagate_device", C.c_void_p(d_steps), int(n), int(rng_offset), C.c_void_p(d_photons),
+                   int(capacity), C.c_void_p(d_hit_count), C.c_void_p(stream))
+
+    def ReplaceIndicesWithIDs(self, photons):
+        photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
+        self._call("clsimhip_replace_indices_with_ids", photons.ctypes.data_as(C.c_void_p), len(photons))
+        return photons
+
+    def KernelTimeMs(self, reset=False):
+        total, launches = C.c_double(), C.c_uint64()
+        self._call("clsimhip_kernel_time_ms", int(bool(reset)), C.byref(total), C.byref(launches))
+        return total.value, launches.value
+
+    def GetTable(self, name):
+        n = self._lib.clsimhip_get_table(self._h, name.encode(), None, 0)
+        if n < 0:
+            _check(int(n), self._h)
+        out = np.zeros(n, dtype=np.float64)
+        self._lib.clsimhip_get_table(self._h, name.encode(), _dp(out), n)
+        return out
+
+    def GetRNGState(self, count):
+        x = np.zeros(count, dtype=np.uint64)
+        self._call("clsimhip_get_rng_state", x.ctypes.data_as(C.c_void_p), count)
+        return x
+
+
+def initializeHIP(device, geometry, medium, wavelengthGenerationBias, wavelengthGenerators,
+                  enableDoubleBuffering=False, doublePrecision=False, stopDetectedPhotons=True, saveAllPhotons=False,
+                  saveAllPhotonsPrescale=0.01, fixedNumberOfAbsorptionLengths=float("nan"), pancakeFactor=1.0,
+                  photonHistoryEntries=0, limitWorkgroupSize=0, approximateNumberOfWorkItems=262144,
+                  seed=12345, streams=None):
+    """Canonical configuration sequence, I3CLSimModuleHelper::initializeOpenCL
+    (ModuleHelper.cxx:303-372)."""
+    conv = I3CLSimStepToPhotonConverterHIP(device)
+    conv.SetWlenGenerators(wavelengthGenerators)
+    conv.SetWlenBias(wavelengthGenerationBias)
+    conv.SetMediumProperties(medium)
+    conv.SetGeometry(geometry)
+    conv.SetEnableDoubleBuffering(enableDoubleBuffering)
+    conv.SetDoublePrecision(doublePrecision)
+    conv.SetStopDetectedPhotons(stopDetectedPhotons)
+    conv.SetSaveAllPhotons(saveAllPhotons)
+    conv.SetSaveAllPhotonsPrescale(saveAllPhotonsPrescale)
+    conv.SetFixedNumberOfAbsorptionLengths(fixedNumberOfAbsorptionLengths)
+    conv.SetDOMPancakeFactor(pancakeFactor)
+    conv.SetPhotonHistoryEntries(photonHistoryEntries)
+    conv.Compile()
+    max_wg = conv.GetMaxWorkgroupSize()
+    if limitWorkgroupSize:
+        max_wg = min(limitWorkgroupSize, max_wg)
+    conv.SetWorkgroupSize(max_wg)
+    wg = max_wg
+    max_items = (int(approximateNumberOfWorkItems) // wg) * wg
+    if max_items == 0:
+        max_items = wg
+    conv.SetMaxNumWorkitems(max_items)
+    if streams is not None:
+        conv.InitializeWithStreams(streams[0][:max_items], streams[1][:max_items])
+    else:
+        conv.Initialize(seed)
+    return conv

@@ -1,0 +1,284 @@
+// extern "C" surface of libclsimhip.so (include/clsimhip.h).  Every entry point
+// catches clsimhip::Error, stores the text for clsimhip_last_error() and returns
+// the status code; nothing C++ crosses the boundary.
+#include <cstring>
+
+#include "converter.h"
+
+using namespace clsimhip;
+
+struct clsimhip_converter { Converter impl; explicit clsimhip_converter(int dev) : impl(dev) {} };
+struct clsimhip_medium { MediumData data; };
+
+namespace {
+thread_local std::string g_create_error;
+
+template <class F>
+int guarded(clsimhip_converter *c, F &&f)
+{
+    try {
+        f();
+        return CLSIMHIP_OK;
+    } catch (const Error &e) {
+        if (c) c->impl.last_error = e.what(); else g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        if (c) c->impl.last_error = e.what(); else g_create_error = e.what();
+        return CLSIMHIP_ERR_ARGUMENT;
+    }
+}
+template <class F>
+int guarded_const(const clsimhip_converter *c, F &&f) { return guarded(const_cast<clsimhip_converter *>(c), f); }
+
+void need(const void *p, const char *what) { if (!p) throw Error(CLSIMHIP_ERR_ARGUMENT, std::string(what) + " is (null)"); }
+
+FunctionData function_from(const clsimhip_function *f)
+{
+    need(f, "function");
+    FunctionData d;
+    d.kind = f->kind;
+    if (f->kind == CLSIMHIP_FUNCTION_TABLE) {
+        if (f->n < 2 || !f->values) throw Error(CLSIMHIP_ERR_ARGUMENT, "values must contain at least 2 elements!");
+        d.start = f->start; d.step = f->step;
+        d.values.assign(f->values, f->values + f->n);
+    } else if (f->kind == CLSIMHIP_FUNCTION_CONSTANT) {
+        d.value = f->value;
+    } else
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown function kind");
+    return d;
+}
+} // namespace
+
+extern "C" {
+
+const char *clsimhip_version(void) { return "clsimhip 0.1 (gfx950)"; }
+
+const char *clsimhip_last_error(const clsimhip_converter *c) { return c ? c->impl.last_error.c_str() : g_create_error.c_str(); }
+
+int clsimhip_medium_create(const clsimhip_medium_desc *desc, clsimhip_medium **out)
+{
+    return guarded(nullptr, [&] {
+        need(desc, "desc"); need(out, "out");
+        *out = new clsimhip_medium{medium_from_desc(*desc)};
+    });
+}
+int clsimhip_medium_create_from_ppc(const char *directory, double depth, int use_tilt, clsimhip_medium **out)
+{
+    return guarded(nullptr, [&] {
+        need(directory, "directory"); need(out, "out");
+        *out = new clsimhip_medium{medium_from_ppc(directory, depth, use_tilt != 0)};
+    });
+}
+int clsimhip_medium_describe(const clsimhip_medium *m, clsimhip_medium_desc *d)
+{
+    return guarded(nullptr, [&] {
+        need(m, "medium"); need(d, "out");
+        const MediumData &s = m->data;
+        std::memset(d, 0, sizeof *d);
+        d->num_layers = s.num_layers; d->layers_z_start = s.layers_z_start; d->layers_height = s.layers_height;
+        d->min_wavelength = s.min_wlen; d->max_wavelength = s.max_wlen; d->lengths_kind = s.lengths_kind;
+        d->abs_length = s.abs_length.data(); d->sca_length = s.sca_length.data();
+        d->alpha = s.alpha; d->kappa = s.kappa; d->A = s.A; d->B = s.B; d->D = s.D; d->E = s.E;
+        d->a_dust400 = s.a_dust400.data(); d->delta_tau = s.delta_tau.data(); d->b400 = s.b400.data();
+        for (int i = 0; i < 5; ++i) { d->n[i] = s.n[i]; d->g[i] = s.g[i]; }
+        d->scatter_kind = s.scatter_kind; d->liu_fraction = s.liu_fraction; d->mean_cosine = s.mean_cosine;
+        d->has_anisotropy = s.has_aniso; d->aniso_azimuth = s.aniso_azimuth; d->aniso_k1 = s.aniso_k1; d->aniso_k2 = s.aniso_k2;
+        d->has_pre_transform = s.has_pre; d->pre_renormalize = s.pre_renorm;
+        d->has_post_transform = s.has_post; d->post_renormalize = s.post_renorm;
+        for (int i = 0; i < 9; ++i) { d->pre_matrix[i] = s.pre[i]; d->post_matrix[i] = s.post[i]; }
+        d->has_tilt = s.has_tilt;
+        d->tilt_num_distances = static_cast<int32_t>(s.tilt_distances.size());
+        d->tilt_num_z = static_cast<int32_t>(s.tilt_z.size());
+        d->tilt_distances = s.tilt_distances.data(); d->tilt_z_coordinates = s.tilt_z.data();
+        d->tilt_z_corrections = s.tilt_corr.data(); d->tilt_azimuth = s.tilt_azimuth;
+    });
+}
+void clsimhip_medium_destroy(clsimhip_medium *m) { delete m; }
+
+int clsimhip_icecube_dom_acceptance(double dom_radius, double efficiency, double *values_out, double *start_out, double *step_out)
+{
+    return guarded(nullptr, [&] {
+        need(values_out, "values_out");
+        std::vector<double> v; double start, step;
+        dom_acceptance(dom_radius, efficiency, v, start, step);
+        std::memcpy(values_out, v.data(), v.size() * sizeof(double));
+        if (start_out) *start_out = start;
+        if (step_out) *step_out = step;
+    });
+}
+int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const clsimhip_medium *m, double *y_out,
+                                           double *first_out, double *spacing_out)
+{
+    return guarded(nullptr, [&] {
+        need(m, "medium"); need(y_out, "y_out");
+        const RandomValueData g = make_cherenkov_generator(function_from(bias), m->data);
+        std::memcpy(y_out, g.y.data(), g.y.size() * sizeof(double));
+        if (first_out) *first_out = g.first;
+        if (spacing_out) *spacing_out = g.spacing;
+    });
+}
+int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count)
+{
+    return guarded(nullptr, [&] { need(a_out, "a_out"); mwc_multipliers(a_out, count); });
+}
+int clsimhip_seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x_out)
+{
+    return guarded(nullptr, [&] { need(a, "a"); need(x_out, "x_out"); seed_streams(a, count, seed, x_out); });
+}
+
+int clsimhip_create(int device_ordinal, clsimhip_converter **out)
+{
+    return guarded(nullptr, [&] { need(out, "out"); *out = new clsimhip_converter(device_ordinal); });
+}
+void clsimhip_destroy(clsimhip_converter *c) { delete c; }
+
+int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_value *gens, size_t n)
+{
+    return guarded(c, [&] {
+        need(c, "converter"); need(gens, "generators");
+        std::vector<RandomValueData> v(n);
+        for (size_t i = 0; i < n; ++i) {
+            v[i].kind = gens[i].kind;
+            if (gens[i].kind == CLSIMHIP_RANDOM_INTERPOLATED) {
+                if (gens[i].n < 2 || !gens[i].y) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified in the vector passed to I3CLSimRandomValueInterpolatedDistribution().");
+                v[i].first = gens[i].first; v[i].spacing = gens[i].spacing;
+                v[i].y.assign(gens[i].y, gens[i].y + gens[i].n);
+            } else if (gens[i].kind == CLSIMHIP_RANDOM_CONSTANT) {
+                v[i].value = gens[i].value;
+            } else
+                throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown random value kind");
+        }
+        c->impl.set_wlen_generators(std::move(v));
+    });
+}
+int clsimhip_set_wlen_bias(clsimhip_converter *c, const clsimhip_function *bias)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.set_wlen_bias(function_from(bias)); });
+}
+int clsimhip_set_medium_properties(clsimhip_converter *c, const clsimhip_medium *m)
+{
+    return guarded(c, [&] { need(c, "converter"); need(m, "medium"); c->impl.set_medium(m->data); });
+}
+int clsimhip_set_geometry(clsimhip_converter *c, size_t n, const int32_t *string_ids, const uint32_t *dom_ids, const double *x,
+                          const double *y, const double *z, const char *const *subdetectors, double om_radius)
+{
+    return guarded(c, [&] {
+        need(c, "converter"); need(string_ids, "string_ids"); need(dom_ids, "dom_ids"); need(x, "x"); need(y, "y"); need(z, "z");
+        need(subdetectors, "subdetectors");
+        GeometryInput g;
+        g.string_ids.assign(string_ids, string_ids + n); g.dom_ids.assign(dom_ids, dom_ids + n);
+        g.x.assign(x, x + n); g.y.assign(y, y + n); g.z.assign(z, z + n);
+        g.subdetectors.resize(n);
+        for (size_t i = 0; i < n; ++i) { need(subdetectors[i], "subdetector name"); g.subdetectors[i] = subdetectors[i]; }
+        g.om_radius = om_radius;
+        c->impl.set_geometry(std::move(g));
+    });
+}
+#define SETTER(name, type, call) \
+    int name(clsimhip_converter *c, type value) { return guarded(c, [&] { need(c, "converter"); c->impl.call; }); }
+SETTER(clsimhip_set_enable_double_buffering, int, set_double_buffering(value != 0))
+SETTER(clsimhip_set_double_precision, int, set_double_precision(value != 0))
+SETTER(clsimhip_set_stop_detected_photons, int, set_stop_detected(value != 0))
+SETTER(clsimhip_set_save_all_photons, int, set_save_all(value != 0))
+SETTER(clsimhip_set_save_all_photons_prescale, double, set_save_all_prescale(value))
+SETTER(clsimhip_set_fixed_number_of_absorption_lengths, double, set_fixed_abs_lengths(value))
+SETTER(clsimhip_set_dom_pancake_factor, double, set_pancake(value))
+SETTER(clsimhip_set_photon_history_entries, uint32_t, set_history_entries(value))
+SETTER(clsimhip_set_workgroup_size, size_t, set_workgroup_size(value))
+SETTER(clsimhip_set_max_num_workitems, size_t, set_max_num_workitems(value))
+#undef SETTER
+
+int clsimhip_compile(clsimhip_converter *c) { return guarded(c, [&] { need(c, "converter"); c->impl.compile(); }); }
+int clsimhip_get_max_workgroup_size(const clsimhip_converter *c, size_t *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.max_workgroup_size(); });
+}
+int clsimhip_initialize(clsimhip_converter *c, uint64_t seed) { return guarded(c, [&] { need(c, "converter"); c->impl.initialize(seed); }); }
+int clsimhip_initialize_with_streams(clsimhip_converter *c, const uint64_t *x, const uint32_t *a, size_t count)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.initialize_with_streams(x, a, count); });
+}
+int clsimhip_is_initialized(const clsimhip_converter *c) { return (c && c->impl.initialized()) ? 1 : 0; }
+
+int clsimhip_enqueue_steps(clsimhip_converter *c, const clsimhip_step *steps, size_t n, uint32_t identifier)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.enqueue_steps(steps, n, identifier); });
+}
+int clsimhip_get_conversion_result(clsimhip_converter *c, uint32_t *identifier, const clsimhip_photon **photons, size_t *n)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.get_result(identifier, photons, n); });
+}
+int clsimhip_release_result(clsimhip_converter *c, const clsimhip_photon *photons)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.release_result(photons); });
+}
+int clsimhip_get_workgroup_size(const clsimhip_converter *c, size_t *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.workgroup_size(); });
+}
+int clsimhip_get_max_num_workitems(const clsimhip_converter *c, size_t *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.max_num_workitems(); });
+}
+int clsimhip_queue_size(const clsimhip_converter *c, size_t *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.queue_size(); });
+}
+int clsimhip_more_photons_available(const clsimhip_converter *c, int *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.more_photons_available() ? 1 : 0; });
+}
+int clsimhip_get_statistics(const clsimhip_converter *c, double out[8])
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); c->impl.statistics(out); });
+}
+int clsimhip_propagate_device(clsimhip_converter *c, const void *d_steps, size_t n, size_t rng_offset, void *d_photons,
+                              size_t capacity, void *d_hit_count, void *stream)
+{
+    return guarded(c, [&] {
+        need(c, "converter");
+        c->impl.propagate_device(d_steps, n, rng_offset, d_photons, capacity, d_hit_count, static_cast<hipStream_t>(stream));
+    });
+}
+int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_photon *photons, size_t n)
+{
+    return guarded_const(c, [&] { need(c, "converter"); if (n) need(photons, "photons"); c->impl.replace_indices(photons, n); });
+}
+int clsimhip_kernel_time_ms(clsimhip_converter *c, int reset, double *total_ms, uint64_t *launches)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.kernel_time(reset != 0, total_ms, launches); });
+}
+long clsimhip_get_table(const clsimhip_converter *c, const char *name, double *out, size_t cap)
+{
+    long n = 0;
+    const int rc = guarded_const(c, [&] { need(c, "converter"); need(name, "name"); n = c->impl.get_table(name, out, cap); });
+    return rc == CLSIMHIP_OK ? n : rc;
+}
+int clsimhip_get_rng_state(clsimhip_converter *c, uint64_t *x_out, size_t count)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.get_rng_state(x_out, count); });
+}
+int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out)
+{
+    return guarded(nullptr, [&] {
+        need(x, "x"); need(out, "out");
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");
+        chk(hipSetDevice(device_ordinal), "hipSetDevice");
+        float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+        chk(hipMalloc(reinterpret_cast<void **>(&dx), n * 4 + 16), "hipMalloc");
+        chk(hipMalloc(reinterpret_cast<void **>(&dout), n * 4 + 16), "hipMalloc");
+        chk(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice), "hipMemcpy");
+        if (y) {
+            chk(hipMalloc(reinterpret_cast<void **>(&dy), n * 4 + 16), "hipMalloc");
+            chk(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        chk(launch_eval_math(what, dx, dy, static_cast<uint32_t>(n), dout, nullptr), "eval_math launch");
+        chk(hipDeviceSynchronize(), "eval_math");
+        chk(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,396 @@
+// Host runtime: see converter.h.  One worker thread owns the HIP stream
+// (upload -> kernel -> download, OpenCL.cxx:1142-1315); callers talk to it through
+// two bounded queues, like the reference's queueToOpenCL_/queueFromOpenCL_.
+#include "converter.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+
+namespace clsimhip {
+
+static_assert(sizeof(clsimhip_step) == sizeof(DevStep), "step layouts");
+static_assert(sizeof(clsimhip_photon) == sizeof(DevPhoton), "photon layouts");
+
+void Converter::hip_check(hipError_t e, const char *what) const
+{
+    if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+Converter::Converter(int device) : device_(device)
+{
+    // configuration and Compile() are host-only; the GPU is required from Initialize() on
+    if (device < 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
+}
+
+Converter::~Converter()
+{
+    if (in_queue_) in_queue_->close();
+    if (out_queue_) out_queue_->close();
+    if (worker_.joinable()) worker_.join();
+    (void)hipSetDevice(device_);
+    for (auto &p : pending_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : free_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (ev_start_) (void)hipEventDestroy(ev_start_);
+    if (ev_stop_) (void)hipEventDestroy(ev_stop_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_);
+    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_photons_);
+    (void)hipFree(d_hit_count_);
+    if (h_steps_) (void)hipHostFree(h_steps_);
+    if (h_photons_) (void)hipHostFree(h_photons_);
+    if (h_hit_count_) (void)hipHostFree(h_hit_count_);
+}
+
+void Converter::set_wlen_generators(std::vector<RandomValueData> g) { guard(); compiled_ = false; generators_ = std::move(g); }
+void Converter::set_wlen_bias(FunctionData b) { guard(); compiled_ = false; bias_ = std::move(b); have_bias_ = true; }
+void Converter::set_medium(MediumData m) { guard(); m.validate(); compiled_ = false; medium_ = std::move(m); have_medium_ = true; }
+void Converter::set_geometry(GeometryInput g) { guard(); compiled_ = false; geometry_ = std::move(g); have_geometry_ = true; }
+
+void Converter::set_workgroup_size(size_t v)
+{
+    guard();
+    if (v == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "workgroup size must not be 0");
+    if (v > max_workgroup_size()) throw Error(CLSIMHIP_ERR_ARGUMENT, "Workgroup size too large!");
+    workgroup_size_ = v;
+}
+void Converter::set_max_num_workitems(size_t v)
+{
+    guard();
+    if (v == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "maximum number of work items must not be 0");
+    max_workitems_ = v;
+}
+
+// OpenCL.cxx:485-533
+void Converter::compile()
+{
+    guard();
+    if (compiled_) return;
+    if (generators_.empty()) throw Error(CLSIMHIP_ERR_CONFIG, "WlenGenerators not set!");
+    if (!have_bias_) throw Error(CLSIMHIP_ERR_CONFIG, "WlenBias not set!");
+    if (!have_medium_) throw Error(CLSIMHIP_ERR_CONFIG, "MediumProperties not set!");
+    if (!have_geometry_) throw Error(CLSIMHIP_ERR_CONFIG, "Geometry not set!");
+    if (double_precision_) throw Error(CLSIMHIP_ERR_CONFIG, "DoublePrecision is not available in the HIP propagator");
+    if (!stop_detected_) throw Error(CLSIMHIP_ERR_CONFIG, "StopDetectedPhotons=false is not available in the HIP propagator");
+    if (save_all_) throw Error(CLSIMHIP_ERR_CONFIG, "SaveAllPhotons is not available in the HIP propagator");
+    if (history_entries_ != 0) throw Error(CLSIMHIP_ERR_CONFIG, "PhotonHistoryEntries>0 is not available in the HIP propagator");
+    if (!std::isnan(fixed_abs_lengths_)) throw Error(CLSIMHIP_ERR_CONFIG, "FixedNumberOfAbsorptionLengths is not available in the HIP propagator");
+    tables_ = compile_tables(medium_, geometry_, generators_, bias_, pancake_);
+    compiled_ = true;
+}
+
+static bool load_multipliers_from_file(const char *path, uint32_t *a, size_t count)
+{
+    // mwcrng_init.h:62-103: binary format = 17-byte tag "safeprimes_base32" + int64 LE each; else text, first column
+    std::ifstream f(path, std::ios::binary);
+    if (!f.good()) return false;
+    char tag[18] = {0};
+    f.read(tag, 17);
+    if (std::strcmp(tag, "safeprimes_base32") == 0) {
+        for (size_t i = 0; i < count; ++i) {
+            int64_t m = 0;
+            f.read(reinterpret_cast<char *>(&m), sizeof m);
+            if (f.fail() || m < 0 || m > 0xffffffffll) return false;
+            a[i] = static_cast<uint32_t>(m);
+        }
+        return true;
+    }
+    f.close();
+    std::ifstream t(path);
+    std::string line;
+    for (size_t i = 0; i < count; ++i) {
+        if (!std::getline(t, line)) return false;
+        char *end = nullptr;
+        const long long m = std::strtoll(line.c_str(), &end, 10);
+        if (end == line.c_str() || m < 0 || m > 0xffffffffll) return false;
+        a[i] = static_cast<uint32_t>(m);
+    }
+    return true;
+}
+
+void Converter::initialize(uint64_t seed)
+{
+    guard();
+    compile();
+    if (max_workitems_ == 0) max_workitems_ = 1048576;
+    std::vector<uint32_t> a(max_workitems_);
+    std::vector<uint64_t> x(max_workitems_);
+    const char *file = std::getenv("CLSIMHIP_SAFEPRIMES_FILE");
+    if (!(file && load_multipliers_from_file(file, a.data(), a.size()))) mwc_multipliers(a.data(), a.size());
+    seed_streams(a.data(), a.size(), seed, x.data());
+    initialize_with_streams(x.data(), a.data(), a.size());
+}
+
+// OpenCL.cxx:217-388
+void Converter::initialize_with_streams(const uint64_t *x, const uint32_t *a, size_t count)
+{
+    guard();
+    if (!x || !a || count == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "RNG streams are (null) or empty");
+    compile();
+    if (workgroup_size_ == 0) workgroup_size_ = max_workgroup_size();
+    if (max_workitems_ == 0) max_workitems_ = count;
+    if (count != max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "number of RNG streams must equal the maximum number of work items");
+    if (max_workitems_ % workgroup_size_ != 0)
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "The maximum number of work items (" + std::to_string(max_workitems_) +
+                                               ") must be a multiple of the workgroup size (" + std::to_string(workgroup_size_) + ").");
+    if (max_workitems_ > 0xffffffffull) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many work items");
+    for (size_t i = 0; i < count; ++i) {
+        // mwcrng_init.h:107: a state outside this range breaks the generator
+        if ((x[i] == 0) | ((static_cast<uint32_t>(x[i] >> 32)) >= (a[i] - 1)) | ((static_cast<uint32_t>(x[i])) >= 0xfffffffful))
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "invalid MWC state word for stream " + std::to_string(i));
+    }
+    // OpenCL.cxx:266-277
+    max_output_photons_ = static_cast<uint32_t>(std::min<size_t>(max_workitems_ * 10, 0xffffffffull));
+    if (max_output_photons_ < 1000) max_output_photons_ = 1000;
+
+    {
+        int count = 0;
+        const hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the propagator has no CPU fallback)");
+        if (device_ >= count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
+    }
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
+    hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
+    setup_device_buffers();
+    hip_check(hipMemcpy(d_rng_x_, x, count * sizeof(uint64_t), hipMemcpyHostToDevice), "upload rng x");
+    hip_check(hipMemcpy(d_rng_a_, a, count * sizeof(uint32_t), hipMemcpyHostToDevice), "upload rng a");
+
+    in_queue_.reset(new BoundedQueue<Job>(5));
+    out_queue_.reset(new BoundedQueue<Result>(2));
+    initialized_ = true;
+    worker_ = std::thread([this] { worker(); });
+}
+
+void Converter::setup_device_buffers()
+{
+    const GeoTables &G = tables_.geo;
+    auto upload = [&](void **dst, const void *src, size_t bytes, const char *what) {
+        hip_check(hipMalloc(dst, std::max<size_t>(bytes, 16)), what);
+        if (bytes) hip_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), what);
+    };
+    upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
+    upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
+    upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
+    upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_x_), max_workitems_ * sizeof(uint64_t)), "rng x");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_a_), max_workitems_ * sizeof(uint32_t)), "rng a");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), max_workitems_ * sizeof(DevStep)), "steps");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_photons_), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_hit_count_), 16), "hit counter");
+    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
+    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_photons_), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
+    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_hit_count_), 16, hipHostMallocDefault), "pinned counter");
+}
+
+KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits) const
+{
+    KParams P = tables_.params;
+    P.tables = d_tables_;
+    P.steps = static_cast<const DevStep *>(d_steps);
+    P.n_steps = static_cast<uint32_t>(n);
+    P.rng_x = d_rng_x_ + rng_offset;
+    P.rng_a = d_rng_a_ + rng_offset;
+    P.out = static_cast<DevPhoton *>(d_photons);
+    P.hit_count = static_cast<uint32_t *>(d_hits);
+    P.max_hits = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffull));
+    P.dom_tx = d_dom_tx_;
+    P.dom_ty = d_dom_ty_;
+    P.dom_tz = d_dom_tz_;
+    return P;
+}
+
+// OpenCL.cxx:1525-1544
+void Converter::enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t identifier)
+{
+    need_init();
+    if (!steps) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps pointer is (null)!");
+    if (n == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps are empty!");
+    if (n > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than maximum number of work items!");
+    if (n % workgroup_size_ != 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "The number of steps is not a multiple of the workgroup size!");
+    Job job;
+    job.id = identifier;
+    job.steps.assign(steps, steps + n);
+    in_queue_->put(std::move(job));
+}
+
+// OpenCL.cxx:1142-1315 (thread body), :824-934 (upload, launch), :994-1086 (download)
+void Converter::worker()
+{
+    (void)hipSetDevice(device_);
+    auto last_done = std::chrono::steady_clock::now();
+    bool first = true;
+    Job job;
+    while (in_queue_->get(job)) {
+        try {
+            const size_t n = job.steps.size();
+            uint64_t generated = 0;
+            for (const clsimhip_step &s : job.steps) generated += s.num_photons;
+            std::memcpy(h_steps_, job.steps.data(), n * sizeof(clsimhip_step));
+            hip_check(hipMemcpyAsync(d_steps_, h_steps_, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
+            hip_check(hipMemsetAsync(d_hit_count_, 0, 4, stream_), "reset hit counter");
+            const KParams P = launch_params(d_steps_, n, 0, d_photons_, max_output_photons_, d_hit_count_);
+            hip_check(hipEventRecord(ev_start_, stream_), "event");
+            hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
+            hip_check(hipEventRecord(ev_stop_, stream_), "event");
+            hip_check(hipMemcpyAsync(h_hit_count_, d_hit_count_, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
+            hip_check(hipStreamSynchronize(stream_), "propagation kernel");
+            uint32_t hits = *h_hit_count_;
+            if (hits > max_output_photons_) {
+                // OpenCL.cxx:1027-1032: logged, truncated
+                std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);
+                hits = max_output_photons_;
+            }
+            std::unique_ptr<std::vector<clsimhip_photon>> photons(new std::vector<clsimhip_photon>(hits));
+            if (hits) {
+                hip_check(hipMemcpyAsync(h_photons_, d_photons_, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, stream_), "download photons");
+                hip_check(hipStreamSynchronize(stream_), "download photons");
+                std::memcpy(photons->data(), h_photons_, static_cast<size_t>(hits) * sizeof(clsimhip_photon));
+                replace_indices(photons->data(), hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
+            }
+            float ms = 0.f;
+            hip_check(hipEventElapsedTime(&ms, ev_start_, ev_stop_), "event time");
+            const auto now = std::chrono::steady_clock::now();
+            {
+                std::lock_guard<std::mutex> lk(stats_mutex_);
+                total_device_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+                if (!first) total_host_ns_ += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(now - last_done).count());
+                else total_host_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+                ++num_kernel_calls_;
+                photons_generated_ += generated;
+                photons_at_doms_ += hits;
+            }
+            first = false;
+            last_done = now;
+            Result r;
+            r.id = job.id;
+            r.photons = std::move(photons);
+            out_queue_->put(std::move(r));
+        } catch (const Error &e) {
+            // the reference's worker log_fatal()s on device errors (OpenCL.cxx:768-774)
+            std::fprintf(stderr, "clsimhip: fatal device error in worker thread: %s\n", e.what());
+            std::abort();
+        }
+    }
+}
+
+// OpenCL.cxx:1604-1619
+void Converter::get_result(uint32_t *identifier, const clsimhip_photon **photons, size_t *n)
+{
+    need_init();
+    if (!identifier || !photons || !n) throw Error(CLSIMHIP_ERR_ARGUMENT, "output pointers are (null)");
+    Result r;
+    if (!out_queue_->get(r)) throw Error(CLSIMHIP_ERR_STATE, "converter is shutting down");
+    *identifier = r.id;
+    *n = r.photons->size();
+    static const clsimhip_photon empty_sentinel{};
+    const clsimhip_photon *key = r.photons->empty() ? nullptr : r.photons->data();
+    *photons = key ? key : &empty_sentinel;
+    if (key) {
+        std::lock_guard<std::mutex> lk(results_mutex_);
+        handed_out_[key] = std::move(r.photons);
+    }
+}
+
+void Converter::release_result(const clsimhip_photon *photons)
+{
+    std::lock_guard<std::mutex> lk(results_mutex_);
+    handed_out_.erase(photons);
+}
+
+size_t Converter::queue_size() const { need_init(); return in_queue_->size(); }
+bool Converter::more_photons_available() const { need_init(); return !out_queue_->empty(); }
+
+void Converter::statistics(double out[8]) const
+{
+    std::lock_guard<std::mutex> lk(stats_mutex_);
+    const double dev = static_cast<double>(total_device_ns_), host = static_cast<double>(total_host_ns_);
+    const double gen = static_cast<double>(photons_generated_);
+    out[0] = dev; out[1] = host; out[2] = static_cast<double>(num_kernel_calls_); out[3] = gen;
+    out[4] = static_cast<double>(photons_at_doms_);
+    out[5] = dev / gen; out[6] = host / gen; out[7] = dev / host;
+}
+
+// OpenCL.cxx:1565-1600
+void Converter::replace_indices(clsimhip_photon *photons, size_t n) const
+{
+    const GeoTables &G = tables_.geo;
+    for (size_t i = 0; i < n; ++i) {
+        const int16_t s = photons[i].string_id;
+        const uint16_t d = photons[i].om_id;
+        if (s < 0 || static_cast<size_t>(s) >= G.string_index_to_id.size() || d >= G.dom_index_to_id[s].size())
+            throw Error(CLSIMHIP_ERR_DEVICE, "photon record with out-of-range string/DOM index");
+        const int string_id = G.string_index_to_id[s];
+        const unsigned dom_id = G.dom_index_to_id[s][d];
+        if (string_id < -32768 || string_id > 32767)
+            throw Error(CLSIMHIP_ERR_CONFIG, "Your detector I3Geometry uses a string ID \"" + std::to_string(string_id) + "\". Large IDs like that are currently not supported by clsim.");
+        if (dom_id > 65535u)
+            throw Error(CLSIMHIP_ERR_CONFIG, "Your detector I3Geometry uses a OM ID \"" + std::to_string(dom_id) + "\". Large IDs like that are currently not supported by clsim.");
+        photons[i].string_id = static_cast<int16_t>(string_id);
+        photons[i].om_id = static_cast<uint16_t>(dom_id);
+    }
+}
+
+void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity,
+                                 void *d_hit_count, hipStream_t stream)
+{
+    need_init();
+    if (!d_steps || !d_photons || !d_hit_count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device pointers are (null)");
+    if (n == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps are empty!");
+    if (rng_offset + n > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than maximum number of work items!");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> lk(ev_mutex_);
+        if (!free_events_.empty()) { ev = free_events_.back(); free_events_.pop_back(); }
+        else { hip_check(hipEventCreate(&ev.first), "hipEventCreate"); hip_check(hipEventCreate(&ev.second), "hipEventCreate"); }
+    }
+    hip_check(hipMemsetAsync(d_hit_count, 0, 4, stream), "reset hit counter");
+    const KParams P = launch_params(d_steps, n, rng_offset, d_photons, capacity, d_hit_count);
+    hip_check(hipEventRecord(ev.first, stream), "event");
+    hip_check(launch_prop_kernel(P, tables_.variant, stream), "propagation kernel launch");
+    hip_check(hipEventRecord(ev.second, stream), "event");
+    std::lock_guard<std::mutex> lk(ev_mutex_);
+    pending_events_.push_back(ev);
+}
+
+void Converter::kernel_time(bool reset, double *total_ms, uint64_t *launches)
+{
+    std::lock_guard<std::mutex> lk(ev_mutex_);
+    for (auto &ev : pending_events_) {
+        hip_check(hipEventSynchronize(ev.second), "hipEventSynchronize");
+        float ms = 0.f;
+        hip_check(hipEventElapsedTime(&ms, ev.first, ev.second), "hipEventElapsedTime");
+        dev_total_ms_ += ms;
+        ++dev_launches_;
+        free_events_.push_back(ev);
+    }
+    pending_events_.clear();
+    if (total_ms) *total_ms = dev_total_ms_;
+    if (launches) *launches = dev_launches_;
+    if (reset) { dev_total_ms_ = 0; dev_launches_ = 0; }
+}
+
+long Converter::get_table(const std::string &name, double *out, size_t cap) const
+{
+    if (!compiled_) throw Error(CLSIMHIP_ERR_STATE, "not compiled");
+    const auto it = tables_.named.find(name);
+    if (it == tables_.named.end()) throw Error(CLSIMHIP_ERR_ARGUMENT, "no table named " + name);
+    const size_t n = it->second.size();
+    if (out) std::memcpy(out, it->second.data(), std::min(n, cap) * sizeof(double));
+    return static_cast<long>(n);
+}
+
+void Converter::get_rng_state(uint64_t *x, size_t count)
+{
+    need_init();
+    if (!x || count > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "bad rng state request");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipDeviceSynchronize(), "sync");
+    hip_check(hipMemcpy(x, d_rng_x_, count * sizeof(uint64_t), hipMemcpyDeviceToHost), "download rng state");
+}
+
+} // namespace clsimhip

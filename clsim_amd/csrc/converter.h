@@ -1,0 +1,175 @@
+// Host runtime of the MI355X step->photon converter: configuration, table
+// compilation, RNG set-up, the worker thread that owns the device, statistics.
+// MI355X-native counterpart of I3CLSimStepToPhotonConverterOpenCL
+// (private/opencl/I3CLSimStepToPhotonConverterOpenCL.cxx).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "host_model.h"
+#include "kparams.h"
+
+namespace clsimhip {
+
+hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
+hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
+size_t prop_kernel_lds_bytes(uint32_t table_words);
+int prop_kernel_block_size();
+
+// Result of Compile(): kernel parameters without buffer pointers, the LDS image,
+// the DOM templates and the named tables the parity tests read back.
+struct CompiledTables {
+    KParams params{};
+    KVariant variant{};
+    std::vector<uint32_t> lds_image;
+    GeoTables geo;
+    std::map<std::string, std::vector<double>> named;
+};
+CompiledTables compile_tables(const MediumData &medium, const GeometryInput &geometry,
+                              const std::vector<RandomValueData> &generators, const FunctionData &bias,
+                              double pancake_factor);
+
+// bounded blocking queue (I3CLSimQueue.h:48-195)
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void put(T v)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return;
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool get(T &out)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    size_t size() const { std::lock_guard<std::mutex> lk(m_); return q_.size(); }
+    bool empty() const { return size() == 0; }
+    void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; not_full_.notify_all(); not_empty_.notify_all(); }
+private:
+    size_t cap_;
+    mutable std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    bool closed_ = false;
+};
+
+class Converter {
+public:
+    explicit Converter(int device);
+    ~Converter();
+
+    // configuration; each throws Error(STATE) once initialized (OpenCL.cxx:1322-1523)
+    void set_wlen_generators(std::vector<RandomValueData> g);
+    void set_wlen_bias(FunctionData b);
+    void set_medium(MediumData m);
+    void set_geometry(GeometryInput g);
+    void set_double_buffering(bool v) { guard(); double_buffering_ = v; }
+    void set_double_precision(bool v) { guard(); double_precision_ = v; }
+    void set_stop_detected(bool v) { guard(); stop_detected_ = v; }
+    void set_save_all(bool v) { guard(); save_all_ = v; }
+    void set_save_all_prescale(double v) { guard(); save_all_prescale_ = v; }
+    void set_fixed_abs_lengths(double v) { guard(); fixed_abs_lengths_ = v; }
+    void set_pancake(double v) { guard(); pancake_ = v; }
+    void set_history_entries(uint32_t v) { guard(); history_entries_ = v; }
+    void set_workgroup_size(size_t v);
+    void set_max_num_workitems(size_t v);
+
+    void compile();
+    void initialize(uint64_t seed);
+    void initialize_with_streams(const uint64_t *x, const uint32_t *a, size_t count);
+    bool initialized() const { return initialized_; }
+    size_t max_workgroup_size() const { return static_cast<size_t>(prop_kernel_block_size()); }
+    size_t workgroup_size() const { return workgroup_size_; }
+    size_t max_num_workitems() const { return max_workitems_; }
+
+    void enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t identifier);
+    void get_result(uint32_t *identifier, const clsimhip_photon **photons, size_t *n);
+    void release_result(const clsimhip_photon *photons);
+    size_t queue_size() const;
+    bool more_photons_available() const;
+    void statistics(double out[8]) const;
+
+    void propagate_device(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity,
+                          void *d_hit_count, hipStream_t stream);
+    void replace_indices(clsimhip_photon *photons, size_t n) const;
+    void kernel_time(bool reset, double *total_ms, uint64_t *launches);
+    long get_table(const std::string &name, double *out, size_t cap) const;
+    void get_rng_state(uint64_t *x, size_t count);
+
+    std::string last_error;
+
+private:
+    struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
+    struct Result { uint32_t id; std::unique_ptr<std::vector<clsimhip_photon>> photons; };
+
+    void guard() const { if (initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP already initialized!"); }
+    void need_init() const { if (!initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP is not initialized!"); }
+    void setup_device_buffers();
+    void worker();
+    void hip_check(hipError_t e, const char *what) const;
+    KParams launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits) const;
+
+    int device_;
+    std::vector<RandomValueData> generators_;
+    FunctionData bias_;
+    MediumData medium_;
+    GeometryInput geometry_;
+    bool have_bias_ = false, have_medium_ = false, have_geometry_ = false;
+    bool double_buffering_ = false, double_precision_ = false, stop_detected_ = true, save_all_ = false;
+    double save_all_prescale_ = 0.01, fixed_abs_lengths_ = NAN, pancake_ = 1.0;
+    uint32_t history_entries_ = 0;
+    size_t workgroup_size_ = 0, max_workitems_ = 0;
+    uint32_t max_output_photons_ = 0;
+
+    bool compiled_ = false, initialized_ = false;
+    CompiledTables tables_;
+
+    // device state
+    uint32_t *d_tables_ = nullptr;
+    int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
+    float *d_dom_tz_ = nullptr;
+    uint64_t *d_rng_x_ = nullptr;
+    uint32_t *d_rng_a_ = nullptr;
+    DevStep *d_steps_ = nullptr;
+    DevPhoton *d_photons_ = nullptr;
+    uint32_t *d_hit_count_ = nullptr;
+    clsimhip_step *h_steps_ = nullptr;       // pinned staging
+    clsimhip_photon *h_photons_ = nullptr;
+    uint32_t *h_hit_count_ = nullptr;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
+
+    // worker + queues (in: capacity 5 like queueToOpenCL_, OpenCL.cxx:77)
+    std::unique_ptr<BoundedQueue<Job>> in_queue_;
+    std::unique_ptr<BoundedQueue<Result>> out_queue_;
+    std::thread worker_;
+    mutable std::mutex results_mutex_;
+    std::map<const clsimhip_photon *, std::unique_ptr<std::vector<clsimhip_photon>>> handed_out_;
+
+    // statistics (OpenCL.cxx:1088-1140, 1621-1640)
+    mutable std::mutex stats_mutex_;
+    uint64_t total_device_ns_ = 0, total_host_ns_ = 0, num_kernel_calls_ = 0, photons_generated_ = 0, photons_at_doms_ = 0;
+
+    // device-resident path: event pairs on the caller's stream
+    std::mutex ev_mutex_;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_, free_events_;
+    double dev_total_ms_ = 0;
+    uint64_t dev_launches_ = 0;
+};
+
+} // namespace clsimhip

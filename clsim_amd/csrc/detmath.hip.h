@@ -1,0 +1,197 @@
+// Device math for the propagator: single precision log/exp/powr/sin/cos (and
+// acos/atan2 for the hit record) built only from IEEE-754 correctly rounded
+// operations -- v_fma_f32, v_mul/add_f32, IEEE divide and sqrt (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt), v_rndne, integer ops -- never from
+// the approximate v_log/v_exp/v_sin/v_cos units, whose results cannot be
+// reproduced bit for bit off the GPU.  The reference calls the OpenCL runtime's
+// builtins here (propagation_kernel.c.cl:52-60), which have no pinned bit
+// pattern; this file defines one.  Compile with -ffp-contract=off: every fused
+// multiply-add below is explicit.
+//
+// Polynomials: Cephes single precision (logf, expf, sinf, cosf), Horner form.
+// powr keeps log(x) as an unevaluated hi+lo pair so that |y*log x| ~ 10 (the
+// lambda^-kappa of the ice model) still rounds within ~1.2 ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DM __device__ __forceinline__
+
+namespace dm {
+
+DM float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DM float sqrt_(float a) { return __builtin_sqrtf(a); }
+DM float rsqrt_(float a) { return 1.0f / __builtin_sqrtf(a); }
+DM float rint_(float a) { return __builtin_rintf(a); }
+DM uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+DM float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+constexpr float LN2_HI = 0.693359375f;
+constexpr float LN2_LO = -2.12194440e-4f;
+constexpr float LOG2E = 1.44269504088896341f;
+
+DM float log_poly(float r)
+{
+    float p = 7.0376836292e-2f;
+    p = fma_(p, r, -1.1514610310e-1f);
+    p = fma_(p, r, 1.1676998740e-1f);
+    p = fma_(p, r, -1.2420140846e-1f);
+    p = fma_(p, r, 1.4249322787e-1f);
+    p = fma_(p, r, -1.6668057665e-1f);
+    p = fma_(p, r, 2.0000714765e-1f);
+    p = fma_(p, r, -2.4999993993e-1f);
+    p = fma_(p, r, 3.3333331174e-1f);
+    return p;
+}
+
+// x = 2^e * m, m in [sqrt(1/2), sqrt(2))
+DM float frexp_sqrt2(float x, int &e)
+{
+    const uint32_t ix = f2u(x);
+    const int32_t d = (int32_t)(ix - 0x3f3504f3u);
+    e = d >> 23;
+    return u2f(ix - ((uint32_t)e << 23));
+}
+
+DM float log_(float x)
+{
+    int e;
+    const float m = frexp_sqrt2(x, e);
+    const float r = m - 1.0f;
+    const float fe = (float)e;
+    const float z = r * r;
+    float y = (r * z) * log_poly(r);
+    y = fma_(fe, LN2_LO, y);
+    y = fma_(-0.5f, z, y);
+    return fma_(fe, LN2_HI, r + y);
+}
+
+DM float exp_poly(float r)
+{
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    return p;
+}
+
+DM float exp_hl(float hi, float lo)
+{
+    if (hi < -86.0f) return 0.0f;
+    if (hi > 88.0f) return u2f(0x7f800000u);
+    const float k = rint_(hi * LOG2E);
+    float r = fma_(-k, LN2_HI, hi);
+    r = fma_(-k, LN2_LO, r);
+    r = r + lo;
+    const float z = r * r;
+    float p = fma_(z, exp_poly(r), r);
+    p = p + 1.0f;
+    const int32_t ik = (int32_t)k;
+    return u2f(f2u(p) + ((uint32_t)ik << 23));
+}
+
+DM float exp_(float x) { return exp_hl(x, 0.0f); }
+
+DM float powr_(float x, float y)
+{
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : u2f(0x7f800000u));
+    int e;
+    const float m = frexp_sqrt2(x, e);
+    const float r = m - 1.0f;
+    const float fe = (float)e;
+    const float z = r * r;
+    float c = (r * z) * log_poly(r);
+    c = fma_(fe, LN2_LO, c);
+    c = fma_(-0.5f, z, c);
+    const float t = fe * LN2_HI;
+    const float hi = t + r;
+    const float bb = hi - t;
+    const float err = (t - (hi - bb)) + (r - bb);
+    const float lo = err + c;
+    const float ph = y * hi;
+    const float pe = fma_(y, hi, -ph);
+    const float pl = fma_(y, lo, pe);
+    return exp_hl(ph, pl);
+}
+
+constexpr float PIO2_1 = 0x1.921fb6p+0f;
+constexpr float PIO2_2 = -0x1.777a5cp-25f;
+constexpr float PIO2_3 = -0x1.ee59dap-50f;
+constexpr float TWO_O_PI = 0.636619772367581343f;
+
+DM void sincos_(float x, float &s, float &c)
+{
+    const float k = rint_(x * TWO_O_PI);
+    float r = fma_(-k, PIO2_1, x);
+    r = fma_(-k, PIO2_2, r);
+    r = fma_(-k, PIO2_3, r);
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fma_(ps, z, 8.3321608736e-3f);
+    ps = fma_(ps, z, -1.6666654611e-1f);
+    ps = fma_(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fma_(pc, z, -1.388731625493765e-3f);
+    pc = fma_(pc, z, 4.166664568298827e-2f);
+    pc = pc * (z * z);
+    pc = fma_(-0.5f, z, pc);
+    pc = pc + 1.0f;
+    const int32_t q = (int32_t)k;
+    const float a = (q & 1) ? pc : ps;
+    const float b = (q & 1) ? ps : pc;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// ---- once per recorded hit: binary64 (IEEE divide/sqrt/fma) ----
+DM double atan_small_d(double t)
+{
+    const double z = t * t;
+    double p = 1.0 / 25.0;
+    p = __builtin_fma(p, -z, 1.0 / 23.0);
+    p = __builtin_fma(p, -z, 1.0 / 21.0);
+    p = __builtin_fma(p, -z, 1.0 / 19.0);
+    p = __builtin_fma(p, -z, 1.0 / 17.0);
+    p = __builtin_fma(p, -z, 1.0 / 15.0);
+    p = __builtin_fma(p, -z, 1.0 / 13.0);
+    p = __builtin_fma(p, -z, 1.0 / 11.0);
+    p = __builtin_fma(p, -z, 1.0 / 9.0);
+    p = __builtin_fma(p, -z, 1.0 / 7.0);
+    p = __builtin_fma(p, -z, 1.0 / 5.0);
+    p = __builtin_fma(p, -z, 1.0 / 3.0);
+    p = __builtin_fma(p, -z, 1.0);
+    return t * p;
+}
+DM double atan2_d(double y, double x)
+{
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double mx = (ax > ay) ? ax : ay;
+    const double mn = (ax > ay) ? ay : ax;
+    double a;
+    if (mx == 0.0) {
+        a = 0.0;
+    } else {
+        double t = mn / mx;
+        double off = 0.0;
+        if (t > 0.41421356237309503) {
+            t = (t - 1.0) / (t + 1.0);
+            off = 0.78539816339744828;
+        }
+        a = off + atan_small_d(t);
+    }
+    if (ay > ax) a = 1.57079632679489656 - a;
+    if (x < 0.0) a = 3.14159265358979323846 - a;
+    if (y < 0.0) a = -a;
+    return a;
+}
+DM float atan2_(float y, float x) { return (float)atan2_d((double)y, (double)x); }
+DM float acos_(float v)
+{
+    const double d = (double)v;
+    const double s = __builtin_sqrt((1.0 - d) * (1.0 + d));
+    return (float)atan2_d(s, d);
+}
+
+} // namespace dm

@@ -1,0 +1,98 @@
+// Kernel parameter block: everything wave-uniform the propagator needs.  It is
+// passed by value (kernarg segment -> SGPRs), so none of it costs vector
+// registers.  Arrays that lanes index divergently (ice layers, tilt grid,
+// spectra, DOM cell index) live in one packed 32-bit word block that every
+// workgroup copies from HBM/L2 into LDS once; `off_*` are word offsets into it.
+//
+// The reference bakes the same values into the OpenCL source as #defines and
+// __constant arrays (MediumPropertiesSource.cxx:207-389, GeometrySource.cxx:1153-1269).
+#pragma once
+#include <stdint.h>
+
+namespace clsimhip {
+
+constexpr int kMaxGenerators = 8;
+constexpr int kMaxSubdetectors = 9;     // sparse_collision_kernel.c.cl:455
+
+#pragma pack(push, 1)
+struct DevStep {                        // I3CLSimStep, 48 B
+    float x, y, z, t;
+    float theta, phi, length, beta;
+    uint32_t num_photons;
+    float weight;
+    uint32_t identifier;
+    uint32_t source_type_and_pad;       // low byte = sourceType
+};
+struct DevPhoton {                      // I3CLSimPhoton, 80 B = 20 words
+    uint32_t w[20];
+};
+#pragma pack(pop)
+static_assert(sizeof(DevStep) == 48, "step record");
+static_assert(sizeof(DevPhoton) == 80, "photon record");
+
+struct KParams {
+    // ---- buffers ----
+    const uint32_t *tables;             // LDS image (table_words words)
+    uint32_t table_words;
+    const DevStep *steps;
+    uint32_t n_steps;
+    uint64_t *rng_x;
+    const uint32_t *rng_a;
+    DevPhoton *out;
+    uint32_t *hit_count;
+    uint32_t max_hits;
+    const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
+    const int16_t *dom_ty;
+    const float *dom_tz;
+
+    // ---- medium ----
+    int32_t num_layers;
+    float layer_bottom, layer_thickness, recip_thickness;
+    uint32_t off_abs_a, off_abs_b, off_sca_b;   // ICECUBE: (D*aDust+E), (1+0.01*dTau), b400 ; CONSTANT: abs, -, sca
+    float neg_kappa, abs_A, neg_B, neg_alpha, ref_wlen_recip, nanometer;
+    float n[5], g[5], micrometer, c_light;
+    float mix_frac, mix_frac_rest, liu_beta, hg_g, hg_one_minus_g2, hg_one_plus_g2, hg_two_g;
+    float an_l[3], an_rl[3], an_azx, an_azy, an_mazy, an_B2, abs_corr_const;
+    float pre[9], post[9];
+    int32_t has_abs_corr, has_pre, has_post, pre_renorm, post_renorm;
+    int32_t scatter_kind;               // CLSIMHIP_SCATTER_*
+    float tilt_const;
+    int32_t tilt_nd, tilt_nz;
+    float tilt_first_z, tilt_dz, tilt_lnx, tilt_lny;
+    uint32_t off_tilt_dist, off_tilt_zcorr;
+
+    // ---- spectra ----
+    int32_t num_gen;
+    int32_t gen_kind[kMaxGenerators], gen_n[kMaxGenerators];
+    float gen_first[kMaxGenerators], gen_spacing[kMaxGenerators], gen_value[kMaxGenerators];
+    uint32_t off_gen_yv[kMaxGenerators], off_gen_ycum[kMaxGenerators];
+    int32_t bias_kind, bias_n;
+    float bias_start, bias_step, bias_value;
+    uint32_t off_bias;
+
+    // ---- detector ----
+    int32_t has_pancake;
+    float pancake, unpancake;           // PANCAKE_FACTOR, (PANCAKE_FACTOR-1)/PANCAKE_FACTOR
+    float om_radius, om_radius_sq, string_max_radius_sq;
+    int32_t num_strings, num_sets, max_layers, num_subdet;
+    uint32_t off_str_x, off_str_y, off_str_top, off_str_bottom; // top = maxZ+R, bottom = minZ-R
+    uint32_t off_str_info;              // set | dom_start << 8
+    uint32_t off_dom_meanx, off_dom_meany;
+    uint32_t off_set_nlayers, off_set_startz, off_set_height;
+    uint32_t off_layer_to_om;           // uint16 pairs
+    int32_t cell_nx[kMaxSubdetectors], cell_ny[kMaxSubdetectors];
+    float cell_wx[kMaxSubdetectors], cell_wy[kMaxSubdetectors], cell_sx[kMaxSubdetectors], cell_sy[kMaxSubdetectors];
+    uint32_t off_cell[kMaxSubdetectors];        // uint16 pairs
+    float dom_mul_x, dom_mul_y;
+};
+
+// kernel variants (the reference's #ifdef switches, OpenCL.cxx:390-442 and the
+// generated *_IS_CONSTANT / NO_FLASHER hints)
+struct KVariant {
+    bool icecube_lengths;   // optimised IceCube abs/scat functions vs per-layer constants
+    bool tilt;              // ScalarFieldIceTiltZShift vs getTiltZShift_IS_CONSTANT
+    bool aniso;             // anisotropy scaling + pre/post transforms present
+    bool flasher;           // more than one wavelength generator (no NO_FLASHER)
+};
+
+} // namespace clsimhip

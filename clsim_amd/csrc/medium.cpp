@@ -1,0 +1,294 @@
+// Host configuration helpers: ice model loader, DOM acceptance, Cherenkov
+// spectrum.  The reference does this in Python / C++ on the host
+// (python/MakeIceCubeMediumProperties.py, python/GetIceCubeDOMAcceptance.py,
+// private/clsim/I3CLSimModuleHelper.cxx); values stay in double here and are
+// turned into kernel constants by tables.cpp.
+#include <cmath>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+
+#include "host_model.h"
+
+namespace clsimhip {
+
+static bool file_exists(const std::string &p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+// numpy.loadtxt semantics: '#' comments, blank lines skipped, whitespace separated
+static std::vector<std::vector<double>> load_table(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f.good()) throw Error(CLSIMHIP_ERR_IO, "cannot open " + path);
+    std::vector<std::vector<double>> rows;
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.resize(hash);
+        std::istringstream ss(line);
+        std::vector<double> row;
+        std::string tok;
+        while (ss >> tok) {
+            char *end = nullptr;
+            const double v = std::strtod(tok.c_str(), &end);
+            if (end == tok.c_str() || *end != '\0') throw Error(CLSIMHIP_ERR_IO, "bad number '" + tok + "' in " + path);
+            row.push_back(v);
+        }
+        if (!row.empty()) rows.push_back(row);
+    }
+    if (rows.empty()) throw Error(CLSIMHIP_ERR_IO, path + " is empty");
+    return rows;
+}
+
+double FunctionData::eval(double wlen) const
+{
+    // I3CLSimFunctionFromTable::GetValue, equal spacing (FromTable.cxx:105-122)
+    if (kind == CLSIMHIP_FUNCTION_CONSTANT) return value;
+    double fbin;
+    double fraction = std::modf((wlen - start) / step, &fbin);
+    int ibin = static_cast<int>(fbin);
+    if ((ibin < 0) || ((ibin == 0) && (fraction < 0))) {
+        ibin = 0;
+        fraction = 0.;
+    } else if (static_cast<size_t>(ibin) >= values.size() - 1) {
+        ibin = static_cast<int>(values.size()) - 2;
+        fraction = 1.;
+    }
+    return values[ibin] + (values[ibin + 1] - values[ibin]) * fraction;
+}
+
+double MediumData::phase_ref_index(double wlen) const
+{
+    // RefIndexIceCube.cxx:84-101
+    const double x = wlen / units::micrometer;
+    return n[0] + x * (n[1] + x * (n[2] + x * (n[3] + x * n[4])));
+}
+
+void MediumData::validate() const
+{
+    if (num_layers < 1) throw Error(CLSIMHIP_ERR_ARGUMENT, "medium needs at least one layer");
+    if (!(layers_height > 0)) throw Error(CLSIMHIP_ERR_ARGUMENT, "layer height must be positive");
+    const size_t nl = static_cast<size_t>(num_layers);
+    if (lengths_kind == CLSIMHIP_LENGTHS_CONSTANT) {
+        if (abs_length.size() != nl || sca_length.size() != nl)
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "abs_length / sca_length need one entry per layer");
+    } else if (lengths_kind == CLSIMHIP_LENGTHS_ICECUBE) {
+        if (a_dust400.size() != nl || delta_tau.size() != nl || b400.size() != nl)
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "a_dust400 / delta_tau / b400 need one entry per layer");
+    } else
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown lengths_kind");
+    if (scatter_kind < CLSIMHIP_SCATTER_HG || scatter_kind > CLSIMHIP_SCATTER_MIXED)
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown scatter_kind");
+    if (has_tilt) {
+        if (tilt_distances.size() < 2 || tilt_z.size() < 2)
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "tilt needs at least 2 distances and 2 z coordinates");
+        if (tilt_corr.size() != tilt_distances.size() * tilt_z.size())
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "tilt correction table has the wrong size");
+    }
+}
+
+MediumData medium_from_desc(const clsimhip_medium_desc &d)
+{
+    MediumData m;
+    m.num_layers = d.num_layers;
+    m.layers_z_start = d.layers_z_start;
+    m.layers_height = d.layers_height;
+    m.min_wlen = d.min_wavelength;
+    m.max_wlen = d.max_wavelength;
+    m.lengths_kind = d.lengths_kind;
+    const size_t nl = d.num_layers > 0 ? static_cast<size_t>(d.num_layers) : 0;
+    if (d.lengths_kind == CLSIMHIP_LENGTHS_CONSTANT) {
+        if (!d.abs_length || !d.sca_length) throw Error(CLSIMHIP_ERR_ARGUMENT, "abs_length / sca_length are null");
+        m.abs_length.assign(d.abs_length, d.abs_length + nl);
+        m.sca_length.assign(d.sca_length, d.sca_length + nl);
+    } else {
+        if (!d.a_dust400 || !d.delta_tau || !d.b400) throw Error(CLSIMHIP_ERR_ARGUMENT, "ice tables are null");
+        m.a_dust400.assign(d.a_dust400, d.a_dust400 + nl);
+        m.delta_tau.assign(d.delta_tau, d.delta_tau + nl);
+        m.b400.assign(d.b400, d.b400 + nl);
+        m.alpha = d.alpha; m.kappa = d.kappa; m.A = d.A; m.B = d.B; m.D = d.D; m.E = d.E;
+    }
+    for (int i = 0; i < 5; ++i) { m.n[i] = d.n[i]; m.g[i] = d.g[i]; }
+    m.scatter_kind = d.scatter_kind;
+    m.liu_fraction = d.liu_fraction;
+    m.mean_cosine = d.mean_cosine;
+    m.has_aniso = d.has_anisotropy != 0;
+    m.aniso_azimuth = d.aniso_azimuth; m.aniso_k1 = d.aniso_k1; m.aniso_k2 = d.aniso_k2;
+    m.has_pre = d.has_pre_transform != 0; m.pre_renorm = d.pre_renormalize != 0;
+    m.has_post = d.has_post_transform != 0; m.post_renorm = d.post_renormalize != 0;
+    for (int i = 0; i < 9; ++i) { m.pre[i] = d.pre_matrix[i]; m.post[i] = d.post_matrix[i]; }
+    m.has_tilt = d.has_tilt != 0;
+    if (m.has_tilt) {
+        if (d.tilt_num_distances < 2 || d.tilt_num_z < 2 || !d.tilt_distances || !d.tilt_z_coordinates || !d.tilt_z_corrections)
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "incomplete tilt description");
+        const size_t nd = d.tilt_num_distances, nz = d.tilt_num_z;
+        m.tilt_distances.assign(d.tilt_distances, d.tilt_distances + nd);
+        m.tilt_z.assign(d.tilt_z_coordinates, d.tilt_z_coordinates + nz);
+        m.tilt_corr.assign(d.tilt_z_corrections, d.tilt_z_corrections + nd * nz);
+        m.tilt_azimuth = d.tilt_azimuth;
+    }
+    m.validate();
+    return m;
+}
+
+// python/MakeIceCubeMediumProperties.py:49-256
+MediumData medium_from_ppc(const std::string &dir, double center_depth, bool use_tilt_if_available)
+{
+    bool use_tilt = false;
+    if (use_tilt_if_available) {
+        const bool has_par = file_exists(dir + "/tilt.par"), has_dat = file_exists(dir + "/tilt.dat");
+        if (has_par && !has_dat) throw Error(CLSIMHIP_ERR_IO, "ice model directory has tilt.par but tilt.dat is missing!");
+        if (has_dat && !has_par) throw Error(CLSIMHIP_ERR_IO, "ice model directory has tilt.dat but tilt.par is missing!");
+        use_tilt = has_par && has_dat;
+    }
+    const auto dat = load_table(dir + "/icemodel.dat");
+    const auto par = load_table(dir + "/icemodel.par");
+    const auto cfg = load_table(dir + "/cfg.txt");
+
+    MediumData m;
+    m.lengths_kind = CLSIMHIP_LENGTHS_ICECUBE;
+    if (par.size() == 6) {
+        m.alpha = par[0][0]; m.kappa = par[1][0]; m.A = par[2][0]; m.B = par[3][0]; m.D = par[4][0]; m.E = par[5][0];
+    } else if (par.size() == 4) {
+        m.alpha = par[0][0]; m.kappa = par[1][0]; m.A = par[2][0]; m.B = par[3][0];
+        m.D = std::pow(400., m.kappa);      // what ppc does (py:84-89)
+        m.E = 0.;
+    } else
+        throw Error(CLSIMHIP_ERR_IO, dir + "/icemodel.par is not a valid Dima-icemodel file (needs 4 or 6 entries)");
+    if (cfg.size() < 4) throw Error(CLSIMHIP_ERR_IO, dir + "/cfg.txt does not have enough configuration lines. It needs at least 4.");
+    m.liu_fraction = cfg[2][0];
+    m.mean_cosine = cfg[3][0];
+    if (cfg.size() > 4 && cfg.size() < 7)
+        throw Error(CLSIMHIP_ERR_IO, dir + "/cfg.txt has more than 4 lines but needs at least 7 for ice anisotropy");
+    if (cfg.size() > 4) {
+        m.has_aniso = true;
+        m.aniso_azimuth = cfg[4][0] * units::deg;
+        m.aniso_k1 = cfg[5][0];
+        m.aniso_k2 = cfg[6][0];
+    }
+    if (m.liu_fraction < 0. || m.liu_fraction > 1.) throw Error(CLSIMHIP_ERR_IO, "Invalid Liu(SAM) scattering fraction configured in cfg.txt");
+    if (m.mean_cosine < -1. || m.mean_cosine > 1.) throw Error(CLSIMHIP_ERR_IO, "Invalid <cos(theta)> configured in cfg.txt");
+
+    const size_t nl = dat.size();
+    if (nl < 2) throw Error(CLSIMHIP_ERR_IO, "There is only a single layer in your layer definition file");
+    for (const auto &r : dat)
+        if (r.size() < 4) throw Error(CLSIMHIP_ERR_IO, "icemodel.dat needs 4 columns");
+    const double layer_height = dat[1][0] - dat[0][0];
+    if (layer_height <= 0.) throw Error(CLSIMHIP_ERR_IO, "ice layer depths are not in increasing order");
+    for (size_t i = 0; i + 1 < nl; ++i)
+        if (std::abs((dat[i + 1][0] - dat[i][0]) - layer_height) > 1e-5) throw Error(CLSIMHIP_ERR_IO, "ice layers are not spaced evenly");
+
+    // file order is top -> bottom; the medium wants bottom -> top (py:148-151)
+    m.num_layers = static_cast<int>(nl);
+    m.a_dust400.resize(nl); m.delta_tau.resize(nl); m.b400.resize(nl);
+    for (size_t i = 0; i < nl; ++i) {
+        const auto &row = dat[nl - 1 - i];
+        m.b400[i] = row[1] / (1. - m.mean_cosine);      // b_e400 -> b_400 (py:153)
+        m.a_dust400[i] = row[2];
+        m.delta_tau[i] = row[3];
+    }
+    // depth in the file is the layer centre (ppc); bottom-most layer first (py:158-163)
+    const double deepest_top = dat[nl - 1][0] - layer_height / 2.;
+    m.layers_z_start = center_depth - (deepest_top + layer_height);
+    m.layers_height = layer_height;
+    m.min_wlen = 265. * units::nanometer;               // ForcedMinWlen / ForcedMaxWlen (py:178-179)
+    m.max_wlen = 675. * units::nanometer;
+    // RefIndexIceCube defaults (RefIndexIceCube.cxx:38-47); group override is always set (py:222-230)
+    const double n_[5] = {1.55749, -1.57988, 3.99993, -4.68271, 2.09354};
+    const double g_[5] = {1.227106, -0.954648, 1.42568, -0.711832, 0.0};
+    for (int i = 0; i < 5; ++i) { m.n[i] = n_[i]; m.g[i] = g_[i]; }
+    m.scatter_kind = CLSIMHIP_SCATTER_MIXED;
+
+    if (m.has_aniso) {
+        // python/util/GetSpiceLeaAnisotropyTransforms.py:39-101
+        const double k1 = std::exp(m.aniso_k1), k2 = std::exp(m.aniso_k2), kz = 1. / (k1 * k2);
+        const double sa = std::sin(m.aniso_azimuth), ca = std::cos(m.aniso_azimuth);
+        const double T[3][3] = {{ca, sa, 0.}, {-sa, ca, 0.}, {0., 0., 1.}};
+        const double diag[3] = {k1, k2, kz};
+        // numpy.linalg.inv of a diagonal matrix: LAPACK getrf/getri gives exactly 1/d
+        const double inv_diag[3] = {1. / k1, 1. / k2, 1. / kz};
+        auto sandwich = [&](const double d[3], double out[9]) {
+            // (T^T . A) . T with numpy.dot's left-to-right sums
+            double ta[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0.;
+                    for (int k = 0; k < 3; ++k) s += T[k][i] * ((k == j) ? d[k] : 0.);
+                    ta[i][j] = s;
+                }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0.;
+                    for (int k = 0; k < 3; ++k) s += ta[i][k] * T[k][j];
+                    out[3 * i + j] = s;
+                }
+        };
+        sandwich(diag, m.pre);
+        sandwich(inv_diag, m.post);
+        m.has_pre = m.has_post = true;
+        m.pre_renorm = m.post_renorm = true;
+    }
+    if (use_tilt) {
+        // python/util/GetIceTiltZShift.py:40-62
+        const auto tpar = load_table(dir + "/tilt.par");
+        const auto tdat = load_table(dir + "/tilt.dat");
+        const size_t nd = tpar.size(), nz = tdat.size();
+        m.has_tilt = true;
+        m.tilt_azimuth = 225. * units::deg;
+        m.tilt_distances.resize(nd);
+        for (size_t i = 0; i < nd; ++i) m.tilt_distances[i] = tpar[i][1];
+        m.tilt_z.resize(nz);
+        for (size_t k = 0; k < nz; ++k) m.tilt_z[k] = center_depth - tdat[nz - 1 - k][0];
+        m.tilt_corr.resize(nd * nz);
+        for (size_t i = 0; i < nd; ++i)
+            for (size_t k = 0; k < nz; ++k) {
+                if (tdat[nz - 1 - k].size() < nd + 1) throw Error(CLSIMHIP_ERR_IO, "tilt.dat has too few columns");
+                m.tilt_corr[i * nz + k] = tdat[nz - 1 - k][i + 1];
+            }
+    }
+    m.validate();
+    return m;
+}
+
+// python/GetIceCubeDOMAcceptance.py:35-115
+void dom_acceptance(double dom_radius, double efficiency, std::vector<double> &values, double &start, double &step)
+{
+    static const double eff_area[43] = {
+        0.0000064522, 0.0000064522, 0.0000064522, 0.0000064522, 0.0000021980, 0.0001339040, 0.0005556810,
+        0.0016953000, 0.0035997000, 0.0061340900, 0.0074592700, 0.0090579800, 0.0099246700, 0.0105769000,
+        0.0110961000, 0.0114214000, 0.0114425000, 0.0111527000, 0.0108086000, 0.0104458000, 0.0099763100,
+        0.0093102500, 0.0087516600, 0.0083225800, 0.0079767200, 0.0075625100, 0.0066377000, 0.0053335800,
+        0.0043789400, 0.0037583500, 0.0033279800, 0.0029212500, 0.0025334900, 0.0021115400, 0.0017363300,
+        0.0013552700, 0.0010546600, 0.0007201020, 0.0004843820, 0.0002911110, 0.0001782310, 0.0001144300,
+        0.0000509155};
+    const double dom_area = M_PI * std::pow(dom_radius, 2.);
+    values.resize(43);
+    for (int i = 0; i < 43; ++i) values[i] = efficiency * ((eff_area[i] * 1.0) / dom_area);
+    start = 260. * units::nanometer;
+    step = 10. * units::nanometer;
+}
+
+// I3CLSimModuleHelper.cxx:175-263 (tabulated bias, dispersion on) with the yield of :52-63
+RandomValueData make_cherenkov_generator(const FunctionData &bias, const MediumData &m)
+{
+    if (bias.kind != CLSIMHIP_FUNCTION_TABLE)
+        throw Error(CLSIMHIP_ERR_CONFIG, "makeCherenkovWavelengthGenerator: only tabulated biases are supported");
+    RandomValueData g;
+    g.kind = CLSIMHIP_RANDOM_INTERPOLATED;
+    g.first = bias.start;
+    g.spacing = bias.step;
+    g.y.resize(bias.values.size());
+    const double beta = 1.;
+    for (size_t i = 0; i < bias.values.size(); ++i) {
+        const double wlen = bias.start + static_cast<double>(i) * bias.step;
+        const double n_phase = m.phase_ref_index(wlen);
+        const double yield = (2. * M_PI / (137. * (wlen * wlen))) * (1. - 1. / (std::pow(beta * n_phase, 2.)));
+        g.y[i] = bias.values[i] * yield;
+    }
+    return g;
+}
+
+} // namespace clsimhip

@@ -1,0 +1,643 @@
+// Photon propagator for gfx950 (MI355X).
+//
+// Replaces the reference's run-time generated OpenCL program
+//   resources/kernels/propagation_kernel.c.cl:406-913       (propKernel)
+//   resources/kernels/sparse_collision_kernel.c.cl:27-587   (DOM intersection)
+//   resources/kernels/mwcrng_kernel.cl:12-28                (MWC RNG)
+//   + generated medium / spectrum / geometry functions (I3CLSimHelperGenerate*.cxx)
+// with a hand-written kernel whose results are bit-identical for every step and
+// RNG stream, but which is organised for the CDNA4 execution model:
+//
+//  * one in-flight photon per lane; lane i owns step i and RNG stream i of the
+//    bunch (the stream must follow the step, propagation_kernel.c.cl:458-461);
+//  * the scatter loop is a WAVE-UNIFORM loop (`while (ballot(alive))`): photon
+//    creation, propagation, DOM search and scattering are predicated phases, so
+//    hit records are emitted at a convergent point by the whole wave;
+//  * hit write-out is wave-aggregated: one atomic per wave claims the slots,
+//    records are staged in LDS and written as contiguous dwords by all lanes;
+//  * ice layer tables, tilt grid, spectra and the DOM cell/layer index are
+//    staged in LDS once per workgroup (lanes index them divergently, which the
+//    scalar/constant path cannot serve); wave-uniform scalars arrive as kernel
+//    arguments in SGPRs;
+//  * wavelength-only factors of the ice functions (lambda^-alpha, lambda^-kappa,
+//    A*exp(-B/lambda)) are evaluated once per photon instead of once per layer
+//    visit -- same operations on the same inputs, so the same bits;
+//  * no MFMA: nothing here is a contraction.  The kernel is bound by fp32 VALU
+//    issue (IEEE divides, polynomial transcendentals) and divergence, not HBM.
+//
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off (no implicit fma; all
+// fused operations are explicit in detmath.hip.h).
+#include <hip/hip_runtime.h>
+
+#include "detmath.hip.h"
+#include "kparams.h"
+
+namespace clsimhip {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kStageRecords = 8;                 // hit records staged per wave and flush
+constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
+constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
+constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
+
+extern __shared__ uint32_t lds_words[];
+
+DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
+DM uint32_t ldsu(uint32_t i) { return lds_words[i]; }
+DM uint32_t lds_u16(uint32_t off, uint32_t i)
+{
+    const uint32_t w = lds_words[off + (i >> 1)];
+    return (i & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// mwcrng_kernel.cl:12-20: x = lo32(x)*a + hi32(x); u = float_rtz(lo32(x)) / 2^32
+DM float rng_co(uint64_t &x, uint32_t a)
+{
+    x = (x & 0xffffffffull) * (uint64_t)a + (x >> 32);
+    const uint32_t lo = (uint32_t)x;
+    const int drop = 8 - (int)__clz(lo);                    // bits below the 24-bit significand
+    const uint32_t t = (drop > 0) ? ((lo >> drop) << drop) : lo;
+    return (float)t * 2.3283064365386963e-10f;              // exact: t has <= 24 significant bits
+}
+DM float rng_oc(uint64_t &x, uint32_t a) { return 1.0f - rng_co(x, a); }
+
+DM float sqr(float a) { return a * a; }
+DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
+DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
+
+struct Vec3 { float x, y, z; };
+
+// RefIndexIceCube.cxx:128-180
+DM float phase_ref_index(const KParams &P, float wlen)
+{
+    const float x = wlen / P.micrometer;
+    return P.n[0] + x * (P.n[1] + x * (P.n[2] + x * (P.n[3] + x * P.n[4])));
+}
+// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163
+DM float group_velocity(const KParams &P, float wlen)
+{
+    const float x = wlen / P.micrometer;
+    const float np = P.n[0] + x * (P.n[1] + x * (P.n[2] + x * (P.n[3] + x * P.n[4])));
+    const float np_corr = P.g[0] + x * (P.g[1] + x * (P.g[2] + x * (P.g[3] + x * P.g[4])));
+    return P.c_light / (np * np_corr);
+}
+
+// Per-photon wavelength factors of the IceCube ice functions.
+struct IceFactors { float sca_pow, abs_pow, abs_exp; };
+
+template <bool ICE>
+DM IceFactors ice_factors(const KParams &P, float wlen)
+{
+    IceFactors f = {0.0f, 0.0f, 0.0f};
+    if (ICE) {
+        // _Optimizers.cxx:237-240: powr(wlen*(1/400nm), -alpha)
+        f.sca_pow = dm::powr_(wlen * P.ref_wlen_recip, P.neg_alpha);
+        // _Optimizers.cxx:170-180: powr(x,-kappa), A*exp(-B/x), x = wlen/nm
+        const float x = wlen / P.nanometer;
+        f.abs_pow = dm::powr_(x, P.neg_kappa);
+        f.abs_exp = P.abs_A * dm::exp_(P.neg_B / x);
+    }
+    return f;
+}
+template <bool ICE>
+DM float scattering_length(const KParams &P, const IceFactors &f, int layer)
+{
+    if (ICE) return 1.0f / (ldsf(P.off_sca_b + layer) * f.sca_pow);
+    return ldsf(P.off_sca_b + layer);                       // FunctionConstant.cxx:81-100
+}
+template <bool ICE>
+DM float absorption_length(const KParams &P, const IceFactors &f, int layer)
+{
+    if (ICE) return 1.0f / (ldsf(P.off_abs_a + layer) * f.abs_pow + f.abs_exp * ldsf(P.off_abs_b + layer));
+    return ldsf(P.off_abs_a + layer);
+}
+
+// HenyeyGreenstein.cxx:69-92
+DM float hg_cos(const KParams &P, float u)
+{
+    const float s = 2.0f * u - 1.0f;
+    const float ii = P.hg_one_minus_g2 / (1.0f + P.hg_g * s);
+    return clampf((P.hg_one_plus_g2 - ii * ii) / P.hg_two_g, -1.0f, 1.0f);
+}
+// SimplifiedLiu.cxx:64-88
+DM float liu_cos(const KParams &P, float u) { return clampf(2.0f * dm::powr_(u, P.liu_beta) - 1.0f, -1.0f, 1.0f); }
+// Mixed.cxx:115-157, single random number form
+DM float scattering_cos(const KParams &P, uint64_t &x, uint32_t a)
+{
+    const float rr = rng_co(x, a);
+    if (P.scatter_kind == 0) return hg_cos(P, rr);
+    if (P.scatter_kind == 1) return liu_cos(P, rr);
+    if (rr < P.mix_frac) return liu_cos(P, rr / P.mix_frac);
+    return hg_cos(P, (1.0f - rr) / P.mix_frac_rest);
+}
+
+// ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
+DM float abs_len_corr(const KParams &P, const Vec3 &d)
+{
+    const float n0 = (P.an_azx * d.x) + (P.an_azy * d.y);
+    const float n1 = (P.an_mazy * d.x) + (P.an_azx * d.y);
+    const float s0 = n0 * n0, s1 = n1 * n1, s2 = d.z * d.z;
+    // dot(float4,float4) with a zero 4th component: the +0 term cannot change a sum of squares
+    const float nB = (s0 * P.an_rl[0] + s1 * P.an_rl[1]) + s2 * P.an_rl[2];
+    const float An = (s0 * P.an_l[0] + s1 * P.an_l[1]) + s2 * P.an_l[2];
+    return 2.0f / ((P.an_B2 - nB) * An);
+}
+// VectorTransformMatrix.cxx:101-135
+DM void apply_matrix(const float m[9], int renorm, Vec3 &d)
+{
+    const float x = (m[0] * d.x) + (m[1] * d.y) + (m[2] * d.z);
+    const float y = (m[3] * d.x) + (m[4] * d.y) + (m[5] * d.z);
+    const float z = (m[6] * d.x) + (m[7] * d.y) + (m[8] * d.z);
+    d.x = x; d.y = y; d.z = z;
+    if (renorm) {
+        const float norm = dm::rsqrt_(d.x * d.x + d.y * d.y + d.z * d.z);
+        d.x = d.x * norm; d.y = d.y * norm; d.z = d.z * norm;
+    }
+}
+
+// ScalarFieldIceTiltZShift.cxx:145-213.  The distance bin is the first j with
+// nr < dist[j] (last bin otherwise); dist is ascending, so it is counted.
+DM float tilt_z_shift(const KParams &P, float px, float py, float pz)
+{
+    const float z_rescaled = (pz - P.tilt_first_z) / P.tilt_dz;
+    const int k = clampi((int)__builtin_floorf(z_rescaled), 0, P.tilt_nz - 2);
+    const float fraction_z_above = z_rescaled - (float)k;
+    const float fraction_z_below = 1.0f - fraction_z_above;
+    const float nr = P.tilt_lnx * px + P.tilt_lny * py;
+    int j = 1;
+    for (int t = 1; t < P.tilt_nd - 1; ++t) j += (nr >= ldsf(P.off_tilt_dist + t)) ? 1 : 0;
+    // j counts leading bins with nr >= dist; ascending order makes that the first failing bin
+    const float thisDist = ldsf(P.off_tilt_dist + j);
+    const float previousDist = ldsf(P.off_tilt_dist + j - 1);
+    const float width = thisDist - previousDist;
+    const float frac_at_lower = (thisDist - nr) / width;
+    const float frac_at_upper = 1.0f - frac_at_lower;
+    const uint32_t lo = P.off_tilt_zcorr + (uint32_t)((j - 1) * P.tilt_nz + k);
+    const uint32_t hi = lo + (uint32_t)P.tilt_nz;
+    const float val_at_lower = (ldsf(lo + 1) * fraction_z_above + ldsf(lo) * fraction_z_below);
+    const float val_at_upper = (ldsf(hi + 1) * fraction_z_above + ldsf(hi) * fraction_z_below);
+    return (val_at_upper * frac_at_upper + val_at_lower * frac_at_lower);
+}
+
+// InterpolatedDistribution.cxx:236-336 (constant spacing).  The reference scans
+// the cumulative table linearly for the first entry >= r; the table is
+// non-decreasing, so a bisection lands on the same bin.
+DM float generate_wavelength(const KParams &P, int gen, uint64_t &x, uint32_t a)
+{
+    if (P.gen_kind[gen] == 1) return P.gen_value[gen];      // RandomValueConstant
+    const float r = rng_oc(x, a);
+    const uint32_t cum = P.off_gen_ycum[gen], yv = P.off_gen_yv[gen];
+    int lo = 1, hi = P.gen_n[gen] - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ldsf(cum + mid) >= r) hi = mid; else lo = mid + 1;
+    }
+    const int k = lo - 1;
+    const float this_acu = (k == 0) ? 0.0f : ldsf(cum + k);
+    const float b = ldsf(yv + k);
+    const float sp = P.gen_spacing[gen];
+    const float x0 = (float)k * sp + P.gen_first[gen];
+    const float slope = (ldsf(yv + k + 1) - b) / sp;
+    const float dy = r - this_acu;
+    if ((b == 0.0f) && (slope == 0.0f)) return x0;
+    else if (b == 0.0f) return x0 + dm::sqrt_(2.0f * dy / slope);
+    else if (slope == 0.0f) return x0 + dy / b;
+    else return x0 + (dm::sqrt_(dy * (2.0f * slope) / (b * b) + 1.0f) - 1.0f) * b / slope;
+}
+
+// FunctionFromTable.cxx:167-300
+DM float wavelength_bias(const KParams &P, float wavelength)
+{
+    if (P.bias_kind == 1) return P.bias_value;
+    const float q = (wavelength - P.bias_start) / P.bias_step;
+    const float fbin = __builtin_truncf(q);
+    float fraction = q - fbin;
+    int ibin = (int)fbin;
+    if ((ibin < 0) || ((ibin == 0) && (fraction < 0.0f))) { ibin = 0; fraction = 0.0f; }
+    else if (ibin >= P.bias_n - 1) { ibin = P.bias_n - 2; fraction = 1.0f; }
+    const float v0 = ldsf(P.off_bias + ibin), v1 = ldsf(P.off_bias + ibin + 1);
+    return v0 + (v1 - v0) * fraction;
+}
+
+// GeometrySource.cxx:685-700
+DM void dom_position(const KParams &P, uint32_t s, uint32_t d, float &x, float &y, float &z)
+{
+    const uint32_t index = (ldsu(P.off_str_info + s) >> 8) + d;
+    x = (float)P.dom_tx[index] * P.dom_mul_x + ldsf(P.off_dom_meanx + s);
+    y = (float)P.dom_ty[index] * P.dom_mul_y + ldsf(P.off_dom_meany + s);
+    z = P.dom_tz[index];
+}
+
+// propagation_kernel.c.cl:83-129
+DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
+{
+    const float b = 2.0f * kPi * u;
+    float sinb, cosb;
+    dm::sincos_(b, sinb, cosb);
+    const float t = 1.0f - d.z * d.z;
+    const float sinth = dm::sqrt_((t > 0.0f) ? t : 0.0f);
+    if (sinth > 0.0f) {
+        const float ox = d.x, oy = d.y, oz = d.z;
+        d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
+        d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
+        d.z = oz * cosa + sina * sinb * sinth;
+    } else {
+        const float sgn = (d.z > 0.0f) ? 1.0f : ((d.z < 0.0f) ? -1.0f : d.z);
+        d.x = sina * cosb;
+        d.y = sina * sinb;
+        d.z = cosa * sgn;
+    }
+    const float recip_length = dm::rsqrt_(sqr(d.x) + sqr(d.y) + sqr(d.z));
+    d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
+}
+
+// propagation_kernel.c.cl:206-223
+DM void sph_dir_from_car(const Vec3 &d, float &theta, float &phi)
+{
+    const float r_inv = dm::rsqrt_(d.x * d.x + d.y * d.y + d.z * d.z);
+    theta = 0.0f;
+    if (__builtin_fabsf(d.z * r_inv) <= 1.0f) theta = dm::acos_(d.z * r_inv);
+    else if (d.z < 0.0f) theta = kPi;
+    if (theta < 0.0f) theta += 2.0f * kPi;
+    phi = dm::atan2_(d.y, d.x);
+    if (phi < 0.0f) phi += 2.0f * kPi;
+}
+
+struct Photon {
+    float px, py, pz, pt;       // position, time
+    Vec3 d;                     // direction
+    float wlen;
+    float sx, sy, sz, st;       // start position, time
+    Vec3 sd;                    // start direction
+    float inv_groupvel, total_path;
+    float abs_lens_left, abs_lens_initial;
+    uint32_t num_scatters;
+    IceFactors ice;
+    int layer;                  // carried layer index (getTiltZShift_IS_CONSTANT, c.cl:521-523)
+};
+
+// propagation_kernel.c.cl:132-184 + :553-589.  The step record is re-read from
+// HBM/L2 here (48 B every ~30 loop iterations) instead of living in registers.
+template <bool ICE, bool TILT, bool FLASHER>
+DM void create_photon(const KParams &P, const DevStep *step_ptr, uint64_t &rx, uint32_t ra, Photon &ph)
+{
+    const DevStep st = *step_ptr;
+    Vec3 step_dir;
+    {   // c.cl:482-489
+        float sin_t, cos_t, sin_p, cos_p;
+        dm::sincos_(st.theta, sin_t, cos_t);
+        dm::sincos_(st.phi, sin_p, cos_p);
+        step_dir.x = sin_t * cos_p; step_dir.y = sin_t * sin_p; step_dir.z = cos_t;
+    }
+    const float shift = st.length * rng_co(rx, ra);
+    const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);
+    ph.px = st.x + step_dir.x * shift;
+    ph.py = st.y + step_dir.y * shift;
+    ph.pz = st.z + step_dir.z * shift;
+    ph.pt = st.t + inv_speed * shift;
+    const uint32_t source_type = st.source_type_and_pad & 0xffu;
+    ph.d = step_dir;
+    if (!FLASHER || source_type == 0) {
+        const float wavelength = generate_wavelength(P, 0, rx, ra);
+        const float rcp = 1.0f / (st.beta * phase_ref_index(P, wavelength));
+        const float cos_c = (rcp < 1.0f) ? rcp : 1.0f;
+        const float sin_c = dm::sqrt_(1.0f - cos_c * cos_c);
+        ph.wlen = wavelength;
+        scatter_direction(cos_c, sin_c, ph.d, rng_co(rx, ra));
+    } else {
+        // generateWavelength(number): 0 for an out-of-range generator (MediumPropertiesSource.cxx:392-432)
+        ph.wlen = (source_type < (uint32_t)P.num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
+    }
+    ph.sx = ph.px; ph.sy = ph.py; ph.sz = ph.pz; ph.st = ph.pt;
+    ph.sd = ph.d;
+    ph.num_scatters = 0;
+    ph.total_path = 0.0f;
+    if (!TILT) ph.layer = clampi((int)((ph.pz - P.layer_bottom) / P.layer_thickness), 0, P.num_layers - 1);
+    ph.inv_groupvel = 1.0f / group_velocity(P, ph.wlen);
+    ph.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
+    ph.abs_lens_left = ph.abs_lens_initial;
+    ph.ice = ice_factors<ICE>(P, ph.wlen);
+}
+
+// propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
+template <bool ICE, bool TILT, bool ANISO>
+DM float propagate_through_layers(const KParams &P, Photon &ph, uint64_t &rx, uint32_t ra)
+{
+    float effective_z;
+    int current_layer;
+    if (TILT) {
+        effective_z = ph.pz - tilt_z_shift(P, ph.px, ph.py, ph.pz);
+        current_layer = clampi((int)((effective_z - P.layer_bottom) / P.layer_thickness), 0, P.num_layers - 1);
+    } else {
+        effective_z = ph.pz - P.tilt_const;
+        current_layer = ph.layer;
+    }
+    const float dz = ph.d.z;
+    // without anisotropy the factor is the literal 1.f: x*1 and x/1 are exact, so both are skipped
+    const float corr = (ANISO && P.has_abs_corr) ? abs_len_corr(P, ph.d) : 1.0f;
+    if (ANISO) ph.abs_lens_left *= corr;
+    const float lower = ((float)current_layer * P.layer_thickness) + P.layer_bottom;
+    float boundary = (dz < 0.0f) ? lower : (lower + P.layer_thickness);
+    const float sca_step_left = -dm::log_(rng_oc(rx, ra));
+    float sca_len = scattering_length<ICE>(P, ph.ice, current_layer);
+    float abs_len = absorption_length<ICE>(P, ph.ice, current_layer);
+    float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * P.recip_thickness;
+    float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * P.recip_thickness;
+    int j = current_layer;
+    if (dz < 0.0f) {
+        while ((j > 0) && (ais < 0.0f) && (aia < 0.0f)) {
+            --j;
+            boundary -= P.layer_thickness;
+            sca_len = scattering_length<ICE>(P, ph.ice, j);
+            abs_len = absorption_length<ICE>(P, ph.ice, j);
+            ais += 1.0f / sca_len;
+            aia += 1.0f / abs_len;
+        }
+    } else {
+        while ((j < P.num_layers - 1) && (ais > 0.0f) && (aia > 0.0f)) {
+            ++j;
+            boundary += P.layer_thickness;
+            sca_len = scattering_length<ICE>(P, ph.ice, j);
+            abs_len = absorption_length<ICE>(P, ph.ice, j);
+            ais -= 1.0f / sca_len;
+            aia -= 1.0f / abs_len;
+        }
+    }
+    float distance, to_absorption;
+    if ((current_layer == j) || (__builtin_fabsf(dz) < kEpsilon)) {
+        distance = sca_step_left * sca_len;
+        to_absorption = ph.abs_lens_left * abs_len;
+    } else {
+        const float recip_dz = 1.0f / dz;
+        distance = (ais * P.layer_thickness * sca_len + boundary - effective_z) * recip_dz;
+        to_absorption = (aia * P.layer_thickness * abs_len + boundary - effective_z) * recip_dz;
+    }
+    if (!TILT) ph.layer = j;
+    if (to_absorption < distance) {
+        distance = to_absorption;
+        ph.abs_lens_left = 0.0f;
+    } else {
+        ph.abs_lens_left = (to_absorption - distance) / abs_len;
+    }
+    if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;
+    return distance;
+}
+
+// sparse_collision_kernel.c.cl:27-192 (STOP_PHOTONS_ON_DETECTION)
+DM void collide_with_string(const KParams &P, uint32_t s, float dir_len_xy_sqr, const Photon &ph, float &step_len,
+                            bool &hit, uint32_t &hit_string, uint32_t &hit_dom)
+{
+    {
+        const float smin = sqr((ph.px - ldsf(P.off_str_x + s)) * ph.d.y - (ph.py - ldsf(P.off_str_y + s)) * ph.d.x) / dir_len_xy_sqr;
+        if (smin > P.string_max_radius_sq) return;
+    }
+    if ((ph.d.z > 0.0f) && (ph.pz > ldsf(P.off_str_top + s))) return;
+    if ((ph.d.z < 0.0f) && (ph.pz < ldsf(P.off_str_bottom + s))) return;
+    const uint32_t set = ldsu(P.off_str_info + s) & 0xffu;
+    const float start_z = ldsf(P.off_set_startz + set), height = ldsf(P.off_set_height + set);
+    const int nl = (int)ldsu(P.off_set_nlayers + set);
+    int low = (int)((ph.pz - start_z) / height);
+    int high = (int)((ph.pz + ph.d.z * step_len - start_z) / height);
+    if (high < low) { const int tmp = low; low = high; high = tmp; }
+    low = clampi(low, 0, nl - 1);
+    high = clampi(high, 0, nl - 1);
+    const uint32_t base = set * (uint32_t)P.max_layers;
+    for (int layer = low; layer <= high; ++layer) {
+        const uint32_t dom = lds_u16(P.off_layer_to_om, base + (uint32_t)layer);
+        if (dom == 0xFFFFu) continue;
+        float dom_x, dom_y, dom_z;
+        dom_position(P, s, dom, dom_x, dom_y, dom_z);
+        const float dx = dom_x - ph.px, dy = dom_y - ph.py, dzz = dom_z - ph.pz;
+        // dot() of float4s whose 4th component is 0: ((x+y)+z); the trailing +0 only matters for -0
+        const float dr2 = (dx * dx + dy * dy) + dzz * dzz;
+        const float urdot = (dx * ph.d.x + dy * ph.d.y) + dzz * ph.d.z;
+        float discr = sqr(urdot) - dr2 + P.om_radius_sq;
+        if (discr < 0.0f) continue;
+        discr = P.has_pancake ? (dm::sqrt_(discr) / P.pancake) : dm::sqrt_(discr);
+        if (urdot + discr < 0.0f) continue;
+        const float smin1 = urdot - discr;
+        if (smin1 < 0.0f) continue;
+        if (smin1 < step_len) {
+            step_len = smin1;
+            hit_string = s;
+            hit_dom = dom;
+            hit = true;
+        }
+    }
+}
+
+// sparse_collision_kernel.c.cl:194-303 + :462-547
+DM bool find_collision(const KParams &P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
+{
+    const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
+    if (dir_len_xy_sqr <= 0.0f) return false;
+    bool hit = false;
+    for (int sd = 0; sd < P.num_subdet; ++sd) {
+        const float sx = P.cell_sx[sd], sy = P.cell_sy[sd], wx = P.cell_wx[sd], wy = P.cell_wy[sd];
+        const int nx = P.cell_nx[sd], ny = P.cell_ny[sd];
+        int low_x = (int)((ph.px - sx) / wx);
+        int low_y = (int)((ph.py - sy) / wy);
+        int high_x = (int)((ph.px + ph.d.x * step_len - sx) / wx);
+        int high_y = (int)((ph.py + ph.d.y * step_len - sy) / wy);
+        if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
+        if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
+        low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);
+        high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
+        for (int cy = low_y; cy <= high_y; ++cy)
+            for (int cx = low_x; cx <= high_x; ++cx) {
+                const uint32_t s = lds_u16(P.off_cell[sd], (uint32_t)(cy * nx + cx));
+                if (s == 0xFFFFu) continue;
+                collide_with_string(P, s, dir_len_xy_sqr, ph, step_len, hit, hit_string, hit_dom);
+            }
+    }
+    return hit;
+}
+
+// propagation_kernel.c.cl:307-404: assemble the 20 words of an I3CLSimPhoton
+DM void make_hit_record(const KParams &P, const Photon &ph, float step_len, float dist_abs_lens, const DevStep *step_ptr,
+                        uint32_t hit_string, uint32_t hit_dom, uint32_t *rec)
+{
+    float dom_x, dom_y, dom_z;
+    dom_position(P, hit_string, hit_dom, dom_x, dom_y, dom_z);
+    if (P.has_pancake) {
+        const float qx = ph.px - dom_x, qy = ph.py - dom_y, qz = ph.pz - dom_z;
+        const float parallel = qx * ph.d.x + qy * ph.d.y + qz * ph.d.z;
+        const float nx = qx - parallel * ph.d.x;
+        const float ny = qy - parallel * ph.d.y;
+        const float nz = qz - parallel * ph.d.z;
+        dom_x += P.unpancake * nx; dom_y += P.unpancake * ny; dom_z += P.unpancake * nz;
+    }
+    float theta, phi, stheta, sphi;
+    sph_dir_from_car(ph.d, theta, phi);
+    sph_dir_from_car(ph.sd, stheta, sphi);
+    const float weight = step_ptr->weight / wavelength_bias(P, ph.wlen);
+    rec[0] = dm::f2u(ph.px + step_len * ph.d.x - dom_x);
+    rec[1] = dm::f2u(ph.py + step_len * ph.d.y - dom_y);
+    rec[2] = dm::f2u(ph.pz + step_len * ph.d.z - dom_z);
+    rec[3] = dm::f2u(ph.pt + step_len * ph.inv_groupvel);
+    rec[4] = dm::f2u(theta);
+    rec[5] = dm::f2u(phi);
+    rec[6] = dm::f2u(ph.wlen);
+    rec[7] = dm::f2u(ph.total_path + step_len);
+    rec[8] = ph.num_scatters;
+    rec[9] = dm::f2u(weight);
+    rec[10] = step_ptr->identifier;
+    rec[11] = (hit_string & 0xffffu) | (hit_dom << 16);     // short stringID, ushort omID
+    rec[12] = dm::f2u(ph.sx);
+    rec[13] = dm::f2u(ph.sy);
+    rec[14] = dm::f2u(ph.sz);
+    rec[15] = dm::f2u(ph.st);
+    rec[16] = dm::f2u(stheta);
+    rec[17] = dm::f2u(sphi);
+    rec[18] = dm::f2u(1.0f / ph.inv_groupvel);
+    rec[19] = dm::f2u(dist_abs_lens);
+}
+
+template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
+__global__ void __launch_bounds__(kBlock) prop_kernel(const KParams P)
+{
+    // stage the table block: one coalesced pass of the workgroup
+    for (uint32_t i = threadIdx.x; i < P.table_words; i += kBlock) lds_words[i] = P.tables[i];
+    uint32_t *stage = lds_words + P.table_words + (threadIdx.x >> 6) * (kStageRecords * 20);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const bool in_range = gid < P.n_steps;
+    const DevStep *step_ptr = P.steps + (in_range ? gid : 0);
+    uint64_t rx = 0;
+    uint32_t ra = 0;
+    uint32_t photons_left = 0;
+    if (in_range) {
+        rx = P.rng_x[gid];
+        ra = P.rng_a[gid];
+        photons_left = step_ptr->num_photons;
+    }
+    Photon ph;
+    ph.abs_lens_left = 0.0f;
+    ph.abs_lens_initial = 0.0f;
+    ph.layer = 0;
+
+    bool alive = photons_left > 0;
+    while (__ballot(alive) != 0ull) {
+        float distance = 0.0f;
+        bool hit = false;
+        uint32_t hit_string = 0, hit_dom = 0;
+        if (alive) {
+            if (ph.abs_lens_left < kEpsilon) create_photon<ICE, TILT, FLASHER>(P, step_ptr, rx, ra, ph);
+            distance = propagate_through_layers<ICE, TILT, ANISO>(P, ph, rx, ra);
+            hit = find_collision(P, ph, distance, hit_string, hit_dom);
+        }
+        // ---- wave-aggregated hit write-out (c.cl:329-385, sparse_collision c.cl:557-578) ----
+        const uint64_t hit_mask = __ballot(hit);
+        if (hit_mask != 0ull) {
+            const uint32_t total = (uint32_t)__popcll(hit_mask);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(P.hit_count, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t rank = (uint32_t)__popcll(hit_mask & ((1ull << lane) - 1ull));
+            for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
+                if (hit && rank >= chunk && rank < chunk + kStageRecords)
+                    make_hit_record(P, ph, distance, ph.abs_lens_initial - ph.abs_lens_left, step_ptr, hit_string, hit_dom,
+                                    stage + (rank - chunk) * 20);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t first = base + chunk;
+                const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
+                // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
+                const uint32_t room = (first < P.max_hits) ? (P.max_hits - first) : 0u;
+                const uint32_t words = ((count < room) ? count : room) * 20u;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(P.out) + (size_t)first * 20u;
+                for (uint32_t w = lane; w < words; w += 64u) dst[w] = stage[w];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (alive) {
+            if (hit) ph.abs_lens_left = 0.0f;                               // c.cl:741-744
+            ph.px += ph.d.x * distance;
+            ph.py += ph.d.y * distance;
+            ph.pz += ph.d.z * distance;
+            ph.pt += ph.inv_groupvel * distance;
+            ph.total_path += distance;
+            if (ph.abs_lens_left < kEpsilon) {
+                --photons_left;
+                alive = photons_left > 0;
+            } else {
+                if (ANISO && P.has_pre) apply_matrix(P.pre, P.pre_renorm, ph.d);
+                const float cos_s = scattering_cos(P, rx, ra);
+                const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
+                scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
+                if (ANISO && P.has_post) apply_matrix(P.post, P.post_renorm, ph.d);
+                ++ph.num_scatters;
+            }
+        }
+    }
+    if (in_range) P.rng_x[gid] = rx;                                        // c.cl:911-912
+}
+
+// ---- math probe used by tests/test_detmath_gpu.py ----
+__global__ void eval_math_kernel(int what, const float *xs, const float *ys, uint32_t n, float *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xs[i], y = ys ? ys[i] : 0.0f;
+    float r = 0.0f, s, c;
+    switch (what) {
+    case 0: r = dm::log_(x); break;
+    case 1: r = dm::exp_(x); break;
+    case 2: dm::sincos_(x, s, c); r = s; break;
+    case 3: dm::sincos_(x, s, c); r = c; break;
+    case 4: r = dm::powr_(x, y); break;
+    case 5: r = dm::acos_(x); break;
+    case 6: r = dm::atan2_(x, y); break;
+    case 7: r = dm::rsqrt_(x); break;
+    case 8: r = dm::sqrt_(x); break;
+    case 9: r = x / y; break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+// ---- host-side launchers (called from converter.cpp) ----
+template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
+static hipError_t launch_variant(const KParams &P, hipStream_t stream)
+{
+    const uint32_t grid = (P.n_steps + kBlock - 1) / kBlock;
+    const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * 20) * 4;
+    hipLaunchKernelGGL((prop_kernel<ICE, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
+{
+    if (P.n_steps == 0) return hipSuccess;
+    const int key = (v.icecube_lengths ? 8 : 0) | (v.tilt ? 4 : 0) | (v.aniso ? 2 : 0) | (v.flasher ? 1 : 0);
+    switch (key) {
+#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d>(P, stream);
+    CASE(0, false, false, false, false) CASE(1, false, false, false, true)
+    CASE(2, false, false, true, false)  CASE(3, false, false, true, true)
+    CASE(4, false, true, false, false)  CASE(5, false, true, false, true)
+    CASE(6, false, true, true, false)   CASE(7, false, true, true, true)
+    CASE(8, true, false, false, false)  CASE(9, true, false, false, true)
+    CASE(10, true, false, true, false)  CASE(11, true, false, true, true)
+    CASE(12, true, true, false, false)  CASE(13, true, true, false, true)
+    CASE(14, true, true, true, false)   CASE(15, true, true, true, true)
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * 20) * 4; }
+int prop_kernel_block_size() { return kBlock; }
+
+hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, what, xs, ys, n, out);
+    return hipGetLastError();
+}
+
+} // namespace clsimhip

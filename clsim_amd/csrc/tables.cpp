@@ -1,0 +1,297 @@
+// Compile(): configuration (doubles) -> kernel constants (float literals) + LDS image.
+//
+// The reference does this by printing OpenCL source
+// (private/opencl/I3CLSimHelperGenerateMediumPropertiesSource{,_Optimizers}.cxx,
+// the GetOpenCLFunction() members under private/clsim/function and random_value,
+// I3CLSimStepToPhotonConverterOpenCL.cxx:390-533).  Each constant below is the
+// float that source text would hold; per-layer combinations that the generated
+// code recomputes on every call ((D*aDust+E), (1+0.01*deltaTau), OM_RADIUS^2,
+// maxZ+OM_RADIUS ...) are folded here with the same single precision operations.
+#include <cmath>
+#include <cstring>
+
+#include "converter.h"
+
+namespace clsimhip {
+namespace {
+
+struct Image {
+    std::vector<uint32_t> words;
+    uint32_t add_floats(const std::vector<float> &v)
+    {
+        const uint32_t off = static_cast<uint32_t>(words.size());
+        for (float f : v) { uint32_t u; std::memcpy(&u, &f, 4); words.push_back(u); }
+        return off;
+    }
+    uint32_t add_words(const std::vector<uint32_t> &v)
+    {
+        const uint32_t off = static_cast<uint32_t>(words.size());
+        words.insert(words.end(), v.begin(), v.end());
+        return off;
+    }
+    uint32_t add_u16(const std::vector<uint16_t> &v)
+    {
+        const uint32_t off = static_cast<uint32_t>(words.size());
+        for (size_t i = 0; i < v.size(); i += 2) {
+            const uint32_t lo = v[i], hi = (i + 1 < v.size()) ? v[i + 1] : 0xFFFFu;
+            words.push_back(lo | (hi << 16));
+        }
+        return off;
+    }
+};
+
+template <class T>
+std::vector<double> as_doubles(const std::vector<T> &v) { return std::vector<double>(v.begin(), v.end()); }
+
+std::vector<float> literals(const std::vector<double> &v)
+{
+    std::vector<float> out(v.size());
+    for (size_t i = 0; i < v.size(); ++i) out[i] = to_float_literal(v[i]);
+    return out;
+}
+
+} // namespace
+
+CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry,
+                              const std::vector<RandomValueData> &generators, const FunctionData &bias, double pancake)
+{
+    m.validate();
+    CompiledTables C;
+    KParams &P = C.params;
+    Image img;
+    auto name = [&](const std::string &k, const std::vector<double> &v) { C.named[k] = v; };
+    auto scalar = [&](const std::string &k, double v) { C.named[k] = std::vector<double>(1, v); };
+
+    // ---------------- medium (MediumPropertiesSource.cxx:207-389) ----------------
+    P.num_layers = m.num_layers;
+    P.layer_bottom = to_float_literal(m.layers_z_start);
+    P.layer_thickness = to_float_literal(m.layers_height);
+    P.recip_thickness = 1.0f / P.layer_thickness;                  // (ONE/MEDIUM_LAYER_THICKNESS), c.cl:639
+    scalar("MEDIUM_LAYERS", m.num_layers);
+    scalar("MEDIUM_LAYER_BOTTOM_POS", P.layer_bottom);
+    scalar("MEDIUM_LAYER_THICKNESS", P.layer_thickness);
+    P.nanometer = to_float_literal(units::nanometer);
+    P.micrometer = to_float_literal(units::micrometer);
+    P.c_light = to_float_literal(units::c_light);
+    for (int i = 0; i < 5; ++i) { P.n[i] = to_float_literal(m.n[i]); P.g[i] = to_float_literal(m.g[i]); }
+    C.variant.icecube_lengths = (m.lengths_kind == CLSIMHIP_LENGTHS_ICECUBE);
+    if (C.variant.icecube_lengths) {
+        // _Optimizers.cxx:123-250 (the per-function form, AbsLenIceCube.cxx:70-93, has the same arithmetic)
+        const std::vector<float> a_dust = literals(m.a_dust400), d_tau = literals(m.delta_tau), b400 = literals(m.b400);
+        const float D = to_float_literal(m.D), E = to_float_literal(m.E);
+        std::vector<float> abs_a(a_dust.size()), abs_b(a_dust.size());
+        for (size_t l = 0; l < a_dust.size(); ++l) {
+            const float t = D * a_dust[l];
+            abs_a[l] = t + E;                                       // (D*aDust400[layer]+E)
+            const float u = 0.01f * d_tau[l];
+            abs_b[l] = 1.f + u;                                     // (1.f + 0.01f*deltaTau[layer])
+        }
+        P.off_abs_a = img.add_floats(abs_a);
+        P.off_abs_b = img.add_floats(abs_b);
+        P.off_sca_b = img.add_floats(b400);
+        P.neg_kappa = -to_float_literal(m.kappa);
+        P.abs_A = to_float_literal(m.A);
+        P.neg_B = -to_float_literal(m.B);
+        P.neg_alpha = -to_float_literal(m.alpha);
+        P.ref_wlen_recip = to_float_literal(1. / (400. * units::nanometer));
+        name("aDust400", as_doubles(a_dust)); name("deltaTau", as_doubles(d_tau)); name("b400", as_doubles(b400));
+        scalar("kappa", -P.neg_kappa); scalar("A", P.abs_A); scalar("B", -P.neg_B); scalar("D", D); scalar("E", E);
+        scalar("alpha", -P.neg_alpha);
+    } else {
+        const std::vector<float> abs_c = literals(m.abs_length), sca_c = literals(m.sca_length);
+        P.off_abs_a = img.add_floats(abs_c);
+        P.off_abs_b = P.off_abs_a;
+        P.off_sca_b = img.add_floats(sca_c);
+        name("absorptionLength", as_doubles(abs_c)); name("scatteringLength", as_doubles(sca_c));
+    }
+    {   // Mixed.cxx:115-157, SimplifiedLiu.cxx:64-88, HenyeyGreenstein.cxx:69-92
+        const double g = m.mean_cosine;
+        P.scatter_kind = m.scatter_kind;
+        P.liu_beta = to_float_literal((1. - g) / (1. + g));
+        P.hg_g = to_float_literal(g);
+        const float g2 = to_float_literal(g * g);
+        P.hg_one_minus_g2 = 1.f - g2;
+        P.hg_one_plus_g2 = 1.f + g2;
+        P.hg_two_g = 2.f * P.hg_g;
+        P.mix_frac = to_float_literal(m.liu_fraction);
+        P.mix_frac_rest = to_float_literal(1. - m.liu_fraction);
+        scalar("liu_beta", P.liu_beta); scalar("hg_g", P.hg_g); scalar("hg_g2", g2);
+        scalar("mix_frac", P.mix_frac); scalar("mix_frac_rest", P.mix_frac_rest);
+    }
+    C.variant.aniso = m.has_aniso || m.has_pre || m.has_post;
+    P.abs_corr_const = to_float_literal(1.);
+    P.has_abs_corr = m.has_aniso ? 1 : 0;
+    if (m.has_aniso) {
+        // ScalarFieldAnisotropyAbsLenScaling.cxx:96-108
+        const double azx = std::cos(m.aniso_azimuth), azy = std::sin(m.aniso_azimuth);
+        const double k1 = std::exp(m.aniso_k1), k2 = std::exp(m.aniso_k2), kz = 1. / (k1 * k2);
+        const double l1 = k1 * k1, l2 = k2 * k2, l3 = kz * kz;
+        const double B2 = 1. / l1 + 1. / l2 + 1. / l3;
+        P.an_l[0] = to_float_literal(l1); P.an_l[1] = to_float_literal(l2); P.an_l[2] = to_float_literal(l3);
+        P.an_rl[0] = to_float_literal(1. / l1); P.an_rl[1] = to_float_literal(1. / l2); P.an_rl[2] = to_float_literal(1. / l3);
+        P.an_azx = to_float_literal(azx); P.an_azy = to_float_literal(azy); P.an_mazy = to_float_literal(-azy);
+        P.an_B2 = to_float_literal(B2);
+        name("anisotropy", {P.an_l[0], P.an_l[1], P.an_l[2], P.an_rl[0], P.an_rl[1], P.an_rl[2], P.an_azx, P.an_azy, P.an_mazy, P.an_B2});
+    }
+    P.has_pre = m.has_pre ? 1 : 0; P.pre_renorm = m.pre_renorm ? 1 : 0;
+    P.has_post = m.has_post ? 1 : 0; P.post_renorm = m.post_renorm ? 1 : 0;
+    for (int i = 0; i < 9; ++i) { P.pre[i] = to_float_literal(m.pre[i]); P.post[i] = to_float_literal(m.post[i]); }
+    if (m.has_pre) name("transformDirectionPreScatter", std::vector<double>(P.pre, P.pre + 9));
+    if (m.has_post) name("transformDirectionPostScatter", std::vector<double>(P.post, P.post + 9));
+    C.variant.tilt = m.has_tilt;
+    P.tilt_const = to_float_literal(0.);
+    if (m.has_tilt) {
+        // ScalarFieldIceTiltZShift.cxx:62-100 (constructor) and :145-213
+        const size_t nd = m.tilt_distances.size(), nz = m.tilt_z.size();
+        double mean_spacing = 0.;
+        for (size_t i = 0; i + 1 < nz; ++i) {
+            const double sp = m.tilt_z[i + 1] - m.tilt_z[i];
+            if (sp <= 0.) throw Error(CLSIMHIP_ERR_ARGUMENT, "zCoordinates (dimension 2) are not in ascending order.");
+            mean_spacing += sp;
+        }
+        mean_spacing /= static_cast<double>(nz - 1);
+        for (size_t i = 0; i + 1 < nz; ++i)
+            if (std::abs((m.tilt_z[i + 1] - m.tilt_z[i]) - mean_spacing) > 1e-5)
+                throw Error(CLSIMHIP_ERR_ARGUMENT, "zCoordinates (dimension 2) are not in equally spaced.");
+        for (size_t i = 0; i + 1 < nd; ++i)
+            if (m.tilt_distances[i + 1] - m.tilt_distances[i] <= 0.)
+                throw Error(CLSIMHIP_ERR_ARGUMENT, "distancesFromOriginAlongTilt (dimension 1) is not in ascending order.");
+        P.tilt_nd = static_cast<int>(nd);
+        P.tilt_nz = static_cast<int>(nz);
+        P.tilt_first_z = to_float_literal(m.tilt_z[0]);
+        P.tilt_dz = to_float_literal(mean_spacing);
+        P.tilt_lnx = to_float_literal(std::cos(m.tilt_azimuth));
+        P.tilt_lny = to_float_literal(std::sin(m.tilt_azimuth));
+        const std::vector<float> dist = literals(m.tilt_distances), corr = literals(m.tilt_corr);
+        // the kernel counts bins on the literals: they must stay strictly ordered after rounding
+        for (size_t i = 0; i + 1 < nd; ++i)
+            if (!(dist[i] < dist[i + 1])) throw Error(CLSIMHIP_ERR_CONFIG, "tilt distances collapse in single precision");
+        P.off_tilt_dist = img.add_floats(dist);
+        P.off_tilt_zcorr = img.add_floats(corr);
+        name("getTiltZShift_data_distancesFromOriginAlongTilt", as_doubles(dist));
+        name("getTiltZShift_data_zCorrections", as_doubles(corr));
+        scalar("getTiltZShift_data_firstZCoord", P.tilt_first_z);
+        scalar("getTiltZShift_data_zCoordSpacing", P.tilt_dz);
+        scalar("getTiltZShift_lnx", P.tilt_lnx); scalar("getTiltZShift_lny", P.tilt_lny);
+    }
+
+    // ---------------- spectra ----------------
+    if (generators.empty()) throw Error(CLSIMHIP_ERR_CONFIG, "no wavelength generator set");
+    if (generators.size() > static_cast<size_t>(kMaxGenerators)) throw Error(CLSIMHIP_ERR_CONFIG, "too many wavelength generators");
+    P.num_gen = static_cast<int>(generators.size());
+    C.variant.flasher = generators.size() > 1;                     // NO_FLASHER, OpenCL.cxx:648-650
+    for (size_t k = 0; k < generators.size(); ++k) {
+        const RandomValueData &g = generators[k];
+        P.gen_kind[k] = g.kind;
+        if (g.kind == CLSIMHIP_RANDOM_CONSTANT) {
+            P.gen_value[k] = to_float_literal(g.value);
+            continue;
+        }
+        // InterpolatedDistribution.cxx:134-175 (InitTables) and :177-234 (WriteTableCode)
+        const size_t n = g.y.size();
+        if (n < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified for an interpolated distribution.");
+        if (!(g.spacing > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "\"xSpacing\" must not be <= 0!");
+        std::vector<double> acu(n, 0.), beta(n, 0.);
+        for (size_t j = 1; j < n; ++j) acu[j] = acu[j - 1] + (g.spacing) * (g.y[j] + g.y[j - 1]) / 2.;
+        const double total = acu[n - 1];
+        for (size_t j = 0; j < n; ++j) { beta[j] = g.y[j] / total; acu[j] = acu[j] / total; }
+        const std::vector<float> yv = literals(beta), ycum = literals(acu);
+        for (size_t j = 0; j + 1 < n; ++j)
+            if (ycum[j] > ycum[j + 1]) throw Error(CLSIMHIP_ERR_CONFIG, "cumulative spectrum is not monotonic (negative density?)");
+        P.gen_n[k] = static_cast<int>(n);
+        P.gen_first[k] = to_float_literal(g.first);
+        P.gen_spacing[k] = to_float_literal(g.spacing);
+        P.off_gen_yv[k] = img.add_floats(yv);
+        P.off_gen_ycum[k] = img.add_floats(ycum);
+        const std::string prefix = "_generateWavelength_" + std::to_string(k);
+        name(prefix + "distYValues", as_doubles(yv));
+        name(prefix + "distYCumulativeValues", as_doubles(ycum));
+    }
+    P.bias_kind = bias.kind;
+    if (bias.kind == CLSIMHIP_FUNCTION_TABLE) {
+        // FunctionFromTable.cxx:167-300
+        if (bias.values.size() < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "values must contain at least 2 elements!");
+        if (!(bias.step > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "wlenStep must not be <= 0!");
+        const std::vector<float> data = literals(bias.values);
+        P.bias_n = static_cast<int>(data.size());
+        P.bias_start = to_float_literal(bias.start);
+        P.bias_step = to_float_literal(bias.step);
+        P.off_bias = img.add_floats(data);
+        name("getWavelengthBias_data", as_doubles(data));
+    } else {
+        P.bias_value = to_float_literal(bias.value);
+    }
+
+    // ---------------- detector (GeometrySource.cxx) ----------------
+    C.geo = build_geometry(geometry);
+    const GeoTables &G = C.geo;
+    if (G.cells.size() > static_cast<size_t>(kMaxSubdetectors)) throw Error(CLSIMHIP_ERR_CONFIG, "more than 9 subdetectors are currently not supported.");
+    P.has_pancake = (pancake != 1.) ? 1 : 0;                       // OpenCL.cxx:432
+    P.pancake = to_float_literal(pancake);
+    P.unpancake = (P.pancake - 1.f) / P.pancake;                   // c.cl:351
+    P.om_radius = G.om_radius;
+    P.om_radius_sq = G.om_radius * G.om_radius;                    // OM_RADIUS*OM_RADIUS, collision c.cl:118
+    P.string_max_radius_sq = G.string_max_radius * G.string_max_radius;   // sqr(GEO_STRING_MAX_RADIUS), collision c.cl:64
+    P.num_strings = G.num_strings;
+    P.num_sets = G.num_sets;
+    P.max_layers = G.max_layers;
+    P.num_subdet = static_cast<int>(G.cells.size());
+    std::vector<float> top(G.num_strings), bottom(G.num_strings);
+    std::vector<uint32_t> info(G.num_strings);
+    for (int s = 0; s < G.num_strings; ++s) {
+        top[s] = G.str_maxz[s] + G.om_radius;                      // collision c.cl:68-69
+        bottom[s] = G.str_minz[s] - G.om_radius;
+        if (G.dom_start[s] >= (1u << 24)) throw Error(CLSIMHIP_ERR_CONFIG, "too many DOMs");
+        info[s] = static_cast<uint32_t>(G.str_set[s]) | (G.dom_start[s] << 8);
+    }
+    P.off_str_x = img.add_floats(G.str_x);
+    P.off_str_y = img.add_floats(G.str_y);
+    P.off_str_top = img.add_floats(top);
+    P.off_str_bottom = img.add_floats(bottom);
+    P.off_str_info = img.add_words(info);
+    P.off_dom_meanx = img.add_floats(G.dom_meanx);
+    P.off_dom_meany = img.add_floats(G.dom_meany);
+    P.off_set_nlayers = img.add_words(std::vector<uint32_t>(G.set_nlayers.begin(), G.set_nlayers.end()));
+    P.off_set_startz = img.add_floats(G.set_startz);
+    P.off_set_height = img.add_floats(G.set_height);
+    P.off_layer_to_om = img.add_u16(G.layer_to_om);
+    for (size_t k = 0; k < G.cells.size(); ++k) {
+        const GeoTables::Cells &c = G.cells[k];
+        P.cell_nx[k] = c.nx; P.cell_ny[k] = c.ny;
+        P.cell_wx[k] = c.wx; P.cell_wy[k] = c.wy; P.cell_sx[k] = c.sx; P.cell_sy[k] = c.sy;
+        P.off_cell[k] = img.add_u16(c.index);
+        const std::string sfx = "_" + std::to_string(k);
+        name("geoCellIndex" + sfx, as_doubles(c.index));
+        name("GEO_CELL" + sfx, {double(c.nx), double(c.ny), c.wx, c.wy, c.sx, c.sy});
+    }
+    P.dom_mul_x = G.dom_mul_x;
+    P.dom_mul_y = G.dom_mul_y;
+    scalar("NUM_STRINGS", G.num_strings); scalar("OM_RADIUS", G.om_radius);
+    scalar("GEO_STRING_MAX_RADIUS", G.string_max_radius);
+    scalar("GEO_LAYER_STRINGSET_NUM", G.num_sets); scalar("GEO_LAYER_STRINGSET_MAX_NUM_LAYERS", G.max_layers);
+    scalar("GEO_MAX_DOM_INDEX", G.max_dom_index);
+    scalar("GEO_DOM_POS_MAX_ABS_X_MULTIPLIER_IN_TEMPLATE", G.dom_mul_x);
+    scalar("GEO_DOM_POS_MAX_ABS_Y_MULTIPLIER_IN_TEMPLATE", G.dom_mul_y);
+    name("geoStringPosX", as_doubles(G.str_x)); name("geoStringPosY", as_doubles(G.str_y));
+    name("geoStringRadius", as_doubles(G.str_radius));
+    name("geoStringMinZ", as_doubles(G.str_minz)); name("geoStringMaxZ", as_doubles(G.str_maxz));
+    name("geoStringInStringSet", as_doubles(G.str_set));
+    name("geoLayerNum", as_doubles(G.set_nlayers));
+    name("geoLayerStartZ", as_doubles(G.set_startz)); name("geoLayerHeight", as_doubles(G.set_height));
+    name("geoLayerToOMNumIndexPerStringSet", as_doubles(G.layer_to_om));
+    name("geoDomPosTemplatePositionsX_flat", as_doubles(G.dom_tx));
+    name("geoDomPosTemplatePositionsY_flat", as_doubles(G.dom_ty));
+    name("geoDomPosTemplatePositionsZ_flat", as_doubles(G.dom_tz));
+    name("geoDomPosStringStartIndexInTemplateDomList", as_doubles(G.dom_start));
+    name("geoDomPosStringMeanPosX", as_doubles(G.dom_meanx)); name("geoDomPosStringMeanPosY", as_doubles(G.dom_meany));
+    name("stringIndexToStringID", as_doubles(G.string_index_to_id));
+    scalar("PANCAKE_FACTOR", P.pancake);
+
+    P.table_words = static_cast<uint32_t>(img.words.size());
+    C.lds_image = std::move(img.words);
+    if (prop_kernel_lds_bytes(P.table_words) > 60 * 1024)
+        throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables do not fit the LDS budget of the propagation kernel");
+    return C;
+}
+
+} // namespace clsimhip

@@ -1,0 +1,226 @@
+/*
+ * clsimhip.h -- C ABI of the MI355X photon propagator (libclsimhip.so).
+ *
+ * This is the drop-in boundary behind clsim's step->photon converter: every
+ * entry point replaces one member of the reference's C++ interface
+ *   public/clsim/I3CLSimStepToPhotonConverter.h:67-192        (abstract interface)
+ *   public/clsim/I3CLSimStepToPhotonConverterOpenCL.h:78-258  (concrete setters)
+ * or one host helper the canonical caller uses to configure it
+ *   private/clsim/I3CLSimModuleHelper.cxx:175-372, python/MakeIceCubeMediumProperties.py,
+ *   python/GetIceCubeDOMAcceptance.py, private/opencl/mwcrng_init.h.
+ * Plain pointers and sizes only; no C++ / torch types.  All functions return
+ * CLSIMHIP_OK (0) or a negative status; clsimhip_last_error() gives the text
+ * (the reference throws I3CLSimStepToPhotonConverter_exception with that text).
+ *
+ * Records are the reference's packed little-endian wire structs:
+ *   step   48 B  public/clsim/I3CLSimStep.h:141-155
+ *   photon 80 B  public/clsim/I3CLSimPhoton.h:194-213
+ */
+#ifndef CLSIMHIP_H
+#define CLSIMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLSIMHIP_OK 0
+#define CLSIMHIP_ERR_ARGUMENT (-1)  /* null / empty / out-of-range argument            */
+#define CLSIMHIP_ERR_STATE (-2)     /* setter after Initialize, use before Initialize   */
+#define CLSIMHIP_ERR_CONFIG (-3)    /* configuration this build cannot run              */
+#define CLSIMHIP_ERR_DEVICE (-4)    /* HIP runtime error / no GPU                       */
+#define CLSIMHIP_ERR_IO (-5)        /* file not found / malformed table                 */
+
+typedef struct clsimhip_converter clsimhip_converter;
+typedef struct clsimhip_medium clsimhip_medium;
+
+/* I3CLSimStep (48 B) and I3CLSimPhoton (80 B), byte-compatible with the reference. */
+#pragma pack(push, 1)
+typedef struct {
+    float x, y, z, time;
+    float theta, phi, length, beta;
+    uint32_t num_photons;
+    float weight;
+    uint32_t identifier;
+    uint8_t source_type, dummy1;
+    uint16_t dummy2;
+} clsimhip_step;
+typedef struct {
+    float x, y, z, time;
+    float theta, phi, wavelength, cherenkov_dist;
+    uint32_t num_scatters;
+    float weight;
+    uint32_t identifier;
+    int16_t string_id;
+    uint16_t om_id;
+    float start_x, start_y, start_z, start_time;
+    float start_theta, start_phi, group_velocity, dist_in_abs_lens;
+} clsimhip_photon;
+#pragma pack(pop)
+
+/* ---- value descriptions (doubles, like the reference's function objects) ---- */
+
+/* I3CLSimFunction: FromTable (equal spacing) or Constant.
+ * private/clsim/function/I3CLSimFunctionFromTable.cxx:70-90, ...Constant.cxx:40-44 */
+#define CLSIMHIP_FUNCTION_TABLE 0
+#define CLSIMHIP_FUNCTION_CONSTANT 1
+typedef struct {
+    int32_t kind;
+    int32_t n;               /* TABLE: number of entries (>=2)            */
+    double start, step;      /* TABLE: first wavelength, spacing [m]      */
+    const double *values;    /* TABLE: n values                           */
+    double value;            /* CONSTANT                                  */
+} clsimhip_function;
+
+/* I3CLSimRandomValue used as wavelength generator: InterpolatedDistribution
+ * (constant x spacing) or Constant (delta peak).
+ * private/clsim/random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:57-74 */
+#define CLSIMHIP_RANDOM_INTERPOLATED 0
+#define CLSIMHIP_RANDOM_CONSTANT 1
+typedef struct {
+    int32_t kind;
+    int32_t n;
+    double first, spacing;   /* INTERPOLATED: x of first point, x spacing  */
+    const double *y;         /* INTERPOLATED: n unnormalised densities      */
+    double value;            /* CONSTANT                                    */
+} clsimhip_random_value;
+
+/* I3CLSimMediumProperties restricted to the function classes of the IceCube
+ * ice models (public/clsim/I3CLSimMediumProperties.h:54-200). */
+#define CLSIMHIP_LENGTHS_CONSTANT 0 /* I3CLSimFunctionConstant per layer          */
+#define CLSIMHIP_LENGTHS_ICECUBE 1  /* I3CLSimFunctionAbsLenIceCube/ScatLenIceCube */
+#define CLSIMHIP_SCATTER_HG 0
+#define CLSIMHIP_SCATTER_LIU 1
+#define CLSIMHIP_SCATTER_MIXED 2    /* Mixed(SimplifiedLiu, HenyeyGreenstein, f)   */
+typedef struct {
+    int32_t num_layers;
+    double layers_z_start, layers_height;
+    double min_wavelength, max_wavelength;          /* ForcedMinWlen / ForcedMaxWlen */
+    int32_t lengths_kind;
+    const double *abs_length, *sca_length;          /* CONSTANT: per layer [m]        */
+    double alpha, kappa, A, B, D, E;                /* ICECUBE                         */
+    const double *a_dust400, *delta_tau, *b400;     /* ICECUBE: per layer, bottom->top */
+    double n[5], g[5];                              /* RefIndexIceCube phase / group   */
+    int32_t scatter_kind;
+    double liu_fraction, mean_cosine;
+    int32_t has_anisotropy;                         /* ScalarFieldAnisotropyAbsLenScaling */
+    double aniso_azimuth, aniso_k1, aniso_k2;
+    int32_t has_pre_transform, pre_renormalize;     /* VectorTransformMatrix            */
+    double pre_matrix[9];
+    int32_t has_post_transform, post_renormalize;
+    double post_matrix[9];
+    int32_t has_tilt;                               /* ScalarFieldIceTiltZShift          */
+    int32_t tilt_num_distances, tilt_num_z;
+    const double *tilt_distances, *tilt_z_coordinates, *tilt_z_corrections; /* [nd][nz] */
+    double tilt_azimuth;
+} clsimhip_medium_desc;
+
+/* ---- medium objects ---- */
+/* deep copy of a description */
+int clsimhip_medium_create(const clsimhip_medium_desc *desc, clsimhip_medium **out);
+/* python/MakeIceCubeMediumProperties.py:49-256: PPC ice tables (icemodel.dat/.par,
+ * cfg.txt[, tilt.dat/.par]) -> medium */
+int clsimhip_medium_create_from_ppc(const char *directory, double detector_center_depth,
+                                    int use_tilt_if_available, clsimhip_medium **out);
+/* view into the object's own arrays (valid until destroy) */
+int clsimhip_medium_describe(const clsimhip_medium *m, clsimhip_medium_desc *out);
+void clsimhip_medium_destroy(clsimhip_medium *m);
+
+/* python/GetIceCubeDOMAcceptance.py:35-115 (43 entries, 260..680 nm); values_out[43] */
+int clsimhip_icecube_dom_acceptance(double dom_radius, double efficiency, double *values_out,
+                                    double *start_out, double *step_out);
+/* I3CLSimModuleHelper::makeCherenkovWavelengthGenerator, tabulated bias
+ * (I3CLSimModuleHelper.cxx:175-263): y_out[bias->n] */
+int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const clsimhip_medium *m,
+                                           double *y_out, double *first_out, double *spacing_out);
+
+/* ---- RNG set-up (private/opencl/mwcrng_init.h:26-117, private/make_safeprimes/main.cxx) ---- */
+/* first `count` MWC multipliers (a*2^32-1 and (a*2^32-2)/2 prime, descending from 4294967118) */
+int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count);
+/* state words with init_MWC_RNG's validity loop; draws come from splitmix64(seed) */
+int clsimhip_seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x_out);
+
+/* ---- converter life cycle (I3CLSimStepToPhotonConverterOpenCL.cxx:68-388) ---- */
+int clsimhip_create(int device_ordinal, clsimhip_converter **out);
+void clsimhip_destroy(clsimhip_converter *c);
+const char *clsimhip_last_error(const clsimhip_converter *c); /* c may be NULL: last create error */
+
+/* setters: CLSIMHIP_ERR_STATE once initialized (OpenCL.cxx:1322-1523) */
+int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_value *gens, size_t n);
+int clsimhip_set_wlen_bias(clsimhip_converter *c, const clsimhip_function *bias);
+int clsimhip_set_medium_properties(clsimhip_converter *c, const clsimhip_medium *m);
+/* I3CLSimSimpleGeometry: parallel arrays, one entry per DOM (public/clsim/I3CLSimSimpleGeometry.h) */
+int clsimhip_set_geometry(clsimhip_converter *c, size_t n, const int32_t *string_ids, const uint32_t *dom_ids,
+                          const double *x, const double *y, const double *z,
+                          const char *const *subdetectors, double om_radius);
+int clsimhip_set_enable_double_buffering(clsimhip_converter *c, int value);
+int clsimhip_set_double_precision(clsimhip_converter *c, int value);           /* only 0 */
+int clsimhip_set_stop_detected_photons(clsimhip_converter *c, int value);      /* only 1 */
+int clsimhip_set_save_all_photons(clsimhip_converter *c, int value);           /* only 0 */
+int clsimhip_set_save_all_photons_prescale(clsimhip_converter *c, double value);
+int clsimhip_set_fixed_number_of_absorption_lengths(clsimhip_converter *c, double value); /* NaN = off */
+int clsimhip_set_dom_pancake_factor(clsimhip_converter *c, double value);
+int clsimhip_set_photon_history_entries(clsimhip_converter *c, uint32_t value); /* only 0 */
+int clsimhip_set_workgroup_size(clsimhip_converter *c, size_t value);
+int clsimhip_set_max_num_workitems(clsimhip_converter *c, size_t value);
+/* Compile(): build the device tables from the configuration (OpenCL.cxx:485-533) */
+int clsimhip_compile(clsimhip_converter *c);
+int clsimhip_get_max_workgroup_size(const clsimhip_converter *c, size_t *out);
+/* Initialize(): RNG streams a[i] = i-th multiplier, x[i] seeded from `seed` (OpenCL.cxx:217-388) */
+int clsimhip_initialize(clsimhip_converter *c, uint64_t seed);
+/* same with caller-supplied streams (count must equal max_num_workitems) */
+int clsimhip_initialize_with_streams(clsimhip_converter *c, const uint64_t *x, const uint32_t *a, size_t count);
+int clsimhip_is_initialized(const clsimhip_converter *c);
+
+/* ---- steady state (OpenCL.cxx:1525-1640) ---- */
+/* EnqueueSteps: copies `n` steps; blocks while 5 bunches are pending.  n must be
+ * non-zero, <= max_num_workitems and a multiple of the workgroup size. */
+int clsimhip_enqueue_steps(clsimhip_converter *c, const clsimhip_step *steps, size_t n, uint32_t identifier);
+/* GetConversionResult: blocks for the next finished bunch.  String/DOM indices are
+ * already replaced by IDs.  *photons stays valid until clsimhip_release_result. */
+int clsimhip_get_conversion_result(clsimhip_converter *c, uint32_t *identifier,
+                                   const clsimhip_photon **photons, size_t *n);
+int clsimhip_release_result(clsimhip_converter *c, const clsimhip_photon *photons);
+int clsimhip_get_workgroup_size(const clsimhip_converter *c, size_t *out);
+int clsimhip_get_max_num_workitems(const clsimhip_converter *c, size_t *out);
+int clsimhip_queue_size(const clsimhip_converter *c, size_t *out);
+int clsimhip_more_photons_available(const clsimhip_converter *c, int *out);
+/* GetStatistics(): [0] TotalDeviceTime ns, [1] TotalHostTime ns, [2] NumKernelCalls,
+ * [3] TotalNumPhotonsGenerated, [4] TotalNumPhotonsAtDOMs, [5] AverageDeviceTimePerPhoton,
+ * [6] AverageHostTimePerPhoton, [7] DeviceUtilization */
+int clsimhip_get_statistics(const clsimhip_converter *c, double out[8]);
+
+/* ---- device-resident path (no reference counterpart: the reference always
+ * stages through host memory, OpenCL.cxx:824-911, 994-1086) ----
+ * Propagates n steps that already live in HBM, on the caller's HIP stream
+ * (hipStream_t passed as void*; NULL = default stream).  d_photons has room for
+ * `capacity` records, *d_hit_count (uint32, zeroed by this call) receives the
+ * number of detected photons (may exceed capacity; only the first `capacity`
+ * are stored).  rng_offset selects the first RNG stream used (stream i of the
+ * bunch = rng_offset + i).  String/DOM fields hold INDICES.  Asynchronous. */
+int clsimhip_propagate_device(clsimhip_converter *c, const void *d_steps, size_t n, size_t rng_offset,
+                              void *d_photons, size_t capacity, void *d_hit_count, void *stream);
+/* index -> ID translation on the device records' host copy (OpenCL.cxx:1565-1600) */
+int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_photon *photons, size_t n);
+/* average duration (ms) of the propagation kernel over the launches recorded since
+ * the last call with reset!=0, measured with HIP events on the launch stream */
+int clsimhip_kernel_time_ms(clsimhip_converter *c, int reset, double *total_ms, uint64_t *launches);
+
+/* ---- introspection used by the parity tests ---- */
+/* copies the compiled table `name` (e.g. "geoStringPosX", "aDust400") converted to
+ * double into out[0..cap); returns the entry count or a negative status */
+long clsimhip_get_table(const clsimhip_converter *c, const char *name, double *out, size_t cap);
+/* current RNG state words (after the bunches run so far) */
+int clsimhip_get_rng_state(clsimhip_converter *c, uint64_t *x_out, size_t count);
+/* evaluates the device math library on the GPU: what = 0 log,1 exp,2 sin,3 cos,4 powr(x,y),
+ * 5 acos,6 atan2(x,y),7 rsqrt,8 sqrt,9 x/y */
+int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out);
+
+const char *clsimhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""Builds the same configuration on both sides: the oracle (numpy builders +
+C restatement) and the product (libclsimhip.so through its Python mirror)."""
+import os
+
+import numpy as np
+
+from clsim_amd import converter as CV
+from clsim_amd import synthetic as S
+from oracle import builders as B
+from oracle import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ICE = os.path.join(ROOT, "clsim_amd", "data", "ice")
+FLASHER_WLEN = 405e-9
+
+_streams = {}
+
+
+def streams(n, seed=12345):
+    """(x, a) for n RNG streams: multipliers from the product's generator are
+    checked against the oracle's in tests/test_rng.py; here the oracle's are used
+    for small n and the product's for large n."""
+    key = (n, seed)
+    if key not in _streams:
+        a = B.mwc_multipliers(n) if n <= 4096 else CV.mwc_multipliers(n)
+        x = B.seed_streams(a, seed) if n <= 4096 else CV.seed_streams(a, seed)
+        _streams[key] = (x, a)
+    return _streams[key]
+
+
+def config(name):
+    """name: 'c1' homogeneous/single string, 'mie' SPICE-Mie/IC86, 'lea' SPICE-Lea/IC86,
+    'flasher' SPICE-Lea/IC86 + 405 nm generator."""
+    if name == "c1":
+        geom = S.single_string_geometry()
+        med_o = B.homogeneous_medium()
+        med_p = CV.MakeHomogeneousMediumProperties()
+    else:
+        geom = S.ic86_geometry()
+        d = os.path.join(ICE, "spice_mie" if name == "mie" else "spice_lea")
+        med_o = B.load_ppc_ice(d)
+        med_p = CV.MakeIceCubeMediumProperties(iceDataDirectory=d)
+    return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=(name == "flasher"))
+
+
+def oracle_tables(cfg, pancake=5.0):
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    bias = B.icecube_dom_acceptance()
+    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
+    if cfg["flasher"]:
+        gens.append(dict(kind="const", value=FLASHER_WLEN))
+    return capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake)
+
+
+def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345):
+    bias = CV.GetIceCubeDOMAcceptance()
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])]
+    if cfg["flasher"]:
+        gens.append(CV.I3CLSimRandomValueConstant(FLASHER_WLEN))
+    geom = CV.I3CLSimSimpleGeometry.from_dict(cfg["geom"])
+    if not initialize:
+        conv = CV.I3CLSimStepToPhotonConverterHIP(device)
+        conv.SetWlenGenerators(gens); conv.SetWlenBias(bias); conv.SetMediumProperties(cfg["med_p"])
+        conv.SetGeometry(geom); conv.SetDOMPancakeFactor(pancake)
+        return conv
+    return CV.initializeHIP(device, geom, cfg["med_p"], bias, gens, pancakeFactor=pancake,
+                            approximateNumberOfWorkItems=max_items, streams=streams(max_items, seed))
+
+
+def steps_for(cfg, n, seed=3, pad_to=256):
+    if cfg["name"] == "c1":
+        return S.cascade_steps(n, seed=seed, vertex=(0.0, 0.0, 0.0), pad_to=pad_to)
+    if cfg["flasher"]:
+        g = cfg["geom"]
+        k = 30 * 60 + 29      # a DOM in the middle of the detector
+        return S.flasher_steps(n, seed=seed, position=(g["x"][k] + 12.0, g["y"][k], g["z"][k]), pad_to=pad_to)
+    return S.cascade_steps(n, seed=seed, pad_to=pad_to)
+
+
+def sort_photons(ph):
+    return capi.sort_photons(ph)
