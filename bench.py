@@ -90,7 +90,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n = (args.bunch // 256) * 256
+    n = (args.bunch // 512) * 512
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
     bias = CV.GetIceCubeDOMAcceptance()

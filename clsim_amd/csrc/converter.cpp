@@ -12,6 +12,7 @@ namespace clsimhip {
 
 static_assert(sizeof(clsimhip_step) == sizeof(DevStep), "step layouts");
 static_assert(sizeof(clsimhip_photon) == sizeof(DevPhoton), "photon layouts");
+constexpr uint32_t kQueueSlots = 256;
 
 void Converter::hip_check(hipError_t e, const char *what) const
 {
@@ -37,7 +38,7 @@ Converter::~Converter()
     if (stream_) (void)hipStreamDestroy(stream_);
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_photons_);
-    (void)hipFree(d_hit_count_);
+    (void)hipFree(d_hit_count_); (void)hipFree(d_queue_);
     if (h_steps_) (void)hipHostFree(h_steps_);
     if (h_photons_) (void)hipHostFree(h_photons_);
     if (h_hit_count_) (void)hipHostFree(h_hit_count_);
@@ -134,7 +135,7 @@ void Converter::initialize_with_streams(const uint64_t *x, const uint32_t *a, si
     if (max_workitems_ % workgroup_size_ != 0)
         throw Error(CLSIMHIP_ERR_ARGUMENT, "The maximum number of work items (" + std::to_string(max_workitems_) +
                                                ") must be a multiple of the workgroup size (" + std::to_string(workgroup_size_) + ").");
-    if (max_workitems_ > 0xffffffffull) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many work items");
+    if (max_workitems_ > 0x7fffffffull) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many work items");
     for (size_t i = 0; i < count; ++i) {
         // mwcrng_init.h:107: a state outside this range breaks the generator
         if ((x[i] == 0) | ((static_cast<uint32_t>(x[i] >> 32)) >= (a[i] - 1)) | ((static_cast<uint32_t>(x[i])) >= 0xfffffffful))
@@ -181,12 +182,15 @@ void Converter::setup_device_buffers()
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), max_workitems_ * sizeof(DevStep)), "steps");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_photons_), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_hit_count_), 16), "hit counter");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), kQueueSlots * sizeof(uint32_t)), "step queue");
+    if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_DOM")) k_dom_ = std::max(1, std::atoi(e));
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_photons_), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_hit_count_), 16, hipHostMallocDefault), "pinned counter");
 }
 
-KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits) const
+KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)
 {
     KParams P = tables_.params;
     P.tables = d_tables_;
@@ -197,6 +201,12 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.out = static_cast<DevPhoton *>(d_photons);
     P.hit_count = static_cast<uint32_t *>(d_hits);
     P.max_hits = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffull));
+    {   // step queue head for this launch (zeroed in stream order)
+        std::lock_guard<std::mutex> lk(ev_mutex_);
+        P.queue = d_queue_ + (queue_slot_++ % kQueueSlots);
+    }
+    hip_check(hipMemsetAsync(P.queue, 0, 4, stream), "reset step queue");
+    P.k_new = k_new_;
     P.dom_tx = d_dom_tx_;
     P.dom_ty = d_dom_ty_;
     P.dom_tz = d_dom_tz_;
@@ -232,7 +242,7 @@ void Converter::worker()
             std::memcpy(h_steps_, job.steps.data(), n * sizeof(clsimhip_step));
             hip_check(hipMemcpyAsync(d_steps_, h_steps_, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
             hip_check(hipMemsetAsync(d_hit_count_, 0, 4, stream_), "reset hit counter");
-            const KParams P = launch_params(d_steps_, n, 0, d_photons_, max_output_photons_, d_hit_count_);
+            const KParams P = launch_params(d_steps_, n, 0, d_photons_, max_output_photons_, d_hit_count_, stream_);
             hip_check(hipEventRecord(ev_start_, stream_), "event");
             hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
             hip_check(hipEventRecord(ev_stop_, stream_), "event");
@@ -349,7 +359,7 @@ void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offse
         else { hip_check(hipEventCreate(&ev.first), "hipEventCreate"); hip_check(hipEventCreate(&ev.second), "hipEventCreate"); }
     }
     hip_check(hipMemsetAsync(d_hit_count, 0, 4, stream), "reset hit counter");
-    const KParams P = launch_params(d_steps, n, rng_offset, d_photons, capacity, d_hit_count);
+    const KParams P = launch_params(d_steps, n, rng_offset, d_photons, capacity, d_hit_count, stream);
     hip_check(hipEventRecord(ev.first, stream), "event");
     hip_check(launch_prop_kernel(P, tables_.variant, stream), "propagation kernel launch");
     hip_check(hipEventRecord(ev.second, stream), "event");

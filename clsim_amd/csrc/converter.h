@@ -122,7 +122,7 @@ private:
     void setup_device_buffers();
     void worker();
     void hip_check(hipError_t e, const char *what) const;
-    KParams launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits) const;
+    KParams launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream);
 
     int device_;
     std::vector<RandomValueData> generators_;
@@ -148,6 +148,9 @@ private:
     DevStep *d_steps_ = nullptr;
     DevPhoton *d_photons_ = nullptr;
     uint32_t *d_hit_count_ = nullptr;
+    uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
+    uint32_t queue_slot_ = 0;
+    int k_new_ = 6, k_dom_ = 0;              // lanes waiting before photons are created (CLSIMHIP_K_NEW overrides)
     clsimhip_step *h_steps_ = nullptr;       // pinned staging
     clsimhip_photon *h_photons_ = nullptr;
     uint32_t *h_hit_count_ = nullptr;

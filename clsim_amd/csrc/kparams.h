@@ -1,8 +1,13 @@
-// Kernel parameter block: everything wave-uniform the propagator needs.  It is
-// passed by value (kernarg segment -> SGPRs), so none of it costs vector
-// registers.  Arrays that lanes index divergently (ice layers, tilt grid,
-// spectra, DOM cell index) live in one packed 32-bit word block that every
-// workgroup copies from HBM/L2 into LDS once; `off_*` are word offsets into it.
+// Kernel parameter block: everything wave-uniform the propagator needs.
+//
+// It is passed by value, i.e. it lives in the kernarg segment; the kernel reads
+// it through a constant-address-space pointer with scalar loads (s_load) close
+// to the use, phase by phase, instead of holding ~150 values in SGPRs for the
+// whole kernel (which spills SGPRs into VGPR lanes on gfx950).  Arrays that
+// lanes index divergently (ice layers, tilt grid, spectra, DOM cell index) live
+// in one 32-bit word image that every workgroup copies from HBM/L2 into LDS
+// once; `off_*` are word offsets into it.  Per-entity values are interleaved
+// into records so that one wide LDS read fetches what a test needs.
 //
 // The reference bakes the same values into the OpenCL source as #defines and
 // __constant arrays (MediumPropertiesSource.cxx:207-389, GeometrySource.cxx:1153-1269).
@@ -41,14 +46,19 @@ struct KParams {
     DevPhoton *out;
     uint32_t *hit_count;
     uint32_t max_hits;
+    uint32_t *queue;                    // next unclaimed step (zeroed before the launch)
+    int32_t k_new;                      // lanes that must be waiting before photons are created
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;
+    int32_t dom_in_lds;                 // templates are part of the LDS image
+    uint32_t off_dom_xy, off_dom_z;     // int16 pairs (x | y<<16), float z
 
     // ---- medium ----
     int32_t num_layers;
     float layer_bottom, layer_thickness, recip_thickness;
-    uint32_t off_abs_a, off_abs_b, off_sca_b;   // ICECUBE: (D*aDust+E), (1+0.01*dTau), b400 ; CONSTANT: abs, -, sca
+    // 4-word records per layer.  ICECUBE: {(D*aDust+E), (1+0.01*dTau), b400, 0}; CONSTANT: {abs, 0, sca, 0}
+    uint32_t off_layers;
     float neg_kappa, abs_A, neg_B, neg_alpha, ref_wlen_recip, nanometer;
     float n[5], g[5], micrometer, c_light;
     float mix_frac, mix_frac_rest, liu_beta, hg_g, hg_one_minus_g2, hg_one_plus_g2, hg_two_g;
@@ -75,14 +85,14 @@ struct KParams {
     float pancake, unpancake;           // PANCAKE_FACTOR, (PANCAKE_FACTOR-1)/PANCAKE_FACTOR
     float om_radius, om_radius_sq, string_max_radius_sq;
     int32_t num_strings, num_sets, max_layers, num_subdet;
-    uint32_t off_str_x, off_str_y, off_str_top, off_str_bottom; // top = maxZ+R, bottom = minZ-R
-    uint32_t off_str_info;              // set | dom_start << 8
-    uint32_t off_dom_meanx, off_dom_meany;
-    uint32_t off_set_nlayers, off_set_startz, off_set_height;
+    // 8-word records per string: {x, y, maxZ+R, minZ-R, set | dom_start<<8, dom mean x, dom mean y, 0}
+    uint32_t off_strings;
+    // 4-word records per string set: {number of z layers, start z, layer height, 0}
+    uint32_t off_sets;
     uint32_t off_layer_to_om;           // uint16 pairs
-    int32_t cell_nx[kMaxSubdetectors], cell_ny[kMaxSubdetectors];
-    float cell_wx[kMaxSubdetectors], cell_wy[kMaxSubdetectors], cell_sx[kMaxSubdetectors], cell_sy[kMaxSubdetectors];
-    uint32_t off_cell[kMaxSubdetectors];        // uint16 pairs
+    // per subdetector, 8 words in LDS: nx, ny, width_x, width_y, start_x, start_y, offset of its
+    // cell index (uint16 pairs), unused -- lanes sit in different subdetectors, so this is indexed per lane
+    uint32_t off_subdet;
     float dom_mul_x, dom_mul_y;
 };
 

@@ -8,17 +8,20 @@
 // with a hand-written kernel whose results are bit-identical for every step and
 // RNG stream, but which is organised for the CDNA4 execution model:
 //
-//  * one in-flight photon per lane; lane i owns step i and RNG stream i of the
-//    bunch (the stream must follow the step, propagation_kernel.c.cl:458-461);
-//  * the scatter loop is a WAVE-UNIFORM loop (`while (ballot(alive))`): photon
-//    creation, propagation, DOM search and scattering are predicated phases, so
-//    hit records are emitted at a convergent point by the whole wave;
+//  * persistent workgroups (as many as the chip holds) pull steps from a global
+//    queue: a lane that finishes its step takes the next one instead of idling
+//    until the slowest of its 64 neighbours is done.  The RNG stream travels with
+//    the step (propagation_kernel.c.cl:458-461, 911-912), never with the lane;
+//  * one in-flight photon per lane; the scatter loop is a WAVE-UNIFORM loop
+//    (ballot), so hit records are emitted at a convergent point by the whole wave;
+//  * photon creation -- 1/29 of a lane's iterations but paid by the whole wave
+//    whenever one lane needs it -- is deferred until k_new lanes wait for it;
 //  * hit write-out is wave-aggregated: one atomic per wave claims the slots,
 //    records are staged in LDS and written as contiguous dwords by all lanes;
-//  * ice layer tables, tilt grid, spectra and the DOM cell/layer index are
-//    staged in LDS once per workgroup (lanes index them divergently, which the
-//    scalar/constant path cannot serve); wave-uniform scalars arrive as kernel
-//    arguments in SGPRs;
+//  * ice layer records, tilt grid, spectra and the DOM cell/string/layer index are
+//    staged in LDS once per workgroup (lanes index them divergently); wave-uniform
+//    scalars are read from the kernarg segment with scalar loads next to their
+//    use (keeping ~150 of them live in SGPRs spills into VGPR lanes);
 //  * wavelength-only factors of the ice functions (lambda^-alpha, lambda^-kappa,
 //    A*exp(-B/lambda)) are evaluated once per photon instead of once per layer
 //    visit -- same operations on the same inputs, so the same bits;
@@ -34,17 +37,34 @@
 
 namespace clsimhip {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 512;                      // 8 waves; two workgroups per CU at <=128 VGPRs
+constexpr int kMinWavesPerSimd = 4;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStageRecords = 8;                 // hit records staged per wave and flush
 constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
 constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
 constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
+constexpr uint32_t kNoStep = 0xffffffffu;
 
-extern __shared__ uint32_t lds_words[];
+// kernel parameters, read with scalar loads from the constant address space
+typedef const __attribute__((address_space(4))) KParams *KP;
+
+// Makes the parameter pointer opaque to the optimiser at this point, so that the
+// loads that follow stay here (phase-local SGPR live ranges) instead of being
+// hoisted to the kernel entry and spilled.
+DM KP fresh_params(KP p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+
+struct Rec4 { float a, b, c, d; };
 
 DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
 DM uint32_t ldsu(uint32_t i) { return lds_words[i]; }
+DM Rec4 lds_rec4(uint32_t i) { return *reinterpret_cast<const Rec4 *>(&lds_words[i]); }   // i % 4 == 0
 DM uint32_t lds_u16(uint32_t off, uint32_t i)
 {
     const uint32_t w = lds_words[off + (i >> 1)];
@@ -69,82 +89,84 @@ DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? 
 struct Vec3 { float x, y, z; };
 
 // RefIndexIceCube.cxx:128-180
-DM float phase_ref_index(const KParams &P, float wlen)
+DM float phase_ref_index(KP P, float wlen)
 {
-    const float x = wlen / P.micrometer;
-    return P.n[0] + x * (P.n[1] + x * (P.n[2] + x * (P.n[3] + x * P.n[4])));
+    const float x = wlen / P->micrometer;
+    return P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
 }
 // MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163
-DM float group_velocity(const KParams &P, float wlen)
+DM float group_velocity(KP P, float wlen)
 {
-    const float x = wlen / P.micrometer;
-    const float np = P.n[0] + x * (P.n[1] + x * (P.n[2] + x * (P.n[3] + x * P.n[4])));
-    const float np_corr = P.g[0] + x * (P.g[1] + x * (P.g[2] + x * (P.g[3] + x * P.g[4])));
-    return P.c_light / (np * np_corr);
+    const float x = wlen / P->micrometer;
+    const float np = P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
+    const float np_corr = P->g[0] + x * (P->g[1] + x * (P->g[2] + x * (P->g[3] + x * P->g[4])));
+    return P->c_light / (np * np_corr);
 }
 
 // Per-photon wavelength factors of the IceCube ice functions.
 struct IceFactors { float sca_pow, abs_pow, abs_exp; };
 
 template <bool ICE>
-DM IceFactors ice_factors(const KParams &P, float wlen)
+DM IceFactors ice_factors(KP P, float wlen)
 {
     IceFactors f = {0.0f, 0.0f, 0.0f};
     if (ICE) {
         // _Optimizers.cxx:237-240: powr(wlen*(1/400nm), -alpha)
-        f.sca_pow = dm::powr_(wlen * P.ref_wlen_recip, P.neg_alpha);
+        f.sca_pow = dm::powr_(wlen * P->ref_wlen_recip, P->neg_alpha);
         // _Optimizers.cxx:170-180: powr(x,-kappa), A*exp(-B/x), x = wlen/nm
-        const float x = wlen / P.nanometer;
-        f.abs_pow = dm::powr_(x, P.neg_kappa);
-        f.abs_exp = P.abs_A * dm::exp_(P.neg_B / x);
+        const float x = wlen / P->nanometer;
+        f.abs_pow = dm::powr_(x, P->neg_kappa);
+        f.abs_exp = P->abs_A * dm::exp_(P->neg_B / x);
     }
     return f;
 }
+// scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100)
 template <bool ICE>
-DM float scattering_length(const KParams &P, const IceFactors &f, int layer)
+DM void layer_lengths(uint32_t off_layers, const IceFactors &f, int layer, float &sca_len, float &abs_len)
 {
-    if (ICE) return 1.0f / (ldsf(P.off_sca_b + layer) * f.sca_pow);
-    return ldsf(P.off_sca_b + layer);                       // FunctionConstant.cxx:81-100
-}
-template <bool ICE>
-DM float absorption_length(const KParams &P, const IceFactors &f, int layer)
-{
-    if (ICE) return 1.0f / (ldsf(P.off_abs_a + layer) * f.abs_pow + f.abs_exp * ldsf(P.off_abs_b + layer));
-    return ldsf(P.off_abs_a + layer);
+    const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
+    if (ICE) {
+        sca_len = 1.0f / (r.c * f.sca_pow);
+        abs_len = 1.0f / (r.a * f.abs_pow + f.abs_exp * r.b);
+    } else {
+        sca_len = r.c;
+        abs_len = r.a;
+    }
 }
 
 // HenyeyGreenstein.cxx:69-92
-DM float hg_cos(const KParams &P, float u)
+DM float hg_cos(KP P, float u)
 {
     const float s = 2.0f * u - 1.0f;
-    const float ii = P.hg_one_minus_g2 / (1.0f + P.hg_g * s);
-    return clampf((P.hg_one_plus_g2 - ii * ii) / P.hg_two_g, -1.0f, 1.0f);
+    const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
+    return clampf((P->hg_one_plus_g2 - ii * ii) / P->hg_two_g, -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
-DM float liu_cos(const KParams &P, float u) { return clampf(2.0f * dm::powr_(u, P.liu_beta) - 1.0f, -1.0f, 1.0f); }
+DM float liu_cos(KP P, float u) { return clampf(2.0f * dm::powr_(u, P->liu_beta) - 1.0f, -1.0f, 1.0f); }
 // Mixed.cxx:115-157, single random number form
-DM float scattering_cos(const KParams &P, uint64_t &x, uint32_t a)
+DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
 {
     const float rr = rng_co(x, a);
-    if (P.scatter_kind == 0) return hg_cos(P, rr);
-    if (P.scatter_kind == 1) return liu_cos(P, rr);
-    if (rr < P.mix_frac) return liu_cos(P, rr / P.mix_frac);
-    return hg_cos(P, (1.0f - rr) / P.mix_frac_rest);
+    const int kind = P->scatter_kind;
+    if (kind == 0) return hg_cos(P, rr);
+    if (kind == 1) return liu_cos(P, rr);
+    if (rr < P->mix_frac) return liu_cos(P, rr / P->mix_frac);
+    return hg_cos(P, (1.0f - rr) / P->mix_frac_rest);
 }
 
 // ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
-DM float abs_len_corr(const KParams &P, const Vec3 &d)
+DM float abs_len_corr(KP P, const Vec3 &d)
 {
-    const float n0 = (P.an_azx * d.x) + (P.an_azy * d.y);
-    const float n1 = (P.an_mazy * d.x) + (P.an_azx * d.y);
+    const float n0 = (P->an_azx * d.x) + (P->an_azy * d.y);
+    const float n1 = (P->an_mazy * d.x) + (P->an_azx * d.y);
     const float s0 = n0 * n0, s1 = n1 * n1, s2 = d.z * d.z;
     // dot(float4,float4) with a zero 4th component: the +0 term cannot change a sum of squares
-    const float nB = (s0 * P.an_rl[0] + s1 * P.an_rl[1]) + s2 * P.an_rl[2];
-    const float An = (s0 * P.an_l[0] + s1 * P.an_l[1]) + s2 * P.an_l[2];
-    return 2.0f / ((P.an_B2 - nB) * An);
+    const float nB = (s0 * P->an_rl[0] + s1 * P->an_rl[1]) + s2 * P->an_rl[2];
+    const float An = (s0 * P->an_l[0] + s1 * P->an_l[1]) + s2 * P->an_l[2];
+    return 2.0f / ((P->an_B2 - nB) * An);
 }
 // VectorTransformMatrix.cxx:101-135
-DM void apply_matrix(const float m[9], int renorm, Vec3 &d)
+DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renorm, Vec3 &d)
 {
     const float x = (m[0] * d.x) + (m[1] * d.y) + (m[2] * d.z);
     const float y = (m[3] * d.x) + (m[4] * d.y) + (m[5] * d.z);
@@ -158,23 +180,24 @@ DM void apply_matrix(const float m[9], int renorm, Vec3 &d)
 
 // ScalarFieldIceTiltZShift.cxx:145-213.  The distance bin is the first j with
 // nr < dist[j] (last bin otherwise); dist is ascending, so it is counted.
-DM float tilt_z_shift(const KParams &P, float px, float py, float pz)
+DM float tilt_z_shift(KP P, float px, float py, float pz)
 {
-    const float z_rescaled = (pz - P.tilt_first_z) / P.tilt_dz;
-    const int k = clampi((int)__builtin_floorf(z_rescaled), 0, P.tilt_nz - 2);
+    const float z_rescaled = (pz - P->tilt_first_z) / P->tilt_dz;
+    const int nz = P->tilt_nz, nd = P->tilt_nd;
+    const uint32_t off_dist = P->off_tilt_dist;
+    const int k = clampi((int)__builtin_floorf(z_rescaled), 0, nz - 2);
     const float fraction_z_above = z_rescaled - (float)k;
     const float fraction_z_below = 1.0f - fraction_z_above;
-    const float nr = P.tilt_lnx * px + P.tilt_lny * py;
+    const float nr = P->tilt_lnx * px + P->tilt_lny * py;
     int j = 1;
-    for (int t = 1; t < P.tilt_nd - 1; ++t) j += (nr >= ldsf(P.off_tilt_dist + t)) ? 1 : 0;
-    // j counts leading bins with nr >= dist; ascending order makes that the first failing bin
-    const float thisDist = ldsf(P.off_tilt_dist + j);
-    const float previousDist = ldsf(P.off_tilt_dist + j - 1);
+    for (int t = 1; t < nd - 1; ++t) j += (nr >= ldsf(off_dist + t)) ? 1 : 0;
+    const float thisDist = ldsf(off_dist + j);
+    const float previousDist = ldsf(off_dist + j - 1);
     const float width = thisDist - previousDist;
     const float frac_at_lower = (thisDist - nr) / width;
     const float frac_at_upper = 1.0f - frac_at_lower;
-    const uint32_t lo = P.off_tilt_zcorr + (uint32_t)((j - 1) * P.tilt_nz + k);
-    const uint32_t hi = lo + (uint32_t)P.tilt_nz;
+    const uint32_t lo = P->off_tilt_zcorr + (uint32_t)((j - 1) * nz + k);
+    const uint32_t hi = lo + (uint32_t)nz;
     const float val_at_lower = (ldsf(lo + 1) * fraction_z_above + ldsf(lo) * fraction_z_below);
     const float val_at_upper = (ldsf(hi + 1) * fraction_z_above + ldsf(hi) * fraction_z_below);
     return (val_at_upper * frac_at_upper + val_at_lower * frac_at_lower);
@@ -183,12 +206,12 @@ DM float tilt_z_shift(const KParams &P, float px, float py, float pz)
 // InterpolatedDistribution.cxx:236-336 (constant spacing).  The reference scans
 // the cumulative table linearly for the first entry >= r; the table is
 // non-decreasing, so a bisection lands on the same bin.
-DM float generate_wavelength(const KParams &P, int gen, uint64_t &x, uint32_t a)
+DM float generate_wavelength(KP P, int gen, uint64_t &x, uint32_t a)
 {
-    if (P.gen_kind[gen] == 1) return P.gen_value[gen];      // RandomValueConstant
+    if (P->gen_kind[gen] == 1) return P->gen_value[gen];      // RandomValueConstant
     const float r = rng_oc(x, a);
-    const uint32_t cum = P.off_gen_ycum[gen], yv = P.off_gen_yv[gen];
-    int lo = 1, hi = P.gen_n[gen] - 1;
+    const uint32_t cum = P->off_gen_ycum[gen], yv = P->off_gen_yv[gen];
+    int lo = 1, hi = P->gen_n[gen] - 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (ldsf(cum + mid) >= r) hi = mid; else lo = mid + 1;
@@ -196,8 +219,8 @@ DM float generate_wavelength(const KParams &P, int gen, uint64_t &x, uint32_t a)
     const int k = lo - 1;
     const float this_acu = (k == 0) ? 0.0f : ldsf(cum + k);
     const float b = ldsf(yv + k);
-    const float sp = P.gen_spacing[gen];
-    const float x0 = (float)k * sp + P.gen_first[gen];
+    const float sp = P->gen_spacing[gen];
+    const float x0 = (float)k * sp + P->gen_first[gen];
     const float slope = (ldsf(yv + k + 1) - b) / sp;
     const float dy = r - this_acu;
     if ((b == 0.0f) && (slope == 0.0f)) return x0;
@@ -207,26 +230,39 @@ DM float generate_wavelength(const KParams &P, int gen, uint64_t &x, uint32_t a)
 }
 
 // FunctionFromTable.cxx:167-300
-DM float wavelength_bias(const KParams &P, float wavelength)
+DM float wavelength_bias(KP P, float wavelength)
 {
-    if (P.bias_kind == 1) return P.bias_value;
-    const float q = (wavelength - P.bias_start) / P.bias_step;
+    if (P->bias_kind == 1) return P->bias_value;
+    const float q = (wavelength - P->bias_start) / P->bias_step;
     const float fbin = __builtin_truncf(q);
     float fraction = q - fbin;
     int ibin = (int)fbin;
+    const int n = P->bias_n;
     if ((ibin < 0) || ((ibin == 0) && (fraction < 0.0f))) { ibin = 0; fraction = 0.0f; }
-    else if (ibin >= P.bias_n - 1) { ibin = P.bias_n - 2; fraction = 1.0f; }
-    const float v0 = ldsf(P.off_bias + ibin), v1 = ldsf(P.off_bias + ibin + 1);
+    else if (ibin >= n - 1) { ibin = n - 2; fraction = 1.0f; }
+    const uint32_t off = P->off_bias;
+    const float v0 = ldsf(off + ibin), v1 = ldsf(off + ibin + 1);
     return v0 + (v1 - v0) * fraction;
 }
 
 // GeometrySource.cxx:685-700
-DM void dom_position(const KParams &P, uint32_t s, uint32_t d, float &x, float &y, float &z)
+DM void dom_position(KP P, uint32_t s, uint32_t d, float &x, float &y, float &z)
 {
-    const uint32_t index = (ldsu(P.off_str_info + s) >> 8) + d;
-    x = (float)P.dom_tx[index] * P.dom_mul_x + ldsf(P.off_dom_meanx + s);
-    y = (float)P.dom_ty[index] * P.dom_mul_y + ldsf(P.off_dom_meany + s);
-    z = P.dom_tz[index];
+    const uint32_t rec = P->off_strings + 8u * s;
+    const uint32_t index = (ldsu(rec + 4) >> 8) + d;
+    int tx, ty;
+    if (P->dom_in_lds) {                // wave-uniform: templates staged in LDS when they fit
+        const uint32_t w = ldsu(P->off_dom_xy + index);
+        tx = (int)(int16_t)(w & 0xffffu);
+        ty = (int)(int16_t)(w >> 16);
+        z = ldsf(P->off_dom_z + index);
+    } else {
+        tx = P->dom_tx[index];
+        ty = P->dom_ty[index];
+        z = P->dom_tz[index];
+    }
+    x = (float)tx * P->dom_mul_x + ldsf(rec + 5);
+    y = (float)ty * P->dom_mul_y + ldsf(rec + 6);
 }
 
 // propagation_kernel.c.cl:83-129
@@ -280,7 +316,7 @@ struct Photon {
 // propagation_kernel.c.cl:132-184 + :553-589.  The step record is re-read from
 // HBM/L2 here (48 B every ~30 loop iterations) instead of living in registers.
 template <bool ICE, bool TILT, bool FLASHER>
-DM void create_photon(const KParams &P, const DevStep *step_ptr, uint64_t &rx, uint32_t ra, Photon &ph)
+DM void create_photon(KP P, const DevStep *step_ptr, uint64_t &rx, uint32_t ra, Photon &ph)
 {
     const DevStep st = *step_ptr;
     Vec3 step_dir;
@@ -307,13 +343,13 @@ DM void create_photon(const KParams &P, const DevStep *step_ptr, uint64_t &rx, u
         scatter_direction(cos_c, sin_c, ph.d, rng_co(rx, ra));
     } else {
         // generateWavelength(number): 0 for an out-of-range generator (MediumPropertiesSource.cxx:392-432)
-        ph.wlen = (source_type < (uint32_t)P.num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
+        ph.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
     }
     ph.sx = ph.px; ph.sy = ph.py; ph.sz = ph.pz; ph.st = ph.pt;
     ph.sd = ph.d;
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
-    if (!TILT) ph.layer = clampi((int)((ph.pz - P.layer_bottom) / P.layer_thickness), 0, P.num_layers - 1);
+    if (!TILT) ph.layer = clampi((int)((ph.pz - P->layer_bottom) / P->layer_thickness), 0, P->num_layers - 1);
     ph.inv_groupvel = 1.0f / group_velocity(P, ph.wlen);
     ph.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
     ph.abs_lens_left = ph.abs_lens_initial;
@@ -322,44 +358,46 @@ DM void create_photon(const KParams &P, const DevStep *step_ptr, uint64_t &rx, u
 
 // propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
 template <bool ICE, bool TILT, bool ANISO>
-DM float propagate_through_layers(const KParams &P, Photon &ph, uint64_t &rx, uint32_t ra)
+DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
 {
+    const float thickness = P->layer_thickness, bottom = P->layer_bottom;
+    const int num_layers = P->num_layers;
+    const uint32_t off_layers = P->off_layers;
     float effective_z;
     int current_layer;
     if (TILT) {
         effective_z = ph.pz - tilt_z_shift(P, ph.px, ph.py, ph.pz);
-        current_layer = clampi((int)((effective_z - P.layer_bottom) / P.layer_thickness), 0, P.num_layers - 1);
+        current_layer = clampi((int)((effective_z - bottom) / thickness), 0, num_layers - 1);
     } else {
-        effective_z = ph.pz - P.tilt_const;
+        effective_z = ph.pz - P->tilt_const;
         current_layer = ph.layer;
     }
     const float dz = ph.d.z;
     // without anisotropy the factor is the literal 1.f: x*1 and x/1 are exact, so both are skipped
-    const float corr = (ANISO && P.has_abs_corr) ? abs_len_corr(P, ph.d) : 1.0f;
+    const float corr = (ANISO && P->has_abs_corr) ? abs_len_corr(P, ph.d) : 1.0f;
     if (ANISO) ph.abs_lens_left *= corr;
-    const float lower = ((float)current_layer * P.layer_thickness) + P.layer_bottom;
-    float boundary = (dz < 0.0f) ? lower : (lower + P.layer_thickness);
+    const float lower = ((float)current_layer * thickness) + bottom;
+    float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
-    float sca_len = scattering_length<ICE>(P, ph.ice, current_layer);
-    float abs_len = absorption_length<ICE>(P, ph.ice, current_layer);
-    float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * P.recip_thickness;
-    float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * P.recip_thickness;
+    float sca_len, abs_len;
+    layer_lengths<ICE>(off_layers, ph.ice, current_layer, sca_len, abs_len);
+    const float recip_thickness = P->recip_thickness;
+    float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
+    float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
     int j = current_layer;
     if (dz < 0.0f) {
         while ((j > 0) && (ais < 0.0f) && (aia < 0.0f)) {
             --j;
-            boundary -= P.layer_thickness;
-            sca_len = scattering_length<ICE>(P, ph.ice, j);
-            abs_len = absorption_length<ICE>(P, ph.ice, j);
+            boundary -= thickness;
+            layer_lengths<ICE>(off_layers, ph.ice, j, sca_len, abs_len);
             ais += 1.0f / sca_len;
             aia += 1.0f / abs_len;
         }
     } else {
-        while ((j < P.num_layers - 1) && (ais > 0.0f) && (aia > 0.0f)) {
+        while ((j < num_layers - 1) && (ais > 0.0f) && (aia > 0.0f)) {
             ++j;
-            boundary += P.layer_thickness;
-            sca_len = scattering_length<ICE>(P, ph.ice, j);
-            abs_len = absorption_length<ICE>(P, ph.ice, j);
+            boundary += thickness;
+            layer_lengths<ICE>(off_layers, ph.ice, j, sca_len, abs_len);
             ais -= 1.0f / sca_len;
             aia -= 1.0f / abs_len;
         }
@@ -370,8 +408,8 @@ DM float propagate_through_layers(const KParams &P, Photon &ph, uint64_t &rx, ui
         to_absorption = ph.abs_lens_left * abs_len;
     } else {
         const float recip_dz = 1.0f / dz;
-        distance = (ais * P.layer_thickness * sca_len + boundary - effective_z) * recip_dz;
-        to_absorption = (aia * P.layer_thickness * abs_len + boundary - effective_z) * recip_dz;
+        distance = (ais * thickness * sca_len + boundary - effective_z) * recip_dz;
+        to_absorption = (aia * thickness * abs_len + boundary - effective_z) * recip_dz;
     }
     if (!TILT) ph.layer = j;
     if (to_absorption < distance) {
@@ -384,27 +422,37 @@ DM float propagate_through_layers(const KParams &P, Photon &ph, uint64_t &rx, ui
     return distance;
 }
 
-// sparse_collision_kernel.c.cl:27-192 (STOP_PHOTONS_ON_DETECTION)
-DM void collide_with_string(const KParams &P, uint32_t s, float dir_len_xy_sqr, const Photon &ph, float &step_len,
+// ---- DOM search: sparse_collision_kernel.c.cl:27-303, 462-547 (STOP_PHOTONS_ON_DETECTION) ----
+struct Detector {               // wave-uniform values of the search, fetched once per call
+    uint32_t off_strings, off_sets, off_layer_to_om;
+    int max_layers;
+    float string_max_radius_sq, om_radius_sq, pancake;
+    int has_pancake;
+};
+
+// collision c.cl:27-192
+DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_xy_sqr, const Photon &ph, float &step_len,
                             bool &hit, uint32_t &hit_string, uint32_t &hit_dom)
 {
+    const Rec4 str = lds_rec4(D.off_strings + 8u * s);      // x, y, maxZ+R, minZ-R
     {
-        const float smin = sqr((ph.px - ldsf(P.off_str_x + s)) * ph.d.y - (ph.py - ldsf(P.off_str_y + s)) * ph.d.x) / dir_len_xy_sqr;
-        if (smin > P.string_max_radius_sq) return;
+        const float smin = sqr((ph.px - str.a) * ph.d.y - (ph.py - str.b) * ph.d.x) / dir_len_xy_sqr;
+        if (smin > D.string_max_radius_sq) return;
     }
-    if ((ph.d.z > 0.0f) && (ph.pz > ldsf(P.off_str_top + s))) return;
-    if ((ph.d.z < 0.0f) && (ph.pz < ldsf(P.off_str_bottom + s))) return;
-    const uint32_t set = ldsu(P.off_str_info + s) & 0xffu;
-    const float start_z = ldsf(P.off_set_startz + set), height = ldsf(P.off_set_height + set);
-    const int nl = (int)ldsu(P.off_set_nlayers + set);
+    if ((ph.d.z > 0.0f) && (ph.pz > str.c)) return;
+    if ((ph.d.z < 0.0f) && (ph.pz < str.d)) return;
+    const uint32_t set = ldsu(D.off_strings + 8u * s + 4) & 0xffu;
+    const Rec4 lay = lds_rec4(D.off_sets + 4u * set);        // nlayers (bits), start z, height
+    const float start_z = lay.b, height = lay.c;
+    const int nl = (int)__builtin_bit_cast(uint32_t, lay.a);
     int low = (int)((ph.pz - start_z) / height);
     int high = (int)((ph.pz + ph.d.z * step_len - start_z) / height);
     if (high < low) { const int tmp = low; low = high; high = tmp; }
     low = clampi(low, 0, nl - 1);
     high = clampi(high, 0, nl - 1);
-    const uint32_t base = set * (uint32_t)P.max_layers;
+    const uint32_t base = set * (uint32_t)D.max_layers;
     for (int layer = low; layer <= high; ++layer) {
-        const uint32_t dom = lds_u16(P.off_layer_to_om, base + (uint32_t)layer);
+        const uint32_t dom = lds_u16(D.off_layer_to_om, base + (uint32_t)layer);
         if (dom == 0xFFFFu) continue;
         float dom_x, dom_y, dom_z;
         dom_position(P, s, dom, dom_x, dom_y, dom_z);
@@ -412,9 +460,9 @@ DM void collide_with_string(const KParams &P, uint32_t s, float dir_len_xy_sqr, 
         // dot() of float4s whose 4th component is 0: ((x+y)+z); the trailing +0 only matters for -0
         const float dr2 = (dx * dx + dy * dy) + dzz * dzz;
         const float urdot = (dx * ph.d.x + dy * ph.d.y) + dzz * ph.d.z;
-        float discr = sqr(urdot) - dr2 + P.om_radius_sq;
+        float discr = sqr(urdot) - dr2 + D.om_radius_sq;
         if (discr < 0.0f) continue;
-        discr = P.has_pancake ? (dm::sqrt_(discr) / P.pancake) : dm::sqrt_(discr);
+        discr = D.has_pancake ? (dm::sqrt_(discr) / D.pancake) : dm::sqrt_(discr);
         if (urdot + discr < 0.0f) continue;
         const float smin1 = urdot - discr;
         if (smin1 < 0.0f) continue;
@@ -427,15 +475,25 @@ DM void collide_with_string(const KParams &P, uint32_t s, float dir_len_xy_sqr, 
     }
 }
 
-// sparse_collision_kernel.c.cl:194-303 + :462-547
-DM bool find_collision(const KParams &P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
+// collision c.cl:194-303 + :462-547
+DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
 {
     const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
     if (dir_len_xy_sqr <= 0.0f) return false;
+    Detector D;
+    D.off_strings = P->off_strings; D.off_sets = P->off_sets; D.off_layer_to_om = P->off_layer_to_om;
+    D.max_layers = P->max_layers;
+    D.string_max_radius_sq = P->string_max_radius_sq; D.om_radius_sq = P->om_radius_sq;
+    D.pancake = P->pancake; D.has_pancake = P->has_pancake;
+    const int num_subdet = P->num_subdet;
+    const uint32_t off_subdet = P->off_subdet;
     bool hit = false;
-    for (int sd = 0; sd < P.num_subdet; ++sd) {
-        const float sx = P.cell_sx[sd], sy = P.cell_sy[sd], wx = P.cell_wx[sd], wy = P.cell_wy[sd];
-        const int nx = P.cell_nx[sd], ny = P.cell_ny[sd];
+    for (int sd = 0; sd < num_subdet; ++sd) {
+        const Rec4 g0 = lds_rec4(off_subdet + 8u * (uint32_t)sd);        // nx, ny (bits), width x, width y
+        const Rec4 g1 = lds_rec4(off_subdet + 8u * (uint32_t)sd + 4u);   // start x, start y, cell offset (bits)
+        const int nx = (int)__builtin_bit_cast(uint32_t, g0.a), ny = (int)__builtin_bit_cast(uint32_t, g0.b);
+        const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
+        const uint32_t cells = __builtin_bit_cast(uint32_t, g1.c);
         int low_x = (int)((ph.px - sx) / wx);
         int low_y = (int)((ph.py - sy) / wy);
         int high_x = (int)((ph.px + ph.d.x * step_len - sx) / wx);
@@ -446,27 +504,28 @@ DM bool find_collision(const KParams &P, const Photon &ph, float &step_len, uint
         high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
         for (int cy = low_y; cy <= high_y; ++cy)
             for (int cx = low_x; cx <= high_x; ++cx) {
-                const uint32_t s = lds_u16(P.off_cell[sd], (uint32_t)(cy * nx + cx));
+                const uint32_t s = lds_u16(cells, (uint32_t)(cy * nx + cx));
                 if (s == 0xFFFFu) continue;
-                collide_with_string(P, s, dir_len_xy_sqr, ph, step_len, hit, hit_string, hit_dom);
+                collide_with_string(P, D, s, dir_len_xy_sqr, ph, step_len, hit, hit_string, hit_dom);
             }
     }
     return hit;
 }
 
 // propagation_kernel.c.cl:307-404: assemble the 20 words of an I3CLSimPhoton
-DM void make_hit_record(const KParams &P, const Photon &ph, float step_len, float dist_abs_lens, const DevStep *step_ptr,
+DM void make_hit_record(KP P, const Photon &ph, float step_len, float dist_abs_lens, const DevStep *step_ptr,
                         uint32_t hit_string, uint32_t hit_dom, uint32_t *rec)
 {
     float dom_x, dom_y, dom_z;
     dom_position(P, hit_string, hit_dom, dom_x, dom_y, dom_z);
-    if (P.has_pancake) {
+    if (P->has_pancake) {
+        const float unpancake = P->unpancake;
         const float qx = ph.px - dom_x, qy = ph.py - dom_y, qz = ph.pz - dom_z;
         const float parallel = qx * ph.d.x + qy * ph.d.y + qz * ph.d.z;
         const float nx = qx - parallel * ph.d.x;
         const float ny = qy - parallel * ph.d.y;
         const float nz = qz - parallel * ph.d.z;
-        dom_x += P.unpancake * nx; dom_y += P.unpancake * ny; dom_z += P.unpancake * nz;
+        dom_x += unpancake * nx; dom_y += unpancake * ny; dom_z += unpancake * nz;
     }
     float theta, phi, stheta, sphi;
     sph_dir_from_car(ph.d, theta, phi);
@@ -495,87 +554,127 @@ DM void make_hit_record(const KParams &P, const Photon &ph, float step_len, floa
 }
 
 template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
-__global__ void __launch_bounds__(kBlock) prop_kernel(const KParams P)
+__global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
-    // stage the table block: one coalesced pass of the workgroup
-    for (uint32_t i = threadIdx.x; i < P.table_words; i += kBlock) lds_words[i] = P.tables[i];
-    uint32_t *stage = lds_words + P.table_words + (threadIdx.x >> 6) * (kStageRecords * 20);
+    // the only kernel argument sits at offset 0 of the kernarg segment
+    const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Pvalue;
+    {   // stage the table image: one coalesced pass of the workgroup
+        const uint32_t words = P0->table_words;
+        const uint32_t *src = P0->tables;
+        for (uint32_t i = threadIdx.x; i < words; i += kBlock) lds_words[i] = src[i];
+    }
+    uint32_t *stage = lds_words + P0->table_words + (threadIdx.x >> 6) * (kStageRecords * 20);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    const bool in_range = gid < P.n_steps;
-    const DevStep *step_ptr = P.steps + (in_range ? gid : 0);
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    uint32_t sidx = kNoStep;
     uint64_t rx = 0;
     uint32_t ra = 0;
     uint32_t photons_left = 0;
-    if (in_range) {
-        rx = P.rng_x[gid];
-        ra = P.rng_a[gid];
-        photons_left = step_ptr->num_photons;
-    }
+    bool alive = true;
     Photon ph;
-    ph.abs_lens_left = 0.0f;
+    ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.abs_lens_initial = 0.0f;
     ph.layer = 0;
 
-    bool alive = photons_left > 0;
-    while (__ballot(alive) != 0ull) {
+    for (;;) {
+        bool need = alive && (ph.abs_lens_left < kEpsilon);
+        const uint64_t m_need = __ballot(need);
+        const uint64_t m_ready = __ballot(alive && !need);
+        if ((m_need | m_ready) == 0ull) break;
+
+        // ---- photon creation, deferred until enough lanes wait for it ----
+        if ((m_ready == 0ull) || ((int)__popcll(m_need) >= fresh_params(P0)->k_new)) {
+            const KP P = fresh_params(P0);
+            const bool want_step = need && (photons_left == 0);
+            const uint64_t m_want = __ballot(want_step);
+            if (m_want != 0ull) {
+                // next steps from the queue: one atomic per wave
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P->queue, (uint32_t)__popcll(m_want));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (want_step) {
+                    uint64_t *rng_x = P->rng_x;
+                    if (sidx != kNoStep) rng_x[sidx] = rx;                      // c.cl:911-912
+                    const uint32_t mine = base + (uint32_t)__popcll(m_want & lanes_below);
+                    if (mine < P->n_steps) {
+                        sidx = mine;
+                        rx = rng_x[mine];                                       // c.cl:458-461
+                        ra = P->rng_a[mine];
+                        photons_left = P->steps[mine].num_photons;
+                    } else {
+                        sidx = kNoStep;
+                        alive = false;
+                        need = false;
+                    }
+                }
+            }
+            if (need && (photons_left > 0)) {
+                create_photon<ICE, TILT, FLASHER>(P, P->steps + sidx, rx, ra, ph);
+                need = false;
+            }
+        }
+
+        // ---- one reference loop iteration for the lanes that hold a photon ----
+        const bool run = alive && !need;
         float distance = 0.0f;
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
-        if (alive) {
-            if (ph.abs_lens_left < kEpsilon) create_photon<ICE, TILT, FLASHER>(P, step_ptr, rx, ra, ph);
-            distance = propagate_through_layers<ICE, TILT, ANISO>(P, ph, rx, ra);
-            hit = find_collision(P, ph, distance, hit_string, hit_dom);
+        if (run) {
+            distance = propagate_through_layers<ICE, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
+            hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
         }
-        // ---- wave-aggregated hit write-out (c.cl:329-385, sparse_collision c.cl:557-578) ----
+        // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
         const uint64_t hit_mask = __ballot(hit);
         if (hit_mask != 0ull) {
+            const KP P = fresh_params(P0);
             const uint32_t total = (uint32_t)__popcll(hit_mask);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P.hit_count, total);
+            if (lane == 0) base = atomicAdd(P->hit_count, total);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t rank = (uint32_t)__popcll(hit_mask & ((1ull << lane) - 1ull));
+            const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
+            const uint32_t max_hits = P->max_hits;
+            uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
             for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
                 if (hit && rank >= chunk && rank < chunk + kStageRecords)
-                    make_hit_record(P, ph, distance, ph.abs_lens_initial - ph.abs_lens_left, step_ptr, hit_string, hit_dom,
-                                    stage + (rank - chunk) * 20);
+                    make_hit_record(P, ph, distance, ph.abs_lens_initial - ph.abs_lens_left, P->steps + sidx, hit_string,
+                                    hit_dom, stage + (rank - chunk) * 20);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t first = base + chunk;
                 const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
                 // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
-                const uint32_t room = (first < P.max_hits) ? (P.max_hits - first) : 0u;
+                const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
                 const uint32_t words = ((count < room) ? count : room) * 20u;
-                uint32_t *dst = reinterpret_cast<uint32_t *>(P.out) + (size_t)first * 20u;
+                uint32_t *dst = out_words + (size_t)first * 20u;
                 for (uint32_t w = lane; w < words; w += 64u) dst[w] = stage[w];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (alive) {
-            if (hit) ph.abs_lens_left = 0.0f;                               // c.cl:741-744
+        if (run) {
+            if (hit) ph.abs_lens_left = 0.0f;                                   // c.cl:741-744
             ph.px += ph.d.x * distance;
             ph.py += ph.d.y * distance;
             ph.pz += ph.d.z * distance;
             ph.pt += ph.inv_groupvel * distance;
             ph.total_path += distance;
             if (ph.abs_lens_left < kEpsilon) {
-                --photons_left;
-                alive = photons_left > 0;
+                --photons_left;                                                 // absorbed or detected
             } else {
-                if (ANISO && P.has_pre) apply_matrix(P.pre, P.pre_renorm, ph.d);
+                const KP P = fresh_params(P0);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d);
                 const float cos_s = scattering_cos(P, rx, ra);
                 const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
-                if (ANISO && P.has_post) apply_matrix(P.post, P.post_renorm, ph.d);
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d);
                 ++ph.num_scatters;
             }
         }
     }
-    if (in_range) P.rng_x[gid] = rx;                                        // c.cl:911-912
 }
 
 // ---- math probe used by tests/test_detmath_gpu.py ----
@@ -605,8 +704,24 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
 static hipError_t launch_variant(const KParams &P, hipStream_t stream)
 {
-    const uint32_t grid = (P.n_steps + kBlock - 1) / kBlock;
     const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * 20) * 4;
+    // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
+    static int resident = 0;            // per variant
+    if (resident == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess && lds_bytes > 64 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<ICE, TILT, ANISO, FLASHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<ICE, TILT, ANISO, FLASHER>, kBlock, lds_bytes);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
+    }
+    const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
+    const uint32_t grid = needed < (uint32_t)resident ? needed : (uint32_t)resident;
     hipLaunchKernelGGL((prop_kernel<ICE, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     return hipGetLastError();
 }

@@ -29,6 +29,8 @@ struct Image {
         words.insert(words.end(), v.begin(), v.end());
         return off;
     }
+    void align(size_t words) { while (words && words_size() % words) this->words.push_back(0u); }
+    size_t words_size() const { return words.size(); }
     uint32_t add_u16(const std::vector<uint16_t> &v)
     {
         const uint32_t off = static_cast<uint32_t>(words.size());
@@ -86,9 +88,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             const float u = 0.01f * d_tau[l];
             abs_b[l] = 1.f + u;                                     // (1.f + 0.01f*deltaTau[layer])
         }
-        P.off_abs_a = img.add_floats(abs_a);
-        P.off_abs_b = img.add_floats(abs_b);
-        P.off_sca_b = img.add_floats(b400);
+        std::vector<float> rec(4 * a_dust.size(), 0.f);
+        for (size_t l = 0; l < a_dust.size(); ++l) { rec[4 * l] = abs_a[l]; rec[4 * l + 1] = abs_b[l]; rec[4 * l + 2] = b400[l]; }
+        P.off_layers = img.add_floats(rec);
         P.neg_kappa = -to_float_literal(m.kappa);
         P.abs_A = to_float_literal(m.A);
         P.neg_B = -to_float_literal(m.B);
@@ -99,9 +101,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         scalar("alpha", -P.neg_alpha);
     } else {
         const std::vector<float> abs_c = literals(m.abs_length), sca_c = literals(m.sca_length);
-        P.off_abs_a = img.add_floats(abs_c);
-        P.off_abs_b = P.off_abs_a;
-        P.off_sca_b = img.add_floats(sca_c);
+        std::vector<float> rec(4 * abs_c.size(), 0.f);
+        for (size_t l = 0; l < abs_c.size(); ++l) { rec[4 * l] = abs_c[l]; rec[4 * l + 2] = sca_c[l]; }
+        P.off_layers = img.add_floats(rec);
         name("absorptionLength", as_doubles(abs_c)); name("scatteringLength", as_doubles(sca_c));
     }
     {   // Mixed.cxx:115-157, SimplifiedLiu.cxx:64-88, HenyeyGreenstein.cxx:69-92
@@ -244,28 +246,52 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         if (G.dom_start[s] >= (1u << 24)) throw Error(CLSIMHIP_ERR_CONFIG, "too many DOMs");
         info[s] = static_cast<uint32_t>(G.str_set[s]) | (G.dom_start[s] << 8);
     }
-    P.off_str_x = img.add_floats(G.str_x);
-    P.off_str_y = img.add_floats(G.str_y);
-    P.off_str_top = img.add_floats(top);
-    P.off_str_bottom = img.add_floats(bottom);
-    P.off_str_info = img.add_words(info);
-    P.off_dom_meanx = img.add_floats(G.dom_meanx);
-    P.off_dom_meany = img.add_floats(G.dom_meany);
-    P.off_set_nlayers = img.add_words(std::vector<uint32_t>(G.set_nlayers.begin(), G.set_nlayers.end()));
-    P.off_set_startz = img.add_floats(G.set_startz);
-    P.off_set_height = img.add_floats(G.set_height);
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    img.align(4);
+    {
+        std::vector<uint32_t> rec(8 * static_cast<size_t>(G.num_strings), 0u);
+        for (int s = 0; s < G.num_strings; ++s) {
+            rec[8 * s + 0] = bits(G.str_x[s]); rec[8 * s + 1] = bits(G.str_y[s]);
+            rec[8 * s + 2] = bits(top[s]); rec[8 * s + 3] = bits(bottom[s]);
+            rec[8 * s + 4] = info[s];
+            rec[8 * s + 5] = bits(G.dom_meanx[s]); rec[8 * s + 6] = bits(G.dom_meany[s]);
+        }
+        P.off_strings = img.add_words(rec);
+    }
+    {
+        std::vector<uint32_t> rec(4 * static_cast<size_t>(G.num_sets), 0u);
+        for (int k = 0; k < G.num_sets; ++k) {
+            rec[4 * k + 0] = G.set_nlayers[k]; rec[4 * k + 1] = bits(G.set_startz[k]); rec[4 * k + 2] = bits(G.set_height[k]);
+        }
+        P.off_sets = img.add_words(rec);
+    }
     P.off_layer_to_om = img.add_u16(G.layer_to_om);
+    std::vector<uint32_t> subdet(8 * G.cells.size(), 0u);
     for (size_t k = 0; k < G.cells.size(); ++k) {
         const GeoTables::Cells &c = G.cells[k];
-        P.cell_nx[k] = c.nx; P.cell_ny[k] = c.ny;
-        P.cell_wx[k] = c.wx; P.cell_wy[k] = c.wy; P.cell_sx[k] = c.sx; P.cell_sy[k] = c.sy;
-        P.off_cell[k] = img.add_u16(c.index);
+        subdet[8 * k + 0] = static_cast<uint32_t>(c.nx); subdet[8 * k + 1] = static_cast<uint32_t>(c.ny);
+        subdet[8 * k + 2] = bits(c.wx); subdet[8 * k + 3] = bits(c.wy);
+        subdet[8 * k + 4] = bits(c.sx); subdet[8 * k + 5] = bits(c.sy);
+        subdet[8 * k + 6] = img.add_u16(c.index);
         const std::string sfx = "_" + std::to_string(k);
         name("geoCellIndex" + sfx, as_doubles(c.index));
         name("GEO_CELL" + sfx, {double(c.nx), double(c.ny), c.wx, c.wy, c.sx, c.sy});
     }
+    img.align(4);
+    P.off_subdet = img.add_words(subdet);
     P.dom_mul_x = G.dom_mul_x;
     P.dom_mul_y = G.dom_mul_y;
+    {   // DOM templates go to LDS too when the whole image stays within the budget of two workgroups per CU
+        std::vector<uint32_t> xy(G.dom_tx.size());
+        for (size_t i = 0; i < xy.size(); ++i)
+            xy[i] = static_cast<uint32_t>(static_cast<uint16_t>(G.dom_tx[i])) | (static_cast<uint32_t>(static_cast<uint16_t>(G.dom_ty[i])) << 16);
+        const size_t with_doms = img.words.size() + 2 * xy.size();
+        if (prop_kernel_lds_bytes(static_cast<uint32_t>(with_doms)) <= 64 * 1024) {
+            P.dom_in_lds = 1;
+            P.off_dom_xy = img.add_words(xy);
+            P.off_dom_z = img.add_floats(G.dom_tz);
+        }
+    }
     scalar("NUM_STRINGS", G.num_strings); scalar("OM_RADIUS", G.om_radius);
     scalar("GEO_STRING_MAX_RADIUS", G.string_max_radius);
     scalar("GEO_LAYER_STRINGSET_NUM", G.num_sets); scalar("GEO_LAYER_STRINGSET_MAX_NUM_LAYERS", G.max_layers);
@@ -289,7 +315,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
 
     P.table_words = static_cast<uint32_t>(img.words.size());
     C.lds_image = std::move(img.words);
-    if (prop_kernel_lds_bytes(P.table_words) > 60 * 1024)
+    if (prop_kernel_lds_bytes(P.table_words) > 64 * 1024)
         throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables do not fit the LDS budget of the propagation kernel");
     return C;
 }

@@ -129,6 +129,18 @@ typedef struct {
 
 typedef struct { uint64_t x; uint32_t a; } rng_t;
 
+#ifdef ORACLE_TRACE
+/* divergence study (tools/divergence_model.py): per loop iteration of one work item:
+ * [0] created a photon, [1] layer-walk trips, [2] cells visited, [3] strings tested,
+ * [4] DOM-layer trips, [5] SimplifiedLiu branch, [6] scattered (not absorbed), [7] hit */
+static __thread uint8_t *g_trace = 0;
+static __thread uint64_t g_trace_cap = 0, g_trace_n = 0;
+static __thread uint8_t g_cur[8];
+#define TR(i, v) (g_cur[i] = (uint8_t)((g_cur[i] + (v)) > 255 ? 255 : (g_cur[i] + (v))))
+#else
+#define TR(i, v) ((void)0)
+#endif
+
 /* mwcrng_kernel.cl:12-20 */
 static inline float rand_co(rng_t *r)
 {
@@ -207,7 +219,7 @@ static inline float makeScatteringCosAngle(const oracle_tables *T, rng_t *rng)
     if (T->scat_kind == 0) return hg_cos(T, rand_co(rng));
     if (T->scat_kind == 1) return liu_cos(T, rand_co(rng));
     const float rr = rand_co(rng);
-    if (rr < T->mix_frac) return liu_cos(T, rr / T->mix_frac);
+    if (rr < T->mix_frac) { TR(5, 1); return liu_cos(T, rr / T->mix_frac); }
     return hg_cos(T, (1.0f - rr) / T->mix_frac_rest);
 }
 /* ScalarFieldAnisotropyAbsLenScaling.cxx:92-140 / ScalarFieldConstant.cxx:61-80 */
@@ -458,7 +470,9 @@ static void checkForCollision_OnString(const oracle_tables *T, unsigned stringNu
     highLayerZ = imin(imax(highLayerZ, 0), (int)T->set_nlayers[stringSet] - 1);
 
     const uint16_t *geoLayerToOMNumIndex = T->layer_to_om + (stringSet * (unsigned)T->max_layers) + lowLayerZ;
+    TR(3, 1);
     for (int layer_z = lowLayerZ; layer_z <= highLayerZ; ++layer_z, ++geoLayerToOMNumIndex) {
+        TR(4, 1);
         const unsigned domNum = *geoLayerToOMNumIndex;
         if (domNum == 0xFFFF) continue;
         float domPosX, domPosY, domPosZ;
@@ -508,6 +522,7 @@ static void checkForCollision_InCell(const oracle_tables *T, int sd, float dirLe
     highCellY = imin(imax(highCellY, 0), ny - 1);
     for (int cell_y = lowCellY; cell_y <= highCellY; ++cell_y) {
         for (int cell_x = lowCellX; cell_x <= highCellX; ++cell_x) {
+            TR(2, 1);
             const unsigned stringNum = T->cell_index[sd][cell_y * nx + cell_x];
             if (stringNum == 0xFFFF) continue;
             checkForCollision_OnString(T, stringNum, dirLenXYSqr, pos, dirw, thisStepLength,
@@ -561,7 +576,11 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
 
     while (photonsLeftToPropagate > 0) {
         ++iters;
+#ifdef ORACLE_TRACE
+        memset(g_cur, 0, 8);
+#endif
         if (abs_lens_left < EPSILON) {
+            TR(0, 1);
             createPhotonFromTrack(T, &step, stepDir, rng, pos, dirw);
             memcpy(startPos, pos, 16); memcpy(startDirw, dirw, 16);
             numScatters = 0; totalPath = 0.0f;
@@ -598,14 +617,14 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
                      currentScaLen = getScatteringLength(T, j, dirw[3]),
                      currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
                      ais += 1.0f / currentScaLen,
-                     aia += 1.0f / currentAbsLen) --j;
+                     aia += 1.0f / currentAbsLen) { --j; TR(1, 1); }
             } else {
                 for (; (j < T->num_layers - 1) && (ais > 0.0f) && (aia > 0.0f);
                      mediumBoundary += thickness,
                      currentScaLen = getScatteringLength(T, j, dirw[3]),
                      currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
                      ais -= 1.0f / currentScaLen,
-                     aia -= 1.0f / currentAbsLen) ++j;
+                     aia -= 1.0f / currentAbsLen) { ++j; TR(1, 1); }
             }
             float distanceToAbsorption;
             if ((currentPhotonLayer == j) || ((om_fabs(photon_dz)) < EPSILON)) {
@@ -628,7 +647,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         const int collided = checkForCollision(T, pos, dirw, inv_groupvel, totalPath, numScatters,
                                                abs_lens_initial - abs_lens_left, startPos, startDirw, &step,
                                                &distancePropagated, sink);
-        if (collided) abs_lens_left = 0.0f;
+        if (collided) { abs_lens_left = 0.0f; TR(7, 1); }
         pos[0] += dirw[0] * distancePropagated;
         pos[1] += dirw[1] * distancePropagated;
         pos[2] += dirw[2] * distancePropagated;
@@ -643,7 +662,11 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             scatterDirectionByAngle(cosScatAngle, sinScatAngle, dirw, rand_co(rng));
             transformDirection(T->has_post, T->post_renorm, T->post, dirw);
             ++numScatters;
+            TR(6, 1);
         }
+#ifdef ORACLE_TRACE
+        if (g_trace && g_trace_n < g_trace_cap) { memcpy(g_trace + 8 * g_trace_n, g_cur, 8); ++g_trace_n; }
+#endif
     }
     if (iterations) *iterations += iters;
 }
@@ -783,3 +806,17 @@ void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *
     }
 }
 size_t oracle_sizeof_tables(void) { return sizeof(oracle_tables); }
+
+#ifdef ORACLE_TRACE
+/* traces ONE step: returns the number of loop iterations written (8 bytes each) */
+uint64_t oracle_trace_step(const oracle_tables *T, const oracle_step *step, uint64_t x, uint32_t a, uint8_t *buf, uint64_t cap)
+{
+    static oracle_photon scratch[4096];
+    hit_sink sink = { scratch, 4096, 0 };
+    rng_t r = { x, a };
+    g_trace = buf; g_trace_cap = cap; g_trace_n = 0;
+    propagate_step(T, step, &r, &sink, 0);
+    g_trace = 0;
+    return g_trace_n;
+}
+#endif
