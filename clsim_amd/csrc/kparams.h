@@ -70,6 +70,16 @@ struct KParams {
     int32_t tilt_nd, tilt_nz;
     float tilt_first_z, tilt_dz, tilt_lnx, tilt_lny;
     uint32_t off_tilt_dist, off_tilt_zcorr;
+    // 4-word records per distance bin j = 1..nd-1 at off_tilt_bins + 4*j: {dist[j], dist[j]-dist[j-1], its reciprocal, ok}
+    uint32_t off_tilt_bins;
+
+    // ---- exact division by invariant divisors ----
+    // For a divisor b that never changes, q = a*r; q' = fma(fma(-b,q,a), r, q) with r = RN(1/b) is the
+    // correctly rounded quotient a/b for all a except for rare divisors (Brisebarre, Muller, Raina 2004).
+    // Compile() proves it per divisor by trying every significand of a; bit set = proven, else the kernel
+    // keeps the IEEE divide.  3 VALU instructions instead of ~11.
+    float rcp_tilt_dz, rcp_layer_thickness, rcp_mix_frac, rcp_mix_frac_rest, rcp_hg_two_g;
+    uint32_t div_ok;                    // bit 0 tilt_dz, 1 layer_thickness, 2 mix_frac, 3 mix_frac_rest, 4 hg_two_g
 
     // ---- spectra ----
     int32_t num_gen;

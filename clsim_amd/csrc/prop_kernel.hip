@@ -83,6 +83,15 @@ DM float rng_co(uint64_t &x, uint32_t a)
 DM float rng_oc(uint64_t &x, uint32_t a) { return 1.0f - rng_co(x, a); }
 
 DM float sqr(float a) { return a * a; }
+// a / b for an invariant divisor b with r = RN(1/b): exact when Compile() proved it (`ok`, wave-uniform)
+DM float div_by(float a, float b, float r, bool ok)
+{
+    if (ok) {
+        const float q = a * r;
+        return dm::fma_(dm::fma_(-b, q, a), r, q);
+    }
+    return a / b;
+}
 DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 
@@ -139,7 +148,7 @@ DM float hg_cos(KP P, float u)
 {
     const float s = 2.0f * u - 1.0f;
     const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
-    return clampf((P->hg_one_plus_g2 - ii * ii) / P->hg_two_g, -1.0f, 1.0f);
+    return clampf(div_by(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, (P->div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
 DM float liu_cos(KP P, float u) { return clampf(2.0f * dm::powr_(u, P->liu_beta) - 1.0f, -1.0f, 1.0f); }
@@ -150,8 +159,9 @@ DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
     const int kind = P->scatter_kind;
     if (kind == 0) return hg_cos(P, rr);
     if (kind == 1) return liu_cos(P, rr);
-    if (rr < P->mix_frac) return liu_cos(P, rr / P->mix_frac);
-    return hg_cos(P, (1.0f - rr) / P->mix_frac_rest);
+    const uint32_t ok = P->div_ok;
+    if (rr < P->mix_frac) return liu_cos(P, div_by(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
+    return hg_cos(P, div_by(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
 }
 
 // ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
@@ -182,7 +192,7 @@ DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renor
 // nr < dist[j] (last bin otherwise); dist is ascending, so it is counted.
 DM float tilt_z_shift(KP P, float px, float py, float pz)
 {
-    const float z_rescaled = (pz - P->tilt_first_z) / P->tilt_dz;
+    const float z_rescaled = div_by(pz - P->tilt_first_z, P->tilt_dz, P->rcp_tilt_dz, (P->div_ok & 1u) != 0);
     const int nz = P->tilt_nz, nd = P->tilt_nd;
     const uint32_t off_dist = P->off_tilt_dist;
     const int k = clampi((int)__builtin_floorf(z_rescaled), 0, nz - 2);
@@ -191,10 +201,12 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     const float nr = P->tilt_lnx * px + P->tilt_lny * py;
     int j = 1;
     for (int t = 1; t < nd - 1; ++t) j += (nr >= ldsf(off_dist + t)) ? 1 : 0;
-    const float thisDist = ldsf(off_dist + j);
-    const float previousDist = ldsf(off_dist + j - 1);
-    const float width = thisDist - previousDist;
-    const float frac_at_lower = (thisDist - nr) / width;
+    const Rec4 bin = lds_rec4(P->off_tilt_bins + 4u * (uint32_t)j);    // dist[j], dist[j]-dist[j-1], 1/width, proven
+    const float thisDist = bin.a;
+    // the proof bit differs per bin: select, the divide is only executed if some lane's bin lacks the proof
+    const float q = (thisDist - nr) * bin.c;
+    float frac_at_lower = dm::fma_(dm::fma_(-bin.b, q, thisDist - nr), bin.c, q);
+    if (__builtin_bit_cast(uint32_t, bin.d) == 0u) frac_at_lower = (thisDist - nr) / bin.b;
     const float frac_at_upper = 1.0f - frac_at_lower;
     const uint32_t lo = P->off_tilt_zcorr + (uint32_t)((j - 1) * nz + k);
     const uint32_t hi = lo + (uint32_t)nz;
@@ -349,7 +361,7 @@ DM void create_photon(KP P, const DevStep *step_ptr, uint64_t &rx, uint32_t ra, 
     ph.sd = ph.d;
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
-    if (!TILT) ph.layer = clampi((int)((ph.pz - P->layer_bottom) / P->layer_thickness), 0, P->num_layers - 1);
+    if (!TILT) ph.layer = clampi((int)div_by(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
     ph.inv_groupvel = 1.0f / group_velocity(P, ph.wlen);
     ph.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
     ph.abs_lens_left = ph.abs_lens_initial;
@@ -367,7 +379,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     int current_layer;
     if (TILT) {
         effective_z = ph.pz - tilt_z_shift(P, ph.px, ph.py, ph.pz);
-        current_layer = clampi((int)((effective_z - bottom) / thickness), 0, num_layers - 1);
+        current_layer = clampi((int)div_by(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, num_layers - 1);
     } else {
         effective_z = ph.pz - P->tilt_const;
         current_layer = ph.layer;
@@ -489,15 +501,19 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
     const uint32_t off_subdet = P->off_subdet;
     bool hit = false;
     for (int sd = 0; sd < num_subdet; ++sd) {
-        const Rec4 g0 = lds_rec4(off_subdet + 8u * (uint32_t)sd);        // nx, ny (bits), width x, width y
-        const Rec4 g1 = lds_rec4(off_subdet + 8u * (uint32_t)sd + 4u);   // start x, start y, cell offset (bits)
+        const Rec4 g0 = lds_rec4(off_subdet + 12u * (uint32_t)sd);        // nx, ny (bits), width x, width y
+        const Rec4 g1 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 4u);   // start x, start y, cell offset, proof bits
+        const Rec4 g2 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 8u);   // 1/width x, 1/width y
         const int nx = (int)__builtin_bit_cast(uint32_t, g0.a), ny = (int)__builtin_bit_cast(uint32_t, g0.b);
         const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
         const uint32_t cells = __builtin_bit_cast(uint32_t, g1.c);
-        int low_x = (int)((ph.px - sx) / wx);
-        int low_y = (int)((ph.py - sy) / wy);
-        int high_x = (int)((ph.px + ph.d.x * step_len - sx) / wx);
-        int high_y = (int)((ph.py + ph.d.y * step_len - sy) / wy);
+        // all lanes are in the same subdetector here, so the proof bits are wave-uniform
+        const uint32_t proven = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, g1.d));
+        const bool okx = (proven & 1u) != 0, oky = (proven & 2u) != 0;
+        int low_x = (int)div_by(ph.px - sx, wx, g2.a, okx);
+        int low_y = (int)div_by(ph.py - sy, wy, g2.b, oky);
+        int high_x = (int)div_by(ph.px + ph.d.x * step_len - sx, wx, g2.a, okx);
+        int high_y = (int)div_by(ph.py + ph.d.y * step_len - sy, wy, g2.b, oky);
         if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
         if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
         low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);

@@ -42,6 +42,25 @@ struct Image {
     }
 };
 
+// Proof by exhaustion that a/b == fma(fma(-b, a*r, a), r, a*r) with r = RN(1/b) for EVERY float a: the
+// three operations scale exactly with the exponent of a and are odd in a, so one binade of a covers all
+// normal a (the kernel's dividends are 0 or far from the subnormal range).
+bool division_by_reciprocal_is_exact(float b, float &r)
+{
+    r = 1.0f / b;
+    if (!(b > 1e-18f && b < 1e18f)) return false;
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        const uint32_t bits = 0x3f800000u | m;
+        float a;
+        std::memcpy(&a, &bits, 4);
+        const float q = a * r;
+        const float rem = std::fmaf(-b, q, a);
+        const float q1 = std::fmaf(rem, r, q);
+        if (q1 != a / b) return false;
+    }
+    return true;
+}
+
 template <class T>
 std::vector<double> as_doubles(const std::vector<T> &v) { return std::vector<double>(v.begin(), v.end()); }
 
@@ -69,6 +88,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     P.layer_bottom = to_float_literal(m.layers_z_start);
     P.layer_thickness = to_float_literal(m.layers_height);
     P.recip_thickness = 1.0f / P.layer_thickness;                  // (ONE/MEDIUM_LAYER_THICKNESS), c.cl:639
+    if (division_by_reciprocal_is_exact(P.layer_thickness, P.rcp_layer_thickness)) P.div_ok |= 2u;
     scalar("MEDIUM_LAYERS", m.num_layers);
     scalar("MEDIUM_LAYER_BOTTOM_POS", P.layer_bottom);
     scalar("MEDIUM_LAYER_THICKNESS", P.layer_thickness);
@@ -117,6 +137,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.hg_two_g = 2.f * P.hg_g;
         P.mix_frac = to_float_literal(m.liu_fraction);
         P.mix_frac_rest = to_float_literal(1. - m.liu_fraction);
+        if (division_by_reciprocal_is_exact(P.mix_frac, P.rcp_mix_frac)) P.div_ok |= 4u;
+        if (division_by_reciprocal_is_exact(P.mix_frac_rest, P.rcp_mix_frac_rest)) P.div_ok |= 8u;
+        if (division_by_reciprocal_is_exact(P.hg_two_g, P.rcp_hg_two_g)) P.div_ok |= 16u;
         scalar("liu_beta", P.liu_beta); scalar("hg_g", P.hg_g); scalar("hg_g2", g2);
         scalar("mix_frac", P.mix_frac); scalar("mix_frac_rest", P.mix_frac_rest);
     }
@@ -170,6 +193,21 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             if (!(dist[i] < dist[i + 1])) throw Error(CLSIMHIP_ERR_CONFIG, "tilt distances collapse in single precision");
         P.off_tilt_dist = img.add_floats(dist);
         P.off_tilt_zcorr = img.add_floats(corr);
+        if (division_by_reciprocal_is_exact(P.tilt_dz, P.rcp_tilt_dz)) P.div_ok |= 1u;
+        {
+            std::vector<uint32_t> bins(4 * nd, 0u);
+            for (size_t j = 1; j < nd; ++j) {
+                const float width = dist[j] - dist[j - 1];          // thisDistanceBinWidth
+                float rcp = 0.f;
+                const bool ok = division_by_reciprocal_is_exact(width, rcp);
+                std::memcpy(&bins[4 * j], &dist[j], 4);
+                std::memcpy(&bins[4 * j + 1], &width, 4);
+                std::memcpy(&bins[4 * j + 2], &rcp, 4);
+                bins[4 * j + 3] = ok ? 1u : 0u;
+            }
+            img.align(4);
+            P.off_tilt_bins = img.add_words(bins);
+        }
         name("getTiltZShift_data_distancesFromOriginAlongTilt", as_doubles(dist));
         name("getTiltZShift_data_zCorrections", as_doubles(corr));
         scalar("getTiltZShift_data_firstZCoord", P.tilt_first_z);
@@ -266,13 +304,16 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.off_sets = img.add_words(rec);
     }
     P.off_layer_to_om = img.add_u16(G.layer_to_om);
-    std::vector<uint32_t> subdet(8 * G.cells.size(), 0u);
+    std::vector<uint32_t> subdet(12 * G.cells.size(), 0u);
     for (size_t k = 0; k < G.cells.size(); ++k) {
         const GeoTables::Cells &c = G.cells[k];
-        subdet[8 * k + 0] = static_cast<uint32_t>(c.nx); subdet[8 * k + 1] = static_cast<uint32_t>(c.ny);
-        subdet[8 * k + 2] = bits(c.wx); subdet[8 * k + 3] = bits(c.wy);
-        subdet[8 * k + 4] = bits(c.sx); subdet[8 * k + 5] = bits(c.sy);
-        subdet[8 * k + 6] = img.add_u16(c.index);
+        subdet[12 * k + 0] = static_cast<uint32_t>(c.nx); subdet[12 * k + 1] = static_cast<uint32_t>(c.ny);
+        subdet[12 * k + 2] = bits(c.wx); subdet[12 * k + 3] = bits(c.wy);
+        subdet[12 * k + 4] = bits(c.sx); subdet[12 * k + 5] = bits(c.sy);
+        subdet[12 * k + 6] = img.add_u16(c.index);
+        float rwx = 0.f, rwy = 0.f;
+        subdet[12 * k + 7] = (division_by_reciprocal_is_exact(c.wx, rwx) ? 1u : 0u) | (division_by_reciprocal_is_exact(c.wy, rwy) ? 2u : 0u);
+        subdet[12 * k + 8] = bits(rwx); subdet[12 * k + 9] = bits(rwy);
         const std::string sfx = "_" + std::to_string(k);
         name("geoCellIndex" + sfx, as_doubles(c.index));
         name("GEO_CELL" + sfx, {double(c.nx), double(c.ny), c.wx, c.wy, c.sx, c.sy});
@@ -313,6 +354,12 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     name("stringIndexToStringID", as_doubles(G.string_index_to_id));
     scalar("PANCAKE_FACTOR", P.pancake);
 
+    scalar("div_ok", P.div_ok);
+    {
+        std::vector<double> flags;
+        for (size_t k = 0; k < G.cells.size(); ++k) flags.push_back(subdet[12 * k + 7]);
+        name("div_ok_cells", flags);
+    }
     P.table_words = static_cast<uint32_t>(img.words.size());
     C.lds_image = std::move(img.words);
     if (prop_kernel_lds_bytes(P.table_words) > 64 * 1024)
