@@ -79,6 +79,7 @@ def main():
     import torch.distributed as dist
     from clsim_amd import converter as CV
     from clsim_amd import synthetic as S
+    from clsim_amd.distributed import gather_hits
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +107,6 @@ def main():
     d_photons = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
     d_count = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.empty((capacity if rank == 0 else 1, 80), dtype=torch.uint8, device=dev) if world > 1 else None
-    counts = torch.zeros(world, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     total_hits = 0
 
@@ -116,22 +116,8 @@ def main():
         if world > 1:
             # gather of detected photons on rank 0: counts, then one point-to-point
             # transfer per peer (7 peers -> 7 distinct xGMI links, no ring)
-            dist.all_gather_into_tensor(counts, d_count)
-            c = counts.cpu().numpy().astype(np.int64)
-            if rank == 0:
-                off = int(c[0])
-                reqs = []
-                for peer in range(1, world):
-                    if c[peer]:
-                        reqs.append(dist.irecv(gathered[off:off + int(c[peer])], src=peer))
-                    off += int(c[peer])
-                for r in reqs:
-                    r.wait()
-                total_hits += int(c.sum())
-            elif c[rank]:
-                dist.send(d_photons[:int(c[rank])], dst=0)
-        else:
-            total_hits += 0
+            got, c = gather_hits(d_photons, int(d_count.cpu().item()), dst=0, out=gathered)
+            total_hits += int(c.sum())
 
     def barrier():
         if world > 1:

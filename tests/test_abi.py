@@ -1,0 +1,100 @@
+"""The C ABI: the shared library loads, exports every symbol include/clsimhip.h
+declares, keeps the reference's record layouts, and fails loudly (no fallback)
+where a GPU is required.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from clsim_amd import _lib
+from clsim_amd import converter as CV
+from clsim_amd.synthetic import PHOTON_DTYPE, STEP_DTYPE
+from tests import common
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "clsimhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(clsimhip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_symbols()
+    assert len(declared) >= 40
+    assert sorted(_lib.SYMBOLS) == declared          # the binding knows exactly the header's functions
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.clsimhip_version()
+
+
+def test_record_layouts_are_the_reference_wire_structs():
+    # public/clsim/I3CLSimStep.h:141-155 (48 B), I3CLSimPhoton.h:194-213 (80 B)
+    assert STEP_DTYPE.itemsize == 48 and PHOTON_DTYPE.itemsize == 80
+    assert STEP_DTYPE.fields["num"][1] == 32 and STEP_DTYPE.fields["id"][1] == 40 and STEP_DTYPE.fields["sourceType"][1] == 44
+    assert PHOTON_DTYPE.fields["numScatters"][1] == 32 and PHOTON_DTYPE.fields["stringID"][1] == 44
+    assert PHOTON_DTYPE.fields["omID"][1] == 46 and PHOTON_DTYPE.fields["sx"][1] == 48 and PHOTON_DTYPE.fields["distInAbsLens"][1] == 76
+
+
+def test_use_before_initialize_raises_like_the_reference():
+    """OpenCL.cxx:1525-1544, 1604-1607: '... is not initialized!'"""
+    conv = common.product_converter(common.config("c1"), 512, initialize=False)
+    assert not conv.IsInitialized()
+    steps = np.zeros(512, dtype=STEP_DTYPE)
+    for call in (lambda: conv.EnqueueSteps(steps, 0), conv.GetConversionResult, conv.QueueSize, conv.MorePhotonsAvailable):
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="not initialized"):
+            call()
+
+
+def test_unsupported_modes_are_refused_at_compile():
+    cfg = common.config("c1")
+    for setter, value in (("SetDoublePrecision", True), ("SetStopDetectedPhotons", False), ("SetSaveAllPhotons", True),
+                          ("SetPhotonHistoryEntries", 4), ("SetFixedNumberOfAbsorptionLengths", 46.0)):
+        conv = common.product_converter(cfg, 512, initialize=False)
+        getattr(conv, setter)(value)
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception) as e:
+            conv.Compile()
+        assert e.value.code == _lib.ERR_CONFIG
+
+
+def test_incomplete_configuration_is_refused():
+    conv = CV.I3CLSimStepToPhotonConverterHIP(0)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="WlenGenerators"):
+        conv.Compile()
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
+        conv.SetWorkgroupSize(100000)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
+        conv.SetMaxNumWorkitems(0)
+
+
+def test_bad_arguments():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.clsimhip_medium_create_from_ppc(b"/nonexistent/dir", 1948.07, 1, C.byref(h)) == _lib.ERR_IO
+    assert b"cannot open" in lib.clsimhip_last_error(None)
+    assert lib.clsimhip_create(0, None) == _lib.ERR_ARGUMENT
+    assert lib.clsimhip_mwc_multipliers(None, 4) == _lib.ERR_ARGUMENT
+    conv = CV.I3CLSimStepToPhotonConverterHIP(0)
+    g = CV.I3CLSimSimpleGeometry([1, 1], [1, 2], [0.0, 0.0], [0.0, 0.0], [0.0, -17.0], ["a", "a"], -1.0)
+    conv.SetGeometry(g)          # stored; rejected when compiled (GeometrySource.cxx:735)
+    conv.SetWlenGenerators([CV.I3CLSimRandomValueConstant(4e-7)])
+    conv.SetWlenBias(CV.I3CLSimFunctionConstant(1.0))
+    conv.SetMediumProperties(CV.MakeHomogeneousMediumProperties())
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="OM radius"):
+        conv.Compile()
+
+
+def test_initialize_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    conv = common.product_converter(common.config("c1"), 512, initialize=False)
+    x, a = common.streams(512)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="no HIP device") as e:
+        conv.InitializeWithStreams(x, a)
+    assert e.value.code == _lib.ERR_DEVICE
+    assert not conv.IsInitialized()

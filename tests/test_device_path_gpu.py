@@ -1,0 +1,126 @@
+"""GPU: the device-resident entry point (clsimhip_propagate_device) used by
+bench.py and by multi-GPU sharding, and size-independent properties at the
+BASELINE bunch size."""
+import numpy as np
+import pytest
+import torch
+
+from clsim_amd.distributed import shard_range
+from clsim_amd.synthetic import PHOTON_DTYPE
+from oracle import capi
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def device_run(conv, steps, capacity, rng_offset=0):
+    dev = torch.device("cuda", 0)
+    n = len(steps)
+    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+    d_out = torch.zeros((capacity, 80), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    conv.PropagateDevice(d_steps.data_ptr(), n, d_out.data_ptr(), capacity, d_cnt.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream, rng_offset=rng_offset)
+    torch.cuda.synchronize()
+    cnt = int(d_cnt.item())
+    raw = d_out[:min(cnt, capacity)].cpu().numpy()
+    return np.frombuffer(raw.tobytes(), dtype=PHOTON_DTYPE).copy(), cnt
+
+
+def test_device_path_equals_oracle_and_host_path():
+    cfg = common.config("lea")
+    steps = common.steps_for(cfg, 3072, seed=8)
+    n = len(steps)
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    conv = common.product_converter(cfg, n)
+    ph_d, cnt_d = device_run(conv, steps, capacity=8192)
+    assert cnt_d == cnt_o
+    assert common.sort_photons(ph_d).tobytes() == common.sort_photons(ph_o).tobytes()     # raw records: indices
+    assert np.array_equal(conv.GetRNGState(n), x_o)
+    ids = conv.ReplaceIndicesWithIDs(ph_d)
+    assert common.sort_photons(ids).tobytes() == common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes()
+    ms, launches = conv.KernelTimeMs(reset=True)
+    assert launches == 1 and ms > 0
+
+
+def test_sharding_invariance():
+    """Config C4 by construction: propagating a bunch as 2, 3 or 8 contiguous shards (each with
+    the matching slice of the RNG streams) yields the same photon multiset as one launch --
+    steps are independent units, nothing is exchanged."""
+    cfg = common.config("mie")
+    steps = common.steps_for(cfg, 4096, seed=12)
+    n = len(steps)
+    conv = common.product_converter(cfg, n)
+    whole, cnt = device_run(conv, steps, capacity=16384)
+    x_whole = conv.GetRNGState(n)
+    for world in (2, 3, 8):
+        conv2 = common.product_converter(cfg, n)
+        parts = []
+        for rank in range(world):
+            lo, hi = shard_range(n, rank, world)
+            ph, c = device_run(conv2, steps[lo:hi], capacity=16384, rng_offset=lo)
+            parts.append(ph)
+        allp = np.concatenate(parts)
+        assert len(allp) == cnt
+        assert common.sort_photons(allp).tobytes() == common.sort_photons(whole).tobytes()
+        assert np.array_equal(conv2.GetRNGState(n), x_whole)
+
+
+def test_baseline_size_properties():
+    """BASELINE configs[1] size (1M steps x 200 photons, SPICE-Mie, 86 strings): determinism across
+    converters, every stream advanced, hit fraction and record sanity; the first 2048 steps are
+    checked bit-exactly against the oracle as part of the big launch (queue order must not matter)."""
+    cfg = common.config("mie")
+    n = 1 << 20
+    steps = common.steps_for(cfg, n, seed=1000)
+    x, a = common.streams(n)
+    conv = common.product_converter(cfg, n)
+    ph1, cnt1 = device_run(conv, steps, capacity=1 << 21)
+    x1 = conv.GetRNGState(n)
+    conv_b = common.product_converter(cfg, n)
+    ph2, cnt2 = device_run(conv_b, steps, capacity=1 << 21)
+    assert cnt1 == cnt2 and common.sort_photons(ph1).tobytes() == common.sort_photons(ph2).tobytes()
+    assert np.array_equal(x1, conv_b.GetRNGState(n))
+    assert np.all(x1 != x)
+    photons = float(steps["num"].sum())
+    assert 2e-4 < cnt1 / photons < 3e-3
+    assert np.all(ph1["stringID"] < 86) and np.all(ph1["omID"] < 60) and np.all(ph1["id"] < n)
+    T = common.oracle_tables(cfg)
+    m = 2048
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps[:m], x, a, threads=8)
+    sub = ph1[ph1["id"] < m]
+    assert len(sub) == cnt_o and common.sort_photons(sub).tobytes() == common.sort_photons(ph_o).tobytes()
+    assert np.array_equal(x1[:m], x_o)
+
+
+def test_converter_queue_semantics():
+    """EnqueueSteps / GetConversionResult: several bunches in flight, identifiers round-trip,
+    statistics add up (OpenCL.cxx:1525-1640); misuse raises the reference's messages."""
+    from clsim_amd import converter as CV
+    cfg = common.config("c1")
+    conv = common.product_converter(cfg, 1024)
+    assert conv.IsInitialized() and conv.GetMaxNumWorkitems() == 1024 and conv.GetWorkgroupSize() == 512
+    steps = common.steps_for(cfg, 1024, seed=4, pad_to=512)
+    for ident in (11, 22, 33):
+        conv.EnqueueSteps(steps, ident)
+    got = [conv.GetConversionResult()[0] for _ in range(3)]
+    assert got == [11, 22, 33]
+    st = conv.GetStatistics()
+    assert st["NumKernelCalls"] == 3 and st["TotalNumPhotonsGenerated"] == 3 * float(steps["num"].sum())
+    assert st["TotalDeviceTime"] > 0 and 0 < st["DeviceUtilization"] <= 1.0001
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="multiple of the workgroup size"):
+        conv.EnqueueSteps(steps[:100], 1)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="greater than maximum"):
+        conv.EnqueueSteps(np.concatenate([steps, steps]), 1)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="empty"):
+        conv.EnqueueSteps(steps[:0], 1)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="already initialized"):
+        conv.SetDOMPancakeFactor(2.0)
+    # all-zero bunch: no photons, streams untouched
+    x_before = conv.GetRNGState(1024)
+    zero = steps.copy(); zero["num"] = 0
+    conv.EnqueueSteps(zero, 9)
+    ident, ph = conv.GetConversionResult()
+    assert ident == 9 and len(ph) == 0 and np.array_equal(conv.GetRNGState(1024), x_before)

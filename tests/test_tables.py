@@ -1,0 +1,102 @@
+"""Host logic, no GPU: the product's Compile() (C++: medium/spectrum/geometry ->
+kernel constants) against the oracle's independent numpy restatement of the
+reference's code generators, table by table and bit by bit."""
+import numpy as np
+import pytest
+
+from clsim_amd import converter as CV
+from clsim_amd import synthetic as S
+from tests import common
+
+PAIRS = {
+    "geoStringPosX": "str_x", "geoStringPosY": "str_y", "geoStringMinZ": "str_minz", "geoStringMaxZ": "str_maxz",
+    "geoStringInStringSet": "str_set", "geoLayerNum": "set_nlayers", "geoLayerStartZ": "set_startz",
+    "geoLayerHeight": "set_height", "geoLayerToOMNumIndexPerStringSet": "layer_to_om",
+    "geoDomPosTemplatePositionsX_flat": "dom_tx", "geoDomPosTemplatePositionsY_flat": "dom_ty",
+    "geoDomPosTemplatePositionsZ_flat": "dom_tz", "geoDomPosStringStartIndexInTemplateDomList": "dom_start",
+    "geoDomPosStringMeanPosX": "dom_meanx", "geoDomPosStringMeanPosY": "dom_meany",
+    "_generateWavelength_0distYValues": "gen0_yv", "_generateWavelength_0distYCumulativeValues": "gen0_ycum",
+    "getWavelengthBias_data": "bias_data",
+}
+SCALARS = {
+    "MEDIUM_LAYER_BOTTOM_POS": "layer_bottom", "MEDIUM_LAYER_THICKNESS": "layer_thickness", "OM_RADIUS": "om_radius",
+    "GEO_STRING_MAX_RADIUS": "string_max_radius", "GEO_DOM_POS_MAX_ABS_X_MULTIPLIER_IN_TEMPLATE": "dom_mul_x",
+    "GEO_DOM_POS_MAX_ABS_Y_MULTIPLIER_IN_TEMPLATE": "dom_mul_y", "liu_beta": "liu_beta", "hg_g": "hg_g", "hg_g2": "hg_g2",
+    "mix_frac": "mix_frac", "mix_frac_rest": "mix_frac_rest", "PANCAKE_FACTOR": "pancake",
+    "GEO_LAYER_STRINGSET_NUM": "num_sets", "GEO_LAYER_STRINGSET_MAX_NUM_LAYERS": "max_layers", "NUM_STRINGS": "num_strings",
+}
+
+
+@pytest.mark.parametrize("name", ["c1", "mie", "lea", "flasher"])
+def test_compiled_tables_equal_oracle(name):
+    cfg = common.config(name)
+    T = common.oracle_tables(cfg)
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    pairs = dict(PAIRS)
+    if cfg["med_o"]["len_mode"] == "icecube":
+        pairs.update(aDust400="aDust400", deltaTau="deltaTau", b400="b400")
+    else:
+        pairs.update(absorptionLength="abs_const", scatteringLength="sca_const")
+    if "tilt" in cfg["med_o"]:
+        pairs.update(getTiltZShift_data_distancesFromOriginAlongTilt="tilt_dist", getTiltZShift_data_zCorrections="tilt_zcorr")
+    for pn, on in pairs.items():
+        p, o = conv.GetTable(pn), T.arrays[on].astype(np.float64)
+        assert p.shape == o.shape and np.array_equal(p, o), pn
+    sc = T.scalars()
+    for pn, on in SCALARS.items():
+        assert np.float32(conv.GetTable(pn)[0]) == np.float32(sc[on]), pn
+    for k, c in enumerate(T.geo["cells"]):
+        assert np.array_equal(conv.GetTable("geoCellIndex_%d" % k), c["index"].astype(np.float64))
+        exp = np.array([c["nx"], c["ny"], c["width_x"], c["width_y"], c["start_x"], c["start_y"]], dtype=np.float64)
+        assert np.array_equal(conv.GetTable("GEO_CELL_%d" % k), exp)
+    if "tilt" in cfg["med_o"]:
+        for pn, on in (("getTiltZShift_data_firstZCoord", "tilt_first_z"), ("getTiltZShift_data_zCoordSpacing", "tilt_dz"),
+                       ("getTiltZShift_lnx", "tilt_lnx"), ("getTiltZShift_lny", "tilt_lny")):
+            assert np.float32(conv.GetTable(pn)[0]) == np.float32(sc[on]), pn
+    if "aniso" in cfg["med_o"]:
+        o = list(sc["an_l"]) + list(sc["an_rl"]) + [sc["an_azx"], sc["an_azy"], sc["an_mazy"], sc["an_B2"]]
+        assert np.array_equal(conv.GetTable("anisotropy").astype(np.float32), np.array(o, dtype=np.float32))
+        for nm, key in (("transformDirectionPreScatter", "pre"), ("transformDirectionPostScatter", "post")):
+            assert np.array_equal(conv.GetTable(nm).astype(np.float32), np.array(sc[key], dtype=np.float32))
+    assert np.array_equal(conv.GetTable("stringIndexToStringID"), T.geo["string_index_to_id"].astype(np.float64))
+
+
+def test_ic86_geometry_structure():
+    """Facts about the synthetic IC86 geometry the rest of the suite relies on:
+    two subdetectors sorted by name, 5160 DOM template entries (jitter => no shared
+    templates), cell grids with at most one string per cell."""
+    cfg = common.config("mie")
+    T = common.oracle_tables(cfg)
+    assert T.geo["subdetectors"] == ["DeepCore", "IceCube"]
+    assert T.geo["num_strings"] == 86 and len(T.geo["dom_tx"]) == 5160
+    for c in T.geo["cells"]:
+        idx = c["index"][c["index"] != 0xFFFF]
+        assert len(set(idx.tolist())) == len(idx)
+    assert sorted(set(T.geo["string_index_to_id"].tolist())) == list(range(1, 87))
+
+
+def test_invariant_divisors_are_proven():
+    """The kernel replaces a/b by fma(fma(-b, a*r, a), r, a*r) only for divisors Compile() proved
+    exact over all significands; for the benchmark configurations every divisor qualifies."""
+    for name in ("c1", "mie", "lea"):
+        cfg = common.config(name)
+        conv = common.product_converter(cfg, 512, initialize=False)
+        conv.Compile()
+        ok = int(conv.GetTable("div_ok")[0])
+        assert ok & 0b11110 == 0b11110
+        if name != "c1":
+            assert ok & 1
+        assert all(int(v) == 3 for v in conv.GetTable("div_ok_cells"))
+
+
+def test_division_proof_is_sound_on_a_sample():
+    """Spot check of the proof itself in numpy float32 (fma emulated in float64, exact for these)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    for b in (np.float32(34.14329147), np.float32(10.0), np.float32(7.00153), np.float32(0.45)):
+        r = np.float32(1.0) / b
+        a = (rng.random(200000) * 4000 - 2000).astype(np.float32)
+        q = a * r
+        rem = (a.astype(np.float64) - b.astype(np.float64) * q.astype(np.float64)).astype(np.float32)
+        q1 = (q.astype(np.float64) + rem.astype(np.float64) * np.float64(r)).astype(np.float32)
+        assert np.array_equal(q1, a / b)
