@@ -1,0 +1,144 @@
+// C++ adapter: the reference's converter interface implemented on the C ABI.
+//
+// `I3CLSimStepToPhotonConverterHIP` has the member functions of
+// I3CLSimStepToPhotonConverter (public/clsim/I3CLSimStepToPhotonConverter.h:67-192)
+// and the concrete setters the canonical caller uses
+// (public/clsim/I3CLSimStepToPhotonConverterOpenCL.h:78-258,
+// private/clsim/I3CLSimModuleHelper.cxx:303-372), with the same names, argument
+// meaning and error behaviour (I3CLSimStepToPhotonConverter_exception).
+//
+// Inside IceTray it derives from the real interface (define
+// CLSIMHIP_WITH_ICETRAY and include the clsim headers first; INTEGRATION.md shows
+// the translation of I3CLSimMediumProperties / I3CLSimSimpleGeometry into the C
+// descriptors).  Stand-alone (this repository's tests) it derives from the
+// minimal interface below, which has the same virtual functions in the same
+// order, and takes the C descriptors directly.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/clsimhip.h"
+
+#ifndef CLSIMHIP_WITH_ICETRAY
+// ---- stand-alone counterparts of the reference types ----
+typedef clsimhip_step I3CLSimStep;                       // public/clsim/I3CLSimStep.h (48 B blob)
+typedef clsimhip_photon I3CLSimPhoton;                   // public/clsim/I3CLSimPhoton.h (80 B blob)
+typedef std::vector<I3CLSimStep> I3CLSimStepSeries;
+typedef std::vector<I3CLSimPhoton> I3CLSimPhotonSeries;
+typedef std::shared_ptr<const I3CLSimStepSeries> I3CLSimStepSeriesConstPtr;
+typedef std::shared_ptr<I3CLSimPhotonSeries> I3CLSimPhotonSeriesPtr;
+
+class I3CLSimStepToPhotonConverter_exception : public std::runtime_error {
+public:
+    explicit I3CLSimStepToPhotonConverter_exception(const std::string &msg) : std::runtime_error(msg) {}
+};
+
+struct I3CLSimStepToPhotonConverter {
+    struct ConversionResult_t {
+        ConversionResult_t() : identifier(0) {}
+        uint32_t identifier;
+        I3CLSimPhotonSeriesPtr photons;
+    };
+    virtual ~I3CLSimStepToPhotonConverter() {}
+    virtual void SetWlenGenerators(const std::vector<clsimhip_random_value> &wlenGenerators) = 0;
+    virtual void SetWlenBias(const clsimhip_function &wlenBias) = 0;
+    virtual void SetMediumProperties(const clsimhip_medium *mediumProperties) = 0;
+    virtual void SetGeometry(const std::vector<int32_t> &stringIDs, const std::vector<uint32_t> &domIDs,
+                             const std::vector<double> &x, const std::vector<double> &y, const std::vector<double> &z,
+                             const std::vector<std::string> &subdetectors, double omRadius) = 0;
+    virtual void Initialize() = 0;
+    virtual bool IsInitialized() const = 0;
+    virtual void EnqueueSteps(I3CLSimStepSeriesConstPtr steps, uint32_t identifier) = 0;
+    virtual std::size_t GetWorkgroupSize() const = 0;
+    virtual std::size_t GetMaxNumWorkitems() const = 0;
+    virtual std::size_t QueueSize() const = 0;
+    virtual bool MorePhotonsAvailable() const = 0;
+    virtual ConversionResult_t GetConversionResult() = 0;
+    virtual std::map<std::string, double> GetStatistics() const { return std::map<std::string, double>(); }
+};
+#endif
+
+class I3CLSimStepToPhotonConverterHIP : public I3CLSimStepToPhotonConverter {
+public:
+    explicit I3CLSimStepToPhotonConverterHIP(int device = 0, uint64_t seed = 12345) : handle_(nullptr), seed_(seed)
+    {
+        if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
+    }
+    ~I3CLSimStepToPhotonConverterHIP() override { clsimhip_destroy(handle_); }
+    I3CLSimStepToPhotonConverterHIP(const I3CLSimStepToPhotonConverterHIP &) = delete;
+    I3CLSimStepToPhotonConverterHIP &operator=(const I3CLSimStepToPhotonConverterHIP &) = delete;
+
+    // ---- interface ----
+    void SetWlenGenerators(const std::vector<clsimhip_random_value> &g) override { check(clsimhip_set_wlen_generators(handle_, g.data(), g.size())); }
+    void SetWlenBias(const clsimhip_function &b) override { check(clsimhip_set_wlen_bias(handle_, &b)); }
+    void SetMediumProperties(const clsimhip_medium *m) override { check(clsimhip_set_medium_properties(handle_, m)); }
+    void SetGeometry(const std::vector<int32_t> &stringIDs, const std::vector<uint32_t> &domIDs, const std::vector<double> &x,
+                     const std::vector<double> &y, const std::vector<double> &z, const std::vector<std::string> &subdetectors,
+                     double omRadius) override
+    {
+        std::vector<const char *> names;
+        for (const std::string &s : subdetectors) names.push_back(s.c_str());
+        check(clsimhip_set_geometry(handle_, stringIDs.size(), stringIDs.data(), domIDs.data(), x.data(), y.data(), z.data(),
+                                    names.data(), omRadius));
+    }
+    void Initialize() override { check(clsimhip_initialize(handle_, seed_)); }
+    void InitializeWithStreams(const std::vector<uint64_t> &x, const std::vector<uint32_t> &a) { check(clsimhip_initialize_with_streams(handle_, x.data(), a.data(), x.size())); }
+    bool IsInitialized() const override { return clsimhip_is_initialized(handle_) != 0; }
+    void EnqueueSteps(I3CLSimStepSeriesConstPtr steps, uint32_t identifier) override
+    {
+        if (!steps) {   // the null check comes after the initialisation check in the reference (OpenCL.cxx:1527-1531)
+            if (!IsInitialized()) throw I3CLSimStepToPhotonConverter_exception("I3CLSimStepToPhotonConverterHIP is not initialized!");
+            throw I3CLSimStepToPhotonConverter_exception("Steps pointer is (null)!");
+        }
+        check(clsimhip_enqueue_steps(handle_, reinterpret_cast<const clsimhip_step *>(steps->data()), steps->size(), identifier));
+    }
+    std::size_t GetWorkgroupSize() const override { size_t v = 0; check(clsimhip_get_workgroup_size(handle_, &v)); return v; }
+    std::size_t GetMaxNumWorkitems() const override { size_t v = 0; check(clsimhip_get_max_num_workitems(handle_, &v)); return v; }
+    std::size_t QueueSize() const override { size_t v = 0; check(clsimhip_queue_size(handle_, &v)); return v; }
+    bool MorePhotonsAvailable() const override { int v = 0; check(clsimhip_more_photons_available(handle_, &v)); return v != 0; }
+    ConversionResult_t GetConversionResult() override
+    {
+        ConversionResult_t r;
+        const clsimhip_photon *p = nullptr;
+        size_t n = 0;
+        check(clsimhip_get_conversion_result(handle_, &r.identifier, &p, &n));
+        r.photons = I3CLSimPhotonSeriesPtr(new I3CLSimPhotonSeries(reinterpret_cast<const I3CLSimPhoton *>(p),
+                                                                   reinterpret_cast<const I3CLSimPhoton *>(p) + n));
+        if (n) check(clsimhip_release_result(handle_, p));
+        return r;
+    }
+    std::map<std::string, double> GetStatistics() const override
+    {
+        double v[8];
+        check(clsimhip_get_statistics(handle_, v));
+        static const char *keys[8] = {"TotalDeviceTime", "TotalHostTime", "NumKernelCalls", "TotalNumPhotonsGenerated",
+                                      "TotalNumPhotonsAtDOMs", "AverageDeviceTimePerPhoton", "AverageHostTimePerPhoton", "DeviceUtilization"};
+        std::map<std::string, double> m;
+        for (int i = 0; i < 8; ++i) m[keys[i]] = v[i];
+        return m;
+    }
+
+    // ---- concrete setters of the OpenCL converter ----
+    void SetEnableDoubleBuffering(bool v) { check(clsimhip_set_enable_double_buffering(handle_, v)); }
+    void SetDoublePrecision(bool v) { check(clsimhip_set_double_precision(handle_, v)); }
+    void SetStopDetectedPhotons(bool v) { check(clsimhip_set_stop_detected_photons(handle_, v)); }
+    void SetSaveAllPhotons(bool v) { check(clsimhip_set_save_all_photons(handle_, v)); }
+    void SetSaveAllPhotonsPrescale(double v) { check(clsimhip_set_save_all_photons_prescale(handle_, v)); }
+    void SetFixedNumberOfAbsorptionLengths(double v) { check(clsimhip_set_fixed_number_of_absorption_lengths(handle_, v)); }
+    void SetDOMPancakeFactor(double v) { check(clsimhip_set_dom_pancake_factor(handle_, v)); }
+    void SetPhotonHistoryEntries(uint32_t v) { check(clsimhip_set_photon_history_entries(handle_, v)); }
+    void SetWorkgroupSize(std::size_t v) { check(clsimhip_set_workgroup_size(handle_, v)); }
+    void SetMaxNumWorkitems(std::size_t v) { check(clsimhip_set_max_num_workitems(handle_, v)); }
+    void Compile() { check(clsimhip_compile(handle_)); }
+    std::size_t GetMaxWorkgroupSize() const { size_t v = 0; check(clsimhip_get_max_workgroup_size(handle_, &v)); return v; }
+    clsimhip_converter *Handle() { return handle_; }
+
+private:
+    void check(int rc) const { if (rc != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(handle_)); }
+    clsimhip_converter *handle_;
+    uint64_t seed_;
+};
