@@ -72,6 +72,7 @@ struct KParams {
     uint32_t off_tilt_dist, off_tilt_zcorr;
     // 4-word records per distance bin j = 1..nd-1 at off_tilt_bins + 4*j: {dist[j], dist[j]-dist[j-1], its reciprocal, ok}
     uint32_t off_tilt_bins;
+    float tilt_inner_dist[6];           // dist[1..nd-2], padded with +inf (used when nd <= 8)
 
     // ---- exact division by invariant divisors ----
     // For a divisor b that never changes, q = a*r; q' = fma(fma(-b,q,a), r, q) with r = RN(1/b) is the
@@ -93,7 +94,7 @@ struct KParams {
     // ---- detector ----
     int32_t has_pancake;
     float pancake, unpancake;           // PANCAKE_FACTOR, (PANCAKE_FACTOR-1)/PANCAKE_FACTOR
-    float om_radius, om_radius_sq, string_max_radius_sq;
+    float om_radius, om_radius_sq, string_max_radius_sq, string_max_radius;
     int32_t num_strings, num_sets, max_layers, num_subdet;
     // 8-word records per string: {x, y, maxZ+R, minZ-R, set | dom_start<<8, dom mean x, dom mean y, 0}
     uint32_t off_strings;

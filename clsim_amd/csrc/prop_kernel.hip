@@ -45,6 +45,7 @@ constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
 constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
 constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
 constexpr uint32_t kNoStep = 0xffffffffu;
+constexpr int kTiltScalarBins = 6;               // inner tilt bin edges kept as scalars (nd <= 8)
 
 // kernel parameters, read with scalar loads from the constant address space
 typedef const __attribute__((address_space(4))) KParams *KP;
@@ -200,7 +201,13 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     const float fraction_z_below = 1.0f - fraction_z_above;
     const float nr = P->tilt_lnx * px + P->tilt_lny * py;
     int j = 1;
-    for (int t = 1; t < nd - 1; ++t) j += (nr >= ldsf(off_dist + t)) ? 1 : 0;
+    if (nd <= kTiltScalarBins + 2) {
+        // inner bin edges live in the parameter block (padded with +inf): compares against SGPRs, no LDS
+#pragma unroll
+        for (int t = 0; t < kTiltScalarBins; ++t) j += (nr >= P->tilt_inner_dist[t]) ? 1 : 0;
+    } else {
+        for (int t = 1; t < nd - 1; ++t) j += (nr >= ldsf(off_dist + t)) ? 1 : 0;
+    }
     const Rec4 bin = lds_rec4(P->off_tilt_bins + 4u * (uint32_t)j);    // dist[j], dist[j]-dist[j-1], 1/width, proven
     const float thisDist = bin.a;
     // the proof bit differs per bin: select, the divide is only executed if some lane's bin lacks the proof
@@ -327,17 +334,21 @@ struct Photon {
 
 // propagation_kernel.c.cl:132-184 + :553-589.  The step record is re-read from
 // HBM/L2 here (48 B every ~30 loop iterations) instead of living in registers.
+// c.cl:482-489: direction of a step from its (theta, phi); evaluated once when a lane takes the step
+DM Vec3 step_direction(const DevStep *step_ptr)
+{
+    float sin_t, cos_t, sin_p, cos_p;
+    dm::sincos_(step_ptr->theta, sin_t, cos_t);
+    dm::sincos_(step_ptr->phi, sin_p, cos_p);
+    Vec3 d;
+    d.x = sin_t * cos_p; d.y = sin_t * sin_p; d.z = cos_t;
+    return d;
+}
+
 template <bool ICE, bool TILT, bool FLASHER>
-DM void create_photon(KP P, const DevStep *step_ptr, uint64_t &rx, uint32_t ra, Photon &ph)
+DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
 {
     const DevStep st = *step_ptr;
-    Vec3 step_dir;
-    {   // c.cl:482-489
-        float sin_t, cos_t, sin_p, cos_p;
-        dm::sincos_(st.theta, sin_t, cos_t);
-        dm::sincos_(st.phi, sin_p, cos_p);
-        step_dir.x = sin_t * cos_p; step_dir.y = sin_t * sin_p; step_dir.z = cos_t;
-    }
     const float shift = st.length * rng_co(rx, ra);
     const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);
     ph.px = st.x + step_dir.x * shift;
@@ -438,7 +449,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
 struct Detector {               // wave-uniform values of the search, fetched once per call
     uint32_t off_strings, off_sets, off_layer_to_om;
     int max_layers;
-    float string_max_radius_sq, om_radius_sq, pancake;
+    float string_max_radius_sq, string_max_radius, om_radius_sq, pancake;
     int has_pancake;
 };
 
@@ -447,9 +458,25 @@ DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_x
                             bool &hit, uint32_t &hit_string, uint32_t &hit_dom)
 {
     const Rec4 str = lds_rec4(D.off_strings + 8u * s);      // x, y, maxZ+R, minZ-R
+    const float wx = str.a - ph.px, wy = str.b - ph.py;
     {
         const float smin = sqr((ph.px - str.a) * ph.d.y - (ph.py - str.b) * ph.d.x) / dir_len_xy_sqr;
         if (smin > D.string_max_radius_sq) return;
+    }
+    {
+        // Not in the reference: a conservative early-out.  The test above is about the INFINITE line.
+        // A DOM of this string can only be hit at a point of the segment [0, step_len] that lies within
+        // GEO_STRING_MAX_RADIUS of the string axis in xy (the hit point is inside the oversized sphere,
+        // whose centre is within maxR - OM_RADIUS of the axis).  If the point of the segment closest to
+        // the axis is an END point and that end point is farther away -- with a margin that exceeds the
+        // float error of these few operations by more than an order of magnitude -- every sphere test
+        // of this string fails, so skipping them cannot change the result.
+        const float along = wx * ph.d.x + wy * ph.d.y;          // (axis - start) . dir_xy
+        const float ex = wx - step_len * ph.d.x, ey = wy - step_len * ph.d.y;
+        const float reach = D.string_max_radius + (1e-3f + 9.5367431640625e-7f * (__builtin_fabsf(ph.px) + __builtin_fabsf(ph.py) + __builtin_fabsf(str.a) + __builtin_fabsf(str.b)));
+        const float reach_sq = reach * reach;
+        if ((along <= 0.0f) && (wx * wx + wy * wy > reach_sq)) return;
+        if ((along >= step_len * dir_len_xy_sqr) && (ex * ex + ey * ey > reach_sq)) return;
     }
     if ((ph.d.z > 0.0f) && (ph.pz > str.c)) return;
     if ((ph.d.z < 0.0f) && (ph.pz < str.d)) return;
@@ -495,7 +522,7 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
     Detector D;
     D.off_strings = P->off_strings; D.off_sets = P->off_sets; D.off_layer_to_om = P->off_layer_to_om;
     D.max_layers = P->max_layers;
-    D.string_max_radius_sq = P->string_max_radius_sq; D.om_radius_sq = P->om_radius_sq;
+    D.string_max_radius_sq = P->string_max_radius_sq; D.string_max_radius = P->string_max_radius; D.om_radius_sq = P->om_radius_sq;
     D.pancake = P->pancake; D.has_pancake = P->has_pancake;
     const int num_subdet = P->num_subdet;
     const uint32_t off_subdet = P->off_subdet;
@@ -590,6 +617,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
     uint32_t ra = 0;
     uint32_t photons_left = 0;
     bool alive = true;
+    Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.abs_lens_initial = 0.0f;
@@ -620,6 +648,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                         rx = rng_x[mine];                                       // c.cl:458-461
                         ra = P->rng_a[mine];
                         photons_left = P->steps[mine].num_photons;
+                        step_dir = step_direction(P->steps + mine);
                     } else {
                         sidx = kNoStep;
                         alive = false;
@@ -628,7 +657,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 }
             }
             if (need && (photons_left > 0)) {
-                create_photon<ICE, TILT, FLASHER>(P, P->steps + sidx, rx, ra, ph);
+                create_photon<ICE, TILT, FLASHER>(P, P->steps + sidx, step_dir, rx, ra, ph);
                 need = false;
             }
         }

@@ -194,6 +194,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.off_tilt_dist = img.add_floats(dist);
         P.off_tilt_zcorr = img.add_floats(corr);
         if (division_by_reciprocal_is_exact(P.tilt_dz, P.rcp_tilt_dz)) P.div_ok |= 1u;
+        for (size_t t6 = 0; t6 < 6; ++t6) P.tilt_inner_dist[t6] = (t6 + 1 < nd - 1) ? dist[t6 + 1] : INFINITY;
         {
             std::vector<uint32_t> bins(4 * nd, 0u);
             for (size_t j = 1; j < nd; ++j) {
@@ -272,6 +273,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     P.om_radius = G.om_radius;
     P.om_radius_sq = G.om_radius * G.om_radius;                    // OM_RADIUS*OM_RADIUS, collision c.cl:118
     P.string_max_radius_sq = G.string_max_radius * G.string_max_radius;   // sqr(GEO_STRING_MAX_RADIUS), collision c.cl:64
+    P.string_max_radius = G.string_max_radius;
     P.num_strings = G.num_strings;
     P.num_sets = G.num_sets;
     P.max_layers = G.max_layers;
