@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libclsimhip.so")
+LIB_PATH = os.environ.get("CLSIMHIP_LIB", os.path.join(HERE, "libclsimhip.so"))
 
 OK, ERR_ARGUMENT, ERR_STATE, ERR_CONFIG, ERR_DEVICE, ERR_IO = 0, -1, -2, -3, -4, -5
 

@@ -37,10 +37,15 @@
 
 namespace clsimhip {
 
-constexpr int kBlock = 512;                      // 8 waves; two workgroups per CU at <=128 VGPRs
-constexpr int kMinWavesPerSimd = 4;
+#ifndef CLSIMHIP_BLOCK
+#define CLSIMHIP_BLOCK 256                       // 4 waves per workgroup, 7 workgroups per CU (70 VGPRs)
+#define CLSIMHIP_MIN_WAVES 7
+#endif
+constexpr int kBlock = CLSIMHIP_BLOCK;
+constexpr int kMinWavesPerSimd = CLSIMHIP_MIN_WAVES;
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kStageRecords = 8;                 // hit records staged per wave and flush
+constexpr int kStageRecords = 8;                 // hit stubs staged per wave and flush
+constexpr int kStubWords = 16;
 constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
 constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
 constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
@@ -319,21 +324,29 @@ DM void sph_dir_from_car(const Vec3 &d, float &theta, float &phi)
     if (phi < 0.0f) phi += 2.0f * kPi;
 }
 
+// Per-lane photon state that the scatter loop touches every iteration.  What only a
+// hit record needs (start position / direction, wavelength, initial absorption budget)
+// is NOT kept: it is a pure function of the step and of the RNG state at the photon's
+// birth, so the rare hit re-derives it from `rx_start` with the very code that created
+// the photon (photon_birth).  7 VGPRs per lane buy an extra wave per SIMD.
 struct Photon {
     float px, py, pz, pt;       // position, time
     Vec3 d;                     // direction
-    float wlen;
-    float sx, sy, sz, st;       // start position, time
-    Vec3 sd;                    // start direction
     float inv_groupvel, total_path;
-    float abs_lens_left, abs_lens_initial;
+    float abs_lens_left;
     uint32_t num_scatters;
     IceFactors ice;
+    uint64_t rx_start;          // RNG state word when the photon was created
     int layer;                  // carried layer index (getTiltZShift_IS_CONSTANT, c.cl:521-523)
 };
 
-// propagation_kernel.c.cl:132-184 + :553-589.  The step record is re-read from
-// HBM/L2 here (48 B every ~30 loop iterations) instead of living in registers.
+struct Birth {                  // propagation_kernel.c.cl:132-184 + :587: what createPhotonFromTrack yields
+    float x, y, z, t;
+    Vec3 d;
+    float wlen;
+    float abs_lens_initial;
+};
+
 // c.cl:482-489: direction of a step from its (theta, phi); evaluated once when a lane takes the step
 DM Vec3 step_direction(const DevStep *step_ptr)
 {
@@ -345,38 +358,51 @@ DM Vec3 step_direction(const DevStep *step_ptr)
     return d;
 }
 
-template <bool ICE, bool TILT, bool FLASHER>
-DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
+// propagation_kernel.c.cl:132-184 + :587.  The step record is re-read from HBM/L2 here
+// (48 B every ~30 loop iterations) instead of living in registers.  Consumes the RNG draws
+// of a photon's birth in the reference's order: position, wavelength, azimuth, absorption budget.
+template <bool FLASHER>
+DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra)
 {
     const DevStep st = *step_ptr;
+    Birth b;
     const float shift = st.length * rng_co(rx, ra);
     const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);
-    ph.px = st.x + step_dir.x * shift;
-    ph.py = st.y + step_dir.y * shift;
-    ph.pz = st.z + step_dir.z * shift;
-    ph.pt = st.t + inv_speed * shift;
+    b.x = st.x + step_dir.x * shift;
+    b.y = st.y + step_dir.y * shift;
+    b.z = st.z + step_dir.z * shift;
+    b.t = st.t + inv_speed * shift;
     const uint32_t source_type = st.source_type_and_pad & 0xffu;
-    ph.d = step_dir;
+    b.d = step_dir;
     if (!FLASHER || source_type == 0) {
         const float wavelength = generate_wavelength(P, 0, rx, ra);
         const float rcp = 1.0f / (st.beta * phase_ref_index(P, wavelength));
         const float cos_c = (rcp < 1.0f) ? rcp : 1.0f;
         const float sin_c = dm::sqrt_(1.0f - cos_c * cos_c);
-        ph.wlen = wavelength;
-        scatter_direction(cos_c, sin_c, ph.d, rng_co(rx, ra));
+        b.wlen = wavelength;
+        scatter_direction(cos_c, sin_c, b.d, rng_co(rx, ra));
     } else {
         // generateWavelength(number): 0 for an out-of-range generator (MediumPropertiesSource.cxx:392-432)
-        ph.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
+        b.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
     }
-    ph.sx = ph.px; ph.sy = ph.py; ph.sz = ph.pz; ph.st = ph.pt;
-    ph.sd = ph.d;
+    b.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
+    return b;
+}
+
+// c.cl:546-596
+template <bool ICE, bool TILT, bool FLASHER>
+DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
+{
+    ph.rx_start = rx;
+    const Birth b = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, ra);
+    ph.px = b.x; ph.py = b.y; ph.pz = b.z; ph.pt = b.t;
+    ph.d = b.d;
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
     if (!TILT) ph.layer = clampi((int)div_by(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
-    ph.inv_groupvel = 1.0f / group_velocity(P, ph.wlen);
-    ph.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
-    ph.abs_lens_left = ph.abs_lens_initial;
-    ph.ice = ice_factors<ICE>(P, ph.wlen);
+    ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
+    ph.abs_lens_left = b.abs_lens_initial;
+    ph.ice = ice_factors<ICE>(P, b.wlen);
 }
 
 // propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
@@ -555,45 +581,67 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
     return hit;
 }
 
-// propagation_kernel.c.cl:307-404: assemble the 20 words of an I3CLSimPhoton
-DM void make_hit_record(KP P, const Photon &ph, float step_len, float dist_abs_lens, const DevStep *step_ptr,
-                        uint32_t hit_string, uint32_t hit_dom, uint32_t *rec)
+// A detected photon leaves the propagation kernel as a 16-word stub written into its 80-byte output
+// slot; assemble_hits_kernel expands it in place into the I3CLSimPhoton record.  Everything saveHit
+// (propagation_kernel.c.cl:307-404) stores is a function of the stub: the birth of the photon is
+// re-derived from the step and the RNG state at its creation (photon_birth), the rest is arithmetic.
+struct HitStub {
+    float px, py, pz, pt;               // photon at the start of its last segment
+    float dx, dy, dz;
+    float step_len;                     // distance to the DOM along the direction (shortened step)
+    float total_path, abs_lens_left, inv_groupvel;
+    uint32_t num_scatters;
+    uint32_t step_index;
+    uint32_t rx_lo, rx_hi;              // RNG state word at the photon's creation
+    uint32_t string_and_dom;            // string index | DOM index << 16
+};
+static_assert(sizeof(HitStub) == 64, "hit stub");
+
+// propagation_kernel.c.cl:307-404: the 20 words of an I3CLSimPhoton
+template <bool FLASHER>
+DM void make_hit_record(KP P, const HitStub &h, uint32_t *rec)
 {
+    const DevStep *step_ptr = P->steps + h.step_index;
+    const Vec3 step_dir = step_direction(step_ptr);
+    uint64_t rx = ((uint64_t)h.rx_hi << 32) | (uint64_t)h.rx_lo;
+    const Birth born = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, P->rng_a[h.step_index]);
+    const uint32_t hit_string = h.string_and_dom & 0xffffu, hit_dom = h.string_and_dom >> 16;
+    const Vec3 d = {h.dx, h.dy, h.dz};
     float dom_x, dom_y, dom_z;
     dom_position(P, hit_string, hit_dom, dom_x, dom_y, dom_z);
     if (P->has_pancake) {
         const float unpancake = P->unpancake;
-        const float qx = ph.px - dom_x, qy = ph.py - dom_y, qz = ph.pz - dom_z;
-        const float parallel = qx * ph.d.x + qy * ph.d.y + qz * ph.d.z;
-        const float nx = qx - parallel * ph.d.x;
-        const float ny = qy - parallel * ph.d.y;
-        const float nz = qz - parallel * ph.d.z;
+        const float qx = h.px - dom_x, qy = h.py - dom_y, qz = h.pz - dom_z;
+        const float parallel = qx * d.x + qy * d.y + qz * d.z;
+        const float nx = qx - parallel * d.x;
+        const float ny = qy - parallel * d.y;
+        const float nz = qz - parallel * d.z;
         dom_x += unpancake * nx; dom_y += unpancake * ny; dom_z += unpancake * nz;
     }
     float theta, phi, stheta, sphi;
-    sph_dir_from_car(ph.d, theta, phi);
-    sph_dir_from_car(ph.sd, stheta, sphi);
-    const float weight = step_ptr->weight / wavelength_bias(P, ph.wlen);
-    rec[0] = dm::f2u(ph.px + step_len * ph.d.x - dom_x);
-    rec[1] = dm::f2u(ph.py + step_len * ph.d.y - dom_y);
-    rec[2] = dm::f2u(ph.pz + step_len * ph.d.z - dom_z);
-    rec[3] = dm::f2u(ph.pt + step_len * ph.inv_groupvel);
+    sph_dir_from_car(d, theta, phi);
+    sph_dir_from_car(born.d, stheta, sphi);
+    const float weight = step_ptr->weight / wavelength_bias(P, born.wlen);
+    rec[0] = dm::f2u(h.px + h.step_len * d.x - dom_x);
+    rec[1] = dm::f2u(h.py + h.step_len * d.y - dom_y);
+    rec[2] = dm::f2u(h.pz + h.step_len * d.z - dom_z);
+    rec[3] = dm::f2u(h.pt + h.step_len * h.inv_groupvel);
     rec[4] = dm::f2u(theta);
     rec[5] = dm::f2u(phi);
-    rec[6] = dm::f2u(ph.wlen);
-    rec[7] = dm::f2u(ph.total_path + step_len);
-    rec[8] = ph.num_scatters;
+    rec[6] = dm::f2u(born.wlen);
+    rec[7] = dm::f2u(h.total_path + h.step_len);
+    rec[8] = h.num_scatters;
     rec[9] = dm::f2u(weight);
     rec[10] = step_ptr->identifier;
-    rec[11] = (hit_string & 0xffffu) | (hit_dom << 16);     // short stringID, ushort omID
-    rec[12] = dm::f2u(ph.sx);
-    rec[13] = dm::f2u(ph.sy);
-    rec[14] = dm::f2u(ph.sz);
-    rec[15] = dm::f2u(ph.st);
+    rec[11] = h.string_and_dom;                             // short stringID, ushort omID
+    rec[12] = dm::f2u(born.x);
+    rec[13] = dm::f2u(born.y);
+    rec[14] = dm::f2u(born.z);
+    rec[15] = dm::f2u(born.t);
     rec[16] = dm::f2u(stheta);
     rec[17] = dm::f2u(sphi);
-    rec[18] = dm::f2u(1.0f / ph.inv_groupvel);
-    rec[19] = dm::f2u(dist_abs_lens);
+    rec[18] = dm::f2u(1.0f / h.inv_groupvel);
+    rec[19] = dm::f2u(born.abs_lens_initial - h.abs_lens_left);   // c.cl:718: after this step's update
 }
 
 template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
@@ -607,7 +655,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
         const uint32_t *src = P0->tables;
         for (uint32_t i = threadIdx.x; i < words; i += kBlock) lds_words[i] = src[i];
     }
-    uint32_t *stage = lds_words + P0->table_words + (threadIdx.x >> 6) * (kStageRecords * 20);
+    uint32_t *stage = lds_words + P0->table_words + (threadIdx.x >> 6) * (kStageRecords * kStubWords);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -620,7 +668,6 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
-    ph.abs_lens_initial = 0.0f;
     ph.layer = 0;
 
     for (;;) {
@@ -683,9 +730,15 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
             const uint32_t max_hits = P->max_hits;
             uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
             for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
-                if (hit && rank >= chunk && rank < chunk + kStageRecords)
-                    make_hit_record(P, ph, distance, ph.abs_lens_initial - ph.abs_lens_left, P->steps + sidx, hit_string,
-                                    hit_dom, stage + (rank - chunk) * 20);
+                if (hit && rank >= chunk && rank < chunk + kStageRecords) {
+                    uint32_t *st = stage + (rank - chunk) * kStubWords;
+                    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
+                    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
+                    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
+                    st[11] = ph.num_scatters; st[12] = sidx;
+                    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
+                    st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -693,9 +746,10 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
                 // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
                 const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
-                const uint32_t words = ((count < room) ? count : room) * 20u;
+                const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
                 uint32_t *dst = out_words + (size_t)first * 20u;
-                for (uint32_t w = lane; w < words; w += 64u) dst[w] = stage[w];
+                // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
+                for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -719,6 +773,34 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 ++ph.num_scatters;
             }
         }
+    }
+}
+
+// Expands the hit stubs of one launch into I3CLSimPhoton records, in place (slot i -> record i).
+template <bool FLASHER>
+__global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue)
+{
+    const KP P = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Pvalue;
+    {
+        const uint32_t words = P->table_words;
+        const uint32_t *src = P->tables;
+        for (uint32_t i = threadIdx.x; i < words; i += 256) lds_words[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t counted = *P->hit_count;
+    const uint32_t n = counted < P->max_hits ? counted : P->max_hits;
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t *slot = out_words + (size_t)i * 20u;
+        HitStub h;
+        uint32_t *hw = reinterpret_cast<uint32_t *>(&h);
+#pragma unroll
+        for (int w = 0; w < kStubWords; ++w) hw[w] = slot[w];
+        uint32_t rec[20];
+        make_hit_record<FLASHER>(P, h, rec);
+#pragma unroll
+        for (int w = 0; w < 20; ++w) slot[w] = rec[w];
     }
 }
 
@@ -749,7 +831,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
 static hipError_t launch_variant(const KParams &P, hipStream_t stream)
 {
-    const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * 20) * 4;
+    const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4;
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
     static int resident = 0;            // per variant
     if (resident == 0) {
@@ -768,6 +850,20 @@ static hipError_t launch_variant(const KParams &P, hipStream_t stream)
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
     const uint32_t grid = needed < (uint32_t)resident ? needed : (uint32_t)resident;
     hipLaunchKernelGGL((prop_kernel<ICE, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    // second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
+    static bool assemble_ready = false;
+    const size_t image_bytes = (size_t)P.table_words * 4;
+    if (!assemble_ready) {
+        if (image_bytes > 64 * 1024) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_hits_kernel<FLASHER>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes);
+            if (err != hipSuccess) return err;
+        }
+        assemble_ready = true;
+    }
+    hipLaunchKernelGGL((assemble_hits_kernel<FLASHER>), dim3(512), dim3(256), image_bytes, stream, P);
     return hipGetLastError();
 }
 
@@ -790,8 +886,10 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * 20) * 4; }
+size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4; }
 int prop_kernel_block_size() { return kBlock; }
+// LDS bytes one workgroup may use so that the intended number of workgroups fits the CU's 160 KB
+size_t prop_kernel_lds_budget() { return (size_t)(160 * 1024) / (size_t)((kMinWavesPerSimd * 256) / kBlock) - 1024; }
 
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream)
 {

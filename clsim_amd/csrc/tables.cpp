@@ -329,7 +329,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         for (size_t i = 0; i < xy.size(); ++i)
             xy[i] = static_cast<uint32_t>(static_cast<uint16_t>(G.dom_tx[i])) | (static_cast<uint32_t>(static_cast<uint16_t>(G.dom_ty[i])) << 16);
         const size_t with_doms = img.words.size() + 2 * xy.size();
-        if (prop_kernel_lds_bytes(static_cast<uint32_t>(with_doms)) <= 64 * 1024) {
+        if (prop_kernel_lds_bytes(static_cast<uint32_t>(with_doms)) <= prop_kernel_lds_budget()) {
             P.dom_in_lds = 1;
             P.off_dom_xy = img.add_words(xy);
             P.off_dom_z = img.add_floats(G.dom_tz);
@@ -364,7 +364,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     }
     P.table_words = static_cast<uint32_t>(img.words.size());
     C.lds_image = std::move(img.words);
-    if (prop_kernel_lds_bytes(P.table_words) > 64 * 1024)
+    if (prop_kernel_lds_bytes(P.table_words) > prop_kernel_lds_budget())
         throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables do not fit the LDS budget of the propagation kernel");
     return C;
 }

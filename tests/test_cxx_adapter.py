@@ -19,7 +19,7 @@ def build(tmp_path):
 
 def test_adapter_configures_and_compiles(tmp_path):
     out = subprocess.check_output([build(tmp_path)], text=True)
-    assert "adapter ok" in out and "workgroup 512" in out
+    assert "adapter ok" in out and "workgroup 256" in out
 
 
 @pytest.mark.gpu

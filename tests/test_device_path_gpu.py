@@ -101,7 +101,7 @@ def test_converter_queue_semantics():
     from clsim_amd import converter as CV
     cfg = common.config("c1")
     conv = common.product_converter(cfg, 1024)
-    assert conv.IsInitialized() and conv.GetMaxNumWorkitems() == 1024 and conv.GetWorkgroupSize() == 512
+    assert conv.IsInitialized() and conv.GetMaxNumWorkitems() == 1024 and conv.GetWorkgroupSize() == conv.GetMaxWorkgroupSize() == 256
     steps = common.steps_for(cfg, 1024, seed=4, pad_to=512)
     for ident in (11, 22, 33):
         conv.EnqueueSteps(steps, ident)
