@@ -56,9 +56,12 @@ def cpu_baseline(args, steps_np, seconds):
     med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
     bias = B.icecube_dom_acceptance()
     T = capi.make_tables(med, geo, [B.cherenkov_wlen_generator(bias, med)], bias, pancake=5.0)
+    from clsim_amd import converter as CV
     probe = 64 * cores
-    a = B.mwc_multipliers(min(len(steps_np), 65536))
-    x = B.seed_streams(a)
+    # stream set-up through the product's generators (tests/test_golden_reference.py pins both
+    # implementations on the reference's multiplier file); the propagation below is the oracle's
+    a = CV.mwc_multipliers(min(len(steps_np), 1 << 19))
+    x = CV.seed_streams(a)
     t0 = time.time()
     capi.propagate(T, steps_np[:probe], x, a, threads=cores)
     rate = steps_np["num"][:probe].sum() / max(time.time() - t0, 1e-6)

@@ -151,7 +151,7 @@ private:
     uint32_t *d_hit_count_ = nullptr;
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
-    int k_new_ = 6, k_dom_ = 0;              // lanes waiting before photons are created (CLSIMHIP_K_NEW overrides)
+    int k_new_ = 8, k_dom_ = 0;              // lanes waiting before photons are created (CLSIMHIP_K_NEW overrides)
     clsimhip_step *h_steps_ = nullptr;       // pinned staging
     clsimhip_photon *h_photons_ = nullptr;
     uint32_t *h_hit_count_ = nullptr;

@@ -86,3 +86,95 @@ def test_output_overflow_truncates_like_reference():
     have = set(raw_o[i:i + 80] for i in range(0, len(raw_o), 80))
     raw = ph_p.tobytes()
     assert all(raw[i:i + 80] in have for i in range(0, len(raw), 80))
+
+
+def _run_custom(med_o, med_p, geom, gens_o, gens_p, steps, pancake=5.0, max_items=None):
+    """Oracle vs product for an ad-hoc configuration (exercises the other kernel variants)."""
+    from clsim_amd import converter as CV
+    from oracle import builders as B
+    n = len(steps)
+    x, a = common.streams(max_items or n)
+    geo = B.build_geometry(geom["string_ids"], geom["dom_ids"], geom["x"], geom["y"], geom["z"], geom["subdetectors"], geom["om_radius"])
+    bias_o = B.icecube_dom_acceptance()
+    T = capi.make_tables(med_o, geo, gens_o(bias_o), bias_o, pancake=pancake)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    bias_p = CV.GetIceCubeDOMAcceptance()
+    conv = CV.initializeHIP(0, CV.I3CLSimSimpleGeometry.from_dict(geom), med_p, bias_p, gens_p(bias_p), pancakeFactor=pancake,
+                            approximateNumberOfWorkItems=n, streams=(x, a))
+    conv.EnqueueSteps(steps, 3)
+    ident, ph_p = conv.GetConversionResult()
+    assert cnt_o > 5 and len(ph_p) == cnt_o
+    assert common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)
+
+
+@pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1"])
+def test_other_kernel_variants(kind):
+    """Variants of the generated program: PANCAKE_FACTOR undefined (pancake = 1), getTiltZShift_IS_CONSTANT with
+    layered ice (carried layer index), a one-layer IceCube medium (un-optimised per-function form, SURVEY 9.7 ii),
+    pure HG / pure Liu scattering, anisotropy without tilt, flasher generator with constant-length medium."""
+    import ctypes as C
+    import os
+    from clsim_amd import _lib
+    from clsim_amd import converter as CV
+    from clsim_amd import synthetic as S
+    from oracle import builders as B
+    cher_o = lambda med: (lambda bias: [B.cherenkov_wlen_generator(bias, med)])
+    ice_dir = lambda m: os.path.join(common.ICE, m)
+
+    def product_medium(desc_edit=None, directory=None, tilt=True):
+        med = CV.MakeIceCubeMediumProperties(iceDataDirectory=directory, useTiltIfAvailable=tilt)
+        if desc_edit is None:
+            return med
+        d = _lib.MediumDesc()
+        assert _lib.load().clsimhip_medium_describe(med._h, C.byref(d)) == 0
+        keep = desc_edit(d)
+        h = C.c_void_p()
+        assert _lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)) == 0
+        return CV.I3CLSimMediumProperties(h, keep=(med, keep))
+
+    geom = S.ic86_geometry()
+    steps = common.steps_for(common.config("mie"), 2048, seed=31)
+    if kind == "no_pancake":
+        med_o = B.load_ppc_ice(ice_dir("spice_mie"))
+        med_p = product_medium(directory=ice_dir("spice_mie"))
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps, pancake=1.0)
+    elif kind == "no_tilt":
+        med_o = B.load_ppc_ice(ice_dir("spice_mie"), use_tilt_if_available=False)
+        med_p = product_medium(directory=ice_dir("spice_mie"), tilt=False)
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind == "lea_no_tilt":
+        med_o = B.load_ppc_ice(ice_dir("spice_lea"), use_tilt_if_available=False)
+        med_p = product_medium(directory=ice_dir("spice_lea"), tilt=False)
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind in ("hg_only", "liu_only"):
+        med_o = B.load_ppc_ice(ice_dir("spice_mie"))
+        med_o["scat"]["kind"] = "hg" if kind == "hg_only" else "liu"
+
+        def edit(d):
+            d.scatter_kind = 0 if kind == "hg_only" else 1
+        med_p = product_medium(edit, ice_dir("spice_mie"))
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind == "single_icecube_layer":
+        full = B.load_ppc_ice(ice_dir("spice_mie"), use_tilt_if_available=False)
+        med_o = dict(full, num_layers=1, layers_z_start=-1000.0, layers_height=2000.0,
+                     aDust400=full["aDust400"][85:86], deltaTau=full["deltaTau"][85:86], b400=full["b400"][85:86])
+        arrays = [np.ascontiguousarray(med_o[k], dtype=np.float64) for k in ("aDust400", "deltaTau", "b400")]
+
+        def edit(d):
+            d.num_layers = 1; d.layers_z_start = -1000.0; d.layers_height = 2000.0
+            d.a_dust400, d.delta_tau, d.b400 = (a.ctypes.data_as(_lib.DP) for a in arrays)
+            return arrays
+        med_p = product_medium(edit, ice_dir("spice_mie"), tilt=False)
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    else:   # flasher_c1: constant lengths + second (constant) generator, single string
+        g1 = S.single_string_geometry()
+        med_o = B.homogeneous_medium()
+        med_p = CV.MakeHomogeneousMediumProperties()
+        st = S.flasher_steps(1024, seed=4, position=(30.0, 20.0, 100.0), pad_to=256)
+        st["sourceType"][:100] = 0          # a few Cherenkov steps in the same bunch
+        st["length"][:100] = 0.001
+        st["num"][100:120] = 0              # and a few empty ones
+        _run_custom(med_o, med_p, g1, lambda bias: [B.cherenkov_wlen_generator(bias, med_o), dict(kind="const", value=405e-9)],
+                    lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p), CV.I3CLSimRandomValueConstant(405e-9)], st)
