@@ -258,6 +258,11 @@ int clsimhip_get_rng_state(clsimhip_converter *c, uint64_t *x_out, size_t count)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.get_rng_state(x_out, count); });
 }
+// not part of the public header: work-queue counters of the last launch (tools/ only)
+int clsimhip_debug_counters(clsimhip_converter *c, uint32_t out[4])
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.debug_counters(out); });
+}
 int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out)
 {
     return guarded(nullptr, [&] {

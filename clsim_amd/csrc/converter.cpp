@@ -38,7 +38,7 @@ Converter::~Converter()
     if (stream_) (void)hipStreamDestroy(stream_);
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_photons_);
-    (void)hipFree(d_hit_count_); (void)hipFree(d_queue_);
+    (void)hipFree(d_hit_count_); (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
     if (h_steps_) (void)hipHostFree(h_steps_);
     if (h_photons_) (void)hipHostFree(h_photons_);
     if (h_hit_count_) (void)hipHostFree(h_hit_count_);
@@ -182,9 +182,10 @@ void Converter::setup_device_buffers()
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), max_workitems_ * sizeof(DevStep)), "steps");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_photons_), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_hit_count_), 16), "hit counter");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), kQueueSlots * sizeof(uint32_t)), "step queue");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_slice_done_), max_workitems_ * sizeof(uint32_t)), "slice counters");
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_DOM")) k_dom_ = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_photons_), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_hit_count_), 16, hipHostMallocDefault), "pinned counter");
@@ -203,10 +204,14 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.max_hits = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffull));
     {   // step queue head for this launch (zeroed in stream order)
         std::lock_guard<std::mutex> lk(ev_mutex_);
-        P.queue = d_queue_ + (queue_slot_++ % kQueueSlots);
+        P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
+        last_queue_ = P.queue;
     }
-    hip_check(hipMemsetAsync(P.queue, 0, 4, stream), "reset step queue");
+    hip_check(hipMemsetAsync(P.queue, 0, 16, stream), "reset step queue");
+    if (k_slices_ != 1) hip_check(hipMemsetAsync(d_slice_done_, 0, n * sizeof(uint32_t), stream), "reset slice counters");
     P.k_new = k_new_;
+    P.slices = k_slices_;
+    P.slice_done = d_slice_done_;
     P.dom_tx = d_dom_tx_;
     P.dom_ty = d_dom_ty_;
     P.dom_tz = d_dom_tz_;
@@ -392,6 +397,14 @@ long Converter::get_table(const std::string &name, double *out, size_t cap) cons
     const size_t n = it->second.size();
     if (out) std::memcpy(out, it->second.data(), std::min(n, cap) * sizeof(double));
     return static_cast<long>(n);
+}
+
+void Converter::debug_counters(uint32_t out[4])
+{
+    need_init();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipDeviceSynchronize(), "sync");
+    if (last_queue_) hip_check(hipMemcpy(out, last_queue_, 16, hipMemcpyDeviceToHost), "download counters");
 }
 
 void Converter::get_rng_state(uint64_t *x, size_t count)

@@ -111,6 +111,7 @@ public:
     void kernel_time(bool reset, double *total_ms, uint64_t *launches);
     long get_table(const std::string &name, double *out, size_t cap) const;
     void get_rng_state(uint64_t *x, size_t count);
+    void debug_counters(uint32_t out[4]);
 
     std::string last_error;
 
@@ -149,9 +150,11 @@ private:
     DevStep *d_steps_ = nullptr;
     DevPhoton *d_photons_ = nullptr;
     uint32_t *d_hit_count_ = nullptr;
+    uint32_t *d_slice_done_ = nullptr;       // per step: slices published (unit queue)
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
-    int k_new_ = 8, k_dom_ = 0;              // lanes waiting before photons are created (CLSIMHIP_K_NEW overrides)
+    uint32_t *last_queue_ = nullptr;
+    int k_new_ = 8, k_slices_ = 0;              // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     clsimhip_step *h_steps_ = nullptr;       // pinned staging
     clsimhip_photon *h_photons_ = nullptr;
     uint32_t *h_hit_count_ = nullptr;

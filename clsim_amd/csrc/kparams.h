@@ -46,8 +46,10 @@ struct KParams {
     DevPhoton *out;
     uint32_t *hit_count;
     uint32_t max_hits;
-    uint32_t *queue;                    // next unclaimed step (zeroed before the launch)
+    uint32_t *queue;                    // [0] next unclaimed work unit, [1] max numPhotons (both zeroed before the launch)
     int32_t k_new;                      // lanes that must be waiting before photons are created
+    int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
+    uint32_t *slice_done;               // per step: slices published so far (zeroed before the launch)
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;

@@ -662,10 +662,30 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
+    // Work units.  A step's photons share one RNG stream, so a step is sequential work (~5700 loop
+    // iterations +-35 %).  Handing out whole steps leaves the last round of a bunch running in waves that are
+    // two thirds empty (1M steps on 458k lanes: 17 % of the kernel time).  Steps are therefore cut into
+    // `slices` slices of U photons that are handed out ROUND-ROBIN over the whole bunch -- slice 0 of every
+    // step, then slice 1 of every step, ... -- so all steps advance together and finish within one slice of
+    // each other.  Slice s of a step may start when slice s-1 has published the stream's state (it was
+    // handed out n units earlier, so it practically always has); the photons of a step are still processed
+    // in order from one RNG stream, whichever lanes do it.
+    const uint32_t n_steps = P0->n_steps;
+    uint32_t slice_photons, total_units;
+    {
+        const uint32_t max_photons = P0->queue[1];                 // scan_steps_kernel
+        const uint32_t target = (uint32_t)P0->slices;
+        slice_photons = (max_photons + target - 1u) / target;
+        if (slice_photons == 0u) slice_photons = 1u;
+        const uint32_t rounds = (max_photons + slice_photons - 1u) / slice_photons;
+        total_units = n_steps * (rounds == 0u ? 1u : rounds);
+    }
     uint32_t sidx = kNoStep;
     uint64_t rx = 0;
     uint32_t ra = 0;
     uint32_t photons_left = 0;
+    uint32_t slice = 0;
+    bool waiting = false;      // holds a unit whose previous slice has not been published yet
     bool alive = true;
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     Photon ph;
@@ -678,36 +698,67 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
         const uint64_t m_ready = __ballot(alive && !need);
         if ((m_need | m_ready) == 0ull) break;
 
-        // ---- photon creation, deferred until enough lanes wait for it ----
-        if ((m_ready == 0ull) || ((int)__popcll(m_need) >= fresh_params(P0)->k_new)) {
+        // ---- new units / new photons, deferred until enough lanes wait for them ----
+        const uint64_t m_poll = __ballot(need && waiting);
+        if ((m_ready == 0ull) || ((int)__popcll(m_need & ~m_poll) >= fresh_params(P0)->k_new)) {
             const KP P = fresh_params(P0);
-            const bool want_step = need && (photons_left == 0);
-            const uint64_t m_want = __ballot(want_step);
+            const bool want_unit = need && (photons_left == 0) && !waiting;
+            const uint64_t m_want = __ballot(want_unit);
             if (m_want != 0ull) {
-                // next steps from the queue: one atomic per wave
+                // next units from the queue: one atomic per wave
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(P->queue, (uint32_t)__popcll(m_want));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (want_step) {
-                    uint64_t *rng_x = P->rng_x;
-                    if (sidx != kNoStep) rng_x[sidx] = rx;                      // c.cl:911-912
-                    const uint32_t mine = base + (uint32_t)__popcll(m_want & lanes_below);
-                    if (mine < P->n_steps) {
-                        sidx = mine;
-                        rx = rng_x[mine];                                       // c.cl:458-461
-                        ra = P->rng_a[mine];
-                        photons_left = P->steps[mine].num_photons;
-                        step_dir = step_direction(P->steps + mine);
+                uint64_t *rng_x = P->rng_x;
+                uint32_t *slice_done = P->slice_done;
+                // publish the finished unit: stream state first (c.cl:911-912), then the slice counter; both
+                // write-through (sc1) so that a lane on another XCD that sees the counter sees the state
+                if (want_unit && (sidx != kNoStep)) __hip_atomic_store(&rng_x[sidx], rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (want_unit) {
+                    if (sidx != kNoStep) __hip_atomic_store(&slice_done[sidx], slice + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t unit = base + (uint32_t)__popcll(m_want & lanes_below);
+                    sidx = kNoStep;
+                    if (unit < total_units) {
+                        const uint32_t s_new = unit / n_steps;
+                        const uint32_t i_new = unit - s_new * n_steps;
+                        const uint32_t num = P->steps[i_new].num_photons;
+                        const uint32_t first = s_new * slice_photons;
+                        if (first < num) {                  // otherwise this step is used up: ask again
+                            sidx = i_new;
+                            slice = s_new;
+                            photons_left = (num - first < slice_photons) ? (num - first) : slice_photons;
+                            waiting = true;
+                        }
                     } else {
-                        sidx = kNoStep;
                         alive = false;
                         need = false;
                     }
                 }
             }
-            if (need && (photons_left > 0)) {
+            if (need && waiting) {
+                const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&P->slice_done[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CLSIMHIP_DEBUG_COUNTERS
+                if (published < slice) atomicAdd(P->queue + 2, 1u);
+#endif
+                if (published >= slice) {
+                    // c.cl:458-461; slice 0 reads the state left by the previous bunch
+                    rx = (slice == 0u) ? P->rng_x[sidx] : __hip_atomic_load(&P->rng_x[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ra = P->rng_a[sidx];
+                    step_dir = step_direction(P->steps + sidx);
+                    waiting = false;
+                }
+            }
+            if (need && !waiting && (photons_left > 0)) {
                 create_photon<ICE, TILT, FLASHER>(P, P->steps + sidx, step_dir, rx, ra, ph);
                 need = false;
+            }
+            // nothing runnable in this wave: every lane waits for another wave's slice
+            if ((m_ready == 0ull) && (__ballot(alive && !need) == 0ull)) {
+#ifdef CLSIMHIP_DEBUG_COUNTERS
+                if (lane == 0) atomicAdd(P->queue + 3, 1u);
+#endif
+                __builtin_amdgcn_s_sleep(16);
             }
         }
 
@@ -778,6 +829,21 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
     }
 }
 
+// meta[1] = largest numPhotons of the bunch (sizes the slices of the unit queue)
+__global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, uint32_t n, uint32_t *meta)
+{
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t v = steps[i].num_photons;
+        m = v > m ? v : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63u) == 0u && m != 0u) atomicMax(meta + 1, m);
+}
+
 // Expands the hit stubs of one launch into I3CLSimPhoton records, in place (slot i -> record i).
 template <bool FLASHER>
 __global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue)
@@ -831,8 +897,9 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 
 // ---- host-side launchers (called from converter.cpp) ----
 template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
-static hipError_t launch_variant(const KParams &P, hipStream_t stream)
+static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
+    KParams P = Pin;
     const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4;
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
     static int resident = 0;            // per variant
@@ -857,6 +924,19 @@ static hipError_t launch_variant(const KParams &P, hipStream_t stream)
     if (const char *e = getenv("CLSIMHIP_GRID")) {
         const int g = atoi(e);
         if (g >= 1 && g <= resident) grid = (uint32_t)g;
+    }
+    // Slices per step (0 = choose here).  Measured on MI355X, 200-photon steps, r = steps per resident lane:
+    // r < 2: slicing only makes lanes wait for their step's previous slice; 2 <= r < 2.6: 16 slices
+    // (+6..12 % over whole steps); 2.6 <= r < 3.5: 12 (+16 %); r >= 3.5: 8 (+8..11 %); more slices than that
+    // cost more in unit hand-outs than the shorter tail returns.
+    {
+        const double r = (double)P.n_steps / ((double)resident * kBlock);
+        if (P.slices <= 0) P.slices = (r < 2.0) ? 1 : (r < 2.6) ? 16 : (r < 3.5) ? 12 : 8;
+        if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0xffffffffull) P.slices = 1;    // 32-bit unit counter
+    }
+    {
+        const uint32_t sgrid = (P.n_steps + 255u) / 256u;
+        hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue);
     }
     hipLaunchKernelGGL((prop_kernel<ICE, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     hipError_t err = hipGetLastError();
