@@ -152,6 +152,13 @@ def main():
         # write per step (48 + 12 + 12 B) plus one 80-byte record per detected photon
         alg_bytes = n * 72.0 + hits_last * 80.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this same command
+            # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken)
+            with open(tpath) as f:
+                traffic = json.load(f).get("bytes_per_launch")
         out = {
             "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,13 +172,13 @@ def main():
                        "hit_gather": "rccl p2p to rank 0" if world > 1 else "none",
                        "hits_last_pass_rank0": hits_last},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "prop_kernel", "avg_kernel_ms": avg_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / (avg_ms * 1e-3))},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

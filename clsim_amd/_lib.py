@@ -47,9 +47,10 @@ class MediumDesc(C.Structure):      # clsimhip_medium_desc
 SYMBOLS = [
     "clsimhip_medium_create", "clsimhip_medium_create_from_ppc", "clsimhip_medium_describe", "clsimhip_medium_destroy",
     "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
-    "clsimhip_mwc_multipliers", "clsimhip_seed_streams",
+    "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
     "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error",
     "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
+    "clsimhip_set_geometry_from_text_file",
     "clsimhip_set_enable_double_buffering", "clsimhip_set_double_precision", "clsimhip_set_stop_detected_photons",
     "clsimhip_set_save_all_photons", "clsimhip_set_save_all_photons_prescale",
     "clsimhip_set_fixed_number_of_absorption_lengths", "clsimhip_set_dom_pancake_factor",
@@ -83,6 +84,7 @@ def load():
         "clsimhip_icecube_dom_acceptance": (i32, [dbl, dbl, DP, DP, DP]),
         "clsimhip_make_cherenkov_wlen_generator": (i32, [C.POINTER(Function), vp, DP, DP, DP]),
         "clsimhip_mwc_multipliers": (i32, [vp, sz]),
+        "clsimhip_mwc_multipliers_from_file": (i32, [C.c_char_p, vp, sz]),
         "clsimhip_seed_streams": (i32, [vp, sz, u64, vp]),
         "clsimhip_create": (i32, [i32, C.POINTER(vp)]),
         "clsimhip_destroy": (None, [vp]),
@@ -91,6 +93,7 @@ def load():
         "clsimhip_set_wlen_bias": (i32, [vp, C.POINTER(Function)]),
         "clsimhip_set_medium_properties": (i32, [vp, vp]),
         "clsimhip_set_geometry": (i32, [vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_char_p), dbl]),
+        "clsimhip_set_geometry_from_text_file": (i32, [vp, C.c_char_p, dbl, C.c_int32, C.c_int32, u32, u32]),
         "clsimhip_set_enable_double_buffering": (i32, [vp, i32]),
         "clsimhip_set_double_precision": (i32, [vp, i32]),
         "clsimhip_set_stop_detected_photons": (i32, [vp, i32]),

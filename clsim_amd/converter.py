@@ -191,6 +191,16 @@ class I3CLSimSimpleGeometry:
         self.om_radius = float(om_radius)
 
     @classmethod
+    def from_text_file(cls, OMRadius, filename, ignoreStringIDsSmallerThan=1, ignoreStringIDsLargerThan=2 ** 31 - 1,
+                       ignoreDomIDsSmallerThan=1, ignoreDomIDsLargerThan=60):
+        """I3CLSimSimpleGeometryTextFile (private/clsim/I3CLSimSimpleGeometryTextFile.cxx:43-100); parsing happens in
+        the library when the geometry is set (clsimhip_set_geometry_from_text_file)."""
+        g = cls([], [], [], [], [], [], OMRadius)
+        g.text_file = (str(filename), int(ignoreStringIDsSmallerThan), int(ignoreStringIDsLargerThan),
+                       int(ignoreDomIDsSmallerThan), int(ignoreDomIDsLargerThan))
+        return g
+
+    @classmethod
     def from_dict(cls, g):
         return cls(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
 
@@ -228,6 +238,10 @@ class I3CLSimStepToPhotonConverterHIP:
 
     def SetGeometry(self, geometry):
         g = geometry
+        if getattr(g, "text_file", None):
+            fn, smin, smax, dmin, dmax = g.text_file
+            self._call("clsimhip_set_geometry_from_text_file", fn.encode(), g.om_radius, smin, smax, dmin, dmax)
+            return
         names = (C.c_char_p * len(g.subdetectors))(*[s.encode() for s in g.subdetectors])
         self._call("clsimhip_set_geometry", len(g.string_ids), g.string_ids.ctypes.data_as(C.c_void_p),
                    g.dom_ids.ctypes.data_as(C.c_void_p), g.x.ctypes.data_as(C.c_void_p),

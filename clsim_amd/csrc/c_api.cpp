@@ -121,6 +121,13 @@ int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count)
 {
     return guarded(nullptr, [&] { need(a_out, "a_out"); mwc_multipliers(a_out, count); });
 }
+int clsimhip_mwc_multipliers_from_file(const char *path, uint32_t *a_out, size_t count)
+{
+    return guarded(nullptr, [&] {
+        need(path, "path"); need(a_out, "a_out");
+        if (!load_multipliers_from_file(path, a_out, count)) throw Error(CLSIMHIP_ERR_IO, std::string("could not read ") + std::to_string(count) + " multipliers from " + path);
+    });
+}
 int clsimhip_seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x_out)
 {
     return guarded(nullptr, [&] { need(a, "a"); need(x_out, "x_out"); seed_streams(a, count, seed, x_out); });
@@ -172,6 +179,14 @@ int clsimhip_set_geometry(clsimhip_converter *c, size_t n, const int32_t *string
         for (size_t i = 0; i < n; ++i) { need(subdetectors[i], "subdetector name"); g.subdetectors[i] = subdetectors[i]; }
         g.om_radius = om_radius;
         c->impl.set_geometry(std::move(g));
+    });
+}
+int clsimhip_set_geometry_from_text_file(clsimhip_converter *c, const char *filename, double om_radius, int32_t string_id_min,
+                                         int32_t string_id_max, uint32_t dom_id_min, uint32_t dom_id_max)
+{
+    return guarded(c, [&] {
+        need(c, "converter"); need(filename, "filename");
+        c->impl.set_geometry(geometry_from_text_file(filename, om_radius, string_id_min, string_id_max, dom_id_min, dom_id_max));
     });
 }
 #define SETTER(name, type, call) \

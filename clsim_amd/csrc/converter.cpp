@@ -81,7 +81,7 @@ void Converter::compile()
     compiled_ = true;
 }
 
-static bool load_multipliers_from_file(const char *path, uint32_t *a, size_t count)
+bool load_multipliers_from_file(const char *path, uint32_t *a, size_t count)
 {
     // mwcrng_init.h:62-103: binary format = 17-byte tag "safeprimes_base32" + int64 LE each; else text, first column
     std::ifstream f(path, std::ios::binary);

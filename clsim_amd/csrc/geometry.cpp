@@ -10,6 +10,7 @@
 // to_float_literal() because the reference prints them with "%.10e".
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 #include <set>
 
 #include "host_model.h"
@@ -126,6 +127,29 @@ inline int16_t to_short(double v)
 }
 
 } // namespace
+
+// I3CLSimSimpleGeometryTextFile.cxx:43-100
+GeometryInput geometry_from_text_file(const std::string &filename, double om_radius, int32_t string_min, int32_t string_max,
+                                      uint32_t dom_min, uint32_t dom_max)
+{
+    std::ifstream f(filename.c_str());
+    if (f.fail()) throw Error(CLSIMHIP_ERR_IO, "Could not open input file");
+    GeometryInput g;
+    g.om_radius = om_radius;
+    int64_t read_string, read_dom;
+    double x, y, z;
+    while (f >> read_string >> read_dom >> x >> y >> z) {
+        if (read_string < INT32_MIN || read_string > INT32_MAX || read_dom < 0 || read_dom > static_cast<int64_t>(UINT32_MAX))
+            throw Error(CLSIMHIP_ERR_IO, "Read error (numeric conversion)!");
+        const int32_t s = static_cast<int32_t>(read_string);
+        const uint32_t d = static_cast<uint32_t>(read_dom);
+        if ((s < string_min) || (s > string_max) || (d < dom_min) || (d > dom_max)) continue;
+        g.string_ids.push_back(s); g.dom_ids.push_back(d);
+        g.x.push_back(x); g.y.push_back(y); g.z.push_back(z);
+        g.subdetectors.push_back("default");
+    }
+    return g;
+}
 
 GeoTables build_geometry(const GeometryInput &in)
 {

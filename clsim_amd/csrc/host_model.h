@@ -108,9 +108,12 @@ struct GeoTables {
     std::vector<std::vector<uint32_t>> dom_index_to_id;
 };
 GeoTables build_geometry(const GeometryInput &in);
+GeometryInput geometry_from_text_file(const std::string &filename, double om_radius, int32_t string_min, int32_t string_max,
+                                      uint32_t dom_min, uint32_t dom_max);
 
 // MWC multipliers / seeding
 void mwc_multipliers(uint32_t *out, size_t count);
 void seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x);
+bool load_multipliers_from_file(const char *path, uint32_t *a, size_t count);
 
 } // namespace clsimhip

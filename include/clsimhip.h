@@ -139,6 +139,9 @@ int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const 
 /* ---- RNG set-up (private/opencl/mwcrng_init.h:26-117, private/make_safeprimes/main.cxx) ---- */
 /* first `count` MWC multipliers (a*2^32-1 and (a*2^32-2)/2 prime, descending from 4294967118) */
 int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count);
+/* first `count` multipliers from a safeprimes file in one of the reference's formats (mwcrng_init.h:62-103:
+ * 17-byte tag "safeprimes_base32" + little-endian int64 each, or text with the multiplier in column 1) */
+int clsimhip_mwc_multipliers_from_file(const char *path, uint32_t *a_out, size_t count);
 /* state words with init_MWC_RNG's validity loop; draws come from splitmix64(seed) */
 int clsimhip_seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x_out);
 
@@ -155,6 +158,11 @@ int clsimhip_set_medium_properties(clsimhip_converter *c, const clsimhip_medium 
 int clsimhip_set_geometry(clsimhip_converter *c, size_t n, const int32_t *string_ids, const uint32_t *dom_ids,
                           const double *x, const double *y, const double *z,
                           const char *const *subdetectors, double om_radius);
+/* I3CLSimSimpleGeometryTextFile (private/clsim/I3CLSimSimpleGeometryTextFile.cxx:43-100): whitespace separated
+ * "string dom x y z" records; strings / DOMs outside [*_min, *_max] are ignored (reference defaults: 1..INT32_MAX,
+ * 1..60); every DOM is in the subdetector "default" */
+int clsimhip_set_geometry_from_text_file(clsimhip_converter *c, const char *filename, double om_radius,
+                                         int32_t string_id_min, int32_t string_id_max, uint32_t dom_id_min, uint32_t dom_id_max);
 int clsimhip_set_enable_double_buffering(clsimhip_converter *c, int value);
 int clsimhip_set_double_precision(clsimhip_converter *c, int value);           /* only 0 */
 int clsimhip_set_stop_detected_photons(clsimhip_converter *c, int value);      /* only 1 */

@@ -334,6 +334,23 @@ def _c_short(v):
     return int(v)        # python int() truncates toward zero
 
 
+def geometry_from_text_file(filename, om_radius, string_min=1, string_max=2 ** 31 - 1, dom_min=1, dom_max=60):
+    """I3CLSimSimpleGeometryTextFile (private/clsim/I3CLSimSimpleGeometryTextFile.cxx:43-100)."""
+    tok = open(filename).read().split()
+    sid, did, xs, ys, zs = [], [], [], [], []
+    for k in range(0, len(tok) - 4, 5):
+        try:
+            s, d = int(tok[k]), int(tok[k + 1])
+            x, y, z = float(tok[k + 2]), float(tok[k + 3]), float(tok[k + 4])
+        except ValueError:
+            break                                   # operator>> stops at the first malformed record
+        if s < string_min or s > string_max or d < dom_min or d > dom_max:
+            continue
+        sid.append(s); did.append(d); xs.append(x); ys.append(y); zs.append(z)
+    return dict(string_ids=np.array(sid, dtype=np.int32), dom_ids=np.array(did, dtype=np.uint32), x=np.array(xs),
+                y=np.array(ys), z=np.array(zs), subdetectors=["default"] * len(sid), om_radius=om_radius)
+
+
 def build_geometry(string_ids, dom_ids, pos_x, pos_y, pos_z, subdetectors, om_radius):
     """I3CLSimHelper::write_geometry_code_and_fill_buffer + generate_get_dom_position_code
     (GeometrySource.cxx:712-1275, 499-709).  Returns every constant the kernel

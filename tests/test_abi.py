@@ -98,3 +98,21 @@ def test_initialize_without_gpu_fails_loudly():
         conv.InitializeWithStreams(x, a)
     assert e.value.code == _lib.ERR_DEVICE
     assert not conv.IsInitialized()
+
+
+def test_safeprimes_file_formats(tmp_path):
+    """mwcrng_init.h:62-103: binary ("safeprimes_base32" + int64 LE) and plain-text multiplier files."""
+    import struct
+    lib = _lib.load()
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "mwc_multipliers.npy"))[:500]
+    binary = tmp_path / "safeprimes_base32.bin"
+    binary.write_bytes(b"safeprimes_base32" + b"".join(struct.pack("<q", int(v)) for v in ref))
+    text = tmp_path / "safeprimes_base32.txt"
+    text.write_text("".join("%d %d %d\n" % (v, int(v) * 2 ** 32 - 1, (int(v) * 2 ** 32 - 2) // 2) for v in ref))
+    for path in (binary, text):
+        out = np.zeros(500, dtype=np.uint32)
+        assert lib.clsimhip_mwc_multipliers_from_file(str(path).encode(), out.ctypes.data_as(C.c_void_p), 500) == 0
+        assert np.array_equal(out, ref)
+    out = np.zeros(501, dtype=np.uint32)
+    assert lib.clsimhip_mwc_multipliers_from_file(str(binary).encode(), out.ctypes.data_as(C.c_void_p), 501) == _lib.ERR_IO
+    assert lib.clsimhip_mwc_multipliers_from_file(b"/nonexistent", out.ctypes.data_as(C.c_void_p), 1) == _lib.ERR_IO

@@ -178,3 +178,36 @@ def test_other_kernel_variants(kind):
         st["num"][100:120] = 0              # and a few empty ones
         _run_custom(med_o, med_p, g1, lambda bias: [B.cherenkov_wlen_generator(bias, med_o), dict(kind="const", value=405e-9)],
                     lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p), CV.I3CLSimRandomValueConstant(405e-9)], st)
+
+
+@pytest.mark.gpu
+def test_text_file_geometry_single_subdetector(tmp_path):
+    """N1: geometry read from an I3CLSimSimpleGeometryTextFile-format file: all 86 strings in the one
+    subdetector "default", i.e. a single fine cell grid instead of the IceCube / DeepCore pair."""
+    from clsim_amd import converter as CV
+    from clsim_amd import synthetic as S
+    from oracle import builders as B
+    g = S.ic86_geometry()
+    path = tmp_path / "geo.txt"
+    with open(path, "w") as f:
+        for i in range(len(g["x"])):
+            f.write("%d %d %.17g %.17g %.17g\n" % (g["string_ids"][i], g["dom_ids"][i], g["x"][i], g["y"][i], g["z"][i]))
+    cfg = common.config("mie")
+    steps = common.steps_for(cfg, 2048, seed=8)
+    n = len(steps)
+    x, a = common.streams(n)
+    go = B.geometry_from_text_file(str(path), g["om_radius"])
+    geo = B.build_geometry(go["string_ids"], go["dom_ids"], go["x"], go["y"], go["z"], go["subdetectors"], go["om_radius"])
+    bias_o = B.icecube_dom_acceptance()
+    T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias_o, cfg["med_o"])], bias_o, pancake=5.0)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    bias_p = CV.GetIceCubeDOMAcceptance()
+    conv = CV.initializeHIP(0, CV.I3CLSimSimpleGeometry.from_text_file(g["om_radius"], str(path)), cfg["med_p"], bias_p,
+                            [CV.makeCherenkovWavelengthGenerator(bias_p, cfg["med_p"])], pancakeFactor=5.0,
+                            approximateNumberOfWorkItems=n, streams=(x, a))
+    conv.EnqueueSteps(steps, 1)
+    _, ph_p = conv.GetConversionResult()
+    assert cnt_o > 50 and len(ph_p) == cnt_o
+    assert common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)

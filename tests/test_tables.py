@@ -100,3 +100,32 @@ def test_division_proof_is_sound_on_a_sample():
         rem = (a.astype(np.float64) - b.astype(np.float64) * q.astype(np.float64)).astype(np.float32)
         q1 = (q.astype(np.float64) + rem.astype(np.float64) * np.float64(r)).astype(np.float32)
         assert np.array_equal(q1, a / b)
+
+
+def test_text_file_geometry(tmp_path):
+    """N1: I3CLSimSimpleGeometryTextFile ingestion ("string dom x y z" records, ID filters, one subdetector)."""
+    from oracle import builders as B
+    g = S.ic86_geometry()
+    path = tmp_path / "geometry.txt"
+    with open(path, "w") as f:
+        f.write("0 1 0.0 0.0 0.0\n")                       # string 0: below the default filter
+        for i in range(len(g["x"])):
+            f.write("%d %d %.17g %.17g %.17g\n" % (g["string_ids"][i], g["dom_ids"][i], g["x"][i], g["y"][i], g["z"][i]))
+        f.write("12 61 1.0 2.0 3.0\n")                     # DOM 61: above the default filter
+    go = B.geometry_from_text_file(str(path), g["om_radius"])
+    assert len(go["x"]) == 5160 and np.array_equal(go["x"], g["x"]) and np.array_equal(go["z"], g["z"])
+    geo = B.build_geometry(go["string_ids"], go["dom_ids"], go["x"], go["y"], go["z"], go["subdetectors"], go["om_radius"])
+    assert geo["subdetectors"] == ["default"] and len(geo["cells"]) == 1
+    cfg = common.config("mie")
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.SetGeometry(CV.I3CLSimSimpleGeometry.from_text_file(g["om_radius"], str(path)))
+    conv.Compile()
+    assert np.array_equal(conv.GetTable("geoCellIndex_0"), geo["cells"][0]["index"].astype(np.float64))
+    c = geo["cells"][0]
+    assert np.array_equal(conv.GetTable("GEO_CELL_0"), np.array([c["nx"], c["ny"], c["width_x"], c["width_y"], c["start_x"], c["start_y"]], dtype=np.float64))
+    for pn, on in (("geoStringPosX", "str_x"), ("geoLayerToOMNumIndexPerStringSet", "layer_to_om"), ("geoDomPosTemplatePositionsX_flat", "dom_tx"),
+                   ("geoStringInStringSet", "str_set")):
+        assert np.array_equal(conv.GetTable(pn), geo[on].astype(np.float64)), pn
+    bad = CV.I3CLSimStepToPhotonConverterHIP(0)
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Could not open input file"):
+        bad.SetGeometry(CV.I3CLSimSimpleGeometry.from_text_file(0.8, str(tmp_path / "missing.txt")))
