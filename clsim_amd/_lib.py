@@ -40,12 +40,18 @@ class MediumDesc(C.Structure):      # clsimhip_medium_desc
                 ("has_post_transform", C.c_int32), ("post_renormalize", C.c_int32), ("post_matrix", C.c_double * 9),
                 ("has_tilt", C.c_int32), ("tilt_num_distances", C.c_int32), ("tilt_num_z", C.c_int32),
                 ("tilt_distances", DP), ("tilt_z_coordinates", DP), ("tilt_z_corrections", DP),
-                ("tilt_azimuth", C.c_double)]
+                ("tilt_azimuth", C.c_double),
+                ("table_num_wavelengths", C.c_int32), ("table_start_wavelength", C.c_double),
+                ("table_wavelength_step", C.c_double), ("table_store_as_16bit", C.c_int32),
+                ("abs_length_table", DP), ("sca_length_table", DP),
+                ("phase_index_kind", C.c_int32), ("group_index_kind", C.c_int32),
+                ("phase_index_table", Function), ("group_index_table", Function)]
 
 
 # every symbol include/clsimhip.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "clsimhip_medium_create", "clsimhip_medium_create_from_ppc", "clsimhip_medium_describe", "clsimhip_medium_destroy",
+    "clsimhip_medium_create", "clsimhip_medium_create_from_ppc",
+    "clsimhip_medium_create_from_photonics", "clsimhip_medium_describe", "clsimhip_medium_destroy",
     "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
     "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
     "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error",
@@ -79,6 +85,7 @@ def load():
     sig = {
         "clsimhip_medium_create": (i32, [C.POINTER(MediumDesc), C.POINTER(vp)]),
         "clsimhip_medium_create_from_ppc": (i32, [C.c_char_p, dbl, i32, C.POINTER(vp)]),
+        "clsimhip_medium_create_from_photonics": (i32, [C.c_char_p, dbl, C.POINTER(vp)]),
         "clsimhip_medium_describe": (i32, [vp, C.POINTER(MediumDesc)]),
         "clsimhip_medium_destroy": (None, [vp]),
         "clsimhip_icecube_dom_acceptance": (i32, [dbl, dbl, DP, DP, DP]),

@@ -105,8 +105,19 @@ class I3CLSimMediumProperties:
         out["n"] = list(d.n); out["g"] = list(d.g)
         out["pre_matrix"] = np.array(list(d.pre_matrix)).reshape(3, 3)
         out["post_matrix"] = np.array(list(d.post_matrix)).reshape(3, 3)
+        out["phase_index_kind"], out["group_index_kind"] = d.phase_index_kind, d.group_index_kind
+        for key in ("phase_index_table", "group_index_table"):
+            f = getattr(d, key)
+            if getattr(d, key.replace("_table", "_kind")) == 1:
+                out[key] = dict(start=f.start, step=f.step, values=arr(f.values, f.n))
         if d.lengths_kind == 0:
             out["abs_length"] = arr(d.abs_length, nl); out["sca_length"] = arr(d.sca_length, nl)
+        elif d.lengths_kind == 2:
+            nw = d.table_num_wavelengths
+            out.update(table_num_wavelengths=nw, table_start_wavelength=d.table_start_wavelength,
+                       table_wavelength_step=d.table_wavelength_step, table_store_as_16bit=bool(d.table_store_as_16bit))
+            out["abs_length_table"] = arr(d.abs_length_table, nl * nw).reshape(nl, nw)
+            out["sca_length_table"] = arr(d.sca_length_table, nl * nw).reshape(nl, nw)
         else:
             out["a_dust400"] = arr(d.a_dust400, nl); out["delta_tau"] = arr(d.delta_tau, nl); out["b400"] = arr(d.b400, nl)
         if d.has_tilt:
@@ -122,6 +133,13 @@ def MakeIceCubeMediumProperties(detectorCenterDepth=1948.07, iceDataDirectory=No
     h = C.c_void_p()
     _check(_lib.load().clsimhip_medium_create_from_ppc(str(iceDataDirectory).encode(), float(detectorCenterDepth),
                                                         1 if useTiltIfAvailable else 0, C.byref(h)))
+    return I3CLSimMediumProperties(h)
+
+
+def MakeIceCubeMediumPropertiesPhotonics(tableFile, detectorCenterDepth=1948.07):
+    """python/MakeIceCubeMediumPropertiesPhotonics.py:47-227 (photonics ice table -> medium)."""
+    h = C.c_void_p()
+    _check(_lib.load().clsimhip_medium_create_from_photonics(str(tableFile).encode(), float(detectorCenterDepth), C.byref(h)))
     return I3CLSimMediumProperties(h)
 
 

@@ -69,6 +69,13 @@ int clsimhip_medium_create_from_ppc(const char *directory, double depth, int use
         *out = new clsimhip_medium{medium_from_ppc(directory, depth, use_tilt != 0)};
     });
 }
+int clsimhip_medium_create_from_photonics(const char *table_file, double depth, clsimhip_medium **out)
+{
+    return guarded(nullptr, [&] {
+        need(table_file, "table_file"); need(out, "out");
+        *out = new clsimhip_medium{medium_from_photonics(table_file, depth)};
+    });
+}
 int clsimhip_medium_describe(const clsimhip_medium *m, clsimhip_medium_desc *d)
 {
     return guarded(nullptr, [&] {
@@ -91,6 +98,16 @@ int clsimhip_medium_describe(const clsimhip_medium *m, clsimhip_medium_desc *d)
         d->tilt_num_z = static_cast<int32_t>(s.tilt_z.size());
         d->tilt_distances = s.tilt_distances.data(); d->tilt_z_coordinates = s.tilt_z.data();
         d->tilt_z_corrections = s.tilt_corr.data(); d->tilt_azimuth = s.tilt_azimuth;
+        d->table_num_wavelengths = s.table_n; d->table_start_wavelength = s.table_start; d->table_wavelength_step = s.table_step;
+        d->table_store_as_16bit = s.table_16bit;
+        d->abs_length_table = s.abs_table.data(); d->sca_length_table = s.sca_table.data();
+        d->phase_index_kind = s.phase_kind; d->group_index_kind = s.group_kind;
+        auto view = [](const FunctionData &f, clsimhip_function &o) {
+            o.kind = f.kind; o.n = static_cast<int32_t>(f.values.size()); o.start = f.start; o.step = f.step;
+            o.values = f.values.data(); o.value = f.value;
+        };
+        view(s.phase_table, d->phase_index_table);
+        view(s.group_table, d->group_index_table);
     });
 }
 void clsimhip_medium_destroy(clsimhip_medium *m) { delete m; }

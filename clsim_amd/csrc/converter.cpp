@@ -36,7 +36,7 @@ Converter::~Converter()
     if (ev_start_) (void)hipEventDestroy(ev_start_);
     if (ev_stop_) (void)hipEventDestroy(ev_stop_);
     if (stream_) (void)hipStreamDestroy(stream_);
-    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_);
+    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_photons_);
     (void)hipFree(d_hit_count_); (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
     if (h_steps_) (void)hipHostFree(h_steps_);
@@ -174,6 +174,7 @@ void Converter::setup_device_buffers()
         if (bytes) hip_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), what);
     };
     upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
+    upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
     upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
@@ -212,6 +213,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.k_new = k_new_;
     P.slices = k_slices_;
     P.slice_done = d_slice_done_;
+    P.len_table = d_len_table_;
     P.dom_tx = d_dom_tx_;
     P.dom_ty = d_dom_ty_;
     P.dom_tz = d_dom_tz_;

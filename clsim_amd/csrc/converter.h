@@ -28,6 +28,7 @@ struct CompiledTables {
     KParams params{};
     KVariant variant{};
     std::vector<uint32_t> lds_image;
+    std::vector<float> len_table;       // KParams::len_table (TABLE lengths)
     GeoTables geo;
     std::map<std::string, std::vector<double>> named;
 };
@@ -144,6 +145,7 @@ private:
     // device state
     uint32_t *d_tables_ = nullptr;
     int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
+    float *d_len_table_ = nullptr;
     float *d_dom_tz_ = nullptr;
     uint64_t *d_rng_x_ = nullptr;
     uint32_t *d_rng_a_ = nullptr;

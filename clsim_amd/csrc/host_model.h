@@ -56,7 +56,13 @@ struct MediumData {                     // I3CLSimMediumProperties (IceCube func
     std::vector<double> abs_length, sca_length;
     double alpha = 0, kappa = 0, A = 0, B = 0, D = 0, E = 0;
     std::vector<double> a_dust400, delta_tau, b400;
+    int table_n = 0;                    // CLSIMHIP_LENGTHS_TABLE: FromTable per layer, [layer][table_n]
+    double table_start = 0, table_step = 0;
+    bool table_16bit = false;
+    std::vector<double> abs_table, sca_table;
     double n[5] = {0, 0, 0, 0, 0}, g[5] = {0, 0, 0, 0, 0};
+    int phase_kind = CLSIMHIP_REFINDEX_ICECUBE, group_kind = CLSIMHIP_REFINDEX_ICECUBE;
+    FunctionData phase_table, group_table;
     int scatter_kind = CLSIMHIP_SCATTER_MIXED;
     double liu_fraction = 0, mean_cosine = 0;
     bool has_aniso = false;
@@ -73,6 +79,7 @@ struct MediumData {                     // I3CLSimMediumProperties (IceCube func
 
 MediumData medium_from_desc(const clsimhip_medium_desc &d);
 MediumData medium_from_ppc(const std::string &dir, double detector_center_depth, bool use_tilt);
+MediumData medium_from_photonics(const std::string &table_file, double detector_center_depth);
 void dom_acceptance(double dom_radius, double efficiency, std::vector<double> &values, double &start, double &step);
 RandomValueData make_cherenkov_generator(const FunctionData &bias, const MediumData &m);
 

@@ -50,6 +50,9 @@ struct KParams {
     int32_t k_new;                      // lanes that must be waiting before photons are created
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
     uint32_t *slice_done;               // per step: slices published so far (zeroed before the launch)
+    // TABLE lengths: one 16-byte record per (wavelength bin, layer): {abs[bin], abs[bin+1], sca[bin], sca[bin+1]}
+    // at len_table[4*(bin*num_layers + layer)], already de-quantised (80 KB for a 171 x 30 photonics table: HBM/L2)
+    const float *len_table;
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;
@@ -63,6 +66,12 @@ struct KParams {
     uint32_t off_layers;
     float neg_kappa, abs_A, neg_B, neg_alpha, ref_wlen_recip, nanometer;
     float n[5], g[5], micrometer, c_light;
+    int32_t len_tab_n;                  // TABLE lengths: common binning of the per-layer FromTable functions
+    float len_tab_start, len_tab_step;
+    int32_t phase_kind, group_kind;     // CLSIMHIP_REFINDEX_*; TABLE: float data in the LDS image
+    int32_t phase_n, group_n;
+    float phase_start, phase_step, group_start, group_step;
+    uint32_t off_phase, off_group;
     float mix_frac, mix_frac_rest, liu_beta, hg_g, hg_one_minus_g2, hg_one_plus_g2, hg_two_g;
     float an_l[3], an_rl[3], an_azx, an_azy, an_mazy, an_B2, abs_corr_const;
     float pre[9], post[9];
@@ -112,7 +121,7 @@ struct KParams {
 // kernel variants (the reference's #ifdef switches, OpenCL.cxx:390-442 and the
 // generated *_IS_CONSTANT / NO_FLASHER hints)
 struct KVariant {
-    bool icecube_lengths;   // optimised IceCube abs/scat functions vs per-layer constants
+    int lengths;            // CLSIMHIP_LENGTHS_*: per-layer constants, optimised IceCube abs/scat functions, per-layer tables
     bool tilt;              // ScalarFieldIceTiltZShift vs getTiltZShift_IS_CONSTANT
     bool aniso;             // anisotropy scaling + pre/post transforms present
     bool flasher;           // more than one wavelength generator (no NO_FLASHER)

@@ -3,8 +3,11 @@
 // (python/MakeIceCubeMediumProperties.py, python/GetIceCubeDOMAcceptance.py,
 // private/clsim/I3CLSimModuleHelper.cxx); values stay in double here and are
 // turned into kernel constants by tables.cpp.
+#include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <limits>
+#include <map>
 #include <sstream>
 #include <sys/stat.h>
 
@@ -62,6 +65,7 @@ double FunctionData::eval(double wlen) const
 
 double MediumData::phase_ref_index(double wlen) const
 {
+    if (phase_kind == CLSIMHIP_REFINDEX_TABLE) return phase_table.eval(wlen);
     // RefIndexIceCube.cxx:84-101
     const double x = wlen / units::micrometer;
     return n[0] + x * (n[1] + x * (n[2] + x * (n[3] + x * n[4])));
@@ -78,8 +82,24 @@ void MediumData::validate() const
     } else if (lengths_kind == CLSIMHIP_LENGTHS_ICECUBE) {
         if (a_dust400.size() != nl || delta_tau.size() != nl || b400.size() != nl)
             throw Error(CLSIMHIP_ERR_ARGUMENT, "a_dust400 / delta_tau / b400 need one entry per layer");
+    } else if (lengths_kind == CLSIMHIP_LENGTHS_TABLE) {
+        if (table_n < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "values must contain at least 2 elements!");      // FromTable.cxx:84
+        if (!(table_step > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "wlenStep must not be <= 0!");              // FromTable.cxx:83
+        if (abs_table.size() != nl * static_cast<size_t>(table_n) || sca_table.size() != abs_table.size())
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "abs_length_table / sca_length_table need num_layers x table_num_wavelengths entries");
     } else
         throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown lengths_kind");
+    for (int which = 0; which < 2; ++which) {
+        const int kind = which ? group_kind : phase_kind;
+        const FunctionData &f = which ? group_table : phase_table;
+        if (kind == CLSIMHIP_REFINDEX_ICECUBE) continue;
+        if (kind != CLSIMHIP_REFINDEX_TABLE) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown refractive index kind");
+        if (f.kind != CLSIMHIP_FUNCTION_TABLE || f.values.size() < 2 || !(f.step > 0.))
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "a tabulated refractive index needs at least 2 values and a positive step");
+    }
+    // FromTable has no derivative: the group velocity cannot come from the dispersion (MediumPropertiesSource.cxx:226-237)
+    if (phase_kind == CLSIMHIP_REFINDEX_TABLE && group_kind != CLSIMHIP_REFINDEX_TABLE)
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "a tabulated phase refractive index needs a tabulated group refractive index override");
     if (scatter_kind < CLSIMHIP_SCATTER_HG || scatter_kind > CLSIMHIP_SCATTER_MIXED)
         throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown scatter_kind");
     if (has_tilt) {
@@ -104,6 +124,16 @@ MediumData medium_from_desc(const clsimhip_medium_desc &d)
         if (!d.abs_length || !d.sca_length) throw Error(CLSIMHIP_ERR_ARGUMENT, "abs_length / sca_length are null");
         m.abs_length.assign(d.abs_length, d.abs_length + nl);
         m.sca_length.assign(d.sca_length, d.sca_length + nl);
+    } else if (d.lengths_kind == CLSIMHIP_LENGTHS_TABLE) {
+        if (!d.abs_length_table || !d.sca_length_table || d.table_num_wavelengths < 0)
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "abs_length_table / sca_length_table are null");
+        const size_t total = nl * static_cast<size_t>(d.table_num_wavelengths);
+        m.table_n = d.table_num_wavelengths;
+        m.table_start = d.table_start_wavelength;
+        m.table_step = d.table_wavelength_step;
+        m.table_16bit = d.table_store_as_16bit != 0;
+        m.abs_table.assign(d.abs_length_table, d.abs_length_table + total);
+        m.sca_table.assign(d.sca_length_table, d.sca_length_table + total);
     } else {
         if (!d.a_dust400 || !d.delta_tau || !d.b400) throw Error(CLSIMHIP_ERR_ARGUMENT, "ice tables are null");
         m.a_dust400.assign(d.a_dust400, d.a_dust400 + nl);
@@ -112,6 +142,16 @@ MediumData medium_from_desc(const clsimhip_medium_desc &d)
         m.alpha = d.alpha; m.kappa = d.kappa; m.A = d.A; m.B = d.B; m.D = d.D; m.E = d.E;
     }
     for (int i = 0; i < 5; ++i) { m.n[i] = d.n[i]; m.g[i] = d.g[i]; }
+    m.phase_kind = d.phase_index_kind;
+    m.group_kind = d.group_index_kind;
+    auto copy_function = [](const clsimhip_function &f, FunctionData &out, const char *what) {
+        if (f.kind != CLSIMHIP_FUNCTION_TABLE || !f.values || f.n < 0) throw Error(CLSIMHIP_ERR_ARGUMENT, std::string(what) + " is not a table");
+        out.kind = CLSIMHIP_FUNCTION_TABLE;
+        out.start = f.start; out.step = f.step;
+        out.values.assign(f.values, f.values + f.n);
+    };
+    if (m.phase_kind == CLSIMHIP_REFINDEX_TABLE) copy_function(d.phase_index_table, m.phase_table, "phase_index_table");
+    if (m.group_kind == CLSIMHIP_REFINDEX_TABLE) copy_function(d.group_index_table, m.group_table, "group_index_table");
     m.scatter_kind = d.scatter_kind;
     m.liu_fraction = d.liu_fraction;
     m.mean_cosine = d.mean_cosine;
@@ -249,6 +289,142 @@ MediumData medium_from_ppc(const std::string &dir, double center_depth, bool use
                 m.tilt_corr[i * nz + k] = tdat[nz - 1 - k][i + 1];
             }
     }
+    m.validate();
+    return m;
+}
+
+// python/MakeIceCubeMediumPropertiesPhotonics.py:47-227
+MediumData medium_from_photonics(const std::string &table_file, double /*detector_center_depth: unused by the reference too*/)
+{
+    std::ifstream f(table_file);
+    if (!f.good()) throw Error(CLSIMHIP_ERR_IO, "cannot open " + table_file);
+    typedef std::vector<std::string> Line;
+    std::vector<Line> parsed;
+    std::string text;
+    while (std::getline(f, text)) {
+        std::istringstream ss(text);
+        Line tokens;
+        std::string tok;
+        while (ss >> tok) tokens.push_back(tok);
+        if (tokens.empty() || tokens[0][0] == '#') continue;       // comment lines (py:57)
+        for (char &c : tokens[0]) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+        parsed.push_back(tokens);
+    }
+    auto number = [&](const std::string &t) {
+        char *end = nullptr;
+        const double v = std::strtod(t.c_str(), &end);
+        if (end == t.c_str() || *end != '\0') throw Error(CLSIMHIP_ERR_IO, "bad number '" + t + "' in " + table_file);
+        return v;
+    };
+    const Line *nlayer = nullptr, *nwvl = nullptr;
+    for (const Line &l : parsed) {
+        if (l[0] == "NLAYER") {
+            if (nlayer) throw Error(CLSIMHIP_ERR_IO, "There is more than one \"NLAYER\" entry in your ice table!");
+            nlayer = &l;
+        } else if (l[0] == "NWVL") {
+            if (nwvl) throw Error(CLSIMHIP_ERR_IO, "There is more than one \"NWVL\" entry in your ice table!");
+            nwvl = &l;
+        }
+    }
+    if (!nlayer) throw Error(CLSIMHIP_ERR_IO, "There is no \"NLAYER\" entry in your ice table!");
+    if (!nwvl) throw Error(CLSIMHIP_ERR_IO, "There is no \"NWVL\" entry in your ice table!");
+    if (nlayer->size() < 2 || nwvl->size() < 4) throw Error(CLSIMHIP_ERR_IO, "incomplete NLAYER / NWVL entry in " + table_file);
+    const long n_layers = std::strtol((*nlayer)[1].c_str(), nullptr, 10);
+    const long n_wlen = std::strtol((*nwvl)[1].c_str(), nullptr, 10);
+    double start = number((*nwvl)[2]) * units::nanometer;
+    const double step = number((*nwvl)[3]) * units::nanometer;
+    start += step / 2.;                                             // bin centres (py:79)
+
+    struct Layer { std::map<std::string, std::vector<double>> v; };
+    std::vector<Layer> layers;
+    Layer cur;
+    size_t rows = 0;
+    bool first = true;
+    for (const Line &l : parsed) {
+        if (l[0] == "NLAYER" || l[0] == "NWVL") continue;
+        if (first && l[0] != "LAYER") throw Error(CLSIMHIP_ERR_IO, "Layer definitions should start with the LAYER keyword (reading " + table_file + ")");
+        first = false;
+        ++rows;
+        if (l[0] == "LAYER") {
+            if (!cur.v.empty()) layers.push_back(cur);
+            cur = Layer();
+        } else if (cur.v.count(l[0]))
+            throw Error(CLSIMHIP_ERR_IO, "Keyword " + l[0] + " is used twice for one layer (reading " + table_file + ")");
+        std::vector<double> vals;
+        for (size_t i = 1; i < l.size(); ++i) vals.push_back(number(l[i]) * 1.);
+        cur.v[l[0]] = vals;
+    }
+    if (rows != static_cast<size_t>(n_layers) * 6)
+        throw Error(CLSIMHIP_ERR_IO, "Expected " + std::to_string(n_layers) + "*6 lines [not counting NLAYER and NWVL] in the icetable file, found " + std::to_string(rows));
+    if (!cur.v.empty()) layers.push_back(cur);
+    if (layers.empty()) throw Error(CLSIMHIP_ERR_IO, "At least one layers is requried (reading " + table_file + ")");
+    auto field = [&](const Layer &l, const char *key) -> const std::vector<double> & {
+        auto it = l.v.find(key);
+        if (it == l.v.end()) throw Error(CLSIMHIP_ERR_IO, std::string("a layer has no ") + key + " entry (reading " + table_file + ")");
+        return it->second;
+    };
+    for (const Layer &l : layers)
+        if (field(l, "LAYER").size() < 2) throw Error(CLSIMHIP_ERR_IO, "LAYER needs two z coordinates (reading " + table_file + ")");
+    const double height = std::fabs(field(layers[0], "LAYER")[1] - field(layers[0], "LAYER")[0]);
+    // layers sorted by their bottom z; an upside-down layer is only compensated for in the key (py:136-153)
+    std::map<double, const Layer *> by_z;
+    for (const Layer &l : layers) {
+        double bottom = field(l, "LAYER")[0], top = field(l, "LAYER")[1];
+        if (bottom > top) std::swap(bottom, top);
+        if (std::fabs((top - bottom) - height) > 0.0001) throw Error(CLSIMHIP_ERR_IO, "Differing layer heights while reading " + table_file);
+        by_z[bottom] = &l;
+    }
+    std::vector<const Layer *> sorted;
+    double end_z = std::numeric_limits<double>::quiet_NaN();
+    for (const auto &kv : by_z) {
+        const double start_z = field(*kv.second, "LAYER")[0];
+        if (!std::isnan(end_z) && std::fabs(end_z - start_z) > 0.0001) throw Error(CLSIMHIP_ERR_IO, "Your layers have holes.");
+        end_z = field(*kv.second, "LAYER")[1];
+        sorted.push_back(kv.second);
+    }
+    const size_t nw = static_cast<size_t>(n_wlen);
+    const double mean_cos = field(*sorted[0], "COS").empty() ? 0. : field(*sorted[0], "COS")[0];
+    const std::vector<double> &group0 = field(*sorted[0], "N_GROUP"), &phase0 = field(*sorted[0], "N_PHASE");
+    for (const Layer *l : sorted) {
+        for (double c : field(*l, "COS"))
+            if (std::fabs(c - mean_cos) > 0.0001) throw Error(CLSIMHIP_ERR_IO, "only a constant mean cosine is supported by clsim");
+        for (const char *key : {"COS", "ABS", "SCAT", "N_GROUP", "N_PHASE"})
+            if (field(*l, key).size() != nw)
+                throw Error(CLSIMHIP_ERR_IO, "Expected " + std::to_string(nw) + " " + key + " values, got " + std::to_string(field(*l, key).size()));
+        for (size_t i = 0; i < nw; ++i) {
+            if (std::fabs(field(*l, "N_GROUP")[i] - group0[i]) > 0.0001)
+                throw Error(CLSIMHIP_ERR_IO, "N_GROUP may not be different for different layers in this version of clsim!");
+            if (std::fabs(field(*l, "N_PHASE")[i] - phase0[i]) > 0.0001)
+                throw Error(CLSIMHIP_ERR_IO, "N_PHASE may not be different for different layers in this version of clsim!");
+        }
+    }
+
+    MediumData m;
+    m.num_layers = static_cast<int>(sorted.size());
+    m.layers_z_start = field(*sorted[0], "LAYER")[0];
+    m.layers_height = height;
+    m.lengths_kind = CLSIMHIP_LENGTHS_TABLE;
+    m.table_n = static_cast<int>(nw);
+    m.table_start = start;
+    m.table_step = step;
+    m.table_16bit = true;                                           // storeDataAsHalfPrecision=True (py:214-219)
+    m.abs_table.reserve(sorted.size() * nw);
+    m.sca_table.reserve(sorted.size() * nw);
+    for (const Layer *l : sorted) {
+        for (double a : field(*l, "ABS")) m.abs_table.push_back(1. / a);
+        for (double b : field(*l, "SCAT")) m.sca_table.push_back((1. / b) * (1. - mean_cos));
+    }
+    m.phase_kind = m.group_kind = CLSIMHIP_REFINDEX_TABLE;
+    m.phase_table.kind = m.group_table.kind = CLSIMHIP_FUNCTION_TABLE;
+    m.phase_table.start = m.group_table.start = start;
+    m.phase_table.step = m.group_table.step = step;
+    m.phase_table.values = phase0;
+    m.group_table.values = group0;
+    m.scatter_kind = CLSIMHIP_SCATTER_HG;
+    m.mean_cosine = mean_cos;
+    // nothing forced: the range is what the tabulated functions cover (MediumProperties.cxx:85-153)
+    m.min_wlen = start;
+    m.max_wlen = start + step * static_cast<double>(nw - 1);
     m.validate();
     return m;
 }

@@ -35,6 +35,7 @@
 #include <cstdlib>
 
 #include "detmath.hip.h"
+#include "../../include/clsimhip.h"
 #include "kparams.h"
 
 namespace clsimhip {
@@ -105,44 +106,77 @@ DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? 
 
 struct Vec3 { float x, y, z; };
 
-// RefIndexIceCube.cxx:128-180
+// FunctionFromTable.cxx:213-232: interpolation bin and fraction of an equally spaced table
+DM void table_bin_fraction(float start, float step, int n, float wlen, int &bin, float &fraction)
+{
+    const float q = (wlen - start) / step;
+    const float fbin = __builtin_truncf(q);
+    fraction = q - fbin;                                // modf
+    bin = (int)fbin;
+    if ((bin < 0) || ((bin == 0) && (fraction < 0.0f))) { bin = 0; fraction = 0.0f; }
+    else if (bin >= n - 1) { bin = n - 2; fraction = 1.0f; }
+}
+// FunctionFromTable.cxx:279-291 (float data in the LDS image)
+DM float table_value(uint32_t off, float start, float step, int n, float wlen)
+{
+    int bin; float fraction;
+    table_bin_fraction(start, step, n, wlen, bin, fraction);
+    const float a = ldsf(off + (uint32_t)bin), b = ldsf(off + (uint32_t)bin + 1u);
+    return a + (b - a) * fraction;                      // mix
+}
+// RefIndexIceCube.cxx:128-180, or one FromTable function for all layers
 DM float phase_ref_index(KP P, float wlen)
 {
+    if (P->phase_kind == CLSIMHIP_REFINDEX_TABLE) return table_value(P->off_phase, P->phase_start, P->phase_step, P->phase_n, wlen);
     const float x = wlen / P->micrometer;
     return P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
 }
-// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163
+// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163 or a FromTable override
 DM float group_velocity(KP P, float wlen)
 {
+    if (P->group_kind == CLSIMHIP_REFINDEX_TABLE)
+        return P->c_light / table_value(P->off_group, P->group_start, P->group_step, P->group_n, wlen);
     const float x = wlen / P->micrometer;
     const float np = P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
     const float np_corr = P->g[0] + x * (P->g[1] + x * (P->g[2] + x * (P->g[3] + x * P->g[4])));
     return P->c_light / (np * np_corr);
 }
 
-// Per-photon wavelength factors of the IceCube ice functions.
+// Per-photon wavelength factors of the medium functions.  ICECUBE: the three transcendental terms;
+// TABLE: interpolation fraction (sca_pow) and the record index of (bin, layer 0) (abs_pow, as bits).
 struct IceFactors { float sca_pow, abs_pow, abs_exp; };
 
-template <bool ICE>
+template <int MED>
 DM IceFactors ice_factors(KP P, float wlen)
 {
     IceFactors f = {0.0f, 0.0f, 0.0f};
-    if (ICE) {
+    if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
         // _Optimizers.cxx:237-240: powr(wlen*(1/400nm), -alpha)
         f.sca_pow = dm::powr_(wlen * P->ref_wlen_recip, P->neg_alpha);
         // _Optimizers.cxx:170-180: powr(x,-kappa), A*exp(-B/x), x = wlen/nm
         const float x = wlen / P->nanometer;
         f.abs_pow = dm::powr_(x, P->neg_kappa);
         f.abs_exp = P->abs_A * dm::exp_(P->neg_B / x);
+    } else if (MED == CLSIMHIP_LENGTHS_TABLE) {
+        int bin;
+        table_bin_fraction(P->len_tab_start, P->len_tab_step, P->len_tab_n, wlen, bin, f.sca_pow);
+        f.abs_pow = __builtin_bit_cast(float, (uint32_t)(bin * P->num_layers));
     }
     return f;
 }
-// scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100)
-template <bool ICE>
-DM void layer_lengths(uint32_t off_layers, const IceFactors &f, int layer, float &sca_len, float &abs_len)
+// scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100,
+// FunctionFromTable.cxx:262-291 behind the switch(layer) of MediumPropertiesSource.cxx:89-123)
+template <int MED>
+DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len)
 {
+    if (MED == CLSIMHIP_LENGTHS_TABLE) {
+        const float4 r = *reinterpret_cast<const float4 *>(len_table + 4u * (__builtin_bit_cast(uint32_t, f.abs_pow) + (uint32_t)layer));
+        abs_len = r.x + (r.y - r.x) * f.sca_pow;
+        sca_len = r.z + (r.w - r.z) * f.sca_pow;
+        return;
+    }
     const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
-    if (ICE) {
+    if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
         sca_len = 1.0f / (r.c * f.sca_pow);
         abs_len = 1.0f / (r.a * f.abs_pow + f.abs_exp * r.b);
     } else {
@@ -392,7 +426,7 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
 }
 
 // c.cl:546-596
-template <bool ICE, bool TILT, bool FLASHER>
+template <int MED, bool TILT, bool FLASHER>
 DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
 {
     ph.rx_start = rx;
@@ -404,16 +438,17 @@ DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
     if (!TILT) ph.layer = clampi((int)div_by(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
     ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
     ph.abs_lens_left = b.abs_lens_initial;
-    ph.ice = ice_factors<ICE>(P, b.wlen);
+    ph.ice = ice_factors<MED>(P, b.wlen);
 }
 
 // propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
-template <bool ICE, bool TILT, bool ANISO>
+template <int MED, bool TILT, bool ANISO>
 DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
 {
     const float thickness = P->layer_thickness, bottom = P->layer_bottom;
     const int num_layers = P->num_layers;
     const uint32_t off_layers = P->off_layers;
+    const float *len_table = (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr;
     float effective_z;
     int current_layer;
     if (TILT) {
@@ -431,7 +466,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
     float sca_len, abs_len;
-    layer_lengths<ICE>(off_layers, ph.ice, current_layer, sca_len, abs_len);
+    layer_lengths<MED>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len);
     const float recip_thickness = P->recip_thickness;
     float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
     float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
@@ -440,7 +475,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         while ((j > 0) && (ais < 0.0f) && (aia < 0.0f)) {
             --j;
             boundary -= thickness;
-            layer_lengths<ICE>(off_layers, ph.ice, j, sca_len, abs_len);
+            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
             ais += 1.0f / sca_len;
             aia += 1.0f / abs_len;
         }
@@ -448,7 +483,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         while ((j < num_layers - 1) && (ais > 0.0f) && (aia > 0.0f)) {
             ++j;
             boundary += thickness;
-            layer_lengths<ICE>(off_layers, ph.ice, j, sca_len, abs_len);
+            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
             ais -= 1.0f / sca_len;
             aia -= 1.0f / abs_len;
         }
@@ -646,7 +681,7 @@ DM void make_hit_record(KP P, const HitStub &h, uint32_t *rec)
     rec[19] = dm::f2u(born.abs_lens_initial - h.abs_lens_left);   // c.cl:718: after this step's update
 }
 
-template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
+template <int MED, bool TILT, bool ANISO, bool FLASHER>
 __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
     // the only kernel argument sits at offset 0 of the kernarg segment
@@ -750,7 +785,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 }
             }
             if (need && !waiting && (photons_left > 0)) {
-                create_photon<ICE, TILT, FLASHER>(P, P->steps + sidx, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER>(P, P->steps + sidx, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -768,7 +803,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
-            distance = propagate_through_layers<ICE, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
+            distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
             hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
@@ -896,7 +931,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 }
 
 // ---- host-side launchers (called from converter.cpp) ----
-template <bool ICE, bool TILT, bool ANISO, bool FLASHER>
+template <int MED, bool TILT, bool ANISO, bool FLASHER>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -908,10 +943,10 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess && lds_bytes > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<ICE, TILT, ANISO, FLASHER>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<ICE, TILT, ANISO, FLASHER>, kBlock, lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER>, kBlock, lds_bytes);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
@@ -938,7 +973,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         const uint32_t sgrid = (P.n_steps + 255u) / 256u;
         hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue);
     }
-    hipLaunchKernelGGL((prop_kernel<ICE, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     // second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
@@ -959,17 +994,18 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
 {
     if (P.n_steps == 0) return hipSuccess;
-    const int key = (v.icecube_lengths ? 8 : 0) | (v.tilt ? 4 : 0) | (v.aniso ? 2 : 0) | (v.flasher ? 1 : 0);
+    if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
+    if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
+    const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     switch (key) {
 #define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d>(P, stream);
-    CASE(0, false, false, false, false) CASE(1, false, false, false, true)
-    CASE(2, false, false, true, false)  CASE(3, false, false, true, true)
-    CASE(4, false, true, false, false)  CASE(5, false, true, false, true)
-    CASE(6, false, true, true, false)   CASE(7, false, true, true, true)
-    CASE(8, true, false, false, false)  CASE(9, true, false, false, true)
-    CASE(10, true, false, true, false)  CASE(11, true, false, true, true)
-    CASE(12, true, true, false, false)  CASE(13, true, true, false, true)
-    CASE(14, true, true, true, false)   CASE(15, true, true, true, true)
+#define CASES(m) \
+    CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
+    CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
+    CASE(8 * m + 4, m, true, false, false)  CASE(8 * m + 5, m, true, false, true)  \
+    CASE(8 * m + 6, m, true, true, false)   CASE(8 * m + 7, m, true, true, true)
+    CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
+#undef CASES
 #undef CASE
     }
     return hipErrorInvalidValue;

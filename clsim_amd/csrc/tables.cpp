@@ -96,8 +96,71 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     P.micrometer = to_float_literal(units::micrometer);
     P.c_light = to_float_literal(units::c_light);
     for (int i = 0; i < 5; ++i) { P.n[i] = to_float_literal(m.n[i]); P.g[i] = to_float_literal(m.g[i]); }
-    C.variant.icecube_lengths = (m.lengths_kind == CLSIMHIP_LENGTHS_ICECUBE);
-    if (C.variant.icecube_lengths) {
+    for (int which = 0; which < 2; ++which) {
+        // FromTable with float data (FromTable.cxx:200-211), one function for all layers
+        const int kind = which ? m.group_kind : m.phase_kind;
+        (which ? P.group_kind : P.phase_kind) = kind;
+        if (kind != CLSIMHIP_REFINDEX_TABLE) continue;
+        const FunctionData &f = which ? m.group_table : m.phase_table;
+        const std::vector<float> data = literals(f.values);
+        (which ? P.group_n : P.phase_n) = static_cast<int32_t>(data.size());
+        (which ? P.group_start : P.phase_start) = to_float_literal(f.start);
+        (which ? P.group_step : P.phase_step) = to_float_literal(f.step);
+        (which ? P.off_group : P.off_phase) = img.add_floats(data);
+        name(which ? "getGroupRefIndex_func0_data" : "getPhaseRefIndex_func0_data", as_doubles(data));
+    }
+    scalar("MEDIUM_MIN_WLEN", to_float_literal(m.min_wlen)); scalar("MEDIUM_MAX_WLEN", to_float_literal(m.max_wlen));
+    C.variant.lengths = m.lengths_kind;
+    if (m.lengths_kind == CLSIMHIP_LENGTHS_TABLE) {
+        // FromTable.cxx:167-300 per layer.  With 16-bit storage the generated function rebuilds
+        //   convert_float(data[bin]) * ((LARGEST-SMALLEST)/65535.f) + SMALLEST
+        // on every call; that value depends on (layer, bin) only, so it is formed here with the same
+        // single precision operations and the kernel only interpolates.
+        const size_t nl = static_cast<size_t>(m.num_layers), nw = static_cast<size_t>(m.table_n);
+        P.len_tab_n = m.table_n;
+        P.len_tab_start = to_float_literal(m.table_start);
+        P.len_tab_step = to_float_literal(m.table_step);
+        std::vector<float> value[2];
+        for (int which = 0; which < 2; ++which) {
+            const std::vector<double> &src = which ? m.sca_table : m.abs_table;
+            std::vector<float> &dst = value[which];
+            dst.resize(nl * nw);
+            std::vector<double> quantised(nl * nw), lo_hi(2 * nl);
+            for (size_t l = 0; l < nl; ++l) {
+                const double *v = &src[l * nw];
+                if (!m.table_16bit) {
+                    for (size_t i = 0; i < nw; ++i) dst[l * nw + i] = to_float_literal(v[i]);
+                    continue;
+                }
+                double smallest = v[0], largest = v[0];
+                for (size_t i = 1; i < nw; ++i) {
+                    if (v[i] < smallest) smallest = v[i];
+                    if (v[i] > largest) largest = v[i];
+                }
+                const float lo = to_float_literal(smallest), hi = to_float_literal(largest);
+                const float scale = (hi - lo) / 65535.f;
+                lo_hi[2 * l] = lo; lo_hi[2 * l + 1] = hi;
+                for (size_t i = 0; i < nw; ++i) {
+                    const double q = 65535. * (v[i] - smallest) / (largest - smallest);
+                    const uint16_t stored = (q >= 0. && q < 65536.) ? static_cast<uint16_t>(q) : 0;   // static_cast<uint16_t>
+                    const float t = static_cast<float>(stored) * scale;
+                    dst[l * nw + i] = t + lo;
+                    quantised[l * nw + i] = stored;
+                }
+            }
+            const std::string fn = which ? "getScatteringLength" : "getAbsorptionLength";
+            if (m.table_16bit) { name(fn + "_data16", quantised); name(fn + "_smallest_largest", lo_hi); }
+            name(fn + "_values", as_doubles(dst));
+        }
+        C.len_table.assign(4 * (nw - 1) * nl, 0.f);
+        for (size_t b = 0; b + 1 < nw; ++b)
+            for (size_t l = 0; l < nl; ++l) {
+                float *rec = &C.len_table[4 * (b * nl + l)];
+                rec[0] = value[0][l * nw + b]; rec[1] = value[0][l * nw + b + 1];
+                rec[2] = value[1][l * nw + b]; rec[3] = value[1][l * nw + b + 1];
+            }
+        P.off_layers = 0;
+    } else if (m.lengths_kind == CLSIMHIP_LENGTHS_ICECUBE) {
         // _Optimizers.cxx:123-250 (the per-function form, AbsLenIceCube.cxx:70-93, has the same arithmetic)
         const std::vector<float> a_dust = literals(m.a_dust400), d_tau = literals(m.delta_tau), b400 = literals(m.b400);
         const float D = to_float_literal(m.D), E = to_float_literal(m.E);

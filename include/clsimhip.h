@@ -91,6 +91,9 @@ typedef struct {
  * ice models (public/clsim/I3CLSimMediumProperties.h:54-200). */
 #define CLSIMHIP_LENGTHS_CONSTANT 0 /* I3CLSimFunctionConstant per layer          */
 #define CLSIMHIP_LENGTHS_ICECUBE 1  /* I3CLSimFunctionAbsLenIceCube/ScatLenIceCube */
+#define CLSIMHIP_LENGTHS_TABLE 2    /* one I3CLSimFunctionFromTable per layer (photonics ice tables) */
+#define CLSIMHIP_REFINDEX_ICECUBE 0 /* I3CLSimFunctionRefIndexIceCube (n[] / g[])  */
+#define CLSIMHIP_REFINDEX_TABLE 1   /* I3CLSimFunctionFromTable, same function for every layer */
 #define CLSIMHIP_SCATTER_HG 0
 #define CLSIMHIP_SCATTER_LIU 1
 #define CLSIMHIP_SCATTER_MIXED 2    /* Mixed(SimplifiedLiu, HenyeyGreenstein, f)   */
@@ -115,6 +118,17 @@ typedef struct {
     int32_t tilt_num_distances, tilt_num_z;
     const double *tilt_distances, *tilt_z_coordinates, *tilt_z_corrections; /* [nd][nz] */
     double tilt_azimuth;
+    /* TABLE lengths (private/clsim/function/I3CLSimFunctionFromTable.cxx:167-300): equal spacing common to
+     * all layers; store_as_16bit = storeDataAsHalfPrecision (linear 16-bit quantisation between the
+     * smallest and largest entry of each function) */
+    int32_t table_num_wavelengths;
+    double table_start_wavelength, table_wavelength_step;
+    int32_t table_store_as_16bit;
+    const double *abs_length_table, *sca_length_table; /* [num_layers][table_num_wavelengths], metres */
+    /* refractive indices; the propagator needs a layer independent group velocity
+     * (propagation_kernel.c.cl:525-527), so there is one function of each kind */
+    int32_t phase_index_kind, group_index_kind;         /* CLSIMHIP_REFINDEX_* */
+    clsimhip_function phase_index_table, group_index_table; /* kind TABLE */
 } clsimhip_medium_desc;
 
 /* ---- medium objects ---- */
@@ -124,6 +138,9 @@ int clsimhip_medium_create(const clsimhip_medium_desc *desc, clsimhip_medium **o
  * cfg.txt[, tilt.dat/.par]) -> medium */
 int clsimhip_medium_create_from_ppc(const char *directory, double detector_center_depth,
                                     int use_tilt_if_available, clsimhip_medium **out);
+/* python/MakeIceCubeMediumPropertiesPhotonics.py:47-227: photonics ice table file (NLAYER / NWVL / per layer
+ * LAYER, ABS, SCAT, COS, N_GROUP, N_PHASE) -> medium with tabulated lengths and refractive indices */
+int clsimhip_medium_create_from_photonics(const char *table_file, double detector_center_depth, clsimhip_medium **out);
 /* view into the object's own arrays (valid until destroy) */
 int clsimhip_medium_describe(const clsimhip_medium *m, clsimhip_medium_desc *out);
 void clsimhip_medium_destroy(clsimhip_medium *m);

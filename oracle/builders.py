@@ -100,7 +100,10 @@ def cherenkov_wlen_generator(bias, medium, beta=1.0):
     y = np.empty(n, dtype=np.float64)
     for i in range(n):
         wl = bias["start"] + float(i) * bias["step"]          # FromTable.cxx:88-90
-        nphase = phase_ref_index_host(wl, medium["n"])
+        if "phase_table" in medium:
+            nphase = from_table_host(medium["phase_table"], wl)
+        else:
+            nphase = phase_ref_index_host(wl, medium["n"])
         y[i] = bias["values"][i] * ((2.0 * math.pi / (137.0 * (wl * wl))) * (1.0 - 1.0 / (math.pow(beta * nphase, 2.0))))
     return dict(kind="interp", first=bias["start"], spacing=bias["step"], y=y)
 
@@ -209,6 +212,94 @@ def load_ppc_ice(directory, detector_center_depth=1948.07, use_tilt_if_available
         zshift = np.array([tdat[i + 1][::-1] for i in range(len(dist))])
         med["tilt"] = dict(distances=dist, zcoords=zcoords, zcorr=zshift, azimuth=225.0 * DEG)
     return med
+
+
+def load_photonics_ice(table_file, detector_center_depth=1948.07):
+    """python/MakeIceCubeMediumPropertiesPhotonics.py:47-227: photonics ice table -> medium with one
+    FromTable function per layer for the absorption / scattering length (stored in 16 bits), tabulated phase and
+    group refractive index (one function for all layers), Henyey-Greenstein scattering, no tilt, no anisotropy."""
+    with open(table_file) as f:
+        raw = f.readlines()
+    parsed = [line.split() for line in raw if line.strip() and line.lstrip()[0] != "#"]
+    nlayer = [l for l in parsed if l[0].upper() == "NLAYER"]
+    nwvl = [l for l in parsed if l[0].upper() == "NWVL"]
+    if len(nlayer) != 1 or len(nwvl) != 1:
+        raise RuntimeError("the ice table needs exactly one NLAYER and one NWVL entry")
+    n_layers = int(nlayer[0][1])
+    n_wlen = int(nwvl[0][1])
+    start = float(nwvl[0][2]) * NANOMETER
+    step = float(nwvl[0][3]) * NANOMETER
+    start += step / 2.0
+    parsed = [l for l in parsed if l[0].upper() not in ("NLAYER", "NWVL")]
+    if len(parsed) != n_layers * 6:
+        raise RuntimeError("expected %d lines in the ice table, found %d" % (n_layers * 6, len(parsed)))
+    if parsed[0][0].upper() != "LAYER":
+        raise RuntimeError("layer definitions should start with the LAYER keyword")
+    layers, cur = [], {}
+    for line in parsed:
+        key = line[0].upper()
+        if key == "LAYER":
+            if cur:
+                layers.append(cur)
+            cur = {}
+        elif key in cur:
+            raise RuntimeError("keyword %s is used twice for one layer" % key)
+        cur[key] = [float(t) * 1.0 for t in line[1:]]
+    if cur:
+        layers.append(cur)
+    if not layers:
+        raise RuntimeError("at least one layer is required")
+    height = abs(layers[0]["LAYER"][1] - layers[0]["LAYER"][0])
+    by_z = {}
+    for layer in layers:
+        bottom, top = layer["LAYER"][0], layer["LAYER"][1]
+        if bottom > top:
+            bottom, top = top, bottom
+        if abs((top - bottom) - height) > 0.0001:
+            raise RuntimeError("differing layer heights")
+        by_z[bottom] = layer
+    layers, end_z = [], None
+    for _, layer in sorted(by_z.items()):
+        start_z = layer["LAYER"][0]
+        if end_z is not None and abs(end_z - start_z) > 0.0001:
+            raise RuntimeError("your layers have holes")
+        end_z = layer["LAYER"][1]
+        layers.append(layer)
+    mean_cos = None
+    for layer in layers:
+        if mean_cos is None:
+            mean_cos = layer["COS"][0]
+        for c in layer["COS"]:
+            if abs(c - mean_cos) > 0.0001:
+                raise RuntimeError("only a constant mean cosine is supported")
+        for key in ("COS", "ABS", "SCAT", "N_GROUP", "N_PHASE"):
+            if len(layer[key]) != n_wlen:
+                raise RuntimeError("expected %d %s values, got %d" % (n_wlen, key, len(layer[key])))
+        for i in range(n_wlen):
+            if abs(layer["N_GROUP"][i] - layers[0]["N_GROUP"][i]) > 0.0001 or abs(layer["N_PHASE"][i] - layers[0]["N_PHASE"][i]) > 0.0001:
+                raise RuntimeError("N_GROUP / N_PHASE may not differ between layers")
+    abs_tab = np.array([[1.0 / a for a in layer["ABS"]] for layer in layers])
+    sca_tab = np.array([[(1.0 / s) * (1.0 - mean_cos) for s in layer["SCAT"]] for layer in layers])
+    last = start + step * float(n_wlen - 1)                     # FromTable.cxx:157-164 (GetMaxWlen)
+    return dict(num_layers=len(layers), layers_z_start=layers[0]["LAYER"][0], layers_height=height,
+                min_wlen=start, max_wlen=last,                  # MediumProperties.cxx:85-153, nothing forced
+                len_mode="table", table=dict(start=start, step=step, n=n_wlen, store16=True, abs=abs_tab, sca=sca_tab),
+                phase_table=dict(kind="table", start=start, step=step, values=np.array(layers[0]["N_PHASE"])),
+                group_table=dict(kind="table", start=start, step=step, values=np.array(layers[0]["N_GROUP"])),
+                n=(0.0,) * 5, g=(0.0,) * 5,
+                scat=dict(kind="hg", mean_cos=float(mean_cos)))
+
+
+def quantize_table(values):
+    """I3CLSimFunctionFromTable::GetOpenCLFunction, 16-bit storage (FromTable.cxx:183-207): -> (smallest literal,
+    largest literal, uint16 data)."""
+    v = np.asarray(values, dtype=np.float64)
+    lo, hi = float(v[0]), float(v[0])
+    for x in v[1:]:
+        if x < lo: lo = float(x)
+        if x > hi: hi = float(x)
+    q = np.array([int(65535.0 * (float(x) - lo) / (hi - lo)) for x in v], dtype=np.uint16)   # static_cast<uint16_t>: truncation
+    return float_literal(lo), float_literal(hi), q
 
 
 def homogeneous_medium(abs_len=100.0, sca_len=25.0, z_start=-1000.0, height=2000.0, mean_cos=0.9, liu_fraction=0.45):

@@ -74,6 +74,12 @@ class Tables(C.Structure):
         ("dom_mul_x", C.c_float), ("dom_mul_y", C.c_float),
         ("dom_tx", C.POINTER(C.c_int16)), ("dom_ty", C.POINTER(C.c_int16)), ("dom_tz", FP),
         ("dom_start", C.POINTER(C.c_uint32)), ("dom_meanx", FP), ("dom_meany", FP),
+        ("tab_n", C.c_int32), ("tab_start", C.c_float), ("tab_step", C.c_float), ("tab_store16", C.c_int32),
+        ("abs_q", C.POINTER(C.c_uint16)), ("sca_q", C.POINTER(C.c_uint16)),
+        ("abs_lo", FP), ("abs_hi", FP), ("sca_lo", FP), ("sca_hi", FP), ("abs_f", FP), ("sca_f", FP),
+        ("phase_mode", C.c_int32), ("group_mode", C.c_int32), ("phase_n", C.c_int32), ("group_n", C.c_int32),
+        ("phase_start", C.c_float), ("phase_step", C.c_float), ("group_start", C.c_float), ("group_step", C.c_float),
+        ("phase_data", FP), ("group_data", FP),
     ]
 
 
@@ -142,6 +148,23 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
         t.len_mode = 0
         t.abs_const = O._ptr("abs_const", fls(m["abs_const"]), C.c_float)
         t.sca_const = O._ptr("sca_const", fls(m["sca_const"]), C.c_float)
+    elif m["len_mode"] == "table":
+        tb = m["table"]
+        t.len_mode = 2
+        t.tab_n, t.tab_start, t.tab_step = tb["n"], fl(tb["start"]), fl(tb["step"])
+        t.tab_store16 = 1 if tb["store16"] else 0
+        if tb["store16"]:
+            qa = [B.quantize_table(row) for row in tb["abs"]]
+            qs = [B.quantize_table(row) for row in tb["sca"]]
+            t.abs_q = O._ptr("abs_q", np.array([q[2] for q in qa], dtype=np.uint16), C.c_uint16)
+            t.sca_q = O._ptr("sca_q", np.array([q[2] for q in qs], dtype=np.uint16), C.c_uint16)
+            t.abs_lo = O._ptr("abs_lo", np.array([q[0] for q in qa], dtype=np.float32), C.c_float)
+            t.abs_hi = O._ptr("abs_hi", np.array([q[1] for q in qa], dtype=np.float32), C.c_float)
+            t.sca_lo = O._ptr("sca_lo", np.array([q[0] for q in qs], dtype=np.float32), C.c_float)
+            t.sca_hi = O._ptr("sca_hi", np.array([q[1] for q in qs], dtype=np.float32), C.c_float)
+        else:
+            t.abs_f = O._ptr("abs_f", fls(tb["abs"]), C.c_float)
+            t.sca_f = O._ptr("sca_f", fls(tb["sca"]), C.c_float)
     else:
         t.len_mode = 1
         t.aDust400 = O._ptr("aDust400", fls(m["aDust400"]), C.c_float)
@@ -156,6 +179,14 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
     for i in range(5):
         t.n[i] = fl(m["n"][i])
         t.g[i] = fl(m["g"][i])
+    for key in ("phase", "group"):                      # tabulated refractive indices (float data)
+        if key + "_table" in m:
+            ft = m[key + "_table"]
+            setattr(t, key + "_mode", 1)
+            setattr(t, key + "_n", len(ft["values"]))
+            setattr(t, key + "_start", fl(ft["start"]))
+            setattr(t, key + "_step", fl(ft["step"]))
+            setattr(t, key + "_data", O._ptr(key + "_data", fls(ft["values"]), C.c_float))
     sc = m["scat"]
     g = sc["mean_cos"]
     t.liu_beta = fl((1.0 - g) / (1.0 + g))

@@ -82,7 +82,7 @@ typedef struct {
     /* ---- medium (MediumPropertiesSource.cxx:207-389) ---- */
     int32_t num_layers;
     float layer_bottom, layer_thickness;
-    int32_t len_mode;           /* 0: per-layer FunctionConstant, 1: IceCube abs/scat */
+    int32_t len_mode;           /* 0: per-layer FunctionConstant, 1: IceCube abs/scat, 2: per-layer FromTable */
     const float *abs_const, *sca_const;
     const float *aDust400, *deltaTau, *b400;
     float kappa, A, B, D, E, alpha, ref_wlen_recip, nanometer;
@@ -125,6 +125,17 @@ typedef struct {
     const float *dom_tz;
     const uint32_t *dom_start;
     const float *dom_meanx, *dom_meany;
+    /* ---- tabulated medium functions (FunctionFromTable.cxx:167-300; MakeIceCubeMediumPropertiesPhotonics.py) ---- */
+    int32_t tab_n;              /* len_mode 2: one FromTable function per layer, common binning */
+    float tab_start, tab_step;
+    int32_t tab_store16;        /* storeDataAsHalfPrecision: 16-bit linear quantisation */
+    const uint16_t *abs_q, *sca_q;      /* [layer][tab_n] */
+    const float *abs_lo, *abs_hi, *sca_lo, *sca_hi;     /* per layer _SMALLEST_ENTRY / _LARGEST_ENTRY */
+    const float *abs_f, *sca_f;         /* [layer][tab_n] float literals when not quantised */
+    int32_t phase_mode, group_mode;     /* 0 RefIndexIceCube, 1 FromTable (float data) */
+    int32_t phase_n, group_n;
+    float phase_start, phase_step, group_start, group_step;
+    const float *phase_data, *group_data;
 } oracle_tables;
 
 typedef struct { uint64_t x; uint32_t a; } rng_t;
@@ -169,14 +180,45 @@ static inline float clampf(float v, float lo, float hi) { return fminf_(fmaxf_(v
 
 /* ---------------- generated medium functions ---------------- */
 
+/* FunctionFromTable.cxx:213-232: <name>_getInterpolationBinAndFraction */
+static inline void tableBinAndFraction(float start, float step, int n, float wavelength, int *bin, float *fraction)
+{
+    const float q = (wavelength - start) / step;
+    const float fbin = __builtin_truncf(q);
+    *fraction = q - fbin;                           /* modf */
+    int ibin = (int)fbin;
+    if ((ibin < 0) || ((ibin == 0) && (*fraction < 0))) { ibin = 0; *fraction = 0.0f; }
+    else if (ibin >= n - 1) { ibin = n - 2; *fraction = 1.0f; }
+    *bin = ibin;
+}
+/* FunctionFromTable.cxx:279-291: float data */
+static inline float fromTableFloat(float start, float step, int n, const float *data, float wavelength)
+{
+    int bin; float fraction;
+    tableBinAndFraction(start, step, n, wavelength, &bin, &fraction);
+    const float a = data[bin], b = data[bin + 1];
+    return a + (b - a) * fraction;                  /* mix */
+}
+/* FunctionFromTable.cxx:262-275: 16-bit data between _SMALLEST_ENTRY and _LARGEST_ENTRY */
+static inline float fromTable16(float start, float step, int n, const uint16_t *data, float lo, float hi, float wavelength)
+{
+    int bin; float fraction;
+    tableBinAndFraction(start, step, n, wavelength, &bin, &fraction);
+    const float a = (float)data[bin] * ((hi - lo) / 65535.f) + lo;
+    const float b = (float)data[bin + 1] * ((hi - lo) / 65535.f) + lo;
+    return a + (b - a) * fraction;
+}
+
 /* RefIndexIceCube.cxx:128-180 */
 static inline float getPhaseRefIndex(const oracle_tables *T, float wlen)
 {
+    if (T->phase_mode == 1) return fromTableFloat(T->phase_start, T->phase_step, T->phase_n, T->phase_data, wlen);
     const float x = wlen / T->micrometer;
     return T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
 }
 static inline float getGroupRefIndex(const oracle_tables *T, float wlen)
 {
+    if (T->group_mode == 1) return fromTableFloat(T->group_start, T->group_step, T->group_n, T->group_data, wlen);
     const float x = wlen / T->micrometer;
     const float np = T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
     const float np_corr = T->g[0] + x * (T->g[1] + x * (T->g[2] + x * (T->g[3] + x * T->g[4])));
@@ -191,12 +233,22 @@ static inline float getGroupVelocity(const oracle_tables *T, float wlen)
 static inline float getScatteringLength(const oracle_tables *T, int layer, float wlen)
 {
     if (T->len_mode == 0) return T->sca_const[layer];
+    if (T->len_mode == 2) {                         /* MediumPropertiesSource.cxx:89-123: switch(layer) over _func<k> */
+        const size_t o = (size_t)layer * (size_t)T->tab_n;
+        if (T->tab_store16) return fromTable16(T->tab_start, T->tab_step, T->tab_n, T->sca_q + o, T->sca_lo[layer], T->sca_hi[layer], wlen);
+        return fromTableFloat(T->tab_start, T->tab_step, T->tab_n, T->sca_f + o, wlen);
+    }
     return 1.0f / (T->b400[layer] * om_powr(wlen * T->ref_wlen_recip, -T->alpha));
 }
 /* _Optimizers.cxx:123-190 */
 static inline float getAbsorptionLength(const oracle_tables *T, int layer, float wlen)
 {
     if (T->len_mode == 0) return T->abs_const[layer];
+    if (T->len_mode == 2) {
+        const size_t o = (size_t)layer * (size_t)T->tab_n;
+        if (T->tab_store16) return fromTable16(T->tab_start, T->tab_step, T->tab_n, T->abs_q + o, T->abs_lo[layer], T->abs_hi[layer], wlen);
+        return fromTableFloat(T->tab_start, T->tab_step, T->tab_n, T->abs_f + o, wlen);
+    }
     const float x = wlen / T->nanometer;
     return 1.0f / ((T->D * T->aDust400[layer] + T->E) * om_powr(x, -T->kappa)
                    + T->A * om_exp(-T->B / x) * (1.0f + 0.01f * T->deltaTau[layer]));

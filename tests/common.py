@@ -11,6 +11,8 @@ from oracle import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ICE = os.path.join(ROOT, "clsim_amd", "data", "ice")
+PHOTONICS = {"photonics_mie": os.path.join(ICE, "photonics_spice_mie", "Ice_table.mie.i3coords.cos090.08Apr2011.txt"),
+             "photonics_wham": os.path.join(ICE, "photonics_wham", "Ice_table.wham.i3coords.cos090.11jul2011.txt")}
 FLASHER_WLEN = 405e-9
 
 _streams = {}
@@ -35,6 +37,10 @@ def config(name):
         geom = S.single_string_geometry()
         med_o = B.homogeneous_medium()
         med_p = CV.MakeHomogeneousMediumProperties()
+    elif name.startswith("photonics"):
+        geom = S.ic86_geometry()
+        med_o = B.load_photonics_ice(PHOTONICS[name])
+        med_p = CV.MakeIceCubeMediumPropertiesPhotonics(PHOTONICS[name])
     else:
         geom = S.ic86_geometry()
         d = os.path.join(ICE, "spice_mie" if name == "mie" else "spice_lea")

@@ -15,6 +15,8 @@ is executed by the REFERENCE's own Python code:
                              util/GetSpiceLeaAnisotropyTransforms.py) passes to the clsim C++
                              constructors for resources/ice/<model>
   * dom_acceptance.json      python/GetIceCubeDOMAcceptance.py
+  * ice_photonics_<m>.npz    what python/MakeIceCubeMediumPropertiesPhotonics.py passes to the clsim C++
+                             constructors for resources/ice/photonics_<m>/*.txt (per-layer FromTable functions)
 
 The reference's Python modules import `icecube` (IceTray), which does not exist
 here.  The loader scripts only use it to CONSTRUCT result objects, so they are
@@ -172,6 +174,38 @@ def main():
         m = mk.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(REF, "resources/ice", model))
         with open(os.path.join(OUT, "ice_%s.json" % model), "w") as f:
             json.dump(to_jsonable(m), f)
+    mkp = load(os.path.join(REF, "python/MakeIceCubeMediumPropertiesPhotonics.py"),
+               "icecube.clsim.MakeIceCubeMediumPropertiesPhotonics")
+    for tag, rel in (("spice_mie", "photonics_spice_mie/Ice_table.mie.i3coords.cos090.08Apr2011.txt"),
+                     ("wham", "photonics_wham/Ice_table.wham.i3coords.cos090.11jul2011.txt")):
+        m = mkp.MakeIceCubeMediumPropertiesPhotonics(tableFile=os.path.join(REF, "resources/ice", rel))
+        n = m.kwargs["layersNum"]
+        rec = dict(layersNum=n, layersZStart=m.kwargs["layersZStart"], layersHeight=m.kwargs["layersHeight"])
+        tabs = {"SetAbsorptionLength": [None] * n, "SetScatteringLength": [None] * n,
+                "SetPhaseRefractiveIndex": [None] * n, "SetGroupRefractiveIndexOverride": [None] * n}
+        for name, a, k in m.calls:
+            if name in tabs:
+                f = a[1]
+                assert f.cls == "I3CLSimFunctionFromTable"
+                tabs[name][a[0]] = (f.args[0], f.args[1], np.array(f.args[2], dtype=np.float64),
+                                    bool(f.kwargs.get("storeDataAsHalfPrecision", False)), id(f))
+            elif name == "SetScatteringCosAngleDistribution":
+                assert a[0].cls == "I3CLSimRandomValueHenyeyGreenstein"
+                rec["meanCosine"] = a[0].kwargs["meanCosine"]
+            elif name == "SetIceTiltZShift":
+                assert a[0].cls == "I3CLSimScalarFieldConstant" and a[0].args == (0.,)
+            elif name == "SetDirectionalAbsorptionLengthCorrection":
+                assert a[0].cls == "I3CLSimScalarFieldConstant" and a[0].args == (1.,)
+            elif name in ("SetPreScatterDirectionTransform", "SetPostScatterDirectionTransform"):
+                assert a[0].cls == "I3CLSimVectorTransformConstant"
+        for name, key in (("SetAbsorptionLength", "abs"), ("SetScatteringLength", "sca"),
+                          ("SetPhaseRefractiveIndex", "phase"), ("SetGroupRefractiveIndexOverride", "group")):
+            t = tabs[name]
+            assert all(x is not None and x[0] == t[0][0] and x[1] == t[0][1] and x[3] == t[0][3] for x in t)
+            rec[key + "_start"], rec[key + "_step"], rec[key + "_16bit"] = t[0][0], t[0][1], t[0][3]
+            rec[key + "_same_object"] = len(set(x[4] for x in t)) == 1
+            rec[key] = np.array([x[2] for x in t])
+        np.savez_compressed(os.path.join(OUT, "ice_photonics_%s.npz" % tag), **rec)
     acc = load(os.path.join(REF, "python/GetIceCubeDOMAcceptance.py"), "icecube.clsim.GetIceCubeDOMAcceptance")
     a = acc.GetIceCubeDOMAcceptance()
     with open(os.path.join(OUT, "dom_acceptance.json"), "w") as f:

@@ -28,7 +28,8 @@ def run_both(name, n_steps, max_items=None, seed=3, threads=8):
     return steps, (ph_o, cnt_o, x_o), (ph_p, x_p), conv
 
 
-@pytest.mark.parametrize("name,n_steps", [("c1", 1000), ("mie", 4096), ("lea", 4096), ("flasher", 2048)])
+@pytest.mark.parametrize("name,n_steps", [("c1", 1000), ("mie", 4096), ("lea", 4096), ("flasher", 2048),
+                                          ("photonics_mie", 4096), ("photonics_wham", 2048)])
 def test_hit_multiset_bit_exact(name, n_steps):
     steps, (ph_o, cnt_o, x_o), (ph_p, x_p), conv = run_both(name, n_steps)
     assert cnt_o > 10, "workload too small to be a test"
@@ -109,7 +110,8 @@ def _run_custom(med_o, med_p, geom, gens_o, gens_p, steps, pancake=5.0, max_item
     assert np.array_equal(conv.GetRNGState(n), x_o)
 
 
-@pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1"])
+@pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1",
+                                  "table_float", "table_with_tilt_and_aniso"])
 def test_other_kernel_variants(kind):
     """Variants of the generated program: PANCAKE_FACTOR undefined (pancake = 1), getTiltZShift_IS_CONSTANT with
     layered ice (carried layer index), a one-layer IceCube medium (un-optimised per-function form, SURVEY 9.7 ii),
@@ -147,6 +149,36 @@ def test_other_kernel_variants(kind):
     elif kind == "lea_no_tilt":
         med_o = B.load_ppc_ice(ice_dir("spice_lea"), use_tilt_if_available=False)
         med_p = product_medium(directory=ice_dir("spice_lea"), tilt=False)
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind in ("table_float", "table_with_tilt_and_aniso"):
+        # per-layer FromTable lengths stored as floats (storeDataAsHalfPrecision=False); and tabulated lengths under
+        # the tilt / anisotropy / Mixed scattering objects of SPICE-Lea (no reference loader builds this mix, the classes allow it)
+        path = common.PHOTONICS["photonics_mie"]
+        med_o = B.load_photonics_ice(path)
+        lea_o = B.load_ppc_ice(ice_dir("spice_lea"))
+        lea_p = CV.MakeIceCubeMediumProperties(iceDataDirectory=ice_dir("spice_lea"))
+        lea_d = _lib.MediumDesc()
+        assert _lib.load().clsimhip_medium_describe(lea_p._h, C.byref(lea_d)) == 0
+        if kind == "table_float":
+            med_o["table"]["store16"] = False
+        else:
+            for key in ("aniso", "pre", "post", "tilt"):
+                med_o[key] = lea_o[key]
+            med_o["scat"] = lea_o["scat"]
+        tab = CV.MakeIceCubeMediumPropertiesPhotonics(path)
+        d = _lib.MediumDesc()
+        assert _lib.load().clsimhip_medium_describe(tab._h, C.byref(d)) == 0
+        if kind == "table_float":
+            d.table_store_as_16bit = 0
+        else:
+            for f in ("scatter_kind", "liu_fraction", "mean_cosine", "has_anisotropy", "aniso_azimuth", "aniso_k1", "aniso_k2",
+                      "has_pre_transform", "pre_renormalize", "pre_matrix", "has_post_transform", "post_renormalize", "post_matrix",
+                      "has_tilt", "tilt_num_distances", "tilt_num_z", "tilt_distances", "tilt_z_coordinates", "tilt_z_corrections",
+                      "tilt_azimuth"):
+                setattr(d, f, getattr(lea_d, f))
+        h = C.c_void_p()
+        assert _lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)) == 0
+        med_p = CV.I3CLSimMediumProperties(h, keep=(tab, lea_p))
         _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
     elif kind in ("hg_only", "liu_only"):
         med_o = B.load_ppc_ice(ice_dir("spice_mie"))

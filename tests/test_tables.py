@@ -129,3 +129,52 @@ def test_text_file_geometry(tmp_path):
     bad = CV.I3CLSimStepToPhotonConverterHIP(0)
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Could not open input file"):
         bad.SetGeometry(CV.I3CLSimSimpleGeometry.from_text_file(0.8, str(tmp_path / "missing.txt")))
+
+
+def test_tabulated_medium_tables(tmp_path):
+    """N1: per-layer FromTable lengths (16-bit storage) and tabulated refractive indices: the product's folded
+    (layer, bin) values against the oracle evaluating the generated function's expression at the table points."""
+    from oracle import builders as B
+    from oracle import capi
+    cfg = common.config("photonics_mie")
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    T = common.oracle_tables(cfg)
+    m = cfg["med_o"]
+    tb = m["table"]
+    q = [B.quantize_table(r) for r in tb["abs"]]
+    assert np.array_equal(conv.GetTable("getAbsorptionLength_data16").reshape(171, 30), np.array([x[2] for x in q]))
+    lo_hi = conv.GetTable("getAbsorptionLength_smallest_largest").reshape(171, 2)
+    assert np.array_equal(lo_hi[:, 0], np.array([x[0] for x in q], dtype=np.float64))
+    assert np.array_equal(lo_hi[:, 1], np.array([x[1] for x in q], dtype=np.float64))
+    assert conv.GetTable("getAbsorptionLength_data16").max() == 65535 and conv.GetTable("getScatteringLength_data16").min() == 0
+    # at a table point the fraction is 0 or 1, so the generated function returns the de-quantised entry itself
+    wl = np.array([B.float_literal(tb["start"]) + np.float32(k) * B.float_literal(tb["step"]) for k in range(30)], dtype=np.float32)
+    wl_mid = (wl[:-1] + np.float32(0.25) * (wl[1:] - wl[:-1])).astype(np.float32)
+    va = conv.GetTable("getAbsorptionLength_values").reshape(171, 30).astype(np.float32)
+    vs = conv.GetTable("getScatteringLength_values").reshape(171, 30).astype(np.float32)
+    for layer in (0, 17, 85, 170):
+        oa, os_ = capi.eval_medium(T, 0, wl_mid, layer), capi.eval_medium(T, 1, wl_mid, layer)
+        q_ = (wl_mid - B.float_literal(tb["start"])) / B.float_literal(tb["step"])
+        frac = (q_ - np.trunc(q_)).astype(np.float32)
+        k = np.trunc(q_).astype(int)
+        assert np.array_equal(oa, va[layer, k] + (va[layer, k + 1] - va[layer, k]) * frac)
+        assert np.array_equal(os_, vs[layer, k] + (vs[layer, k + 1] - vs[layer, k]) * frac)
+        # quantisation error bound: (largest - smallest) / 65535 per entry
+        assert np.all(np.abs(va[layer] - tb["abs"][layer]) <= (tb["abs"][layer].max() - tb["abs"][layer].min()) / 65535.0 * 1.01 + 1e-6)
+    assert np.array_equal(conv.GetTable("getPhaseRefIndex_func0_data"), B.float_literals(m["phase_table"]["values"]).astype(np.float64))
+    assert np.array_equal(conv.GetTable("getGroupRefIndex_func0_data"), B.float_literals(m["group_table"]["values"]).astype(np.float64))
+    assert conv.GetTable("MEDIUM_MIN_WLEN")[0] == B.float_literal(305e-9) and conv.GetTable("MEDIUM_MAX_WLEN")[0] == B.float_literal(m["max_wlen"])
+    # the wavelength generator is built from the tabulated phase index on both sides
+    bias = B.icecube_dom_acceptance()
+    yv, ycum = B.interp_dist_tables(B.cherenkov_wlen_generator(bias, m))
+    assert np.array_equal(conv.GetTable("_generateWavelength_0distYValues"), yv.astype(np.float64))
+    assert np.array_equal(conv.GetTable("_generateWavelength_0distYCumulativeValues"), ycum.astype(np.float64))
+    # error paths of the table file reader
+    bad = tmp_path / "bad.txt"
+    bad.write_text("NLAYER 1\nLAYER 0 10\nABS 1 1\n")
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="NWVL"):
+        CV.MakeIceCubeMediumPropertiesPhotonics(str(bad))
+    bad.write_text("NLAYER 2\nNWVL 2 300 10\nLAYER 0 10\nABS 1 1\nSCAT 1 1\nCOS .9 .9\nN_GROUP 1.3 1.3\nN_PHASE 1.3 1.3\n")
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Expected 2\\*6"):
+        CV.MakeIceCubeMediumPropertiesPhotonics(str(bad))
