@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
     ap.add_argument("--photons-per-step", type=int, default=200)
     ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
+                         "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -55,7 +58,10 @@ def cpu_baseline(args, steps_np, seconds):
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
     bias = B.icecube_dom_acceptance()
-    T = capi.make_tables(med, geo, [B.cherenkov_wlen_generator(bias, med)], bias, pancake=5.0)
+    gens = [B.cherenkov_wlen_generator(bias, med)]
+    if args.workload == "c5":
+        gens.append(dict(kind="const", value=405e-9))
+    T = capi.make_tables(med, geo, gens, bias, pancake=5.0)
     from clsim_amd import converter as CV
     probe = 64 * cores
     # stream set-up through the product's generators (tests/test_golden_reference.py pins both
@@ -78,6 +84,11 @@ def cpu_baseline(args, steps_np, seconds):
 
 def main():
     args = parse()
+    if args.workload == "c3":
+        args.ice, args.bunch = "spice_lea", (args.bunch if args.bunch != (1 << 20) else 5 * (1 << 20))   # 10M steps = 2 such bunches:
+        # a converter holds at most 6 139 850 streams (all 32-bit safeprime multipliers, OpenCL.cxx:250)
+    elif args.workload == "c5":
+        args.ice, args.photons_per_step = "spice_lea", (400 if args.photons_per_step == 200 else args.photons_per_step)
     import torch
     import torch.distributed as dist
     from clsim_amd import converter as CV
@@ -98,15 +109,23 @@ def main():
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
     bias = CV.GetIceCubeDOMAcceptance()
-    gen = CV.makeCherenkovWavelengthGenerator(bias, medium)
-    geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
-    conv = CV.initializeHIP(local_rank, geom, medium, bias, [gen], pancakeFactor=5.0,
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, medium)]
+    g86 = S.ic86_geometry()
+    geom = CV.I3CLSimSimpleGeometry.from_dict(g86)
+    if args.workload == "c5":
+        gens.append(CV.I3CLSimRandomValueConstant(405e-9))          # delta-peak spectrum (ModuleHelper.cxx:81-88)
+    conv = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0,
                             approximateNumberOfWorkItems=n, seed=12345 + rank)
-    steps_np = S.cascade_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step)
+    if args.workload == "c5":
+        k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))   # a DOM near the detector centre
+        steps_np = S.flasher_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step,
+                                   position=(float(g86["x"][k]), float(g86["y"][k]), float(g86["z"][k])))
+    else:
+        steps_np = S.cascade_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step)
     photons_per_pass = int(steps_np["num"].sum())
 
     d_steps = torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)
-    capacity = 4 * 1024 * 1024
+    capacity = (4 if args.workload == "c2" else 48) * 1024 * 1024
     d_photons = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
     d_count = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.empty((capacity if rank == 0 else 1, 80), dtype=torch.uint8, device=dev) if world > 1 else None
@@ -154,7 +173,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath) and world == 1:
+        if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and args.photons_per_step == 200:
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this same command
             # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken)
             with open(tpath) as f:
@@ -167,7 +186,8 @@ def main():
             "config": {"workload": "%d I3CLSimSteps x %d photons per GPU and pass, %s ice (171 layers%s), synthetic 86-string "
                                    "detector (5160 DOMs), DOM oversize 5; BASELINE.json configs[%d]" %
                                    (n, args.photons_per_step, args.ice, " + tilt" if True else "",
-                                    1 if world == 1 else 3),
+                                    {"c2": 1 if world == 1 else 3, "c3": 2, "c5": 4}[args.workload]),
+                       "kind": {"c2": "cascade steps", "c3": "cascade steps", "c5": "flasher steps (405 nm point source at a DOM)"}[args.workload],
                        "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
                        "hit_gather": "rccl p2p to rank 0" if world > 1 else "none",
                        "hits_last_pass_rank0": hits_last},
