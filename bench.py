@@ -42,6 +42,9 @@ def parse():
                     help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
                          "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="time EnqueueSteps -> GetConversionResult instead (host buffers, PCIe transfers and the index->ID "
+                         "conversion included, double buffering on); NOT the headline value, see DESIGN.md 6")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -114,7 +117,7 @@ def main():
     geom = CV.I3CLSimSimpleGeometry.from_dict(g86)
     if args.workload == "c5":
         gens.append(CV.I3CLSimRandomValueConstant(405e-9))          # delta-peak spectrum (ModuleHelper.cxx:81-88)
-    conv = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0,
+    conv = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=args.host_path,
                             approximateNumberOfWorkItems=n, seed=12345 + rank)
     if args.workload == "c5":
         k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))   # a DOM near the detector centre
@@ -131,6 +134,30 @@ def main():
     gathered = torch.empty((capacity if rank == 0 else 1, 80), dtype=torch.uint8, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
     total_hits = 0
+
+    if args.host_path:
+        # the reference's own calling pattern (benchmark.py:300-360): a producer thread enqueues bunches, the
+        # consumer takes results; wall clock from the first enqueue to the last result
+        import threading
+        for _ in range(args.warmup):
+            conv.EnqueueSteps(steps_np, 0)
+            conv.GetConversionResult()
+        t0 = time.perf_counter()
+        producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(args.steps)])
+        producer.start()
+        hits = 0
+        for _ in range(args.steps):
+            _, ph = conv.GetConversionResult()
+            hits += len(ph)
+        producer.join()
+        elapsed = time.perf_counter() - t0
+        st = conv.GetStatistics()
+        print(json.dumps({"metric": "propagated photons/sec through EnqueueSteps/GetConversionResult (host buffers)",
+                          "value": photons_per_pass * args.steps / elapsed, "unit": "photons/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "hits": hits,
+                          "device_utilization": st["DeviceUtilization"], "device_ns_per_photon": st["AverageDeviceTimePerPhoton"],
+                          "host_ns_per_photon": st["AverageHostTimePerPhoton"], "config": {"workload": args.workload, "steps_per_bunch": n}}))
+        return
 
     def one_pass():
         nonlocal total_hits

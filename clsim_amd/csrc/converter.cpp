@@ -1,6 +1,8 @@
-// Host runtime: see converter.h.  One worker thread owns the HIP stream
-// (upload -> kernel -> download, OpenCL.cxx:1142-1315); callers talk to it through
-// two bounded queues, like the reference's queueToOpenCL_/queueFromOpenCL_.
+// Host runtime: see converter.h.  One worker thread owns the HIP streams
+// (upload -> kernel on the compute stream, photon download on the copy stream,
+// OpenCL.cxx:1142-1315); callers talk to it through two bounded queues, like the
+// reference's queueToOpenCL_/queueFromOpenCL_.  With double buffering one bunch
+// is on the GPU while the previous one is downloaded and converted.
 #include "converter.h"
 
 #include <chrono>
@@ -36,12 +38,19 @@ Converter::~Converter()
     if (ev_start_) (void)hipEventDestroy(ev_start_);
     if (ev_stop_) (void)hipEventDestroy(ev_stop_);
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    for (Slot &sl : slots_) {
+        if (sl.start) (void)hipEventDestroy(sl.start);
+        if (sl.stop) (void)hipEventDestroy(sl.stop);
+        if (sl.counted) (void)hipEventDestroy(sl.counted);
+        (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count);
+        if (sl.h_steps) (void)hipHostFree(sl.h_steps);
+        if (sl.h_photons) (void)hipHostFree(sl.h_photons);
+        if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
+    }
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_);
-    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_photons_);
-    (void)hipFree(d_hit_count_); (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
-    if (h_steps_) (void)hipHostFree(h_steps_);
-    if (h_photons_) (void)hipHostFree(h_photons_);
-    if (h_hit_count_) (void)hipHostFree(h_hit_count_);
+    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
+    (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
 }
 
 void Converter::set_wlen_generators(std::vector<RandomValueData> g) { guard(); compiled_ = false; generators_ = std::move(g); }
@@ -154,6 +163,7 @@ void Converter::initialize_with_streams(const uint64_t *x, const uint32_t *a, si
     }
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
     hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
     setup_device_buffers();
@@ -180,16 +190,23 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_x_), max_workitems_ * sizeof(uint64_t)), "rng x");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_a_), max_workitems_ * sizeof(uint32_t)), "rng a");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), max_workitems_ * sizeof(DevStep)), "steps");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_photons_), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_hit_count_), 16), "hit counter");
+    num_slots_ = double_buffering_ ? 2 : 1;
+    for (int i = 0; i < num_slots_; ++i) {
+        Slot &sl = slots_[i];
+        hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_steps), max_workitems_ * sizeof(DevStep)), "steps");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_photons), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_hit_count), 16), "hit counter");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_steps), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_photons), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
+        hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_hit_count), 16, hipHostMallocDefault), "pinned counter");
+        hip_check(hipEventCreate(&sl.start), "hipEventCreate");
+        hip_check(hipEventCreate(&sl.stop), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&sl.counted, hipEventDisableTiming), "hipEventCreate");
+    }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_slice_done_), max_workitems_ * sizeof(uint32_t)), "slice counters");
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
-    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
-    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_photons_), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
-    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_hit_count_), 16, hipHostMallocDefault), "pinned counter");
 }
 
 KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)
@@ -234,63 +251,103 @@ void Converter::enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t ide
     in_queue_->put(std::move(job));
 }
 
-// OpenCL.cxx:1142-1315 (thread body), :824-934 (upload, launch), :994-1086 (download)
+// OpenCL.cxx:824-934: upload, launch; everything is queued on the compute stream, nothing waits
+void Converter::submit(Slot &s, const Job &job)
+{
+    const size_t n = job.steps.size();
+    s.id = job.id;
+    s.generated = 0;
+    for (const clsimhip_step &st : job.steps) s.generated += st.num_photons;
+    std::memcpy(s.h_steps, job.steps.data(), n * sizeof(clsimhip_step));
+    hip_check(hipMemcpyAsync(s.d_steps, s.h_steps, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
+    hip_check(hipMemsetAsync(s.d_hit_count, 0, 4, stream_), "reset hit counter");
+    const KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
+    hip_check(hipEventRecord(s.start, stream_), "event");
+    hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
+    hip_check(hipEventRecord(s.stop, stream_), "event");
+    hip_check(hipMemcpyAsync(s.h_hit_count, s.d_hit_count, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
+    hip_check(hipEventRecord(s.counted, stream_), "event");
+}
+
+// OpenCL.cxx:994-1086: wait for the bunch, download and convert its photons (on the copy stream, so that the
+// next bunch's kernel -- already queued on the compute stream -- runs meanwhile), hand the result out
+void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done, bool &first)
+{
+    hip_check(hipEventSynchronize(s.counted), "propagation kernel");
+    uint32_t hits = *s.h_hit_count;
+    if (hits > max_output_photons_) {
+        // OpenCL.cxx:1027-1032: logged, truncated
+        std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);
+        hits = max_output_photons_;
+    }
+    std::unique_ptr<std::vector<clsimhip_photon>> photons(new std::vector<clsimhip_photon>(hits));
+    if (hits) {
+        hip_check(hipMemcpyAsync(s.h_photons, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
+        hip_check(hipStreamSynchronize(copy_stream_), "download photons");
+        std::memcpy(photons->data(), s.h_photons, static_cast<size_t>(hits) * sizeof(clsimhip_photon));
+        replace_indices(photons->data(), hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
+    }
+    float ms = 0.f;
+    hip_check(hipEventElapsedTime(&ms, s.start, s.stop), "event time");
+    const auto now = std::chrono::steady_clock::now();
+    {
+        std::lock_guard<std::mutex> lk(stats_mutex_);
+        total_device_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+        if (!first) total_host_ns_ += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(now - last_done).count());
+        else total_host_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
+        ++num_kernel_calls_;
+        photons_generated_ += s.generated;
+        photons_at_doms_ += hits;
+    }
+    first = false;
+    last_done = now;
+    Result r;
+    r.id = s.id;
+    r.photons = std::move(photons);
+    out_queue_->put(std::move(r));
+}
+
+// OpenCL.cxx:1142-1315 (thread body).  With double buffering the worker keeps one bunch on the GPU and one in
+// post-processing; it never holds a finished bunch back waiting for more input.
 void Converter::worker()
 {
     (void)hipSetDevice(device_);
     auto last_done = std::chrono::steady_clock::now();
     bool first = true;
+    int cur = 0, pending = -1;
     Job job;
-    while (in_queue_->get(job)) {
-        try {
-            const size_t n = job.steps.size();
-            uint64_t generated = 0;
-            for (const clsimhip_step &s : job.steps) generated += s.num_photons;
-            std::memcpy(h_steps_, job.steps.data(), n * sizeof(clsimhip_step));
-            hip_check(hipMemcpyAsync(d_steps_, h_steps_, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
-            hip_check(hipMemsetAsync(d_hit_count_, 0, 4, stream_), "reset hit counter");
-            const KParams P = launch_params(d_steps_, n, 0, d_photons_, max_output_photons_, d_hit_count_, stream_);
-            hip_check(hipEventRecord(ev_start_, stream_), "event");
-            hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
-            hip_check(hipEventRecord(ev_stop_, stream_), "event");
-            hip_check(hipMemcpyAsync(h_hit_count_, d_hit_count_, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
-            hip_check(hipStreamSynchronize(stream_), "propagation kernel");
-            uint32_t hits = *h_hit_count_;
-            if (hits > max_output_photons_) {
-                // OpenCL.cxx:1027-1032: logged, truncated
-                std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);
-                hits = max_output_photons_;
+    try {
+        for (;;) {
+            bool have;
+            if (pending < 0) {
+                have = in_queue_->get(job);
+                if (!have) break;
+            } else {
+                // a bunch is running: take the next one as soon as it arrives, but stop waiting when the kernel is done
+                have = false;
+                while (!(have = in_queue_->get_for(job, 200))) {
+                    if (hipEventQuery(slots_[pending].counted) == hipSuccess || in_queue_->closed()) break;
+                }
+                if (!have) {
+                    finish(slots_[pending], last_done, first);
+                    pending = -1;
+                    continue;
+                }
             }
-            std::unique_ptr<std::vector<clsimhip_photon>> photons(new std::vector<clsimhip_photon>(hits));
-            if (hits) {
-                hip_check(hipMemcpyAsync(h_photons_, d_photons_, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, stream_), "download photons");
-                hip_check(hipStreamSynchronize(stream_), "download photons");
-                std::memcpy(photons->data(), h_photons_, static_cast<size_t>(hits) * sizeof(clsimhip_photon));
-                replace_indices(photons->data(), hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
+            submit(slots_[cur], job);
+            if (pending >= 0) finish(slots_[pending], last_done, first);
+            if (num_slots_ == 2) {
+                pending = cur;
+                cur ^= 1;
+            } else {
+                finish(slots_[cur], last_done, first);
             }
-            float ms = 0.f;
-            hip_check(hipEventElapsedTime(&ms, ev_start_, ev_stop_), "event time");
-            const auto now = std::chrono::steady_clock::now();
-            {
-                std::lock_guard<std::mutex> lk(stats_mutex_);
-                total_device_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
-                if (!first) total_host_ns_ += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(now - last_done).count());
-                else total_host_ns_ += static_cast<uint64_t>(static_cast<double>(ms) * 1e6);
-                ++num_kernel_calls_;
-                photons_generated_ += generated;
-                photons_at_doms_ += hits;
-            }
-            first = false;
-            last_done = now;
-            Result r;
-            r.id = job.id;
-            r.photons = std::move(photons);
-            out_queue_->put(std::move(r));
-        } catch (const Error &e) {
-            // the reference's worker log_fatal()s on device errors (OpenCL.cxx:768-774)
-            std::fprintf(stderr, "clsimhip: fatal device error in worker thread: %s\n", e.what());
-            std::abort();
         }
+        if (pending >= 0) finish(slots_[pending], last_done, first);
+    } catch (const Error &e) {
+        // the reference's worker log_fatal()s on device errors (OpenCL.cxx:768-774)
+        std::fprintf(stderr, "clsimhip: fatal device error in worker thread: %s\n", e.what());
+        std::abort();
     }
 }
 

@@ -3,6 +3,7 @@
 // MI355X-native counterpart of I3CLSimStepToPhotonConverterOpenCL
 // (private/opencl/I3CLSimStepToPhotonConverterOpenCL.cxx).
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
@@ -59,6 +60,18 @@ public:
         not_full_.notify_one();
         return true;
     }
+    // waits at most `us` microseconds; false if nothing arrived (or the queue was closed and is empty)
+    bool get_for(T &out, long us)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (!not_empty_.wait_for(lk, std::chrono::microseconds(us), [&] { return !q_.empty() || closed_; })) return false;
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    bool closed() const { std::lock_guard<std::mutex> lk(m_); return closed_; }
     size_t size() const { std::lock_guard<std::mutex> lk(m_); return q_.size(); }
     bool empty() const { return size() == 0; }
     void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; not_full_.notify_all(); not_empty_.notify_all(); }
@@ -149,18 +162,30 @@ private:
     float *d_dom_tz_ = nullptr;
     uint64_t *d_rng_x_ = nullptr;
     uint32_t *d_rng_a_ = nullptr;
-    DevStep *d_steps_ = nullptr;
-    DevPhoton *d_photons_ = nullptr;
-    uint32_t *d_hit_count_ = nullptr;
+    // One buffer set per bunch in flight (OpenCL.cxx:296-340 allocates numBuffers = 1 or 2 of each): while
+    // the kernel of bunch k+1 runs, the photons of bunch k are downloaded on the copy stream and converted.
+    struct Slot {
+        DevStep *d_steps = nullptr;
+        DevPhoton *d_photons = nullptr;
+        uint32_t *d_hit_count = nullptr;
+        clsimhip_step *h_steps = nullptr;       // pinned staging
+        clsimhip_photon *h_photons = nullptr;
+        uint32_t *h_hit_count = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr, counted = nullptr;
+        uint32_t id = 0;
+        uint64_t generated = 0;
+    };
+    Slot slots_[2];
+    int num_slots_ = 1;
+    void submit(Slot &s, const Job &job);
+    void finish(Slot &s, std::chrono::steady_clock::time_point &last_done, bool &first);
     uint32_t *d_slice_done_ = nullptr;       // per step: slices published (unit queue)
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
     uint32_t *last_queue_ = nullptr;
     int k_new_ = 8, k_slices_ = 0;              // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
-    clsimhip_step *h_steps_ = nullptr;       // pinned staging
-    clsimhip_photon *h_photons_ = nullptr;
-    uint32_t *h_hit_count_ = nullptr;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
+    hipStream_t copy_stream_ = nullptr;      // photon download
     hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
 
     // worker + queues (in: capacity 5 like queueToOpenCL_, OpenCL.cxx:77)

@@ -59,7 +59,7 @@ def oracle_tables(cfg, pancake=5.0):
     return capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake)
 
 
-def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345):
+def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345, double_buffering=False):
     bias = CV.GetIceCubeDOMAcceptance()
     gens = [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])]
     if cfg["flasher"]:
@@ -70,7 +70,7 @@ def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, se
         conv.SetWlenGenerators(gens); conv.SetWlenBias(bias); conv.SetMediumProperties(cfg["med_p"])
         conv.SetGeometry(geom); conv.SetDOMPancakeFactor(pancake)
         return conv
-    return CV.initializeHIP(device, geom, cfg["med_p"], bias, gens, pancakeFactor=pancake,
+    return CV.initializeHIP(device, geom, cfg["med_p"], bias, gens, pancakeFactor=pancake, enableDoubleBuffering=double_buffering,
                             approximateNumberOfWorkItems=max_items, streams=streams(max_items, seed))
 
 

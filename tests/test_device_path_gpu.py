@@ -124,3 +124,32 @@ def test_converter_queue_semantics():
     conv.EnqueueSteps(zero, 9)
     ident, ph = conv.GetConversionResult()
     assert ident == 9 and len(ph) == 0 and np.array_equal(conv.GetRNGState(1024), x_before)
+
+
+def test_double_buffering_pipelines_bunches_with_identical_results():
+    """EnableDoubleBuffering (OpenCL.cxx:232, 296-340): two buffer sets, the next bunch's kernel runs while the
+    previous bunch is downloaded and converted.  Bunches still see the RNG streams in order: every result equals the
+    single-buffered converter's and the oracle's, identifiers come back in order, from a producer thread."""
+    import threading
+    cfg = common.config("mie")
+    n = 2048
+    T = common.oracle_tables(cfg)
+    x, a = common.streams(n)
+    bunches = [common.steps_for(cfg, n, seed=40 + b) for b in range(5)]
+    bunches[3]["num"][:] = 0                       # an empty bunch in the middle of the pipeline
+    expected, xo = [], x
+    for st in bunches:
+        ph, cnt, xo, _ = capi.propagate(T, st, xo, a, threads=8)
+        expected.append(common.sort_photons(capi.replace_indices_with_ids(ph, T.geo)).tobytes())
+    for double in (False, True):
+        conv = common.product_converter(cfg, n, double_buffering=double)
+        producer = threading.Thread(target=lambda: [conv.EnqueueSteps(st, 100 + b) for b, st in enumerate(bunches)])
+        producer.start()
+        for b in range(len(bunches)):
+            ident, ph = conv.GetConversionResult()
+            assert ident == 100 + b
+            assert common.sort_photons(ph).tobytes() == expected[b], (double, b)
+        producer.join()
+        assert np.array_equal(conv.GetRNGState(n), xo)
+        st = conv.GetStatistics()
+        assert st["NumKernelCalls"] == len(bunches) and not conv.MorePhotonsAvailable()
