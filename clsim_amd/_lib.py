@@ -62,7 +62,8 @@ SYMBOLS = [
     "clsimhip_set_fixed_number_of_absorption_lengths", "clsimhip_set_dom_pancake_factor",
     "clsimhip_set_photon_history_entries", "clsimhip_set_workgroup_size", "clsimhip_set_max_num_workitems",
     "clsimhip_compile", "clsimhip_get_max_workgroup_size", "clsimhip_initialize", "clsimhip_initialize_with_streams",
-    "clsimhip_is_initialized", "clsimhip_enqueue_steps", "clsimhip_get_conversion_result", "clsimhip_release_result",
+    "clsimhip_is_initialized", "clsimhip_enqueue_steps", "clsimhip_get_conversion_result", "clsimhip_get_result_histories",
+    "clsimhip_release_result",
     "clsimhip_get_workgroup_size", "clsimhip_get_max_num_workitems", "clsimhip_queue_size",
     "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
@@ -118,6 +119,7 @@ def load():
         "clsimhip_is_initialized": (i32, [vp]),
         "clsimhip_enqueue_steps": (i32, [vp, vp, sz, u32]),
         "clsimhip_get_conversion_result": (i32, [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(sz)]),
+        "clsimhip_get_result_histories": (i32, [vp, vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(u32)]),
         "clsimhip_release_result": (i32, [vp, vp]),
         "clsimhip_get_workgroup_size": (i32, [vp, C.POINTER(sz)]),
         "clsimhip_get_max_num_workitems": (i32, [vp, C.POINTER(sz)]),

@@ -230,6 +230,7 @@ class I3CLSimStepToPhotonConverterHIP:
         self._lib = _lib.load()
         self._h = C.c_void_p()
         _check(self._lib.clsimhip_create(int(device), C.byref(self._h)))
+        self._history_entries = 0
 
     def __del__(self):
         try:
@@ -272,7 +273,9 @@ class I3CLSimStepToPhotonConverterHIP:
     def SetSaveAllPhotonsPrescale(self, v): self._call("clsimhip_set_save_all_photons_prescale", float(v))
     def SetFixedNumberOfAbsorptionLengths(self, v): self._call("clsimhip_set_fixed_number_of_absorption_lengths", float(v))
     def SetDOMPancakeFactor(self, v): self._call("clsimhip_set_dom_pancake_factor", float(v))
-    def SetPhotonHistoryEntries(self, v): self._call("clsimhip_set_photon_history_entries", int(v))
+    def SetPhotonHistoryEntries(self, v):
+        self._call("clsimhip_set_photon_history_entries", int(v))
+        self._history_entries = int(v)
     def SetWorkgroupSize(self, v): self._call("clsimhip_set_workgroup_size", int(v))
     def SetMaxNumWorkitems(self, v): self._call("clsimhip_set_max_num_workitems", int(v))
 
@@ -300,16 +303,28 @@ class I3CLSimStepToPhotonConverterHIP:
         steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
         self._call("clsimhip_enqueue_steps", steps.ctypes.data_as(C.c_void_p), len(steps), int(identifier))
 
-    def GetConversionResult(self):
+    def GetConversionResult(self, with_histories=False):
+        """ConversionResult_t (I3CLSimStepToPhotonConverter.h:70-90): (identifier, photons), plus with
+        with_histories=True the photonHistories as a list of [k_i, 4] arrays (k_i = min(numScatters_i,
+        PhotonHistoryEntries); None when no histories are recorded)."""
         ident, ptr, n = C.c_uint32(), C.c_void_p(), C.c_size_t()
         self._call("clsimhip_get_conversion_result", C.byref(ident), C.byref(ptr), C.byref(n))
+        histories = None
         if n.value:
             buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
             photons = np.frombuffer(buf, dtype=PHOTON_DTYPE).copy()
+            if with_histories:
+                hp, entries = C.POINTER(C.c_float)(), C.c_uint32()
+                self._call("clsimhip_get_result_histories", ptr, C.byref(hp), C.byref(entries))
+                if hp and entries.value:
+                    flat = np.ctypeslib.as_array(hp, shape=(n.value, entries.value, 4)).copy()
+                    histories = [flat[i, :min(int(photons["numScatters"][i]), entries.value)] for i in range(n.value)]
             self._call("clsimhip_release_result", ptr)
         else:
             photons = np.zeros(0, dtype=PHOTON_DTYPE)
-        return ident.value, photons
+            if with_histories and self._history_entries:
+                histories = []
+        return (ident.value, photons, histories) if with_histories else (ident.value, photons)
 
     def _size(self, name):
         v = C.c_size_t()

@@ -240,6 +240,10 @@ int clsimhip_get_conversion_result(clsimhip_converter *c, uint32_t *identifier, 
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.get_result(identifier, photons, n); });
 }
+int clsimhip_get_result_histories(clsimhip_converter *c, const clsimhip_photon *photons, const float **histories, uint32_t *entries)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.result_histories(photons, histories, entries); });
+}
 int clsimhip_release_result(clsimhip_converter *c, const clsimhip_photon *photons)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.release_result(photons); });

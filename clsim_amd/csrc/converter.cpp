@@ -43,14 +43,15 @@ Converter::~Converter()
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.stop) (void)hipEventDestroy(sl.stop);
         if (sl.counted) (void)hipEventDestroy(sl.counted);
-        (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count);
+        (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count); (void)hipFree(sl.d_hist_out);
+        if (sl.h_hist) (void)hipHostFree(sl.h_hist);
         if (sl.h_steps) (void)hipHostFree(sl.h_steps);
         if (sl.h_photons) (void)hipHostFree(sl.h_photons);
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
     }
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
-    (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
+    (void)hipFree(d_queue_); (void)hipFree(d_slice_done_); (void)hipFree(d_hist_ring_);
 }
 
 void Converter::set_wlen_generators(std::vector<RandomValueData> g) { guard(); compiled_ = false; generators_ = std::move(g); }
@@ -82,11 +83,19 @@ void Converter::compile()
     if (!have_medium_) throw Error(CLSIMHIP_ERR_CONFIG, "MediumProperties not set!");
     if (!have_geometry_) throw Error(CLSIMHIP_ERR_CONFIG, "Geometry not set!");
     if (double_precision_) throw Error(CLSIMHIP_ERR_CONFIG, "DoublePrecision is not available in the HIP propagator");
+    // Both modes are unusable in the reference at this revision: without STOP_PHOTONS_ON_DETECTION the collision
+    // code indexes dom_bitmask[stringNum/64] in an array of (GEO_MAX_DOM_INDEX+63)/64 words -- out of bounds from
+    // the 65th string on (sparse_collision_kernel.c.cl:85-103); SAVE_ALL_PHOTONS leaves out the geometry source
+    // (OpenCL.cxx:461-466) that saveHit() needs for geometryGetDomPosition (propagation_kernel.c.cl:339).
     if (!stop_detected_) throw Error(CLSIMHIP_ERR_CONFIG, "StopDetectedPhotons=false is not available in the HIP propagator");
     if (save_all_) throw Error(CLSIMHIP_ERR_CONFIG, "SaveAllPhotons is not available in the HIP propagator");
-    if (history_entries_ != 0) throw Error(CLSIMHIP_ERR_CONFIG, "PhotonHistoryEntries>0 is not available in the HIP propagator");
-    if (!std::isnan(fixed_abs_lengths_)) throw Error(CLSIMHIP_ERR_CONFIG, "FixedNumberOfAbsorptionLengths is not available in the HIP propagator");
+    if (history_entries_ > 1024) throw Error(CLSIMHIP_ERR_CONFIG, "PhotonHistoryEntries > 1024 is not supported");
     tables_ = compile_tables(medium_, geometry_, generators_, bias_, pancake_);
+    if (!std::isnan(fixed_abs_lengths_)) {                      // OpenCL.cxx:425-431
+        tables_.params.has_fixed_abs = 1;
+        tables_.params.fixed_abs = to_float_literal(fixed_abs_lengths_);
+    }
+    tables_.params.history_n = static_cast<int32_t>(history_entries_);   // OpenCL.cxx:416-419
     compiled_ = true;
 }
 
@@ -188,6 +197,11 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
     upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
+    if (history_entries_) {
+        const size_t bytes = prop_kernel_max_lanes() * history_entries_ * 16;
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_hist_ring_), bytes), "history ring");
+        hip_check(hipMemset(d_hist_ring_, 0, bytes), "history ring");
+    }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_x_), max_workitems_ * sizeof(uint64_t)), "rng x");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_rng_a_), max_workitems_ * sizeof(uint32_t)), "rng a");
     num_slots_ = double_buffering_ ? 2 : 1;
@@ -199,6 +213,11 @@ void Converter::setup_device_buffers()
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_steps), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_photons), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_hit_count), 16, hipHostMallocDefault), "pinned counter");
+        if (history_entries_) {
+            const size_t bytes = static_cast<size_t>(max_output_photons_) * history_entries_ * 16;
+            hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_hist_out), bytes), "photon histories");
+            hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_hist), bytes, hipHostMallocDefault), "pinned photon histories");
+        }
         hip_check(hipEventCreate(&sl.start), "hipEventCreate");
         hip_check(hipEventCreate(&sl.stop), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(&sl.counted, hipEventDisableTiming), "hipEventCreate");
@@ -231,6 +250,8 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.slices = k_slices_;
     P.slice_done = d_slice_done_;
     P.len_table = d_len_table_;
+    P.hist_ring = d_hist_ring_;
+    P.hist_out = nullptr;               // set per slot by submit(); the device path has no history output
     P.dom_tx = d_dom_tx_;
     P.dom_ty = d_dom_ty_;
     P.dom_tz = d_dom_tz_;
@@ -261,7 +282,8 @@ void Converter::submit(Slot &s, const Job &job)
     std::memcpy(s.h_steps, job.steps.data(), n * sizeof(clsimhip_step));
     hip_check(hipMemcpyAsync(s.d_steps, s.h_steps, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
     hip_check(hipMemsetAsync(s.d_hit_count, 0, 4, stream_), "reset hit counter");
-    const KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
+    KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
+    P.hist_out = s.d_hist_out;
     hip_check(hipEventRecord(s.start, stream_), "event");
     hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
     hip_check(hipEventRecord(s.stop, stream_), "event");
@@ -287,6 +309,24 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
         std::memcpy(photons->data(), s.h_photons, static_cast<size_t>(hits) * sizeof(clsimhip_photon));
         replace_indices(photons->data(), hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
     }
+    std::unique_ptr<std::vector<float>> histories;
+    if (hits && history_entries_) {
+        // ConvertPhotonHistories (OpenCL.cxx:940-989): unroll each ring into forward order
+        const size_t N = history_entries_;
+        hip_check(hipMemcpyAsync(s.h_hist, s.d_hist_out, static_cast<size_t>(hits) * N * 16, hipMemcpyDeviceToHost, copy_stream_), "download photon histories");
+        hip_check(hipStreamSynchronize(copy_stream_), "download photon histories");
+        histories.reset(new std::vector<float>(static_cast<size_t>(hits) * N * 4, 0.f));
+        for (size_t i = 0; i < hits; ++i) {
+            const uint32_t num_scatters = (*photons)[i].num_scatters;
+            if (num_scatters == 0) continue;
+            const size_t recorded = std::min<size_t>(num_scatters, N);
+            size_t cur = (num_scatters <= N) ? 0 : (num_scatters % N);
+            for (size_t j = 0; j < recorded; ++j) {
+                std::memcpy(&(*histories)[(i * N + j) * 4], &s.h_hist[(i * N + cur) * 4], 16);
+                if (++cur >= N) cur = 0;
+            }
+        }
+    }
     float ms = 0.f;
     hip_check(hipEventElapsedTime(&ms, s.start, s.stop), "event time");
     const auto now = std::chrono::steady_clock::now();
@@ -304,6 +344,7 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
     Result r;
     r.id = s.id;
     r.photons = std::move(photons);
+    r.histories = std::move(histories);
     out_queue_->put(std::move(r));
 }
 
@@ -365,8 +406,23 @@ void Converter::get_result(uint32_t *identifier, const clsimhip_photon **photons
     *photons = key ? key : &empty_sentinel;
     if (key) {
         std::lock_guard<std::mutex> lk(results_mutex_);
-        handed_out_[key] = std::move(r.photons);
+        handed_out_[key] = std::move(r);
     }
+}
+
+void Converter::result_histories(const clsimhip_photon *photons, const float **histories, uint32_t *entries)
+{
+    need_init();
+    if (!histories || !entries) throw Error(CLSIMHIP_ERR_ARGUMENT, "output pointers are (null)");
+    *histories = nullptr;
+    *entries = history_entries_;
+    std::lock_guard<std::mutex> lk(results_mutex_);
+    auto it = handed_out_.find(photons);
+    if (it == handed_out_.end()) {
+        if (photons) throw Error(CLSIMHIP_ERR_ARGUMENT, "not a result handed out by GetConversionResult (or already released)");
+        return;
+    }
+    if (it->second.histories) *histories = it->second.histories->data();
 }
 
 void Converter::release_result(const clsimhip_photon *photons)
@@ -415,6 +471,7 @@ void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offse
     if (!d_steps || !d_photons || !d_hit_count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device pointers are (null)");
     if (n == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps are empty!");
     if (rng_offset + n > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than maximum number of work items!");
+    if (history_entries_) throw Error(CLSIMHIP_ERR_STATE, "photon histories are only delivered through EnqueueSteps/GetConversionResult");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     std::pair<hipEvent_t, hipEvent_t> ev;
     {

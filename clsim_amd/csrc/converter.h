@@ -21,6 +21,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
 int prop_kernel_block_size();
+size_t prop_kernel_max_lanes();
 size_t prop_kernel_lds_budget();
 
 // Result of Compile(): kernel parameters without buffer pointers, the LDS image,
@@ -114,6 +115,7 @@ public:
 
     void enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t identifier);
     void get_result(uint32_t *identifier, const clsimhip_photon **photons, size_t *n);
+    void result_histories(const clsimhip_photon *photons, const float **histories, uint32_t *entries);
     void release_result(const clsimhip_photon *photons);
     size_t queue_size() const;
     bool more_photons_available() const;
@@ -131,7 +133,11 @@ public:
 
 private:
     struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
-    struct Result { uint32_t id; std::unique_ptr<std::vector<clsimhip_photon>> photons; };
+    struct Result {
+        uint32_t id;
+        std::unique_ptr<std::vector<clsimhip_photon>> photons;
+        std::unique_ptr<std::vector<float>> histories;     // [photons][history_entries_][4], forward order
+    };
 
     void guard() const { if (initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP already initialized!"); }
     void need_init() const { if (!initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP is not initialized!"); }
@@ -159,6 +165,7 @@ private:
     uint32_t *d_tables_ = nullptr;
     int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
     float *d_len_table_ = nullptr;
+    float *d_hist_ring_ = nullptr;           // per resident lane: the last history_entries_ scatter points
     float *d_dom_tz_ = nullptr;
     uint64_t *d_rng_x_ = nullptr;
     uint32_t *d_rng_a_ = nullptr;
@@ -168,6 +175,8 @@ private:
         DevStep *d_steps = nullptr;
         DevPhoton *d_photons = nullptr;
         uint32_t *d_hit_count = nullptr;
+        float *d_hist_out = nullptr;            // photon histories of the slot's hits (history_entries_ float4 each)
+        float *h_hist = nullptr;
         clsimhip_step *h_steps = nullptr;       // pinned staging
         clsimhip_photon *h_photons = nullptr;
         uint32_t *h_hit_count = nullptr;
@@ -193,7 +202,7 @@ private:
     std::unique_ptr<BoundedQueue<Result>> out_queue_;
     std::thread worker_;
     mutable std::mutex results_mutex_;
-    std::map<const clsimhip_photon *, std::unique_ptr<std::vector<clsimhip_photon>>> handed_out_;
+    std::map<const clsimhip_photon *, Result> handed_out_;
 
     // statistics (OpenCL.cxx:1088-1140, 1621-1640)
     mutable std::mutex stats_mutex_;

@@ -53,6 +53,13 @@ struct KParams {
     // TABLE lengths: one 16-byte record per (wavelength bin, layer): {abs[bin], abs[bin+1], sca[bin], sca[bin+1]}
     // at len_table[4*(bin*num_layers + layer)], already de-quantised (80 KB for a 171 x 30 photonics table: HBM/L2)
     const float *len_table;
+    // SAVE_PHOTON_HISTORY (c.cl:452-455, 833-837, 387-392): ring of the last history_n scatter points per lane
+    // (float4: x, y, z, absorption lengths left), copied to hist_out[slot * history_n ..] when the lane's photon is detected
+    float *hist_ring;
+    float *hist_out;
+    int32_t history_n;
+    int32_t has_fixed_abs;              // PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS (c.cl:582-588)
+    float fixed_abs;
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;

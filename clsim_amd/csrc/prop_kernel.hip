@@ -421,7 +421,8 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
         // generateWavelength(number): 0 for an out-of-range generator (MediumPropertiesSource.cxx:392-432)
         b.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
     }
-    b.abs_lens_initial = -dm::log_(rng_oc(rx, ra));
+    // c.cl:582-588: a fixed budget draws no random number
+    b.abs_lens_initial = P->has_fixed_abs ? P->fixed_abs : -dm::log_(rng_oc(rx, ra));
     return b;
 }
 
@@ -636,7 +637,7 @@ static_assert(sizeof(HitStub) == 64, "hit stub");
 
 // propagation_kernel.c.cl:307-404: the 20 words of an I3CLSimPhoton
 template <bool FLASHER>
-DM void make_hit_record(KP P, const HitStub &h, uint32_t *rec)
+DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
 {
     const DevStep *step_ptr = P->steps + h.step_index;
     const Vec3 step_dir = step_direction(step_ptr);
@@ -679,6 +680,7 @@ DM void make_hit_record(KP P, const HitStub &h, uint32_t *rec)
     rec[17] = dm::f2u(sphi);
     rec[18] = dm::f2u(1.0f / h.inv_groupvel);
     rec[19] = dm::f2u(born.abs_lens_initial - h.abs_lens_left);   // c.cl:718: after this step's update
+    return born.abs_lens_initial;
 }
 
 template <int MED, bool TILT, bool ANISO, bool FLASHER>
@@ -841,6 +843,12 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            const uint32_t hn = (uint32_t)P->history_n;
+            if ((hn != 0u) && hit && (base + rank < max_hits)) {                // c.cl:387-392
+                const float4 *ring = reinterpret_cast<const float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
+                float4 *dst = reinterpret_cast<float4 *>(P->hist_out) + (size_t)(base + rank) * hn;
+                for (uint32_t k = 0; k < hn; ++k) dst[k] = ring[k];
+            }
         }
         if (run) {
             if (hit) ph.abs_lens_left = 0.0f;                                   // c.cl:741-744
@@ -853,6 +861,11 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 --photons_left;                                                 // absorbed or detected
             } else {
                 const KP P = fresh_params(P0);
+                const uint32_t hn = (uint32_t)P->history_n;
+                if (hn != 0u) {                                                 // c.cl:833-837
+                    float4 *ring = reinterpret_cast<float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
+                    ring[ph.num_scatters % hn] = make_float4(ph.px, ph.py, ph.pz, ph.abs_lens_left);
+                }
                 if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d);
                 const float cos_s = scattering_cos(P, rx, ra);
                 const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
@@ -901,9 +914,15 @@ __global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue
 #pragma unroll
         for (int w = 0; w < kStubWords; ++w) hw[w] = slot[w];
         uint32_t rec[20];
-        make_hit_record<FLASHER>(P, h, rec);
+        const float abs_lens_initial = make_hit_record<FLASHER>(P, h, rec);
 #pragma unroll
         for (int w = 0; w < 20; ++w) slot[w] = rec[w];
+        // c.cl:836: the ring holds the absorption lengths LEFT at each scatter; the reference stores initial - left
+        const uint32_t hn = (uint32_t)P->history_n;
+        for (uint32_t k = 0; k < hn; ++k) {
+            float *w = P->hist_out + ((size_t)i * hn + k) * 4u + 3u;
+            *w = abs_lens_initial - *w;
+        }
     }
 }
 
@@ -1013,6 +1032,13 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 
 size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4; }
 int prop_kernel_block_size() { return kBlock; }
+// upper bound of the lanes of one launch (persistent grid: at most 2048 resident threads per CU)
+size_t prop_kernel_max_lanes()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (size_t)cus * 2048u;
+}
 // LDS bytes one workgroup may use so that the intended number of workgroups fits the CU's 160 KB
 size_t prop_kernel_lds_budget() { return (size_t)(160 * 1024) / (size_t)((kMinWavesPerSimd * 256) / kBlock) - 1024; }
 

@@ -207,6 +207,13 @@ int clsimhip_enqueue_steps(clsimhip_converter *c, const clsimhip_step *steps, si
  * already replaced by IDs.  *photons stays valid until clsimhip_release_result. */
 int clsimhip_get_conversion_result(clsimhip_converter *c, uint32_t *identifier,
                                    const clsimhip_photon **photons, size_t *n);
+/* ConversionResult_t::photonHistories (I3CLSimStepToPhotonConverter.h:70-90) of the result that `photons` belongs to,
+ * as ConvertPhotonHistories builds them (OpenCL.cxx:940-989): `*entries` float[4] records per photon {x, y, z,
+ * absorption lengths travelled} in forward order (most recent scatter last); photon i has
+ * min(numScatters_i, *entries) of them, the rest of its block is zero.  *histories is NULL when
+ * PhotonHistoryEntries is 0 or the result is empty; valid until clsimhip_release_result(photons). */
+int clsimhip_get_result_histories(clsimhip_converter *c, const clsimhip_photon *photons, const float **histories,
+                                  uint32_t *entries);
 int clsimhip_release_result(clsimhip_converter *c, const clsimhip_photon *photons);
 int clsimhip_get_workgroup_size(const clsimhip_converter *c, size_t *out);
 int clsimhip_get_max_num_workitems(const clsimhip_converter *c, size_t *out);

@@ -80,6 +80,7 @@ class Tables(C.Structure):
         ("phase_mode", C.c_int32), ("group_mode", C.c_int32), ("phase_n", C.c_int32), ("group_n", C.c_int32),
         ("phase_start", C.c_float), ("phase_step", C.c_float), ("group_start", C.c_float), ("group_step", C.c_float),
         ("phase_data", FP), ("group_data", FP),
+        ("has_fixed_abs", C.c_int32), ("fixed_abs", C.c_float), ("history_n", C.c_int32),
     ]
 
 
@@ -130,7 +131,7 @@ class OracleTables:
         return out
 
 
-def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=True):
+def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=True, fixed_abs_lengths=None, history_entries=0):
     """The oracle's counterpart of Compile() (OpenCL.cxx:485-533): converts the
     descriptions (doubles) into the literals of the generated OpenCL program."""
     fl = B.float_literal
@@ -138,6 +139,10 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
     O = OracleTables()
     t = O.t
     t.stop_detected = 1 if stop_detected else 0
+    if fixed_abs_lengths is not None and not np.isnan(fixed_abs_lengths):    # OpenCL.cxx:425-431
+        t.has_fixed_abs = 1
+        t.fixed_abs = fl(fixed_abs_lengths)
+    t.history_n = int(history_entries)                                       # OpenCL.cxx:416-419
     t.has_pancake = 1 if pancake != 1.0 else 0          # OpenCL.cxx:432
     t.pancake = fl(pancake)
     m = medium
@@ -283,10 +288,12 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
     return O
 
 
-def propagate(tables, steps, x, a, max_hits=None, threads=1):
+def propagate(tables, steps, x, a, max_hits=None, threads=1, history=False):
     """Runs the restated propKernel on steps (STEP_DTYPE) with RNG streams (x,a).
     Returns (photons[:min(count,max_hits)], count, x_after, iterations).
-    String / DOM fields hold INDICES, like the kernel's raw output."""
+    String / DOM fields hold INDICES, like the kernel's raw output.
+    history=True (tables.t.history_n > 0): single-threaded, returns the raw photonHistory buffer
+    ([hits, history_n, 4] float32) as a fifth value."""
     L = lib()
     steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
     n = len(steps)
@@ -298,11 +305,39 @@ def propagate(tables, steps, x, a, max_hits=None, threads=1):
     it = C.c_uint64(0)
     args = [C.byref(tables.t), steps.ctypes.data_as(C.c_void_p), C.c_uint32(n), x.ctypes.data_as(C.c_void_p),
             a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(max_hits)]
+    if history:
+        nh = int(tables.t.history_n)
+        raw = np.zeros((max_hits, max(nh, 1), 4), dtype=np.float32)
+        L.oracle_propagate_hist.restype = C.c_uint32
+        cnt = L.oracle_propagate_hist(*args, C.byref(it), raw.ctypes.data_as(C.c_void_p))
+        k = min(cnt, max_hits)
+        return out[:k], cnt, x, it.value, raw[:k]
     if threads == 1:
         cnt = L.oracle_propagate(*args, C.byref(it))
     else:
         cnt = L.oracle_propagate_mt(*args, C.c_int(threads), C.byref(it))
     return out[:min(cnt, max_hits)], cnt, x, it.value
+
+
+def convert_photon_histories(raw, photons, entries):
+    """ConvertPhotonHistories (OpenCL.cxx:940-989): the ring buffer of each photon in forward order (most recent
+    scatter last); only min(numScatters, entries) points exist.  Returns a list of [k, 4] arrays."""
+    out = []
+    for i in range(len(photons)):
+        ns = int(photons["numScatters"][i])
+        if ns == 0 or entries == 0:
+            out.append(np.zeros((0, 4), dtype=np.float32))
+            continue
+        k = min(ns, entries)
+        cur = 0 if ns <= entries else ns % entries
+        rows = []
+        for _ in range(k):
+            rows.append(raw[i, cur])
+            cur += 1
+            if cur >= entries:
+                cur = 0
+        out.append(np.array(rows, dtype=np.float32))
+    return out
 
 
 def replace_indices_with_ids(photons, geo):

@@ -136,6 +136,10 @@ typedef struct {
     int32_t phase_n, group_n;
     float phase_start, phase_step, group_start, group_step;
     const float *phase_data, *group_data;
+    /* ---- more compile-time switches (OpenCL.cxx:416-431) ---- */
+    int32_t has_fixed_abs;      /* PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS defined */
+    float fixed_abs;
+    int32_t history_n;          /* NUM_PHOTONS_IN_HISTORY (SAVE_PHOTON_HISTORY when > 0) */
 } oracle_tables;
 
 typedef struct { uint64_t x; uint32_t a; } rng_t;
@@ -456,10 +460,13 @@ static void sphDirFromCar(const float d[4], float out[2])
     out[0] = theta; out[1] = phi;
 }
 
+#define ORACLE_MAX_HISTORY 64
 typedef struct {
     oracle_photon *out;
     uint32_t max_hits;
     uint32_t count;             /* keeps counting past max_hits (c.cl:329-330) */
+    float *hist_out;            /* photonHistory: history_n float4 per output slot, or NULL */
+    const float *cur_hist;      /* currentPhotonHistory of the work item */
 } hit_sink;
 
 /* c.cl:307-404 */
@@ -498,6 +505,9 @@ static void saveHit(const oracle_tables *T, const float pos[4], const float dirw
     sphDirFromCar(startDirw, o->startDir);
     o->groupVelocity = 1.0f / inv_groupvel;
     o->distInAbsLens = distAbsLens;
+    if (T->history_n > 0 && sink->hist_out)        /* c.cl:387-392: the whole ring, valid or not */
+        memcpy(sink->hist_out + (size_t)myIndex * 4u * (size_t)T->history_n, sink->cur_hist,
+               (size_t)T->history_n * 16u);
 }
 
 /* sparse_collision_kernel.c.cl:27-192 (STOP_PHOTONS_ON_DETECTION branch) */
@@ -625,6 +635,11 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
     const float thickness = T->layer_thickness;
     const float recip_thickness = 1.0f / thickness;
     uint64_t iters = 0;
+    /* c.cl:452-455: private array of the work item, never cleared between photons (the reference leaves it
+     * uninitialised; only the entries ConvertPhotonHistories reads, OpenCL.cxx:940-989, are defined) */
+    float currentPhotonHistory[ORACLE_MAX_HISTORY][4];
+    memset(currentPhotonHistory, 0, sizeof currentPhotonHistory);
+    sink->cur_hist = &currentPhotonHistory[0][0];
 
     while (photonsLeftToPropagate > 0) {
         ++iters;
@@ -639,7 +654,8 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             if (!T->has_tilt)
                 carriedLayer = imin(imax(findLayerForGivenZPos(T, pos[2]), 0), T->num_layers - 1);
             inv_groupvel = 1.0f / getGroupVelocity(T, dirw[3]);
-            abs_lens_initial = -om_log(rand_oc(rng));
+            if (T->has_fixed_abs) abs_lens_initial = T->fixed_abs;          /* c.cl:582-588 */
+            else abs_lens_initial = -om_log(rand_oc(rng));
             abs_lens_left = abs_lens_initial;
         }
         float distancePropagated;
@@ -708,6 +724,11 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         if (abs_lens_left < EPSILON) {
             --photonsLeftToPropagate;
         } else {
+            if (T->history_n > 0) {                                         /* c.cl:833-837 */
+                float *h = currentPhotonHistory[numScatters % (uint32_t)T->history_n];
+                h[0] = pos[0]; h[1] = pos[1]; h[2] = pos[2];
+                h[3] = abs_lens_initial - abs_lens_left;
+            }
             transformDirection(T->has_pre, T->pre_renorm, T->pre, dirw);
             const float cosScatAngle = makeScatteringCosAngle(T, rng);
             const float sinScatAngle = om_sqrt(1.0f - sqr(cosScatAngle));
@@ -729,10 +750,12 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
  * (capacity max_hits) in step order.  Returns the hit counter (which may exceed
  * max_hits, like the reference's atomic counter).  x[] is updated in place
  * (c.cl:911-912). */
-uint32_t oracle_propagate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
-                          const uint32_t *a, oracle_photon *out, uint32_t max_hits, uint64_t *iterations)
+uint32_t oracle_propagate_hist(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
+                               const uint32_t *a, oracle_photon *out, uint32_t max_hits, uint64_t *iterations,
+                               float *hist_out)
 {
-    hit_sink sink = { out, max_hits, 0 };
+    if (T->history_n > ORACLE_MAX_HISTORY) return 0xffffffffu;
+    hit_sink sink = { out, max_hits, 0, hist_out, NULL };
     uint64_t it = 0;
     for (uint32_t i = 0; i < n; ++i) {
         rng_t r = { x[i], a[i] };
@@ -741,6 +764,11 @@ uint32_t oracle_propagate(const oracle_tables *T, const oracle_step *steps, uint
     }
     if (iterations) *iterations = it;
     return sink.count;
+}
+uint32_t oracle_propagate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
+                          const uint32_t *a, oracle_photon *out, uint32_t max_hits, uint64_t *iterations)
+{
+    return oracle_propagate_hist(T, steps, n, x, a, out, max_hits, iterations, NULL);
 }
 
 /* Multi-threaded variant used as the CPU baseline (bench.py cpu_baseline): one
@@ -767,7 +795,7 @@ uint32_t oracle_propagate_mt(const oracle_tables *T, const oracle_step *steps, u
                 cap = need * 2 + 4096;
                 buf = (oracle_photon *)realloc(buf, (size_t)cap * sizeof(oracle_photon));
             }
-            hit_sink sink = { buf + cnt, cap - cnt, 0 };
+            hit_sink sink = { buf + cnt, cap - cnt, 0, NULL, NULL };
             propagate_step(T, &steps[i], &r, &sink, &it);
             cnt += sink.count;
             x[i] = r.x;

@@ -53,12 +53,17 @@ def test_use_before_initialize_raises_like_the_reference():
 def test_unsupported_modes_are_refused_at_compile():
     cfg = common.config("c1")
     for setter, value in (("SetDoublePrecision", True), ("SetStopDetectedPhotons", False), ("SetSaveAllPhotons", True),
-                          ("SetPhotonHistoryEntries", 4), ("SetFixedNumberOfAbsorptionLengths", 46.0)):
+                          ("SetPhotonHistoryEntries", 5000)):
         conv = common.product_converter(cfg, 512, initialize=False)
         getattr(conv, setter)(value)
         with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception) as e:
             conv.Compile()
         assert e.value.code == _lib.ERR_CONFIG
+    # restated modes compile (they only need the GPU from Initialize on)
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.SetPhotonHistoryEntries(4)
+    conv.SetFixedNumberOfAbsorptionLengths(46.0)
+    conv.Compile()
 
 
 def test_incomplete_configuration_is_refused():
