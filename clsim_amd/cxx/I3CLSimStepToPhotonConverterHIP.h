@@ -31,6 +31,21 @@ typedef std::vector<I3CLSimStep> I3CLSimStepSeries;
 typedef std::vector<I3CLSimPhoton> I3CLSimPhotonSeries;
 typedef std::shared_ptr<const I3CLSimStepSeries> I3CLSimStepSeriesConstPtr;
 typedef std::shared_ptr<I3CLSimPhotonSeries> I3CLSimPhotonSeriesPtr;
+struct I3CLSimPhotonHistory {                            // public/clsim/I3CLSimPhotonHistory.h:41-70 (accessors used here)
+    std::size_t size() const { return posX_.size(); }
+    float GetX(std::size_t i) const { return posX_[i]; }
+    float GetY(std::size_t i) const { return posY_[i]; }
+    float GetZ(std::size_t i) const { return posZ_[i]; }
+    float GetDistanceInAbsorptionLengths(std::size_t i) const { return distanceInAbsorptionLengths_[i]; }
+    void push_back(float x, float y, float z, float abslens)
+    {
+        posX_.push_back(x); posY_.push_back(y); posZ_.push_back(z); distanceInAbsorptionLengths_.push_back(abslens);
+    }
+private:
+    std::vector<float> posX_, posY_, posZ_, distanceInAbsorptionLengths_;
+};
+typedef std::vector<I3CLSimPhotonHistory> I3CLSimPhotonHistorySeries;
+typedef std::shared_ptr<I3CLSimPhotonHistorySeries> I3CLSimPhotonHistorySeriesPtr;
 
 class I3CLSimStepToPhotonConverter_exception : public std::runtime_error {
 public:
@@ -42,6 +57,7 @@ struct I3CLSimStepToPhotonConverter {
         ConversionResult_t() : identifier(0) {}
         uint32_t identifier;
         I3CLSimPhotonSeriesPtr photons;
+        I3CLSimPhotonHistorySeriesPtr photonHistories;  // null unless PhotonHistoryEntries > 0
     };
     virtual ~I3CLSimStepToPhotonConverter() {}
     virtual void SetWlenGenerators(const std::vector<clsimhip_random_value> &wlenGenerators) = 0;
@@ -108,7 +124,23 @@ public:
         check(clsimhip_get_conversion_result(handle_, &r.identifier, &p, &n));
         r.photons = I3CLSimPhotonSeriesPtr(new I3CLSimPhotonSeries(reinterpret_cast<const I3CLSimPhoton *>(p),
                                                                    reinterpret_cast<const I3CLSimPhoton *>(p) + n));
-        if (n) check(clsimhip_release_result(handle_, p));
+        if (n) {
+            // I3CLSimPhotonHistory (public/clsim/I3CLSimPhotonHistory.h): per photon the recorded scatter points
+            const float *h = nullptr;
+            uint32_t entries = 0;
+            check(clsimhip_get_result_histories(handle_, p, &h, &entries));
+            if (h && entries) {
+                r.photonHistories = I3CLSimPhotonHistorySeriesPtr(new I3CLSimPhotonHistorySeries(n));
+                for (size_t i = 0; i < n; ++i) {
+                    const uint32_t k = p[i].num_scatters < entries ? p[i].num_scatters : entries;
+                    for (uint32_t j = 0; j < k; ++j) {
+                        const float *e = h + (i * entries + j) * 4;
+                        (*r.photonHistories)[i].push_back(e[0], e[1], e[2], e[3]);
+                    }
+                }
+            }
+            check(clsimhip_release_result(handle_, p));
+        }
         return r;
     }
     std::map<std::string, double> GetStatistics() const override
