@@ -49,7 +49,7 @@ Converter::~Converter()
         if (sl.h_photons) (void)hipHostFree(sl.h_photons);
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
     }
-    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_);
+    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
     (void)hipFree(d_queue_); (void)hipFree(d_slice_done_); (void)hipFree(d_hist_ring_);
 }
@@ -194,6 +194,7 @@ void Converter::setup_device_buffers()
     };
     upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
     upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
+    upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size(), "string proximity map");
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
     upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
@@ -250,6 +251,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.slices = k_slices_;
     P.slice_done = d_slice_done_;
     P.len_table = d_len_table_;
+    P.prox_map = d_prox_map_;
     P.hist_ring = d_hist_ring_;
     P.hist_out = nullptr;               // set per slot by submit(); the device path has no history output
     P.dom_tx = d_dom_tx_;

@@ -31,6 +31,7 @@ struct CompiledTables {
     KVariant variant{};
     std::vector<uint32_t> lds_image;
     std::vector<float> len_table;       // KParams::len_table (TABLE lengths)
+    std::vector<uint8_t> prox_map;      // KParams::prox_map
     GeoTables geo;
     std::map<std::string, std::vector<double>> named;
 };
@@ -165,6 +166,7 @@ private:
     uint32_t *d_tables_ = nullptr;
     int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
     float *d_len_table_ = nullptr;
+    uint8_t *d_prox_map_ = nullptr;
     float *d_hist_ring_ = nullptr;           // per resident lane: the last history_entries_ scatter points
     float *d_dom_tz_ = nullptr;
     uint64_t *d_rng_x_ = nullptr;

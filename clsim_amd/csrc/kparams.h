@@ -60,6 +60,13 @@ struct KParams {
     int32_t history_n;
     int32_t has_fixed_abs;              // PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS (c.cl:582-588)
     float fixed_abs;
+    // String proximity map: prox_n x prox_n bytes over the xy bounding box of the string axes; entry * 0.25 m is a
+    // proven lower bound of the xy distance from anywhere in that cell to the surface of the nearest string cylinder
+    // (axis + largest DOM offset + OM radius).  A step shorter than the bound cannot reach a DOM: the DOM search,
+    // which would find nothing, is skipped (64 KB, L2 resident).
+    const uint8_t *prox_map;
+    int32_t prox_n;
+    float prox_x0, prox_y0, prox_inv_cell;
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;

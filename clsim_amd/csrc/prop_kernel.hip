@@ -578,6 +578,15 @@ DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_x
     }
 }
 
+// String proximity map (kparams.h): xy distance [m] that a photon at (x, y) can travel before it could touch a DOM
+DM float free_flight_bound(KP P, float x, float y)
+{
+    const int n = P->prox_n;
+    const int ix = clampi((int)((x - P->prox_x0) * P->prox_inv_cell), 0, n - 1);
+    const int iy = clampi((int)((y - P->prox_y0) * P->prox_inv_cell), 0, n - 1);
+    return (float)P->prox_map[iy * n + ix] * 0.25f;
+}
+
 // collision c.cl:194-303 + :462-547
 DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
 {
@@ -805,8 +814,10 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
+            const float free_flight = free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
-            hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+            // the search cannot find a DOM closer than the nearest string cylinder: skip it when the step ends before
+            if (!(distance < free_flight)) hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
         const uint64_t hit_mask = __ballot(hit);

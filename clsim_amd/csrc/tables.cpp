@@ -7,6 +7,7 @@
 // float that source text would hold; per-layer combinations that the generated
 // code recomputes on every call ((D*aDust+E), (1+0.01*deltaTau), OM_RADIUS^2,
 // maxZ+OM_RADIUS ...) are folded here with the same single precision operations.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -397,6 +398,54 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             P.off_dom_xy = img.add_words(xy);
             P.off_dom_z = img.add_floats(G.dom_tz);
         }
+    }
+    {   // string proximity map (kparams.h).  Everything in double, rounded towards "search anyway".
+        int n = 256;
+        if (const char *e = std::getenv("CLSIMHIP_PROX_N")) n = std::max(8, std::min(4096, std::atoi(e)));
+        double x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY, reach = 0.;
+        for (int s = 0; s < G.num_strings; ++s) {
+            x_lo = std::min<double>(x_lo, G.str_x[s]); x_hi = std::max<double>(x_hi, G.str_x[s]);
+            y_lo = std::min<double>(y_lo, G.str_y[s]); y_hi = std::max<double>(y_hi, G.str_y[s]);
+        }
+        // largest xy offset of a DOM (as the kernel reconstructs it from the int16 templates) from its string's axis
+        for (int s = 0; s < G.num_strings; ++s) {
+            const size_t first = G.dom_start[s], last = (s + 1 < G.num_strings) ? G.dom_start[s + 1] : G.dom_tx.size();
+            for (size_t i = first; i < last; ++i) {
+                const double dx = double(G.dom_tx[i]) * G.dom_mul_x + G.dom_meanx[s] - G.str_x[s];
+                const double dy = double(G.dom_ty[i]) * G.dom_mul_y + G.dom_meany[s] - G.str_y[s];
+                reach = std::max(reach, std::sqrt(dx * dx + dy * dy));
+            }
+        }
+        reach += double(G.om_radius) + 0.05;                        // DOM sphere (never pancaked laterally) + safety
+        const double margin = 30.;                                  // the map extends a little beyond the outer strings
+        x_lo -= margin; y_lo -= margin; x_hi += margin; y_hi += margin;
+        const double cell = std::max(std::max(x_hi - x_lo, y_hi - y_lo) / n, 0.5);
+        P.prox_n = n;
+        P.prox_x0 = static_cast<float>(x_lo);
+        P.prox_y0 = static_cast<float>(y_lo);
+        P.prox_inv_cell = static_cast<float>(1. / cell);
+        // cell the kernel computes for a point: (int)((x - x0) * inv_cell) in float; each cell is grown by `slack`
+        // for that arithmetic (relative error < 4e-7 of |x| + |x0|, n cells) and border cells reach to infinity
+        const double x0f = P.prox_x0, y0f = P.prox_y0, cellf = 1. / double(P.prox_inv_cell);
+        const double slack = 1e-3 * cellf + 1e-5 * (std::fabs(x0f) + std::fabs(y0f) + n * cellf);
+        C.prox_map.assign(static_cast<size_t>(n) * n, 0);
+        for (int iy = 0; iy < n; ++iy)
+            for (int ix = 0; ix < n; ++ix) {
+                const double rx0 = (ix == 0) ? -INFINITY : x0f + ix * cellf - slack, rx1 = (ix == n - 1) ? INFINITY : x0f + (ix + 1) * cellf + slack;
+                const double ry0 = (iy == 0) ? -INFINITY : y0f + iy * cellf - slack, ry1 = (iy == n - 1) ? INFINITY : y0f + (iy + 1) * cellf + slack;
+                double nearest = INFINITY;
+                for (int s = 0; s < G.num_strings; ++s) {
+                    const double ax = G.str_x[s], ay = G.str_y[s];
+                    const double dx = std::max(std::max(rx0 - ax, ax - rx1), 0.), dy = std::max(std::max(ry0 - ay, ay - ry1), 0.);
+                    nearest = std::min(nearest, std::sqrt(dx * dx + dy * dy));
+                }
+                // a segment of length L moves at most L * |d_xy| <= L * (1 + 1e-5) in xy
+                const double bound = (nearest - reach) / 1.00001;
+                const double q = std::floor(bound / 0.25);
+                C.prox_map[static_cast<size_t>(iy) * n + ix] = static_cast<uint8_t>(q < 0. ? 0. : (q > 255. ? 255. : q));
+            }
+        name("string_proximity_map", as_doubles(C.prox_map));
+        name("STRING_PROXIMITY_GRID", {double(n), P.prox_x0, P.prox_y0, P.prox_inv_cell, reach});
     }
     scalar("NUM_STRINGS", G.num_strings); scalar("OM_RADIUS", G.om_radius);
     scalar("GEO_STRING_MAX_RADIUS", G.string_max_radius);

@@ -178,3 +178,34 @@ def test_tabulated_medium_tables(tmp_path):
     bad.write_text("NLAYER 2\nNWVL 2 300 10\nLAYER 0 10\nABS 1 1\nSCAT 1 1\nCOS .9 .9\nN_GROUP 1.3 1.3\nN_PHASE 1.3 1.3\n")
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Expected 2\\*6"):
         CV.MakeIceCubeMediumPropertiesPhotonics(str(bad))
+
+
+def test_string_proximity_map_is_a_lower_bound():
+    """The DOM search is skipped for steps shorter than the map's entry (prop_kernel.hip: free_flight_bound): the
+    entry must never exceed the true xy distance from any point of its cell to the nearest DOM sphere."""
+    for name in ("mie", "c1"):
+        cfg = common.config(name)
+        conv = common.product_converter(cfg, 512, initialize=False)
+        conv.Compile()
+        n, x0, y0, inv_cell, reach = conv.GetTable("STRING_PROXIMITY_GRID")
+        n = int(n)
+        m = conv.GetTable("string_proximity_map").reshape(n, n)
+        g = cfg["geom"]
+        rng = np.random.Generator(np.random.PCG64(7))
+        lo = min(g["x"].min(), g["y"].min()) - 200.0
+        hi = max(g["x"].max(), g["y"].max()) + 200.0
+        pts = rng.uniform(lo, hi, size=(40000, 2))
+        near = rng.integers(0, len(g["x"]), size=20000)                 # and points close to DOMs
+        pts = np.concatenate([pts, np.stack([g["x"][near], g["y"][near]], axis=1) + rng.normal(0, 6.0, size=(20000, 2))])
+        xf, yf = pts[:, 0].astype(np.float32), pts[:, 1].astype(np.float32)
+        ix = np.clip(((xf - np.float32(x0)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1)   # the kernel's arithmetic
+        iy = np.clip(((yf - np.float32(y0)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1)
+        bound = m[iy, ix] * 0.25
+        dom_xy = np.unique(np.stack([g["x"], g["y"]], axis=1), axis=0)
+        true = np.full(len(pts), np.inf)
+        for k in range(0, len(dom_xy), 256):
+            d = np.hypot(xf[:, None].astype(np.float64) - dom_xy[None, k:k + 256, 0], yf[:, None].astype(np.float64) - dom_xy[None, k:k + 256, 1])
+            true = np.minimum(true, d.min(axis=1))
+        true -= g["om_radius"]
+        assert np.all(bound <= np.maximum(true, 0.0)), name
+        assert (bound > 0).mean() > 0.5          # and it is useful: most of the volume is free flight
