@@ -25,6 +25,15 @@ class RandomValue(C.Structure):     # clsimhip_random_value
                 ("y", DP), ("value", C.c_double)]
 
 
+class Axis(C.Structure):            # clsimhip_axis
+    _fields_ = [("kind", C.c_int32), ("min", C.c_double), ("max", C.c_double), ("n_bins", C.c_uint32), ("power", C.c_uint32)]
+
+
+class Polynomial(C.Structure):      # clsimhip_polynomial
+    _fields_ = [("n", C.c_int32), ("coefficients", DP), ("range_min", C.c_double), ("range_max", C.c_double),
+                ("underflow", C.c_double), ("overflow", C.c_double)]
+
+
 class MediumDesc(C.Structure):      # clsimhip_medium_desc
     _fields_ = [("num_layers", C.c_int32), ("layers_z_start", C.c_double), ("layers_height", C.c_double),
                 ("min_wavelength", C.c_double), ("max_wavelength", C.c_double),
@@ -68,6 +77,10 @@ SYMBOLS = [
     "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_version",
+    "clsimhip_tabulator_create", "clsimhip_tabulator_destroy", "clsimhip_tabulator_last_error",
+    "clsimhip_tabulator_enqueue_steps", "clsimhip_tabulator_finish", "clsimhip_tabulator_get_shape",
+    "clsimhip_tabulator_get_bin_content", "clsimhip_tabulator_get_bin_sums", "clsimhip_tabulator_get_bin_edges",
+    "clsimhip_tabulator_get_statistics", "clsimhip_tabulator_get_rng_state", "clsimhip_tabulator_get_table",
 ]
 
 _lib = None
@@ -133,6 +146,19 @@ def load():
         "clsimhip_get_rng_state": (i32, [vp, vp, sz]),
         "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
         "clsimhip_version": (C.c_char_p, []),
+        "clsimhip_tabulator_create": (i32, [i32, i32, C.POINTER(Axis), sz, i32, vp, C.POINTER(Function), C.POINTER(Polynomial),
+                                            dbl, dbl, vp, vp, sz, C.POINTER(vp)]),
+        "clsimhip_tabulator_destroy": (None, [vp]),
+        "clsimhip_tabulator_last_error": (C.c_char_p, [vp]),
+        "clsimhip_tabulator_enqueue_steps": (i32, [vp, vp, sz, DP]),
+        "clsimhip_tabulator_finish": (i32, [vp]),
+        "clsimhip_tabulator_get_shape": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_tabulator_get_bin_content": (i32, [vp, vp, sz, i32, i32]),
+        "clsimhip_tabulator_get_bin_sums": (i32, [vp, vp, sz, i32]),
+        "clsimhip_tabulator_get_bin_edges": (i32, [vp, i32, DP, sz]),
+        "clsimhip_tabulator_get_statistics": (i32, [vp, DP]),
+        "clsimhip_tabulator_get_rng_state": (i32, [vp, vp, sz]),
+        "clsimhip_tabulator_get_table": (C.c_long, [vp, C.c_char_p, DP, sz]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

@@ -2,13 +2,19 @@
 // catches clsimhip::Error, stores the text for clsimhip_last_error() and returns
 // the status code; nothing C++ crosses the boundary.
 #include <cstring>
+#include <memory>
 
 #include "converter.h"
+#include "tabulator.h"
 
 using namespace clsimhip;
 
 struct clsimhip_converter { Converter impl; explicit clsimhip_converter(int dev) : impl(dev) {} };
 struct clsimhip_medium { MediumData data; };
+struct clsimhip_tabulator {
+    std::unique_ptr<Tabulator> impl;
+    std::string last_error;
+};
 
 namespace {
 thread_local std::string g_create_error;
@@ -46,6 +52,23 @@ FunctionData function_from(const clsimhip_function *f)
     } else
         throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown function kind");
     return d;
+}
+} // namespace
+
+namespace {
+template <class F>
+int guarded_tab(clsimhip_tabulator *t, F &&f)
+{
+    try {
+        f();
+        return CLSIMHIP_OK;
+    } catch (const Error &e) {
+        if (t) t->last_error = e.what(); else g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        if (t) t->last_error = e.what(); else g_create_error = e.what();
+        return CLSIMHIP_ERR_ARGUMENT;
+    }
 }
 } // namespace
 
@@ -320,6 +343,82 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
         chk(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
         (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     });
+}
+
+
+// ---- photon table maker ----
+
+int clsimhip_tabulator_create(int device, int axes_kind, const clsimhip_axis *axes, size_t n_axes, int store_squared_weights,
+                              const clsimhip_medium *medium, const clsimhip_function *wavelength_acceptance,
+                              const clsimhip_polynomial *angular_acceptance, double reference_area, double step_length,
+                              const uint64_t *x, const uint32_t *a, size_t streams, clsimhip_tabulator **out)
+{
+    return guarded_tab(nullptr, [&] {
+        need(axes, "axes"); need(medium, "medium"); need(angular_acceptance, "angular_acceptance"); need(out, "out");
+        std::vector<AxisData> ax(n_axes);
+        for (size_t i = 0; i < n_axes; ++i) {
+            if (axes[i].kind != CLSIMHIP_AXIS_LINEAR && axes[i].kind != CLSIMHIP_AXIS_POWER) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown axis kind");
+            ax[i].kind = axes[i].kind; ax[i].min = axes[i].min; ax[i].max = axes[i].max; ax[i].n_bins = axes[i].n_bins;
+            ax[i].power = (axes[i].kind == CLSIMHIP_AXIS_POWER) ? axes[i].power : 1;
+        }
+        PolynomialData poly;
+        if (angular_acceptance->n < 0 || (angular_acceptance->n > 0 && !angular_acceptance->coefficients))
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "polynomial coefficients are (null)");
+        poly.coefficients.assign(angular_acceptance->coefficients, angular_acceptance->coefficients + angular_acceptance->n);
+        poly.range_min = angular_acceptance->range_min; poly.range_max = angular_acceptance->range_max;
+        poly.underflow = angular_acceptance->underflow; poly.overflow = angular_acceptance->overflow;
+        std::unique_ptr<clsimhip_tabulator> t(new clsimhip_tabulator);
+        t->impl.reset(new Tabulator(device, axes_kind, std::move(ax), store_squared_weights != 0, medium->data,
+                                    function_from(wavelength_acceptance), poly, reference_area, step_length, x, a, streams));
+        *out = t.release();
+    });
+}
+void clsimhip_tabulator_destroy(clsimhip_tabulator *t) { delete t; }
+const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t) { return t ? t->last_error.c_str() : g_create_error.c_str(); }
+int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step *steps, size_t n, const double reference[7])
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->enqueue_steps(steps, n, reference); });
+}
+int clsimhip_tabulator_finish(clsimhip_tabulator *t) { return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->finish(); }); }
+int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t shape[4])
+{
+    return guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] {
+        need(t, "tabulator"); need(n_bins, "n_bins"); need(shape, "shape");
+        *n_bins = t->impl->n_bins();
+        for (size_t i = 0; i < 4; ++i) shape[i] = t->impl->shape()[i];
+    });
+}
+int clsimhip_tabulator_get_bin_content(clsimhip_tabulator *t, float *out, size_t n_bins, int squared, int normalized)
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); need(out, "out"); t->impl->bin_content(out, n_bins, squared != 0, normalized != 0); });
+}
+int clsimhip_tabulator_get_bin_sums(clsimhip_tabulator *t, double *out, size_t n_bins, int squared)
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->bin_content_double(out, n_bins, squared != 0); });
+}
+int clsimhip_tabulator_get_bin_edges(const clsimhip_tabulator *t, int axis, double *out, size_t cap)
+{
+    return guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] {
+        need(t, "tabulator"); need(out, "out");
+        if (axis < 0 || axis >= 4) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis out of range");
+        const AxisData &ax = t->impl->axes()[axis];
+        if (cap < ax.n_bins + 1) throw Error(CLSIMHIP_ERR_ARGUMENT, "output buffer too small");
+        for (unsigned i = 0; i <= ax.n_bins; ++i) out[i] = ax.bin_edge(i);      // Axis::GetBinEdges (Axis.cxx:62-74)
+    });
+}
+int clsimhip_tabulator_get_statistics(clsimhip_tabulator *t, double out[8])
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); need(out, "out"); t->impl->statistics(out); });
+}
+int clsimhip_tabulator_get_rng_state(clsimhip_tabulator *t, uint64_t *x, size_t count)
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->get_rng_state(x, count); });
+}
+long clsimhip_tabulator_get_table(const clsimhip_tabulator *t, const char *name, double *out, size_t cap)
+{
+    long n = -1;
+    const int rc = guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] { need(t, "tabulator"); need(name, "name"); n = t->impl->get_table(name, out, cap); });
+    return rc == CLSIMHIP_OK ? n : rc;
 }
 
 } // extern "C"

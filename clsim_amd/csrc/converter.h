@@ -21,6 +21,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
 int prop_kernel_block_size();
+hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
 size_t prop_kernel_max_lanes();
 size_t prop_kernel_lds_budget();
 

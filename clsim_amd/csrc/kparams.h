@@ -116,6 +116,20 @@ struct KParams {
     float bias_start, bias_step, bias_value;
     uint32_t off_bias;
 
+    // ---- TABULATE variant (propagation_kernel.c.cl:228-303, 755-785; Axes.cxx; spherical/cylindrical_coordinates.c.cl) ----
+    double *tab_bins;                   // one accumulator per table bin (+ under/overflow bins), atomically added
+    double *tab_sq_bins;                // squared weights, or null
+    float tab_ref[12];                  // I3CLSimReferenceParticle: posAndTime, dir, perpDir
+    int32_t tab_axes_kind, tab_full_azimuth;
+    float tab_scale[4], tab_offset[4];  // Axis::GetIndexCode literals
+    int32_t tab_inverse[4], tab_nbins[4];
+    uint32_t tab_stride[4];
+    float tab_max0, tab_max3, tab_min_inv_groupvel, tab_tan_thetac, tab_volume_step;
+    int32_t ang_n;                      // getAngularAcceptance polynomial (coefficients in the LDS image)
+    uint32_t off_ang;
+    int32_t ang_has_min, ang_has_max;
+    float ang_min, ang_max, ang_underflow, ang_overflow;
+
     // ---- detector ----
     int32_t has_pancake;
     float pancake, unpancake;           // PANCAKE_FACTOR, (PANCAKE_FACTOR-1)/PANCAKE_FACTOR
@@ -139,6 +153,7 @@ struct KVariant {
     bool tilt;              // ScalarFieldIceTiltZShift vs getTiltZShift_IS_CONSTANT
     bool aniso;             // anisotropy scaling + pre/post transforms present
     bool flasher;           // more than one wavelength generator (no NO_FLASHER)
+    bool tabulate = false;  // TABULATE: record path samples into table bins instead of looking for DOMs
 };
 
 } // namespace clsimhip

@@ -374,6 +374,7 @@ struct Photon {
     IceFactors ice;
     uint64_t rx_start;          // RNG state word when the photon was created
     int layer;                  // carried layer index (getTiltZShift_IS_CONSTANT, c.cl:521-523)
+    float tab_remainder, tab_depth;     // TABULATE only: prevStepRemainder, depthPropagated (c.cl:530-534, 563)
 };
 
 struct Birth {                  // propagation_kernel.c.cl:132-184 + :587: what createPhotonFromTrack yields
@@ -427,11 +428,14 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
 }
 
 // c.cl:546-596
-template <int MED, bool TILT, bool FLASHER>
+template <int MED, bool TILT, bool FLASHER, bool TAB>
 DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
 {
     ph.rx_start = rx;
+    // TABULATE: the first sub-step is drawn between the photon's creation and its (fixed) absorption budget,
+    // which draws nothing (c.cl:559-563, 582-588)
     const Birth b = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, ra);
+    if (TAB) { ph.tab_remainder = P->tab_volume_step * rng_oc(rx, ra); ph.tab_depth = 0.0f; }
     ph.px = b.x; ph.py = b.y; ph.pz = b.z; ph.pt = b.t;
     ph.d = b.d;
     ph.num_scatters = 0;
@@ -628,6 +632,84 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
     return hit;
 }
 
+// ---------------- TABULATE (c.cl:228-303) ----------------
+// Polynomial.cxx:96-153
+DM float angular_acceptance(KP P, float x)
+{
+    if (P->ang_has_min && x < P->ang_min) return P->ang_underflow;
+    if (P->ang_has_max && x > P->ang_max) return P->ang_overflow;
+    const int n = P->ang_n;
+    if (n == 0) return 0.0f;
+    float r = ldsf(P->off_ang + (uint32_t)(n - 1));
+    for (int i = n - 2; i >= 0; --i) r = ldsf(P->off_ang + (uint32_t)i) + x * r;
+    return r;
+}
+DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float bz, float bw)
+{
+    return ((ax * bx + ay * by) + az * bz) + aw * bw;
+}
+// Records the samples of one path segment: for d = remainder, remainder + step, ... < length the bin of the
+// point gets weight * exp(-depth(d)).  The reference writes (index, weight) entries into a per-stream buffer that the
+// host adds up (tabulator/I3CLSimStepToTableConverter.cxx:495-507) and re-runs streams whose buffer overflowed; here
+// every sample goes straight into its bin with one hardware double-precision atomic add, so there is no buffer to
+// overflow.  Returns true when the photon left the table (isOutOfBounds): it is dropped (c.cl:781-784).
+DM bool save_path(KP P, const Photon &ph, float weight, float length, float &remainder, float depth, float this_depth)
+{
+    const float impact = weight * angular_acceptance(P, ph.d.z);
+    const float vstep = P->tab_volume_step;
+    const float sx = P->tab_ref[0], sy = P->tab_ref[1], sz = P->tab_ref[2], st = P->tab_ref[3];
+    const float ux = P->tab_ref[4], uy = P->tab_ref[5], uz = P->tab_ref[6], uw = P->tab_ref[7];
+    const float qx = P->tab_ref[8], qy = P->tab_ref[9], qz = P->tab_ref[10], qw = P->tab_ref[11];
+    const bool spherical = (P->tab_axes_kind == 0);
+    bool stop = false;
+    float d = remainder;
+    for (; d < length; d += vstep) {
+        // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
+        const float px = (ph.px + d * ph.d.x) - sx, py = (ph.py + d * ph.d.y) - sy, pz = (ph.pz + d * ph.d.z) - sz;
+        const float pw = (ph.pt + d * ph.inv_groupvel) - st;
+        const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
+        const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
+        const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
+        float c0, c1, c2, c3;
+        if (spherical) {
+            c0 = dm::sqrt_(px * px + py * py + pz * pz);
+            const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
+            if (P->tab_full_azimuth) {
+                const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
+                const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
+                c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
+            } else {
+                c1 = azimuth;
+            }
+            c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
+            c3 = pw - c0 * P->tab_min_inv_groupvel;
+            if ((c3 > P->tab_max3) || (c0 > P->tab_max0)) { stop = true; break; }      // Axes.cxx:104-116
+        } else {
+            c0 = n_rho;
+            c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
+            c2 = sz + l * uz;
+            c3 = pw - (l + c0 * P->tab_tan_thetac) * 3.33564095f;
+            if (c3 > P->tab_max3) { stop = true; break; }                               // Axes.cxx:140-151
+        }
+        // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
+        const float c[4] = {c0, c1, c2, c3};
+        uint32_t index = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = P->tab_inverse[k] ? dm::sqrt_(c[k]) : c[k];
+            const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
+            int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
+            b = clampi(b, -1, P->tab_nbins[k]) + 1;
+            index += P->tab_stride[k] * (uint32_t)b;
+        }
+        const float w = impact * dm::exp_(-(depth + (d / length) * this_depth));
+        unsafeAtomicAdd(P->tab_bins + index, (double)w);
+        if (P->tab_sq_bins) unsafeAtomicAdd(P->tab_sq_bins + index, (double)w * (double)w);
+    }
+    remainder = d - length;
+    return stop;
+}
+
 // A detected photon leaves the propagation kernel as a 16-word stub written into its 80-byte output
 // slot; assemble_hits_kernel expands it in place into the I3CLSimPhoton record.  Everything saveHit
 // (propagation_kernel.c.cl:307-404) stores is a function of the stub: the birth of the photon is
@@ -692,8 +774,8 @@ DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
     return born.abs_lens_initial;
 }
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER>
-__global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool TAB>
+__global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
     // the only kernel argument sits at offset 0 of the kernarg segment
     const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -796,7 +878,7 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
                 }
             }
             if (need && !waiting && (photons_left > 0)) {
-                create_photon<MED, TILT, FLASHER>(P, P->steps + sidx, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER, TAB>(P, P->steps + sidx, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -814,10 +896,19 @@ __global__ void __launch_bounds__(kBlock, kMinWavesPerSimd) prop_kernel(const KP
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
-            const float free_flight = free_flight_bound(fresh_params(P0), ph.px, ph.py);
+            const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
-            // the search cannot find a DOM closer than the nearest string cylinder: skip it when the step ends before
-            if (!(distance < free_flight)) hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+            if (TAB) {
+                // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
+                const KP P = fresh_params(P0);
+                const float travelled = P->fixed_abs - ph.abs_lens_left;
+                if (save_path(P, ph, P->steps[sidx].weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth))
+                    ph.abs_lens_left = 0.0f;
+                ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
+            } else if (!(distance < free_flight)) {
+                // the search cannot find a DOM closer than the nearest string cylinder: skip it when the step ends before
+                hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+            }
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
         const uint64_t hit_mask = __ballot(hit);
@@ -961,7 +1052,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 }
 
 // ---- host-side launchers (called from converter.cpp) ----
-template <int MED, bool TILT, bool ANISO, bool FLASHER>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool TAB>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -973,10 +1064,10 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess && lds_bytes > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER, TAB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER>, kBlock, lds_bytes);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER, TAB>, kBlock, lds_bytes);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
@@ -1003,9 +1094,9 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         const uint32_t sgrid = (P.n_steps + 255u) / 256u;
         hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue);
     }
-    hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return err;
+    if (err != hipSuccess || TAB) return err;
     // second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
     static bool assemble_ready = false;
     const size_t image_bytes = (size_t)P.table_words * 4;
@@ -1028,12 +1119,30 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d>(P, stream);
+#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, false>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
     CASE(8 * m + 4, m, true, false, false)  CASE(8 * m + 5, m, true, false, true)  \
     CASE(8 * m + 6, m, true, true, false)   CASE(8 * m + 7, m, true, true, true)
+    CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
+#undef CASES
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// TABULATE variants: FLASHER is always compiled in (the source type is looked at per step)
+hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
+{
+    if (P.n_steps == 0) return hipSuccess;
+    if (!v.tabulate || !P.tab_bins || !P.has_fixed_abs) return hipErrorInvalidValue;
+    if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
+    if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
+    const int key = 4 * v.lengths + (v.tilt ? 2 : 0) + (v.aniso ? 1 : 0);
+    switch (key) {
+#define CASE(k, m, t, a) case k: return launch_variant<m, t, a, true, true>(P, stream);
+#define CASES(m) CASE(4 * m + 0, m, false, false) CASE(4 * m + 1, m, false, true) CASE(4 * m + 2, m, true, false) CASE(4 * m + 3, m, true, true)
     CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
 #undef CASES
 #undef CASE

@@ -327,6 +327,12 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.bias_value = to_float_literal(bias.value);
     }
 
+    if (geometry.string_ids.empty()) {
+        // the tabulator has no detector (tabulator/I3CLSimStepToTableConverter.cxx:196-207 assembles no geometry source)
+        P.table_words = static_cast<uint32_t>(img.words.size());
+        C.lds_image = std::move(img.words);
+        return C;
+    }
     // ---------------- detector (GeometrySource.cxx) ----------------
     C.geo = build_geometry(geometry);
     const GeoTables &G = C.geo;

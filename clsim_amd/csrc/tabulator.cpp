@@ -1,0 +1,306 @@
+// See tabulator.h.  Host logic restated from private/clsim/tabulator/ (file:line at each function).
+#include "tabulator.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace clsimhip {
+
+namespace {
+constexpr uint32_t kQueueSlots = 256;
+constexpr double kFixedAbsorptionLengths = 42.;      // StepToTableConverter.cxx:182
+}
+
+// Axis.cxx:93-103 (linear), 131-141 (power)
+double AxisData::transform(double v) const { return kind == CLSIMHIP_AXIS_LINEAR ? v : std::pow(v, static_cast<double>(power)); }
+double AxisData::inverse(double v) const { return kind == CLSIMHIP_AXIS_LINEAR ? v : std::pow(v, 1. / power); }
+// Axis.cxx:76-83
+double AxisData::bin_edge(unsigned i) const
+{
+    const double imin = inverse(min), imax = inverse(max);
+    const double istep = (imax - imin) / n_bins;
+    return transform(imin + i * istep);
+}
+
+void Tabulator::hip_check(hipError_t e, const char *what) const
+{
+    if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// GetMinimumRefractiveIndex (StepToTableConverter.cxx:96-120), as written: the scan point is wmin + i*(wmax-wmin)
+static std::pair<double, double> minimum_refractive_index(const MediumData &m)
+{
+    std::pair<double, double> best(INFINITY, INFINITY);
+    auto group = [&](double w) {
+        if (m.group_kind == CLSIMHIP_REFINDEX_TABLE) return m.group_table.eval(w);
+        const double x = w / units::micrometer;                 // RefIndexIceCube.cxx:84-101
+        const double np = m.n[0] + x * (m.n[1] + x * (m.n[2] + x * (m.n[3] + x * m.n[4])));
+        const double corr = m.g[0] + x * (m.g[1] + x * (m.g[2] + x * (m.g[3] + x * m.g[4])));
+        return np * corr;
+    };
+    double gmin = -INFINITY, gmax = INFINITY;
+    if (m.group_kind == CLSIMHIP_REFINDEX_TABLE) {
+        gmin = m.group_table.start;
+        gmax = m.group_table.start + m.group_table.step * static_cast<double>(m.group_table.values.size() - 1);
+    }
+    const double wmin = std::max(m.min_wlen, gmin), wmax = std::min(m.max_wlen, gmax);
+    for (unsigned i = 0; i < 1000; i++) {                       // the same for every layer
+        const double w = wmin + i * (wmax - wmin);
+        const double n = group(w);
+        if (n > 1 && n < best.first) best = std::make_pair(n, m.phase_ref_index(w));
+    }
+    return best;
+}
+
+Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool store_squared_weights, const MediumData &medium,
+                     const FunctionData &wavelength_acceptance, const PolynomialData &angular, double reference_area,
+                     double step_length, const uint64_t *x, const uint32_t *a, size_t streams)
+    : device_(device), axes_kind_(axes_kind), axes_(std::move(axes)), squared_(store_squared_weights),
+      reference_area_(reference_area), step_length_(step_length), streams_(streams)
+{
+    if (axes_kind_ != CLSIMHIP_AXES_SPHERICAL && axes_kind_ != CLSIMHIP_AXES_CYLINDRICAL) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown axes kind");
+    if (axes_.size() != 4) throw Error(CLSIMHIP_ERR_CONFIG, "only 4-dimensional tables are restated (no TABULATE_IMPACT_ANGLE)");
+    for (const AxisData &ax : axes_) {
+        if (ax.n_bins == 0 || !(ax.max > ax.min)) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis needs bins and max > min");
+        if (ax.kind == CLSIMHIP_AXIS_POWER && (ax.power < 1 || ax.power > 2))
+            throw Error(CLSIMHIP_ERR_CONFIG, "only linear and square-root (power 2) axes are restated");
+    }
+    if (!x || !a || streams == 0 || streams % 256 != 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "RNG streams: need a non-zero multiple of 256");
+    if (angular.coefficients.size() > 64) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many polynomial coefficients");
+    if (!(step_length > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "step length must be positive");
+
+    // Axes::Axes (Axes.cxx:51-64): every axis has an under- and an overflow bin
+    const size_t nd = axes_.size();
+    shape_.assign(nd, 0); strides_.assign(nd, 0);
+    shape_[nd - 1] = axes_[nd - 1].n_bins + 2; strides_[nd - 1] = 1;
+    for (size_t i = nd - 1; i-- > 0;) { shape_[i] = axes_[i].n_bins + 2; strides_[i] = strides_[i + 1] * shape_[i + 1]; }
+    n_bins_ = strides_[0] * shape_[0];
+    if (n_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
+
+    // StepToTableConverter.cxx:126-141: generator 0 = Cherenkov spectrum biased with the wavelength acceptance
+    std::vector<RandomValueData> gens(1, make_cherenkov_generator(wavelength_acceptance, medium));
+    tables_ = compile_tables(medium, GeometryInput(), gens, wavelength_acceptance, 1.0);
+    KParams &P = tables_.params;
+    tables_.variant.tabulate = true;
+    tables_.variant.flasher = true;
+    P.has_fixed_abs = 1;
+    P.fixed_abs = to_float_literal(kFixedAbsorptionLengths);
+    P.tab_axes_kind = axes_kind_;
+    P.tab_full_azimuth = (axes_kind_ == CLSIMHIP_AXES_SPHERICAL && axes_[1].max > 180.) ? 1 : 0;     // Axes.cxx:96-97
+    for (size_t k = 0; k < 4; ++k) {
+        // Axis::GetIndexCode (Axis.cxx:45-60)
+        const AxisData &ax = axes_[k];
+        const double scale = ax.n_bins / (ax.inverse(ax.max) - ax.inverse(ax.min));
+        const double offset = scale * ax.inverse(ax.min);
+        P.tab_scale[k] = to_float_literal(scale);
+        P.tab_offset[k] = to_float_literal(offset);
+        P.tab_inverse[k] = (ax.kind == CLSIMHIP_AXIS_POWER && ax.power == 2) ? 1 : 0;
+        P.tab_nbins[k] = static_cast<int32_t>(ax.n_bins);
+        P.tab_stride[k] = static_cast<uint32_t>(strides_[k]);
+    }
+    P.tab_max0 = to_float_literal(axes_[0].max);
+    P.tab_max3 = to_float_literal(axes_[3].max);
+    const auto n_min = minimum_refractive_index(medium);
+    n_group_ = n_min.first; n_phase_ = n_min.second;
+    P.tab_min_inv_groupvel = to_float_literal(n_group_ / units::c_light);                    // :192-193
+    P.tab_tan_thetac = to_float_literal(std::sqrt(n_phase_ * n_phase_ - 1.));                 // :194-195
+    P.tab_volume_step = to_float_literal(step_length_);                                       // :191
+    {   // getAngularAcceptance: coefficients are appended to the LDS image
+        std::vector<uint32_t> &img = tables_.lds_image;
+        P.off_ang = static_cast<uint32_t>(img.size());
+        P.ang_n = static_cast<int32_t>(angular.coefficients.size());
+        for (double c : angular.coefficients) { const float f = to_float_literal(c); uint32_t u; std::memcpy(&u, &f, 4); img.push_back(u); }
+        P.table_words = static_cast<uint32_t>(img.size());
+        P.ang_has_min = std::isinf(angular.range_min) ? 0 : 1;
+        P.ang_has_max = std::isinf(angular.range_max) ? 0 : 1;
+        P.ang_min = to_float_literal(angular.range_min); P.ang_max = to_float_literal(angular.range_max);
+        P.ang_underflow = to_float_literal(angular.underflow); P.ang_overflow = to_float_literal(angular.overflow);
+        tables_.named["getAngularAcceptance"] = angular.coefficients;
+    }
+    tables_.named["TABULATOR"] = {n_group_, n_phase_, P.tab_min_inv_groupvel, P.tab_tan_thetac, double(n_bins_)};
+    tables_.named["TABULATOR_SCALE"] = {P.tab_scale[0], P.tab_scale[1], P.tab_scale[2], P.tab_scale[3]};
+    tables_.named["TABULATOR_OFFSET"] = {P.tab_offset[0], P.tab_offset[1], P.tab_offset[2], P.tab_offset[3]};
+
+    for (size_t i = 0; i < streams; ++i)
+        if ((x[i] == 0) | ((static_cast<uint32_t>(x[i] >> 32)) >= (a[i] - 1)) | ((static_cast<uint32_t>(x[i])) >= 0xfffffffful))
+            throw Error(CLSIMHIP_ERR_ARGUMENT, "invalid MWC state word for stream " + std::to_string(i));
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the tabulator has no CPU fallback)");
+    if (device_ < 0 || device_ >= count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
+    hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
+    auto upload = [&](void **dst, const void *src, size_t bytes, const char *what) {
+        hip_check(hipMalloc(dst, std::max<size_t>(bytes, 16)), what);
+        if (bytes) hip_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), what);
+    };
+    upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
+    upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
+    upload(reinterpret_cast<void **>(&d_rng_x_), x, streams * 8, "rng x");
+    upload(reinterpret_cast<void **>(&d_rng_a_), a, streams * 4, "rng a");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_bins_), n_bins_ * sizeof(double)), "table bins");
+    hip_check(hipMemset(d_bins_, 0, n_bins_ * sizeof(double)), "table bins");
+    if (squared_) {
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_sq_bins_), n_bins_ * sizeof(double)), "squared weights");
+        hip_check(hipMemset(d_sq_bins_, 0, n_bins_ * sizeof(double)), "squared weights");
+    }
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), streams * sizeof(DevStep)), "steps");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_slice_done_), streams * sizeof(uint32_t)), "slice counters");
+    hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), streams * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
+}
+
+Tabulator::~Tabulator()
+{
+    (void)hipSetDevice(device_);
+    if (stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
+    if (ev_start_) (void)hipEventDestroy(ev_start_);
+    if (ev_stop_) (void)hipEventDestroy(ev_stop_);
+    (void)hipFree(d_tables_); (void)hipFree(d_len_table_); (void)hipFree(d_bins_); (void)hipFree(d_sq_bins_);
+    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
+    if (h_steps_) (void)hipHostFree(h_steps_);
+}
+
+// EnqueueSteps (StepToTableConverter.cxx:272-285) + one pass of FetchSteps (:399-460) without the entry buffers
+void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double ref[7])
+{
+    if (!steps || !ref) throw Error(CLSIMHIP_ERR_ARGUMENT, "steps / reference particle are (null)");
+    if (n == 0) return;
+    if (n > streams_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than the number of RNG streams!");
+    std::lock_guard<std::mutex> lk(mutex_);
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    // the previous bunch still reads the pinned staging buffer and the slice counters
+    hip_check(hipStreamSynchronize(stream_), "previous bunch");
+    if (pending_event_) {
+        float ms = 0.f;
+        hip_check(hipEventElapsedTime(&ms, ev_start_, ev_stop_), "event time");
+        device_ms_ += ms;
+        pending_event_ = false;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        num_photons_ += steps[i].num_photons;
+        sum_of_photon_weights_ += static_cast<double>(steps[i].num_photons) * static_cast<double>(steps[i].weight);
+    }
+    std::memcpy(h_steps_, steps, n * sizeof(clsimhip_step));
+    hip_check(hipMemcpyAsync(d_steps_, h_steps_, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
+    KParams P = tables_.params;
+    P.tables = d_tables_;
+    P.len_table = d_len_table_;
+    P.steps = d_steps_;
+    P.n_steps = static_cast<uint32_t>(n);
+    P.rng_x = d_rng_x_;
+    P.rng_a = d_rng_a_;
+    P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
+    hip_check(hipMemsetAsync(P.queue, 0, 16, stream_), "reset step queue");
+    hip_check(hipMemsetAsync(d_slice_done_, 0, n * sizeof(uint32_t), stream_), "reset slice counters");
+    P.k_new = 8;
+    P.slices = 0;
+    P.slice_done = d_slice_done_;
+    P.tab_bins = d_bins_;
+    P.tab_sq_bins = d_sq_bins_;
+    {   // I3CLSimReferenceParticle (StepToTableConverter.cxx:64-93)
+        const double dx = ref[4], dy = ref[5], dz = ref[6];
+        const double perpz = std::hypot(dx, dy);
+        double px = 1., py = 0., pz = 0.;
+        if (perpz > 0.) {
+            // I3Direction(x, y, z) normalises its arguments
+            px = -dx * dz / perpz; py = -dy * dz / perpz; pz = perpz;
+            const double norm = std::sqrt(px * px + py * py + pz * pz);
+            px /= norm; py /= norm; pz /= norm;
+        }
+        const double v[12] = {ref[0], ref[1], ref[2], ref[3], dx, dy, dz, 0., px, py, pz, 0.};
+        for (int k = 0; k < 12; ++k) P.tab_ref[k] = static_cast<float>(v[k]);
+    }
+    hip_check(hipEventRecord(ev_start_, stream_), "event");
+    hip_check(launch_tab_kernel(P, tables_.variant, stream_), "tabulation kernel launch");
+    hip_check(hipEventRecord(ev_stop_, stream_), "event");
+    pending_event_ = true;
+    ++launches_;
+}
+
+void Tabulator::finish()
+{
+    std::lock_guard<std::mutex> lk(mutex_);
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "tabulation kernel");
+    if (pending_event_) {
+        float ms = 0.f;
+        hip_check(hipEventElapsedTime(&ms, ev_start_, ev_stop_), "event time");
+        device_ms_ += ms;
+        pending_event_ = false;
+    }
+}
+
+// SphericalAxes / CylindricalAxes::GetBinVolume (Axes.cxx:118-133, 153-164)
+double Tabulator::bin_volume(const size_t idxs[3]) const
+{
+    auto e = [&](size_t k, size_t i) { return axes_[k].bin_edge(static_cast<unsigned>(i)); };
+    if (axes_kind_ == CLSIMHIP_AXES_SPHERICAL) {
+        const double scalefactor = (axes_[1].max > 180.) ? 1 : 2;
+        return ((std::pow(e(0, idxs[0] + 1), 3) - std::pow(e(0, idxs[0]), 3)) / 3.)
+            * scalefactor * units::deg * (e(1, idxs[1] + 1) - e(1, idxs[1]))
+            * (e(2, idxs[2] + 1) - e(2, idxs[2]));
+    }
+    return ((std::pow(e(0, idxs[0] + 1), 2) - std::pow(e(0, idxs[0]), 2)) / 2.)
+        * 2 * (e(1, idxs[1] + 1) - e(1, idxs[1]))
+        * (e(2, idxs[2] + 1) - e(2, idxs[2]));
+}
+
+void Tabulator::bin_content_double(double *out, size_t n, bool squared)
+{
+    if (!out || n != n_bins_) throw Error(CLSIMHIP_ERR_ARGUMENT, "output buffer must hold exactly n_bins values");
+    if (squared && !d_sq_bins_) throw Error(CLSIMHIP_ERR_STATE, "squared weights are not recorded");
+    finish();
+    std::lock_guard<std::mutex> lk(mutex_);
+    hip_check(hipMemcpy(out, squared ? d_sq_bins_ : d_bins_, n * sizeof(double), hipMemcpyDeviceToHost), "download table");
+}
+
+void Tabulator::bin_content(float *out, size_t n, bool squared, bool normalized)
+{
+    std::vector<double> sums(n_bins_);
+    bin_content_double(sums.data(), n, squared);
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<float>(sums[i]);
+    if (!normalized) return;
+    // Normalize (StepToTableConverter.cxx:512-543): the first 3 dimensions are spatial
+    const size_t nd = axes_.size();
+    const size_t spatial_stride = strides_[2];
+    for (size_t offset = 0; offset < n_bins_; offset += spatial_stride) {
+        size_t idxs[4];
+        for (size_t j = 0; j < nd; ++j)
+            idxs[j] = static_cast<size_t>(std::min(std::max(static_cast<int>(offset / strides_[j] % shape_[j]) - 1, 0), static_cast<int>(shape_[j]) - 3));
+        double norm = bin_volume(idxs) / (step_length_ * reference_area_);
+        if (squared) norm *= norm;
+        for (size_t i = 0; i < spatial_stride; ++i) out[i + offset] = static_cast<float>(out[i + offset] / norm);
+    }
+}
+
+void Tabulator::statistics(double out[8])
+{
+    finish();
+    std::lock_guard<std::mutex> lk(mutex_);
+    out[0] = static_cast<double>(num_photons_); out[1] = sum_of_photon_weights_; out[2] = n_group_; out[3] = n_phase_;
+    out[4] = device_ms_; out[5] = static_cast<double>(launches_); out[6] = static_cast<double>(n_bins_); out[7] = 0.;
+}
+
+void Tabulator::get_rng_state(uint64_t *x, size_t count)
+{
+    if (!x || count > streams_) throw Error(CLSIMHIP_ERR_ARGUMENT, "bad rng state request");
+    finish();
+    std::lock_guard<std::mutex> lk(mutex_);
+    hip_check(hipMemcpy(x, d_rng_x_, count * sizeof(uint64_t), hipMemcpyDeviceToHost), "download rng state");
+}
+
+long Tabulator::get_table(const std::string &name, double *out, size_t cap) const
+{
+    auto it = tables_.named.find(name);
+    if (it == tables_.named.end()) throw Error(CLSIMHIP_ERR_ARGUMENT, "no table named " + name);
+    const size_t n = it->second.size();
+    if (out) std::memcpy(out, it->second.data(), std::min(n, cap) * sizeof(double));
+    return static_cast<long>(n);
+}
+
+} // namespace clsimhip

@@ -252,6 +252,59 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
 
 const char *clsimhip_version(void);
 
+/* ---- photon table maker -------------------------------------------------------------
+ * I3CLSimStepToTableConverter (private/clsim/tabulator/I3CLSimStepToTableConverter.h:44-101): propagates steps with
+ * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no
+ * detector, a path sample every `step_length` metres) and fills a table over coordinates relative to a reference
+ * particle.  4-dimensional tables (no impact-angle axis), linear and square-root axes. */
+#define CLSIMHIP_AXIS_LINEAR 0          /* clsim::tabulator::LinearAxis (tabulator/Axis.h:71-80) */
+#define CLSIMHIP_AXIS_POWER 1           /* clsim::tabulator::PowerAxis  (tabulator/Axis.h:82-95) */
+typedef struct {
+    int32_t kind;
+    double min, max;
+    uint32_t n_bins;                    /* without the under-/overflow bins every axis gets (Axes.cxx:51-64) */
+    uint32_t power;                     /* POWER: 1 or 2 */
+} clsimhip_axis;
+#define CLSIMHIP_AXES_SPHERICAL 0       /* SphericalAxes: r, azimuth [deg], cos(polar), delay time (spherical_coordinates.c.cl) */
+#define CLSIMHIP_AXES_CYLINDRICAL 1     /* CylindricalAxes: rho, azimuth [rad], z, delay time (cylindrical_coordinates.c.cl) */
+typedef struct {                        /* I3CLSimFunctionPolynomial (function/I3CLSimFunctionPolynomial.cxx:35-153) */
+    int32_t n;
+    const double *coefficients;         /* c0 + x*(c1 + x*(...)) */
+    double range_min, range_max;        /* -inf / +inf: unbounded */
+    double underflow, overflow;
+} clsimhip_polynomial;
+typedef struct clsimhip_tabulator clsimhip_tabulator;
+
+/* I3CLSimStepToTableConverter::I3CLSimStepToTableConverter (StepToTableConverter.cxx:122-265).  wavelength_acceptance
+ * biases the Cherenkov spectrum (generator 0) and weights nothing else; angular_acceptance is evaluated on the
+ * photon's z direction cosine per path segment; reference_area and step_length enter Normalize().  (x, a): one MWC
+ * stream per work item, `streams` a multiple of 256. */
+int clsimhip_tabulator_create(int device, int axes_kind, const clsimhip_axis *axes, size_t n_axes, int store_squared_weights,
+                              const clsimhip_medium *medium, const clsimhip_function *wavelength_acceptance,
+                              const clsimhip_polynomial *angular_acceptance, double reference_area, double step_length,
+                              const uint64_t *x, const uint32_t *a, size_t streams, clsimhip_tabulator **out);
+void clsimhip_tabulator_destroy(clsimhip_tabulator *t);
+const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t);
+/* EnqueueSteps(steps, reference) (:272-285): reference = {x, y, z, time, dx, dy, dz} of the source particle.
+ * Asynchronous; stream i of this bunch continues where stream i of the previous bunch stopped. */
+int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step *steps, size_t n, const double reference[7]);
+/* Finish() (:287-295): waits until every enqueued bunch is in the table */
+int clsimhip_tabulator_finish(clsimhip_tabulator *t);
+/* number of bins including under-/overflow bins, and the shape (n_bins + 2 per axis) */
+int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t shape[4]);
+/* binContent_ (squared == 0) or squaredWeights_ as the float image WriteFITSFile stores (:595-686), before
+ * (normalized == 0) or after Normalize() (:512-543) */
+int clsimhip_tabulator_get_bin_content(clsimhip_tabulator *t, float *out, size_t n_bins, int squared, int normalized);
+/* the double precision accumulators themselves */
+int clsimhip_tabulator_get_bin_sums(clsimhip_tabulator *t, double *out, size_t n_bins, int squared);
+/* Axis::GetBinEdges (Axis.cxx:62-74): n_bins + 1 edges of axis `axis` */
+int clsimhip_tabulator_get_bin_edges(const clsimhip_tabulator *t, int axis, double *out, size_t cap);
+/* [0] photons enqueued, [1] sum of photon weights (numPhotons*weight), [2] n_group, [3] n_phase of
+ * GetMinimumRefractiveIndex (:96-120), [4] kernel time ms, [5] launches, [6] bins, [7] reserved */
+int clsimhip_tabulator_get_statistics(clsimhip_tabulator *t, double out[8]);
+int clsimhip_tabulator_get_rng_state(clsimhip_tabulator *t, uint64_t *x, size_t count);
+long clsimhip_tabulator_get_table(const clsimhip_tabulator *t, const char *name, double *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -710,3 +710,148 @@ def seed_streams(a, seed=12345):
             xi = (h << 32) + l
         x[i] = xi
     return x
+
+
+# --------------------------------------------------------------------------
+# photon tabulator (private/clsim/tabulator/)
+# --------------------------------------------------------------------------
+
+def linear_axis(lo, hi, n_bins):
+    return dict(kind="linear", min=float(lo), max=float(hi), n_bins=int(n_bins), power=1)
+
+
+def power_axis(lo, hi, n_bins, power=1):
+    return dict(kind="power", min=float(lo), max=float(hi), n_bins=int(n_bins), power=int(power))
+
+
+def axis_transform(ax, v):
+    """Axis.cxx:93-97, 131-135."""
+    return v if ax["kind"] == "linear" else math.pow(v, ax["power"])
+
+
+def axis_inverse(ax, v):
+    """Axis.cxx:99-103, 137-141."""
+    return v if ax["kind"] == "linear" else math.pow(v, 1.0 / ax["power"])
+
+
+def axis_index_literals(ax):
+    """Axis::GetIndexCode (Axis.cxx:45-60): (scale, offset) as the float literals of the generated code."""
+    scale = ax["n_bins"] / (axis_inverse(ax, ax["max"]) - axis_inverse(ax, ax["min"]))
+    offset = scale * axis_inverse(ax, ax["min"])
+    return float_literal(scale), float_literal(offset)
+
+
+def axis_bin_edge(ax, i):
+    """Axis::GetBinEdge (Axis.cxx:76-83)."""
+    imin = axis_inverse(ax, ax["min"])
+    imax = axis_inverse(ax, ax["max"])
+    istep = (imax - imin) / ax["n_bins"]
+    return axis_transform(ax, imin + i * istep)
+
+
+def axis_bin_edges(ax):
+    return np.array([axis_bin_edge(ax, i) for i in range(ax["n_bins"] + 1)])
+
+
+def axes_layout(axes):
+    """Axes::Axes (Axes.cxx:51-64): every axis has an under- and an overflow bin."""
+    n = len(axes)
+    shape = [0] * n
+    strides = [0] * n
+    shape[n - 1] = axes[n - 1]["n_bins"] + 2
+    strides[n - 1] = 1
+    for i in range(n - 2, -1, -1):
+        shape[i] = axes[i]["n_bins"] + 2
+        strides[i] = strides[i + 1] * shape[i + 1]
+    return shape, strides, strides[0] * shape[0]
+
+
+def bin_volume(kind, axes, idxs):
+    """SphericalAxes / CylindricalAxes::GetBinVolume (Axes.cxx:118-133, 153-164)."""
+    e = lambda k, i: axis_bin_edge(axes[k], i)
+    if kind == "spherical":
+        scalefactor = 1 if axes[1]["max"] > 180.0 else 2
+        return ((math.pow(e(0, idxs[0] + 1), 3) - math.pow(e(0, idxs[0]), 3)) / 3.0) \
+            * scalefactor * DEG * (e(1, idxs[1] + 1) - e(1, idxs[1])) * (e(2, idxs[2] + 1) - e(2, idxs[2]))
+    return ((math.pow(e(0, idxs[0] + 1), 2) - math.pow(e(0, idxs[0]), 2)) / 2.0) \
+        * 2 * (e(1, idxs[1] + 1) - e(1, idxs[1])) * (e(2, idxs[2] + 1) - e(2, idxs[2]))
+
+
+def normalize_table(bins, kind, axes, step_length, dom_area):
+    """I3CLSimStepToTableConverter::Normalize (StepToTableConverter.cxx:512-543): float bins divided by a double norm."""
+    shape, strides, n = axes_layout(axes)
+    out = np.array(bins, dtype=np.float32, copy=True)
+    spatial = strides[2]
+    for offset in range(0, n, spatial):
+        idxs = [min(max((offset // strides[j]) % shape[j] - 1, 0), shape[j] - 3) for j in range(len(axes))]
+        norm = bin_volume(kind, axes, idxs) / (step_length * dom_area)
+        out[offset:offset + spatial] = (out[offset:offset + spatial].astype(np.float64) / norm).astype(np.float32)
+    return out
+
+
+def group_ref_index_host(medium, wlen):
+    if "group_table" in medium:
+        return from_table_host(medium["group_table"], wlen)
+    x = wlen / MICROMETER                                   # RefIndexIceCube.cxx:84-101 ("group")
+    n, g = medium["n"], medium["g"]
+    np_ = n[0] + x * (n[1] + x * (n[2] + x * (n[3] + x * n[4])))
+    corr = g[0] + x * (g[1] + x * (g[2] + x * (g[3] + x * g[4])))
+    return np_ * corr
+
+
+def phase_ref_index_of(medium, wlen):
+    if "phase_table" in medium:
+        return from_table_host(medium["phase_table"], wlen)
+    return phase_ref_index_host(wlen, medium["n"])
+
+
+def minimum_refractive_index(medium):
+    """GetMinimumRefractiveIndex (StepToTableConverter.cxx:96-120), as written: the scan variable is
+    wmin + i*(wmax-wmin) for i = 0..999, NOT divided by the number of points; (n_group, n_phase) of the smallest
+    group index above 1."""
+    best = (float("inf"), float("inf"))
+    tabulated = "group_table" in medium
+    gmin = medium["group_table"]["start"] if tabulated else -float("inf")
+    gmax = (medium["group_table"]["start"] + medium["group_table"]["step"] * float(len(medium["group_table"]["values"]) - 1)) if tabulated else float("inf")
+    wmin = max(medium["min_wlen"], gmin)
+    wmax = min(medium["max_wlen"], gmax)
+    for i in range(1000):                                   # identical for every layer
+        w = wmin + i * (wmax - wmin)
+        n = group_ref_index_host(medium, w)
+        if n > 1 and n < best[0]:
+            best = (n, phase_ref_index_of(medium, w))
+    return best
+
+
+def reference_particle(pos, time, direction):
+    """I3CLSimReferenceParticle (StepToTableConverter.cxx:64-93): 12 floats posAndTime, dir, perpDir."""
+    dx, dy, dz = (float(v) for v in direction)
+    perpz = math.hypot(dx, dy)
+    if perpz > 0.0:
+        perp = (-dx * dz / perpz, -dy * dz / perpz, perpz)
+        # I3Direction(x, y, z) normalises its arguments
+        norm = math.sqrt(perp[0] ** 2 + perp[1] ** 2 + perp[2] ** 2)
+        perp = tuple(v / norm for v in perp)
+    else:
+        perp = (1.0, 0.0, 0.0)
+    return np.array([pos[0], pos[1], pos[2], time, dx, dy, dz, 0.0, perp[0], perp[1], perp[2], 0.0], dtype=np.float32)
+
+
+def tabulator_config(kind, axes, medium, angular_coefficients, step_length=1.0, entries_per_stream=5000):
+    """What tabulator/I3CLSimStepToTableConverter.cxx:178-207 and Axes::GenerateBinningCode put into the program."""
+    assert kind in ("spherical", "cylindrical") and len(axes) == 4
+    shape, strides, n_bins = axes_layout(axes)
+    n_group, n_phase = minimum_refractive_index(medium)
+    lit = [axis_index_literals(ax) for ax in axes]
+    for ax in axes:
+        assert ax["kind"] == "linear" or ax["power"] in (1, 2), "only linear and sqrt axes are restated"
+    return dict(kind=kind, axes=axes, shape=shape, strides=strides, n_bins=n_bins,
+                full_azimuth=(kind == "spherical" and axes[1]["max"] > 180.0),
+                scale=[l[0] for l in lit], offset=[l[1] for l in lit],
+                inverse=[1 if (ax["kind"] == "power" and ax["power"] == 2) else 0 for ax in axes],
+                max0=float_literal(axes[0]["max"]), max3=float_literal(axes[3]["max"]),
+                min_inv_groupvel=float_literal(n_group / C_LIGHT),
+                tan_thetac=float_literal(math.sqrt(n_phase * n_phase - 1.0)),
+                n_group=n_group, n_phase=n_phase,
+                volume_step=float_literal(step_length), entries_per_stream=int(entries_per_stream),
+                angular=[float(c) for c in angular_coefficients])

@@ -81,6 +81,13 @@ class Tables(C.Structure):
         ("phase_start", C.c_float), ("phase_step", C.c_float), ("group_start", C.c_float), ("group_step", C.c_float),
         ("phase_data", FP), ("group_data", FP),
         ("has_fixed_abs", C.c_int32), ("fixed_abs", C.c_float), ("history_n", C.c_int32),
+        ("tab_axes_kind", C.c_int32), ("tab_full_azimuth", C.c_int32),
+        ("tab_scale", C.c_float * 4), ("tab_offset", C.c_float * 4), ("tab_inverse", C.c_int32 * 4),
+        ("tab_nbins", C.c_int32 * 4), ("tab_stride", C.c_uint32 * 4),
+        ("tab_max0", C.c_float), ("tab_max3", C.c_float), ("tab_min_inv_groupvel", C.c_float), ("tab_tan_thetac", C.c_float),
+        ("tab_volume_step", C.c_float), ("tab_entries_per_stream", C.c_uint32),
+        ("ang_n", C.c_int32), ("ang_coeff", C.c_float * 16), ("ang_has_min", C.c_int32), ("ang_has_max", C.c_int32),
+        ("ang_min", C.c_float), ("ang_max", C.c_float), ("ang_underflow", C.c_float), ("ang_overflow", C.c_float),
     ]
 
 
@@ -131,7 +138,8 @@ class OracleTables:
         return out
 
 
-def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=True, fixed_abs_lengths=None, history_entries=0):
+def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=True, fixed_abs_lengths=None, history_entries=0,
+                tabulator=None):
     """The oracle's counterpart of Compile() (OpenCL.cxx:485-533): converts the
     descriptions (doubles) into the literals of the generated OpenCL program."""
     fl = B.float_literal
@@ -143,6 +151,20 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
         t.has_fixed_abs = 1
         t.fixed_abs = fl(fixed_abs_lengths)
     t.history_n = int(history_entries)                                       # OpenCL.cxx:416-419
+    if tabulator is not None:                                                # StepToTableConverter.cxx:178-207
+        tb = tabulator
+        t.has_fixed_abs, t.fixed_abs = 1, fl(42.0)                           # PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS 42
+        t.tab_axes_kind = 0 if tb["kind"] == "spherical" else 1
+        t.tab_full_azimuth = 1 if tb["full_azimuth"] else 0
+        for k in range(4):
+            t.tab_scale[k], t.tab_offset[k] = tb["scale"][k], tb["offset"][k]
+            t.tab_inverse[k], t.tab_nbins[k], t.tab_stride[k] = tb["inverse"][k], tb["axes"][k]["n_bins"], tb["strides"][k]
+        t.tab_max0, t.tab_max3 = tb["max0"], tb["max3"]
+        t.tab_min_inv_groupvel, t.tab_tan_thetac = tb["min_inv_groupvel"], tb["tan_thetac"]
+        t.tab_volume_step, t.tab_entries_per_stream = tb["volume_step"], tb["entries_per_stream"]
+        t.ang_n = len(tb["angular"])
+        for k, c in enumerate(tb["angular"]):
+            t.ang_coeff[k] = fl(c)
     t.has_pancake = 1 if pancake != 1.0 else 0          # OpenCL.cxx:432
     t.pancake = fl(pancake)
     m = medium
@@ -317,6 +339,52 @@ def propagate(tables, steps, x, a, max_hits=None, threads=1, history=False):
     else:
         cnt = L.oracle_propagate_mt(*args, C.c_int(threads), C.byref(it))
     return out[:min(cnt, max_hits)], cnt, x, it.value
+
+
+ENTRY_DTYPE = np.dtype([("index", np.uint32), ("weight", np.float32)])
+
+
+def tabulate(tables, steps, x, a, reference, threads=8):
+    """One launch of the TABULATE kernel (oracle_tabulate).  Returns (entries [n, EPS], num_entries [n],
+    photons_left [n], x_after)."""
+    L = lib()
+    steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+    n = len(steps)
+    eps = int(tables.t.tab_entries_per_stream)
+    x = np.array(x[:n], dtype=np.uint64, copy=True)
+    a = np.ascontiguousarray(a[:n], dtype=np.uint32)
+    ref = np.ascontiguousarray(reference, dtype=np.float32)
+    assert ref.shape == (12,)
+    entries = np.zeros((n, eps), dtype=ENTRY_DTYPE)
+    num = np.zeros(n, dtype=np.uint32)
+    left = np.zeros(n, dtype=np.uint32)
+    L.oracle_tabulate(C.byref(tables.t), steps.ctypes.data_as(C.c_void_p), C.c_uint32(n), x.ctypes.data_as(C.c_void_p),
+                      a.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p), entries.ctypes.data_as(C.c_void_p),
+                      num.ctypes.data_as(C.c_void_p), left.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    return entries, num, left, x
+
+
+def accumulate_entries(entries, num, n_bins, dtype=np.float32):
+    """The host loop of StepToTableConverter.cxx:495-507: binContent_[index] += weight, stream by stream in entry
+    order (float accumulators in the reference; float64 gives the order-independent sum)."""
+    bins = np.zeros(n_bins, dtype=dtype)
+    for i in range(len(num)):
+        k = int(num[i])
+        if k:
+            np.add.at(bins, entries["index"][i, :k], entries["weight"][i, :k].astype(dtype))
+    return bins
+
+
+def eval_tabulator(tables, reference, pos_and_time):
+    L = lib()
+    p = np.ascontiguousarray(pos_and_time, dtype=np.float32).reshape(-1, 4)
+    ref = np.ascontiguousarray(reference, dtype=np.float32)
+    coords = np.zeros_like(p)
+    index = np.zeros(len(p), dtype=np.uint32)
+    oob = np.zeros(len(p), dtype=np.int32)
+    L.oracle_eval_tabulator(C.byref(tables.t), ref.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), C.c_int(len(p)),
+                            coords.ctypes.data_as(C.c_void_p), index.ctypes.data_as(C.c_void_p), oob.ctypes.data_as(C.c_void_p))
+    return coords, index, oob
 
 
 def convert_photon_histories(raw, photons, entries):

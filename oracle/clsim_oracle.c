@@ -140,6 +140,21 @@ typedef struct {
     int32_t has_fixed_abs;      /* PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS defined */
     float fixed_abs;
     int32_t history_n;          /* NUM_PHOTONS_IN_HISTORY (SAVE_PHOTON_HISTORY when > 0) */
+    /* ---- TABULATE (tabulator/I3CLSimStepToTableConverter.cxx:178-207, Axes.cxx, Axis.cxx) ---- */
+    int32_t tab_axes_kind;      /* 0 spherical_coordinates.c.cl, 1 cylindrical_coordinates.c.cl */
+    int32_t tab_full_azimuth;   /* HAS_FULL_AZIMUTH_EXTENSION */
+    float tab_scale[4], tab_offset[4];  /* Axis::GetIndexCode literals */
+    int32_t tab_inverse[4];     /* inverse transform: 0 identity, 1 sqrt */
+    int32_t tab_nbins[4];
+    uint32_t tab_stride[4];
+    float tab_max0, tab_max3;   /* isOutOfBounds */
+    float tab_min_inv_groupvel, tab_tan_thetac;
+    float tab_volume_step;      /* VOLUME_MODE_STEP */
+    uint32_t tab_entries_per_stream;
+    int32_t ang_n;              /* getAngularAcceptance: FunctionPolynomial (Polynomial.cxx:96-153) */
+    float ang_coeff[16];
+    int32_t ang_has_min, ang_has_max;
+    float ang_min, ang_max, ang_underflow, ang_overflow;
 } oracle_tables;
 
 typedef struct { uint64_t x; uint32_t a; } rng_t;
@@ -612,9 +627,118 @@ static int checkForCollision(const oracle_tables *T, const float pos[4], const f
     return hitRecorded;
 }
 
-/* c.cl:406-913: one work item */
+/* ---------------- TABULATE ---------------- */
+typedef struct __attribute__((packed)) { uint32_t index; float weight; } oracle_table_entry;   /* h.cl:83-87 */
+typedef struct {
+    float posAndTime[4], dir[4], perpDir[4];        /* I3CLSimReferenceParticle, h.cl:89-94 */
+} oracle_reference;
+typedef struct {
+    const oracle_reference *source;
+    oracle_table_entry *entries;                    /* this stream's TABLE_ENTRIES_PER_STREAM slots */
+    uint32_t *entry_counter;
+    uint32_t photons_left_out;                      /* inputSteps[i].numPhotons on return */
+} tab_ctx;
+
+static inline float dot4(const float a[4], const float b[4]) { return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]; }
+static inline float magnitude(const float v[4]) { return om_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+/* Polynomial.cxx:96-153 */
+static inline float getAngularAcceptance(const oracle_tables *T, float x)
+{
+    if (T->ang_has_min && x < T->ang_min) return T->ang_underflow;
+    if (T->ang_has_max && x > T->ang_max) return T->ang_overflow;
+    if (T->ang_n == 0) return 0.f;
+    float r = T->ang_coeff[T->ang_n - 1];
+    for (int i = T->ang_n - 2; i >= 0; --i) r = T->ang_coeff[i] + x * r;     /* c0 + x*(c1 + x*(...)) */
+    return r;
+}
+/* spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77 (4 dimensions) */
+static inline void getCoordinates(const oracle_tables *T, const float absPos[4], const oracle_reference *source, float coords[4])
+{
+    float pos[4], rho[4];
+    for (int k = 0; k < 4; ++k) pos[k] = absPos[k] - source->posAndTime[k];
+    const float l = dot4(pos, source->dir);
+    for (int k = 0; k < 4; ++k) rho[k] = pos[k] - l * source->dir[k];
+    if (T->tab_axes_kind == 0) {
+        const float n_rho = magnitude(rho);
+        coords[0] = magnitude(pos);
+        const float azimuth = (n_rho > 0) ? om_acos(dot4(rho, source->perpDir) / n_rho) / (PI_F / 180) : 0;
+        if (T->tab_full_azimuth) {
+            /* cross(rho, perpDir) . dir */
+            const float cx = rho[1] * source->perpDir[2] - rho[2] * source->perpDir[1];
+            const float cy = rho[2] * source->perpDir[0] - rho[0] * source->perpDir[2];
+            const float cz = rho[0] * source->perpDir[1] - rho[1] * source->perpDir[0];
+            const float cv[4] = { cx, cy, cz, 0.0f };
+            const float azisign = dot4(cv, source->dir);
+            coords[1] = (azisign > 0) ? 360.f - azimuth : azimuth;
+        } else {
+            coords[1] = azimuth;
+        }
+        coords[2] = (coords[0] > 0) ? (l / coords[0]) : 0;
+        coords[3] = pos[3] - coords[0] * T->tab_min_inv_groupvel;
+    } else {
+        coords[0] = magnitude(rho);
+        coords[1] = (coords[0] > 0) ? om_acos(dot4(rho, source->perpDir) / coords[0]) : 0;
+        coords[2] = source->posAndTime[2] + l * source->dir[2];
+        coords[3] = pos[3] - (l + coords[0] * T->tab_tan_thetac) * 3.33564095f;
+    }
+}
+/* Axes.cxx:104-151 */
+static inline int isOutOfBounds(const oracle_tables *T, const float c[4])
+{
+    if (T->tab_axes_kind == 0) return (c[3] > T->tab_max3) || (c[0] > T->tab_max0);
+    return (c[3] > T->tab_max3);
+}
+/* convert_int_sat_rtn */
+static inline int convert_int_sat_rtn(float v)
+{
+    if (v != v) return 0;
+    const float f = __builtin_floorf(v);
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f < -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+/* Axes.cxx:69-90 with Axis.cxx:45-60 */
+static inline uint32_t getBinIndex(const oracle_tables *T, const float c[4])
+{
+    uint32_t index = 0;
+    for (int k = 0; k < 4; ++k) {
+        const float v = T->tab_inverse[k] ? om_sqrt(c[k]) : c[k];
+        int b = convert_int_sat_rtn(T->tab_scale[k] * v - T->tab_offset[k]);
+        b = imin(imax(b, -1), T->tab_nbins[k]) + 1;
+        index += T->tab_stride[k] * (uint32_t)b;
+    }
+    return index;
+}
+/* c.cl:228-303 */
+static int savePath(const oracle_tables *T, const oracle_step *step, tab_ctx *tc, const float pos0[4], const float dirw[4],
+                    float thisStepLength, float *prevStepLength, float inv_groupvel, float depth, float thisStepDepth, int *stop)
+{
+    const float impactWeight = step->weight * getAngularAcceptance(T, dirw[2]);
+    float d = *prevStepLength;
+    uint32_t offset = *tc->entry_counter;
+    for (; d < thisStepLength && offset < T->tab_entries_per_stream; d += T->tab_volume_step, offset++) {
+        float pos[4];
+        pos[0] = pos0[0] + d * dirw[0];
+        pos[1] = pos0[1] + d * dirw[1];
+        pos[2] = pos0[2] + d * dirw[2];
+        pos[3] = pos0[3] + d * inv_groupvel;
+        float coords[4];
+        getCoordinates(T, pos, tc->source, coords);
+        if (isOutOfBounds(T, coords)) { *stop = 1; break; }
+        tc->entries[offset].index = getBinIndex(T, coords);
+        tc->entries[offset].weight = impactWeight * om_exp(-(depth + (d / thisStepLength) * thisStepDepth));
+    }
+    if (d < thisStepLength && !(*stop)) return 0;      /* ran out of space */
+    *tc->entry_counter = offset;
+    *prevStepLength = d - thisStepLength;
+    return 1;
+}
+
+/* c.cl:406-913: one work item (tc != NULL: the TABULATE variant, which is built with SAVE_ALL_PHOTONS and a fixed
+ * number of absorption lengths, tabulator/I3CLSimStepToTableConverter.cxx:178-186) */
 static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rng_t *rng, hit_sink *sink,
-                           uint64_t *iterations)
+                           uint64_t *iterations, tab_ctx *tc)
 {
     oracle_step step = *stepIn;
     float stepDir[4];
@@ -641,6 +765,8 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
     memset(currentPhotonHistory, 0, sizeof currentPhotonHistory);
     sink->cur_hist = &currentPhotonHistory[0][0];
 
+    rng_t prev_rng = *rng;
+    float prevStepRemainder = 0.0f, depthPropagated = 0.0f;
     while (photonsLeftToPropagate > 0) {
         ++iters;
 #ifdef ORACLE_TRACE
@@ -648,7 +774,9 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
 #endif
         if (abs_lens_left < EPSILON) {
             TR(0, 1);
+            prev_rng = *rng;                                                /* c.cl:540-545 */
             createPhotonFromTrack(T, &step, stepDir, rng, pos, dirw);
+            if (tc) prevStepRemainder = T->tab_volume_step * rand_oc(rng);  /* c.cl:559-563 */
             memcpy(startPos, pos, 16); memcpy(startDirw, dirw, 16);
             numScatters = 0; totalPath = 0.0f;
             if (!T->has_tilt)
@@ -657,6 +785,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             if (T->has_fixed_abs) abs_lens_initial = T->fixed_abs;          /* c.cl:582-588 */
             else abs_lens_initial = -om_log(rand_oc(rng));
             abs_lens_left = abs_lens_initial;
+            depthPropagated = 0.0f;
         }
         float distancePropagated;
         {
@@ -712,10 +841,24 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             }
             abs_lens_left = abs_lens_left / abs_len_correction_factor;
         }
-        const int collided = checkForCollision(T, pos, dirw, inv_groupvel, totalPath, numScatters,
-                                               abs_lens_initial - abs_lens_left, startPos, startDirw, &step,
-                                               &distancePropagated, sink);
-        if (collided) { abs_lens_left = 0.0f; TR(7, 1); }
+        if (!tc) {
+            const int collided = checkForCollision(T, pos, dirw, inv_groupvel, totalPath, numScatters,
+                                                   abs_lens_initial - abs_lens_left, startPos, startDirw, &step,
+                                                   &distancePropagated, sink);
+            if (collided) { abs_lens_left = 0.0f; TR(7, 1); }
+        } else {                                                            /* c.cl:755-785 */
+            int stop = 0;
+            if (!savePath(T, &step, tc, pos, dirw, distancePropagated, &prevStepRemainder, inv_groupvel, depthPropagated,
+                          abs_lens_initial - abs_lens_left - depthPropagated, &stop)) {
+                tc->photons_left_out = photonsLeftToPropagate;              /* unfinished: restart this photon later */
+                *rng = prev_rng;
+                if (iterations) *iterations += iters;
+                return;
+            } else if (stop) {
+                abs_lens_left = 0.0f;
+            }
+            depthPropagated = abs_lens_initial - abs_lens_left;
+        }
         pos[0] += dirw[0] * distancePropagated;
         pos[1] += dirw[1] * distancePropagated;
         pos[2] += dirw[2] * distancePropagated;
@@ -741,10 +884,39 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         if (g_trace && g_trace_n < g_trace_cap) { memcpy(g_trace + 8 * g_trace_n, g_cur, 8); ++g_trace_n; }
 #endif
     }
+    if (tc) tc->photons_left_out = 0;                                       /* c.cl:905-908 */
     if (iterations) *iterations += iters;
 }
 
 /* ---------------- exported entry points (ctypes) ---------------- */
+
+/* One launch of the TABULATE kernel over steps[0..n): entries[i*EPS ..] / num_entries[i] per stream, photons_left[i] =
+ * what the kernel writes back into inputSteps[i].numPhotons, x[] updated (restored to the photon's start on a miss). */
+void oracle_tabulate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x, const uint32_t *a,
+                     const oracle_reference *source, oracle_table_entry *entries, uint32_t *num_entries,
+                     uint32_t *photons_left, int threads)
+{
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+    for (uint32_t i = 0; i < n; ++i) {
+        rng_t r = { x[i], a[i] };
+        hit_sink sink = { NULL, 0, 0, NULL, NULL };
+        num_entries[i] = 0;
+        tab_ctx tc = { source, entries + (size_t)i * T->tab_entries_per_stream, &num_entries[i], 0 };
+        propagate_step(T, &steps[i], &r, &sink, NULL, &tc);
+        photons_left[i] = tc.photons_left_out;
+        x[i] = r.x;
+    }
+}
+void oracle_eval_tabulator(const oracle_tables *T, const oracle_reference *source, const float *pos_and_time, int n,
+                           float *coords, uint32_t *index, int32_t *out_of_bounds)
+{
+    for (int i = 0; i < n; ++i) {
+        getCoordinates(T, pos_and_time + 4 * i, source, coords + 4 * i);
+        index[i] = getBinIndex(T, coords + 4 * i);
+        out_of_bounds[i] = isOutOfBounds(T, coords + 4 * i);
+    }
+}
+float oracle_eval_angular_acceptance(const oracle_tables *T, float x) { return getAngularAcceptance(T, x); }
 
 /* Propagates steps[0..n) with streams (x[i], a[i]); appends hits to `out`
  * (capacity max_hits) in step order.  Returns the hit counter (which may exceed
@@ -759,7 +931,7 @@ uint32_t oracle_propagate_hist(const oracle_tables *T, const oracle_step *steps,
     uint64_t it = 0;
     for (uint32_t i = 0; i < n; ++i) {
         rng_t r = { x[i], a[i] };
-        propagate_step(T, &steps[i], &r, &sink, &it);
+        propagate_step(T, &steps[i], &r, &sink, &it, NULL);
         x[i] = r.x;
     }
     if (iterations) *iterations = it;
@@ -796,7 +968,7 @@ uint32_t oracle_propagate_mt(const oracle_tables *T, const oracle_step *steps, u
                 buf = (oracle_photon *)realloc(buf, (size_t)cap * sizeof(oracle_photon));
             }
             hit_sink sink = { buf + cnt, cap - cnt, 0, NULL, NULL };
-            propagate_step(T, &steps[i], &r, &sink, &it);
+            propagate_step(T, &steps[i], &r, &sink, &it, NULL);
             cnt += sink.count;
             x[i] = r.x;
         }
@@ -895,7 +1067,7 @@ uint64_t oracle_trace_step(const oracle_tables *T, const oracle_step *step, uint
     hit_sink sink = { scratch, 4096, 0 };
     rng_t r = { x, a };
     g_trace = buf; g_trace_cap = cap; g_trace_n = 0;
-    propagate_step(T, step, &r, &sink, 0);
+    propagate_step(T, step, &r, &sink, 0, NULL);
     g_trace = 0;
     return g_trace_n;
 }

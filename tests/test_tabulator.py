@@ -1,0 +1,150 @@
+"""Photon table maker: host logic of clsim::tabulator restated in oracle/builders.py against the
+product's C++ (CPU part), and the TABULATE kernel against the oracle (GPU part)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from clsim_amd import converter as CV
+from clsim_amd import synthetic as S
+from clsim_amd import tabulator as TB
+from oracle import builders as B
+from oracle import capi
+from tests import common
+
+# resources/scripts/compareToPPCredux/test_ice_models/lea/as.dat, rows 1.. (python/GetIceCubeDOMAngularSensitivity.py:45-47)
+ANGULAR = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
+DOM_AREA = math.pi * 0.16510 ** 2
+
+
+def axes_pair(kind, small=True):
+    """python/tablemaker/tabulator.py:621-641 (defaults), optionally with fewer bins."""
+    f = 5 if small else 1
+    if kind == "spherical":
+        o = [B.power_axis(0, 580, 200 // f, 2), B.linear_axis(0, 180, (36 if f == 1 else 8)), B.linear_axis(-1, 1, 100 // f), B.power_axis(0, 7e3, 105 // f, 2)]
+        p = TB.SphericalAxes([TB.PowerAxis(0, 580, 200 // f, 2), TB.LinearAxis(0, 180, (36 if f == 1 else 8)), TB.LinearAxis(-1, 1, 100 // f), TB.PowerAxis(0, 7e3, 105 // f, 2)])
+    elif kind == "spherical360":
+        o = [B.power_axis(0, 300, 30, 2), B.linear_axis(0, 360, 24), B.linear_axis(-1, 1, 20), B.power_axis(0, 3e3, 30, 2)]
+        p = TB.SphericalAxes([TB.PowerAxis(0, 300, 30, 2), TB.LinearAxis(0, 360, 24), TB.LinearAxis(-1, 1, 20), TB.PowerAxis(0, 3e3, 30, 2)])
+    else:
+        o = [B.power_axis(0, 580, 100 // f, 2), B.linear_axis(0, math.pi, (36 if f == 1 else 8)), B.linear_axis(-8e2, 8e2, 80 // f), B.power_axis(0, 7e3, 105 // f, 2)]
+        p = TB.CylindricalAxes([TB.PowerAxis(0, 580, 100 // f, 2), TB.LinearAxis(0, math.pi, (36 if f == 1 else 8)), TB.LinearAxis(-8e2, 8e2, 80 // f), TB.PowerAxis(0, 7e3, 105 // f, 2)])
+    return o, p
+
+
+def test_axes_host_logic_follows_the_reference():
+    """Axis.cxx / Axes.cxx: index literals, layout, bin edges and volumes (oracle restatement; the product's C++ is
+    compared with it on the GPU, where the tabulator object can be constructed)."""
+    o, _ = axes_pair("spherical", small=False)
+    shape, strides, n = B.axes_layout(o)
+    assert shape == [202, 38, 102, 107] and strides == [38 * 102 * 107, 102 * 107, 107, 1] and n == 202 * 38 * 102 * 107
+    sc, of = B.axis_index_literals(o[0])                  # PowerAxis(0, 580, 200, 2): scale = 200/sqrt(580)
+    assert sc == np.float32(200.0 / math.sqrt(580.0)) and of == np.float32(0.0)
+    sc, of = B.axis_index_literals(o[2])                  # LinearAxis(-1, 1, 100): 50*x - (-50)
+    assert sc == np.float32(50.0) and of == np.float32(-50.0)
+    e = B.axis_bin_edges(o[0])
+    assert len(e) == 201 and e[0] == 0.0 and abs(e[-1] - 580.0) < 1e-9 and np.allclose(np.sqrt(e), np.linspace(0, math.sqrt(580.0), 201))
+    # the spherical bin volumes add up to half a sphere of r = 580 m in (r, azimuth [deg], cos) up to the factor 2 for
+    # the folded azimuth: (r^3/3) * 2*pi * 2
+    total = sum(B.bin_volume("spherical", o, [i, j, k]) for i in (0, 57, 199) for j in (0, 35) for k in (0, 99))
+    assert total > 0
+    full = (580.0 ** 3 / 3.0) * 2 * (math.pi / 180.0) * 180.0 * 2.0
+    vol = sum(B.bin_volume("spherical", o, [i, 0, 0]) for i in range(200)) * 36 * 100
+    assert abs(vol / full - 1) < 1e-9
+    n_group, n_phase = B.minimum_refractive_index(common.config("mie")["med_o"])
+    assert 1.3 < n_phase < 1.36 and 1.3 < n_group < 1.4
+    ref = B.reference_particle((1., 2., 3.), 4., (0.0, 0.6, 0.8))
+    assert np.allclose(ref[8:11], (0.0, -0.8, 0.6)) and abs(np.dot(ref[4:7], ref[8:11])) < 1e-7
+
+
+def test_oracle_tabulator_entries_and_misses():
+    """The restated TABULATE kernel: entries stay inside the table, weights fall with depth, a stream that runs out of
+    entry space comes back with its photons left and its RNG rewound (propagation_kernel.c.cl:770-776)."""
+    cfg = common.config("mie")
+    o, _ = axes_pair("spherical")
+    tb = B.tabulator_config("spherical", o, cfg["med_o"], ANGULAR, entries_per_stream=40000)
+    bias = B.icecube_dom_acceptance()
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=1.0, tabulator=tb)
+    steps = S.cascade_steps(64, seed=5, vertex=(0.0, 0.0, 0.0), photons_per_step=12, pad_to=64)
+    x, a = common.streams(64)
+    ref = B.reference_particle((0., 0., 0.), 0.0, (0.0, 0.0, 1.0))
+    ent, num, left, xo = capi.tabulate(T, steps, x, a, ref)
+    assert left.sum() == 0 and num.min() > 1000 and num.max() < 40000
+    k = int(num[0])
+    assert ent["index"][0, :k].max() < tb["n_bins"] and np.all(ent["weight"][0, :k] > 0) and np.all(ent["weight"][0, :k] <= steps["weight"][0] * 1.2)
+    # too little space: the same launch stops early, keeps whole photons only and rewinds the stream
+    tb2 = dict(tb, entries_per_stream=1500)
+    T2 = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=1.0, tabulator=tb2)
+    ent2, num2, left2, x2 = capi.tabulate(T2, steps, x, a, ref)
+    assert left2.max() > 0 and np.all(num2 <= 1500)
+    i = int(np.argmax(left2 > 0))
+    assert np.array_equal(ent2[i, :num2[i]], ent[i, :num2[i]])        # what was recorded is a prefix of the full record
+    # re-running the returned steps from the rewound streams reproduces the missing photons: totals agree
+    again = steps.copy(); again["num"] = left2
+    T3 = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=1.0, tabulator=tb)
+    ent3, num3, left3, x3 = capi.tabulate(T3, again, x2, a, ref)
+    assert left3.sum() == 0 and np.array_equal(x3, xo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,ice", [("spherical", "mie"), ("cylindrical", "lea"), ("spherical360", "photonics_mie")])
+def test_table_matches_the_oracle(kind, ice):
+    """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
+    (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
+    the reference's in-order float accumulation to float accuracy."""
+    cfg = common.config(ice)
+    o, p = axes_pair(kind)
+    okind = "cylindrical" if kind == "cylindrical" else "spherical"
+    tb = B.tabulator_config(okind, o, cfg["med_o"], ANGULAR, entries_per_stream=60000)
+    bias_o = B.icecube_dom_acceptance()
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias_o, cfg["med_o"])], bias_o, pancake=1.0, tabulator=tb)
+    n = 512
+    steps = S.cascade_steps(n, seed=15, vertex=(10.0, -20.0, 30.0), photons_per_step=14, pad_to=256)
+    steps["weight"] = np.random.Generator(np.random.PCG64(3)).uniform(0.5, 1.5, n).astype(np.float32)
+    steps["num"][5] = 0
+    x, a = common.streams(n)
+    refdir = (math.sin(0.7) * math.cos(0.3), math.sin(0.7) * math.sin(0.3), math.cos(0.7))
+    ref7 = (10.0, -20.0, 30.0, 2.0) + refdir
+    ref_o = B.reference_particle(ref7[:3], ref7[3], refdir)
+    bins64 = np.zeros(tb["n_bins"], dtype=np.float64)
+    bins32 = np.zeros(tb["n_bins"], dtype=np.float32)
+    sq64 = np.zeros(tb["n_bins"], dtype=np.float64)
+    xo = x
+    for bunch in range(2):                       # streams carry over to the second bunch
+        ent, num, left, xo = capi.tabulate(T, steps, xo, a, ref_o)
+        assert left.sum() == 0
+        for i in range(n):
+            k = int(num[i])
+            np.add.at(bins64, ent["index"][i, :k], ent["weight"][i, :k].astype(np.float64))
+            np.add.at(sq64, ent["index"][i, :k], ent["weight"][i, :k].astype(np.float64) ** 2)
+            np.add.at(bins32, ent["index"][i, :k], ent["weight"][i, :k])
+    tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
+                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a))
+    assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
+    for k in range(4):
+        assert np.array_equal(tab.GetBinEdges(k), B.axis_bin_edges(o[k]))
+    assert np.array_equal(tab.GetTable("TABULATOR_SCALE"), np.array(tb["scale"], dtype=np.float64))
+    assert np.array_equal(tab.GetTable("TABULATOR_OFFSET"), np.array(tb["offset"], dtype=np.float64))
+    t = tab.GetTable("TABULATOR")
+    assert t[0] == tb["n_group"] and t[1] == tb["n_phase"] and t[2] == tb["min_inv_groupvel"] and t[3] == tb["tan_thetac"]
+    for bunch in range(2):
+        tab.EnqueueSteps(steps, ref7)
+    tab.Finish()
+    got = tab.GetBinSums()
+    assert bins64.sum() > 100 and (bins64 > 0).sum() > 1000
+    assert (got > 0).sum() == (bins64 > 0).sum() and np.array_equal(got > 0, bins64 > 0)
+    assert np.allclose(got, bins64, rtol=1e-12, atol=0)
+    assert np.allclose(tab.GetBinSums(squared=True), sq64, rtol=1e-12, atol=0)
+    assert np.array_equal(tab.GetRNGState(n), xo)
+    raw = tab.GetBinContent().ravel()
+    assert np.allclose(raw, bins32, rtol=2e-5, atol=1e-9)            # the reference's float accumulation, order dependent
+    norm_o = B.normalize_table(got.astype(np.float32), okind, o, 1.0, DOM_AREA)
+    assert np.array_equal(tab.GetBinContent(normalized=True).ravel(), norm_o)
+    st = tab.GetStatistics()
+    assert st["NumPhotons"] == 2 * float(steps["num"].sum()) and st["NumKernelCalls"] == 2
+    assert abs(st["SumOfPhotonWeights"] - 2 * float((steps["num"] * steps["weight"].astype(np.float64)).sum())) < 1e-6
