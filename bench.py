@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
     ap.add_argument("--photons-per-step", type=int, default=200)
     ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab"],
                     help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
-                         "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea")
+                         "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea; tab: the "
+                         "table-maker half of configs[4] (point cascade, default spherical axes, SPICE-Mie) -- prints its own line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="time EnqueueSteps -> GetConversionResult instead (host buffers, PCIe transfers and the index->ID "
@@ -85,6 +86,74 @@ def cpu_baseline(args, steps_np, seconds):
                       (n, args.photons_per_step, photons, hits, dt, cores)}
 
 
+def tabulator_bench(args, torch, device):
+    """Table maker (python/tablemaker/tabulator.py defaults): cascade-like steps at the origin,
+    spherical table 200 x 36 x 100 x 105 bins (+ under/overflow), SPICE-Mie, 42 absorption lengths per photon, one
+    path sample per metre.  Not the headline metric: prints photons/s and path samples/s of the TABULATE kernel and the
+    oracle's rate on the host cores (the reference runs this kernel as a single CPU work item)."""
+    import math
+    from clsim_amd import converter as CV
+    from clsim_amd import synthetic as S
+    from clsim_amd import tabulator as TB
+    n = (min(args.bunch, 1 << 17) // 256) * 256
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
+    axes = TB.SphericalAxes([TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)])
+    ang = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
+    a = CV.mwc_multipliers(n)
+    x = CV.seed_streams(a)
+    tab = TB.I3CLSimStepToTableConverterHIP(device, axes, False, medium, math.pi * 0.16510 ** 2, CV.GetIceCubeDOMAcceptance(),
+                                            TB.I3CLSimFunctionPolynomial(ang), (x, a))
+    steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=args.photons_per_step)
+    ref = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+    for _ in range(args.warmup):
+        tab.EnqueueSteps(steps, ref)
+    tab.Finish()
+    before = float(tab.GetBinSums().sum()) if args.warmup else 0.0
+    k0 = tab.GetStatistics()["KernelTimeMs"]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tab.EnqueueSteps(steps, ref)
+    tab.Finish()
+    elapsed = time.perf_counter() - t0
+    st = tab.GetStatistics()
+    kernel_ms = (st["KernelTimeMs"] - k0) / args.steps
+    photons = int(steps["num"].sum())
+    sums = tab.GetBinSums()
+    occupied = int((sums > 0).sum())
+    out = {"metric": "tabulated photons/sec (TABULATE kernel, 1 GPU)", "value": photons * args.steps / elapsed, "unit": "photons/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "kernel_ms_per_pass": kernel_ms, "photons_per_pass": photons, "table_bins": tab.n_bins, "occupied_bins": occupied,
+           "sum_of_weights_per_pass": (float(sums.sum()) - before) / args.steps,
+           "config": {"workload": "%d steps x %d photons at the origin, spherical axes 200x36x100x105, spice_mie, 42 absorption lengths, "
+                                  "1 m sampling; BASELINE.json configs[4] (tablemaker half)" % (n, args.photons_per_step)}}
+    if not args.no_cpu_baseline:
+        # path samples are counted by the oracle on a small sample of the same steps (they are the same on both sides)
+        from oracle import builders as B
+        from oracle import capi
+        capi.build()
+        cores = os.cpu_count() or 1
+        med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
+        o_axes = [B.power_axis(0, 580, 200, 2), B.linear_axis(0, 180, 36), B.linear_axis(-1, 1, 100), B.power_axis(0, 7e3, 105, 2)]
+        m = max(cores, 256)
+        small = steps[:m].copy()
+        small["num"] = 8
+        tb = B.tabulator_config("spherical", o_axes, med, ang, entries_per_stream=40000)
+        bias = B.icecube_dom_acceptance()
+        g = S.single_string_geometry()
+        geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+        T = capi.make_tables(med, geo, [B.cherenkov_wlen_generator(bias, med)], bias, pancake=1.0, tabulator=tb)
+        t1 = time.time()
+        ent, num, left, _ = capi.tabulate(T, small, x[:m], a[:m], B.reference_particle(ref[:3], ref[3], ref[4:]), threads=cores)
+        dt = time.time() - t1
+        done = int(small["num"].sum() - left.sum())
+        out["samples_per_photon"] = float(num.sum()) / max(done, 1)
+        out["path_samples_per_sec"] = out["samples_per_photon"] * out["value"]
+        out["cpu_baseline"] = {"value": done / dt, "unit": "photons/s", "cores": cores, "kind": "port",
+                               "sample": "%d steps x 8 photons (%d path samples) in %.1f s, %d threads; the reference runs this kernel "
+                                         "as ONE work item (StepToTableConverter.cxx:259)" % (m, int(num.sum()), dt, cores)}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     if args.workload == "c3":
@@ -108,6 +177,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "tab":
+        return tabulator_bench(args, torch, local_rank)
     n = (args.bunch // 512) * 512
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))

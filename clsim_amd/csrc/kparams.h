@@ -119,7 +119,11 @@ struct KParams {
     // ---- TABULATE variant (propagation_kernel.c.cl:228-303, 755-785; Axes.cxx; spherical/cylindrical_coordinates.c.cl) ----
     double *tab_bins;                   // one accumulator per table bin (+ under/overflow bins), atomically added
     double *tab_sq_bins;                // squared weights, or null
-    float tab_ref[12];                  // I3CLSimReferenceParticle: posAndTime, dir, perpDir
+    float tab_ref[12];                  // I3CLSimReferenceParticle: posAndTime, dir, perpDir (copied to LDS by the kernel)
+    // 25-word record in the LDS image: scale[4], offset[4], nbins[4], stride[4], inverse[4], max0, max3,
+    // min_inv_groupvel, tan_thetac, volume_step -- read from LDS inside the sampling loop (scalar loads there
+    // stall on every use: the loop's atomics make the compiler reload kernel arguments each trip)
+    uint32_t off_tab;
     int32_t tab_axes_kind, tab_full_azimuth;
     float tab_scale[4], tab_offset[4];  // Axis::GetIndexCode literals
     int32_t tab_inverse[4], tab_nbins[4];

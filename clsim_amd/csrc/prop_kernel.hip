@@ -653,20 +653,22 @@ DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float 
 // host adds up (tabulator/I3CLSimStepToTableConverter.cxx:495-507) and re-runs streams whose buffer overflowed; here
 // every sample goes straight into its bin with one hardware double-precision atomic add, so there is no buffer to
 // overflow.  Returns true when the photon left the table (isOutOfBounds): it is dropped (c.cl:781-784).
-DM bool save_path(KP P, const Photon &ph, float weight, float length, float &remainder, float depth, float this_depth)
+DM bool save_path(KP P, const uint32_t *ref_lds, const Photon &ph, float weight, float length, float &remainder, float depth, float this_depth)
 {
     const float impact = weight * angular_acceptance(P, ph.d.z);
-    const float vstep = P->tab_volume_step;
-    const float sx = P->tab_ref[0], sy = P->tab_ref[1], sz = P->tab_ref[2], st = P->tab_ref[3];
-    const float ux = P->tab_ref[4], uy = P->tab_ref[5], uz = P->tab_ref[6], uw = P->tab_ref[7];
-    const float qx = P->tab_ref[8], qy = P->tab_ref[9], qz = P->tab_ref[10], qw = P->tab_ref[11];
+    const uint32_t T = P->off_tab;
     const bool spherical = (P->tab_axes_kind == 0);
+    const bool full_azimuth = (P->tab_full_azimuth != 0);
+    const float vstep = ldsf(T + 24u);
+    double *bins = P->tab_bins, *sq_bins = P->tab_sq_bins;
+    auto R = [&](int k) { return __builtin_bit_cast(float, ref_lds[k]); };
     bool stop = false;
     float d = remainder;
     for (; d < length; d += vstep) {
         // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
-        const float px = (ph.px + d * ph.d.x) - sx, py = (ph.py + d * ph.d.y) - sy, pz = (ph.pz + d * ph.d.z) - sz;
-        const float pw = (ph.pt + d * ph.inv_groupvel) - st;
+        const float px = (ph.px + d * ph.d.x) - R(0), py = (ph.py + d * ph.d.y) - R(1), pz = (ph.pz + d * ph.d.z) - R(2);
+        const float pw = (ph.pt + d * ph.inv_groupvel) - R(3);
+        const float ux = R(4), uy = R(5), uz = R(6), uw = R(7), qx = R(8), qy = R(9), qz = R(10), qw = R(11);
         const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
         const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
         const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
@@ -674,7 +676,7 @@ DM bool save_path(KP P, const Photon &ph, float weight, float length, float &rem
         if (spherical) {
             c0 = dm::sqrt_(px * px + py * py + pz * pz);
             const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
-            if (P->tab_full_azimuth) {
+            if (full_azimuth) {
                 const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
                 const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
                 c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
@@ -682,29 +684,29 @@ DM bool save_path(KP P, const Photon &ph, float weight, float length, float &rem
                 c1 = azimuth;
             }
             c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
-            c3 = pw - c0 * P->tab_min_inv_groupvel;
-            if ((c3 > P->tab_max3) || (c0 > P->tab_max0)) { stop = true; break; }      // Axes.cxx:104-116
+            c3 = pw - c0 * ldsf(T + 22u);
+            if ((c3 > ldsf(T + 21u)) || (c0 > ldsf(T + 20u))) { stop = true; break; }  // Axes.cxx:104-116
         } else {
             c0 = n_rho;
             c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
-            c2 = sz + l * uz;
-            c3 = pw - (l + c0 * P->tab_tan_thetac) * 3.33564095f;
-            if (c3 > P->tab_max3) { stop = true; break; }                               // Axes.cxx:140-151
+            c2 = R(2) + l * uz;
+            c3 = pw - (l + c0 * ldsf(T + 23u)) * 3.33564095f;
+            if (c3 > ldsf(T + 21u)) { stop = true; break; }                             // Axes.cxx:140-151
         }
         // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
         const float c[4] = {c0, c1, c2, c3};
         uint32_t index = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float v = P->tab_inverse[k] ? dm::sqrt_(c[k]) : c[k];
-            const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
+            const float v = ldsu(T + 16u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
+            const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 4u + (uint32_t)k));
             int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-            b = clampi(b, -1, P->tab_nbins[k]) + 1;
-            index += P->tab_stride[k] * (uint32_t)b;
+            b = clampi(b, -1, (int)ldsu(T + 8u + (uint32_t)k)) + 1;
+            index += ldsu(T + 12u + (uint32_t)k) * (uint32_t)b;
         }
         const float w = impact * dm::exp_(-(depth + (d / length) * this_depth));
-        unsafeAtomicAdd(P->tab_bins + index, (double)w);
-        if (P->tab_sq_bins) unsafeAtomicAdd(P->tab_sq_bins + index, (double)w * (double)w);
+        unsafeAtomicAdd(bins + index, (double)w);
+        if (sq_bins) unsafeAtomicAdd(sq_bins + index, (double)w * (double)w);
     }
     remainder = d - length;
     return stop;
@@ -786,6 +788,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         for (uint32_t i = threadIdx.x; i < words; i += kBlock) lds_words[i] = src[i];
     }
     uint32_t *stage = lds_words + P0->table_words + (threadIdx.x >> 6) * (kStageRecords * kStubWords);
+    // TABULATE: no hits are staged; the first 12 words behind the image hold the reference particle instead
+    if (TAB && threadIdx.x < 12u) lds_words[P0->table_words + threadIdx.x] = __builtin_bit_cast(uint32_t, P0->tab_ref[threadIdx.x]);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -902,7 +906,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
                 const KP P = fresh_params(P0);
                 const float travelled = P->fixed_abs - ph.abs_lens_left;
-                if (save_path(P, ph, P->steps[sidx].weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth))
+                if (save_path(P, lds_words + P->table_words, ph, P->steps[sidx].weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth))
                     ph.abs_lens_left = 0.0f;
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
             } else if (!(distance < free_flight)) {

@@ -106,6 +106,19 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     P.tab_min_inv_groupvel = to_float_literal(n_group_ / units::c_light);                    // :192-193
     P.tab_tan_thetac = to_float_literal(std::sqrt(n_phase_ * n_phase_ - 1.));                 // :194-195
     P.tab_volume_step = to_float_literal(step_length_);                                       // :191
+    {   // sampling-loop constants (kparams.h: off_tab)
+        std::vector<uint32_t> &img = tables_.lds_image;
+        while (img.size() % 4) img.push_back(0u);
+        P.off_tab = static_cast<uint32_t>(img.size());
+        auto putf = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); img.push_back(u); };
+        for (int k = 0; k < 4; ++k) putf(P.tab_scale[k]);
+        for (int k = 0; k < 4; ++k) putf(P.tab_offset[k]);
+        for (int k = 0; k < 4; ++k) img.push_back(static_cast<uint32_t>(P.tab_nbins[k]));
+        for (int k = 0; k < 4; ++k) img.push_back(P.tab_stride[k]);
+        for (int k = 0; k < 4; ++k) img.push_back(static_cast<uint32_t>(P.tab_inverse[k]));
+        putf(P.tab_max0); putf(P.tab_max3); putf(P.tab_min_inv_groupvel); putf(P.tab_tan_thetac); putf(P.tab_volume_step);
+        while (img.size() % 4) img.push_back(0u);
+    }
     {   // getAngularAcceptance: coefficients are appended to the LDS image
         std::vector<uint32_t> &img = tables_.lds_image;
         P.off_ang = static_cast<uint32_t>(img.size());
