@@ -406,7 +406,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         }
     }
     {   // string proximity map (kparams.h).  Everything in double, rounded towards "search anyway".
-        int n = 256;
+        // resolution hardly matters (measured 32^2 ... 1024^2: within 1.5 %); a 64^2 copy in LDS was 1.5 % SLOWER
+        // than the L2-resident map (the load is issued before the layer walk and is long back when it is needed)
+        int n = 128;
         if (const char *e = std::getenv("CLSIMHIP_PROX_N")) n = std::max(8, std::min(4096, std::atoi(e)));
         double x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY, reach = 0.;
         for (int s = 0; s < G.num_strings; ++s) {
