@@ -49,6 +49,8 @@ constexpr int kMinWavesPerSimd = CLSIMHIP_MIN_WAVES;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStageRecords = 8;                 // hit stubs staged per wave and flush
 constexpr int kStubWords = 16;
+constexpr int kTabSlots = 512;                   // TABULATE: path samples one wave pools per loop trip
+constexpr int kTabWaveWords = 2 * kTabSlots + 64;
 constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
 constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
 constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
@@ -653,62 +655,155 @@ DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float 
 // host adds up (tabulator/I3CLSimStepToTableConverter.cxx:495-507) and re-runs streams whose buffer overflowed; here
 // every sample goes straight into its bin with one hardware double-precision atomic add, so there is no buffer to
 // overflow.  Returns true when the photon left the table (isOutOfBounds): it is dropped (c.cl:781-784).
-DM bool save_path(KP P, const uint32_t *ref_lds, const Photon &ph, float weight, float length, float &remainder, float depth, float this_depth)
+// One path sample (the body of the loop of c.cl:256-287): the table bin of the point at distance d along the segment
+// and whether it is out of bounds (isOutOfBounds, Axes.cxx:104-116, 140-151).
+struct Segment { float px, py, pz, pt, dx, dy, dz, igv; };
+DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uint32_t &index)
 {
-    const float impact = weight * angular_acceptance(P, ph.d.z);
     const uint32_t T = P->off_tab;
-    const bool spherical = (P->tab_axes_kind == 0);
-    const bool full_azimuth = (P->tab_full_azimuth != 0);
-    const float vstep = ldsf(T + 24u);
-    double *bins = P->tab_bins, *sq_bins = P->tab_sq_bins;
     auto R = [&](int k) { return __builtin_bit_cast(float, ref_lds[k]); };
-    bool stop = false;
-    float d = remainder;
-    for (; d < length; d += vstep) {
-        // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
-        const float px = (ph.px + d * ph.d.x) - R(0), py = (ph.py + d * ph.d.y) - R(1), pz = (ph.pz + d * ph.d.z) - R(2);
-        const float pw = (ph.pt + d * ph.inv_groupvel) - R(3);
-        const float ux = R(4), uy = R(5), uz = R(6), uw = R(7), qx = R(8), qy = R(9), qz = R(10), qw = R(11);
-        const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
-        const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
-        const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
-        float c0, c1, c2, c3;
-        if (spherical) {
-            c0 = dm::sqrt_(px * px + py * py + pz * pz);
-            const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
-            if (full_azimuth) {
-                const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
-                const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
-                c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
-            } else {
-                c1 = azimuth;
-            }
-            c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
-            c3 = pw - c0 * ldsf(T + 22u);
-            if ((c3 > ldsf(T + 21u)) || (c0 > ldsf(T + 20u))) { stop = true; break; }  // Axes.cxx:104-116
+    // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
+    const float px = (g.px + d * g.dx) - R(0), py = (g.py + d * g.dy) - R(1), pz = (g.pz + d * g.dz) - R(2);
+    const float pw = (g.pt + d * g.igv) - R(3);
+    const float ux = R(4), uy = R(5), uz = R(6), uw = R(7), qx = R(8), qy = R(9), qz = R(10), qw = R(11);
+    const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
+    const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
+    const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
+    float c0, c1, c2, c3;
+    if (P->tab_axes_kind == 0) {
+        c0 = dm::sqrt_(px * px + py * py + pz * pz);
+        const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
+        if (P->tab_full_azimuth) {
+            const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
+            const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
+            c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
         } else {
-            c0 = n_rho;
-            c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
-            c2 = R(2) + l * uz;
-            c3 = pw - (l + c0 * ldsf(T + 23u)) * 3.33564095f;
-            if (c3 > ldsf(T + 21u)) { stop = true; break; }                             // Axes.cxx:140-151
+            c1 = azimuth;
         }
-        // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
-        const float c[4] = {c0, c1, c2, c3};
-        uint32_t index = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float v = ldsu(T + 16u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
-            const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 4u + (uint32_t)k));
-            int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-            b = clampi(b, -1, (int)ldsu(T + 8u + (uint32_t)k)) + 1;
-            index += ldsu(T + 12u + (uint32_t)k) * (uint32_t)b;
-        }
-        const float w = impact * dm::exp_(-(depth + (d / length) * this_depth));
-        unsafeAtomicAdd(bins + index, (double)w);
-        if (sq_bins) unsafeAtomicAdd(sq_bins + index, (double)w * (double)w);
+        c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
+        c3 = pw - c0 * ldsf(T + 22u);
+        if ((c3 > ldsf(T + 21u)) || (c0 > ldsf(T + 20u))) return true;
+    } else {
+        c0 = n_rho;
+        c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
+        c2 = R(2) + l * uz;
+        c3 = pw - (l + c0 * ldsf(T + 23u)) * 3.33564095f;
+        if (c3 > ldsf(T + 21u)) return true;
     }
-    remainder = d - length;
+    // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
+    const float c[4] = {c0, c1, c2, c3};
+    index = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v = ldsu(T + 16u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
+        const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 4u + (uint32_t)k));
+        int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
+        b = clampi(b, -1, (int)ldsu(T + 8u + (uint32_t)k)) + 1;
+        index += ldsu(T + 12u + (uint32_t)k) * (uint32_t)b;
+    }
+    return false;
+}
+DM void add_to_bin(KP P, uint32_t index, float w)
+{
+    unsafeAtomicAdd(P->tab_bins + index, (double)w);
+    if (P->tab_sq_bins) unsafeAtomicAdd(P->tab_sq_bins + index, (double)w * (double)w);
+}
+
+// savePath for a whole wave (called by all 64 lanes; `active` lanes bring one path segment each).
+// The reference walks each segment in its own work item: d = remainder; while (d < length) { sample(d); d += step; }
+// and drops the photon at the first sample that is out of bounds.  Segment lengths are exponentially distributed, so a
+// wave that lets every lane walk its own segment runs the longest walk with a fifth of its lanes busy.  Here the
+// wave pools its samples: every lane lists its d values (the same repeated float additions) in LDS, the pooled
+// samples are evaluated 64 at a time by whichever lanes, and a sample is added to the table unless its segment
+// went out of bounds at an earlier sample.  Bins and weights are those of the per-lane walk, bit for bit.
+// Returns true for lanes whose photon left the table.
+DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool active, const Photon &ph, float weight,
+                       float length, float &remainder, float depth, float this_depth)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const float vstep = ldsf(P->off_tab + 24u);
+    const float impact = active ? weight * angular_acceptance(P, ph.d.z) : 0.0f;
+    // number of samples and the value d ends with
+    uint32_t n = 0;
+    float d_end = remainder;
+    if (active) for (; d_end < length; d_end += vstep) ++n;
+    // exclusive prefix sum over the wave
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t first = incl - n;
+    bool stop = false;
+    if (total == 0u) {
+        // nothing to record
+    } else if (total > (uint32_t)kTabSlots) {
+        // (rare) more samples than the pool holds: every lane walks its own segment
+        if (active) {
+            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
+            float d = remainder;
+            for (; d < length; d += vstep) {
+                uint32_t index;
+                if (sample_bin(P, ref_lds, g, d, index)) { stop = true; break; }
+                add_to_bin(P, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
+            }
+            d_end = d;
+        }
+    } else {
+        uint32_t *slot_d = wave_lds, *slot_owner = wave_lds + kTabSlots;
+        int *first_oob = reinterpret_cast<int *>(wave_lds + 2 * kTabSlots);
+        first_oob[lane] = 0x7fffffff;
+        if (active) {
+            float d = remainder;
+            for (uint32_t j = 0; j < n; ++j, d += vstep) {
+                slot_d[first + j] = __builtin_bit_cast(uint32_t, d);
+                slot_owner[first + j] = lane | (j << 8);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t slot = base + lane;
+            const bool have = slot < total;
+            const uint32_t tag = have ? slot_owner[slot] : 0u;
+            const int owner = (int)(tag & 0xffu);
+            const int j = (int)(tag >> 8);
+            const float d = have ? __builtin_bit_cast(float, slot_d[slot]) : 0.0f;
+            // the owner's segment
+            Segment g;
+            g.px = __shfl(ph.px, owner); g.py = __shfl(ph.py, owner); g.pz = __shfl(ph.pz, owner); g.pt = __shfl(ph.pt, owner);
+            g.dx = __shfl(ph.d.x, owner); g.dy = __shfl(ph.d.y, owner); g.dz = __shfl(ph.d.z, owner);
+            g.igv = __shfl(ph.inv_groupvel, owner);
+            const float o_length = __shfl(length, owner), o_depth = __shfl(depth, owner), o_this = __shfl(this_depth, owner);
+            const float o_impact = __shfl(impact, owner);
+            uint32_t index = 0;
+            bool oob = false;
+            if (have) {
+                oob = sample_bin(P, ref_lds, g, d, index);
+                if (oob) atomicMin(&first_oob[owner], j);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (have && !oob && j < first_oob[owner])
+                add_to_bin(P, index, o_impact * dm::exp_(-(o_depth + (d / o_length) * o_this)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            const int s_ = first_oob[lane];
+            if (s_ != 0x7fffffff) {
+                stop = true;
+                d_end = __builtin_bit_cast(float, slot_d[first + (uint32_t)s_]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (active) remainder = d_end - length;
     return stop;
 }
 
@@ -902,16 +997,22 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         if (run) {
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
-            if (TAB) {
-                // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
-                const KP P = fresh_params(P0);
-                const float travelled = P->fixed_abs - ph.abs_lens_left;
-                if (save_path(P, lds_words + P->table_words, ph, P->steps[sidx].weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth))
-                    ph.abs_lens_left = 0.0f;
-                ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
-            } else if (!(distance < free_flight)) {
+            if (!TAB && !(distance < free_flight)) {
                 // the search cannot find a DOM closer than the nearest string cylinder: skip it when the step ends before
                 hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+            }
+        }
+        if (TAB) {
+            // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
+            const KP P = fresh_params(P0);
+            const float travelled = P->fixed_abs - ph.abs_lens_left;
+            const float weight = run ? P->steps[sidx].weight : 0.0f;
+            uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
+            const bool left_table = save_path_wave(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
+                                                   ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth);
+            if (run) {
+                if (left_table) ph.abs_lens_left = 0.0f;
+                ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
             }
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
@@ -1060,7 +1161,8 @@ template <int MED, bool TILT, bool ANISO, bool FLASHER, bool TAB>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
-    const size_t lds_bytes = (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4;
+    const size_t lds_bytes = TAB ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
+                                 : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4;
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
     static int resident = 0;            // per variant
     if (resident == 0) {

@@ -90,21 +90,24 @@ def test_oracle_tabulator_entries_and_misses():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,ice", [("spherical", "mie"), ("cylindrical", "lea"), ("spherical360", "photonics_mie")])
-def test_table_matches_the_oracle(kind, ice):
+@pytest.mark.parametrize("kind,ice,step_length", [("spherical", "mie", 1.0), ("cylindrical", "lea", 1.0), ("spherical360", "photonics_mie", 1.0),
+                                                  ("spherical", "lea", 0.2)])
+def test_table_matches_the_oracle(kind, ice, step_length):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
-    the reference's in-order float accumulation to float accuracy."""
+    the reference's in-order float accumulation to float accuracy.  step_length 0.2 m makes most waves exceed the
+    sample pool, i.e. exercises the per-lane walk next to the pooled one."""
     cfg = common.config(ice)
     o, p = axes_pair(kind)
     okind = "cylindrical" if kind == "cylindrical" else "spherical"
-    tb = B.tabulator_config(okind, o, cfg["med_o"], ANGULAR, entries_per_stream=60000)
+    fine = step_length != 1.0
+    tb = B.tabulator_config(okind, o, cfg["med_o"], ANGULAR, step_length=step_length, entries_per_stream=60000)
     bias_o = B.icecube_dom_acceptance()
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias_o, cfg["med_o"])], bias_o, pancake=1.0, tabulator=tb)
-    n = 512
-    steps = S.cascade_steps(n, seed=15, vertex=(10.0, -20.0, 30.0), photons_per_step=14, pad_to=256)
+    n = 256 if fine else 512
+    steps = S.cascade_steps(n, seed=15, vertex=(10.0, -20.0, 30.0), photons_per_step=(3 if fine else 14), pad_to=256)
     steps["weight"] = np.random.Generator(np.random.PCG64(3)).uniform(0.5, 1.5, n).astype(np.float32)
     steps["num"][5] = 0
     x, a = common.streams(n)
@@ -124,7 +127,7 @@ def test_table_matches_the_oracle(kind, ice):
             np.add.at(sq64, ent["index"][i, :k], ent["weight"][i, :k].astype(np.float64) ** 2)
             np.add.at(bins32, ent["index"][i, :k], ent["weight"][i, :k])
     tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
-                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a))
+                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=step_length)
     assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
     for k in range(4):
         assert np.array_equal(tab.GetBinEdges(k), B.axis_bin_edges(o[k]))
@@ -143,7 +146,7 @@ def test_table_matches_the_oracle(kind, ice):
     assert np.array_equal(tab.GetRNGState(n), xo)
     raw = tab.GetBinContent().ravel()
     assert np.allclose(raw, bins32, rtol=2e-5, atol=1e-9)            # the reference's float accumulation, order dependent
-    norm_o = B.normalize_table(got.astype(np.float32), okind, o, 1.0, DOM_AREA)
+    norm_o = B.normalize_table(got.astype(np.float32), okind, o, step_length, DOM_AREA)
     assert np.array_equal(tab.GetBinContent(normalized=True).ravel(), norm_o)
     st = tab.GetStatistics()
     assert st["NumPhotons"] == 2 * float(steps["num"].sum()) and st["NumKernelCalls"] == 2
