@@ -153,3 +153,28 @@ def test_double_buffering_pipelines_bunches_with_identical_results():
         assert np.array_equal(conv.GetRNGState(n), xo)
         st = conv.GetStatistics()
         assert st["NumKernelCalls"] == len(bunches) and not conv.MorePhotonsAvailable()
+
+
+@pytest.mark.parametrize("slices,k_new", [(1, 8), (3, 8), (16, 8), (64, 1), (7, 64)])
+def test_ragged_bunch_under_every_schedule(slices, k_new, monkeypatch):
+    """Work-unit scheduling must not change results: a bunch whose steps hold 0 ... 1500 photons (empty steps, single
+    photons, steps longer than a slice, steps shorter than the slice grid) is cut into `slices` slices per step with
+    photon creation deferred until `k_new` lanes wait, and compared with the oracle, which knows neither."""
+    monkeypatch.setenv("CLSIMHIP_SLICES", str(slices))
+    monkeypatch.setenv("CLSIMHIP_K_NEW", str(k_new))
+    cfg = common.config("mie")
+    steps = common.steps_for(cfg, 2048, seed=77)
+    n = len(steps)
+    rng = np.random.Generator(np.random.PCG64(5))
+    num = rng.choice([0, 1, 2, 7, 63, 64, 65, 200, 399, 1500], size=n, p=[.1, .1, .1, .1, .1, .1, .1, .2, .08, .02])
+    steps["num"] = num.astype(np.uint32)
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    conv = common.product_converter(cfg, n)
+    ph_d, cnt_d = device_run(conv, steps, capacity=1 << 16)
+    assert cnt_d == cnt_o and cnt_o > 50
+    assert common.sort_photons(ph_d).tobytes() == common.sort_photons(ph_o).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)
+    # streams of empty steps are untouched
+    assert np.array_equal(x_o[num == 0], np.asarray(x)[:n][num == 0])
