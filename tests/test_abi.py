@@ -121,3 +121,15 @@ def test_safeprimes_file_formats(tmp_path):
     out = np.zeros(501, dtype=np.uint32)
     assert lib.clsimhip_mwc_multipliers_from_file(str(binary).encode(), out.ctypes.data_as(C.c_void_p), 501) == _lib.ERR_IO
     assert lib.clsimhip_mwc_multipliers_from_file(b"/nonexistent", out.ctypes.data_as(C.c_void_p), 1) == _lib.ERR_IO
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/clsimhip.h compiles as C99 with -pedantic and the record sizes hold."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "clsimhip.h"\n'
+                   'int main(void) { return (sizeof(clsimhip_step) == 48 && sizeof(clsimhip_photon) == 80) ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
