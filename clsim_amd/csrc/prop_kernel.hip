@@ -1178,22 +1178,36 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
     }
-    // Every resident workgroup slot is used: measured on the 1M-step bunch, 1792 workgroups (7 waves per
-    // SIMD, 2.3 steps per lane) beat a grid trimmed to a whole number of steps per lane (1366: -5 %,
-    // 1024: -10 %) -- latency hiding is worth more than an even tail.  CLSIMHIP_GRID overrides for tuning.
+    // Grid and slices per step.  The kernel is instruction-issue bound: from 5 waves per SIMD on, more resident waves
+    // add (almost) no throughput, but every resident lane is one more consumer of the same n steps, and a lane that
+    // sees only two or three steps per bunch schedules badly however they are sliced.  Measured on MI355X (200-photon
+    // steps, SPICE-Mie, n = 0.26M ... 4M, 5/6/7 workgroups per CU x 1/6/8/12/16 slices; r = steps per lane):
+    //   * use the largest grid (7, 6, 5 workgroups per CU) that still leaves r >= 4, at least 5 per CU
+    //     (1M steps: 5 per CU 1.71e9 photons/s, 7 per CU 1.49e9; 4M steps: 7 per CU 1.90e9, 5 per CU 1.78e9);
+    //   * r < 1: whole steps (slicing only adds hand-offs); r < 5: 12 slices; else 8.  16 and more slices never pay:
+    //     every configuration with 16 slices stalls at 1.5e9 photons/s, 24 at 1.2e9 (hand-off cost).
+    // CLSIMHIP_GRID / CLSIMHIP_SLICES (converter) override for tuning.
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
-    uint32_t grid = needed < (uint32_t)resident ? needed : (uint32_t)resident;
+    uint32_t grid = (uint32_t)resident;
+    {
+        int dev = 0, cus = 1;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus < 1) cus = 1;
+        const int per_cu = resident / cus;
+        const int floor_per_cu = per_cu < 5 ? per_cu : 5;
+        int chosen = floor_per_cu;
+        for (int k = per_cu; k >= floor_per_cu; --k)
+            if ((double)P.n_steps / ((double)cus * k * kBlock) >= 4.0) { chosen = k; break; }
+        grid = (uint32_t)(cus * chosen);
+    }
     if (const char *e = getenv("CLSIMHIP_GRID")) {
         const int g = atoi(e);
         if (g >= 1 && g <= resident) grid = (uint32_t)g;
     }
-    // Slices per step (0 = choose here).  Measured on MI355X, 200-photon steps, r = steps per resident lane:
-    // r < 2: slicing only makes lanes wait for their step's previous slice; 2 <= r < 2.6: 16 slices
-    // (+6..12 % over whole steps); 2.6 <= r < 3.5: 12 (+16 %); r >= 3.5: 8 (+8..11 %); more slices than that
-    // cost more in unit hand-outs than the shorter tail returns.
+    if (needed < grid) grid = needed;
     {
-        const double r = (double)P.n_steps / ((double)resident * kBlock);
-        if (P.slices <= 0) P.slices = (r < 2.0) ? 1 : (r < 2.6) ? 16 : (r < 3.5) ? 12 : 8;
+        const double r = (double)P.n_steps / ((double)grid * kBlock);
+        if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : (r < 5.0) ? 12 : 8;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0xffffffffull) P.slices = 1;    // 32-bit unit counter
     }
     {
