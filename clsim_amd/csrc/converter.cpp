@@ -51,7 +51,7 @@ Converter::~Converter()
     }
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
-    (void)hipFree(d_queue_); (void)hipFree(d_slice_done_); (void)hipFree(d_hist_ring_);
+    (void)hipFree(d_queue_); (void)hipFree(d_work_); (void)hipFree(d_hist_ring_);
 }
 
 void Converter::set_wlen_generators(std::vector<RandomValueData> g) { guard(); compiled_ = false; generators_ = std::move(g); }
@@ -224,7 +224,7 @@ void Converter::setup_device_buffers()
         hip_check(hipEventCreateWithFlags(&sl.counted, hipEventDisableTiming), "hipEventCreate");
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_slice_done_), max_workitems_ * sizeof(uint32_t)), "slice counters");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), max_workitems_ * sizeof(WorkRecord)), "work records");
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
 }
@@ -246,10 +246,9 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
         last_queue_ = P.queue;
     }
     hip_check(hipMemsetAsync(P.queue, 0, 16, stream), "reset step queue");
-    if (k_slices_ != 1) hip_check(hipMemsetAsync(d_slice_done_, 0, n * sizeof(uint32_t), stream), "reset slice counters");
     P.k_new = k_new_;
     P.slices = k_slices_;
-    P.slice_done = d_slice_done_;
+    P.work = d_work_;
     P.len_table = d_len_table_;
     P.prox_map = d_prox_map_;
     P.hist_ring = d_hist_ring_;

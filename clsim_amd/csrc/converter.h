@@ -191,7 +191,7 @@ private:
     int num_slots_ = 1;
     void submit(Slot &s, const Job &job);
     void finish(Slot &s, std::chrono::steady_clock::time_point &last_done, bool &first);
-    uint32_t *d_slice_done_ = nullptr;       // per step: slices published (unit queue)
+    WorkRecord *d_work_ = nullptr;           // per step: work record (kparams.h), rebuilt by every launch
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
     uint32_t *last_queue_ = nullptr;

@@ -32,6 +32,16 @@ struct DevPhoton {                      // I3CLSimPhoton, 80 B = 20 words
     uint32_t w[20];
 };
 #pragma pack(pop)
+// One 64-byte line per step: everything a lane needs to take over a slice of the step (the step itself, the state of
+// its RNG stream, the multiplier, how many slices have been published).  Built by scan_steps_kernel at the start of a
+// launch; a hand-off reads and writes this one line instead of four arrays.
+struct WorkRecord {
+    DevStep step;
+    uint64_t x;
+    uint32_t a;
+    uint32_t done;
+};
+static_assert(sizeof(WorkRecord) == 64, "work record");
 static_assert(sizeof(DevStep) == 48, "step record");
 static_assert(sizeof(DevPhoton) == 80, "photon record");
 
@@ -49,7 +59,7 @@ struct KParams {
     uint32_t *queue;                    // [0] next unclaimed work unit, [1] max numPhotons (both zeroed before the launch)
     int32_t k_new;                      // lanes that must be waiting before photons are created
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
-    uint32_t *slice_done;               // per step: slices published so far (zeroed before the launch)
+    WorkRecord *work;                   // per step, filled by scan_steps_kernel (done = slices published so far)
     // TABLE lengths: one 16-byte record per (wavelength bin, layer): {abs[bin], abs[bin+1], sca[bin], sca[bin+1]}
     // at len_table[4*(bin*num_layers + layer)], already de-quantised (80 KB for a 171 x 30 photonics table: HBM/L2)
     const float *len_table;

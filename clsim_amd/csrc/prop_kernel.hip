@@ -913,6 +913,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     uint32_t photons_left = 0;
     uint32_t slice = 0;
     bool waiting = false;      // holds a unit whose previous slice has not been published yet
+    bool last_slice = false;   // the unit ends its step
     bool alive = true;
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     Photon ph;
@@ -936,25 +937,30 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(P->queue, (uint32_t)__popcll(m_want));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                uint64_t *rng_x = P->rng_x;
-                uint32_t *slice_done = P->slice_done;
-                // publish the finished unit: stream state first (c.cl:911-912), then the slice counter; both
-                // write-through (sc1) so that a lane on another XCD that sees the counter sees the state
-                if (want_unit && (sidx != kNoStep)) __hip_atomic_store(&rng_x[sidx], rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WorkRecord *work = P->work;
+                // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
+                // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
+                // state first, then the slice counter, both write-through (sc1) so that a lane on another XCD that
+                // sees the counter sees the state
+                if (want_unit && (sidx != kNoStep)) {
+                    if (last_slice) P->rng_x[sidx] = rx;
+                    else __hip_atomic_store(&work[sidx].x, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (want_unit) {
-                    if (sidx != kNoStep) __hip_atomic_store(&slice_done[sidx], slice + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((sidx != kNoStep) && !last_slice) __hip_atomic_store(&work[sidx].done, slice + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t unit = base + (uint32_t)__popcll(m_want & lanes_below);
                     sidx = kNoStep;
                     if (unit < total_units) {
                         const uint32_t s_new = unit / n_steps;
                         const uint32_t i_new = unit - s_new * n_steps;
-                        const uint32_t num = P->steps[i_new].num_photons;
+                        const uint32_t num = work[i_new].step.num_photons;
                         const uint32_t first = s_new * slice_photons;
                         if (first < num) {                  // otherwise this step is used up: ask again
                             sidx = i_new;
                             slice = s_new;
-                            photons_left = (num - first < slice_photons) ? (num - first) : slice_photons;
+                            last_slice = (num - first <= slice_photons);
+                            photons_left = last_slice ? (num - first) : slice_photons;
                             waiting = true;
                         }
                     } else {
@@ -964,20 +970,21 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
             if (need && waiting) {
-                const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&P->slice_done[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WorkRecord *rec = P->work + sidx;
+                const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&rec->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef CLSIMHIP_DEBUG_COUNTERS
                 if (published < slice) atomicAdd(P->queue + 2, 1u);
 #endif
                 if (published >= slice) {
                     // c.cl:458-461; slice 0 reads the state left by the previous bunch
-                    rx = (slice == 0u) ? P->rng_x[sidx] : __hip_atomic_load(&P->rng_x[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ra = P->rng_a[sidx];
-                    step_dir = step_direction(P->steps + sidx);
+                    rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ra = rec->a;
+                    step_dir = step_direction(&rec->step);
                     waiting = false;
                 }
             }
             if (need && !waiting && (photons_left > 0)) {
-                create_photon<MED, TILT, FLASHER, TAB>(P, P->steps + sidx, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER, TAB>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -1006,7 +1013,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
             const KP P = fresh_params(P0);
             const float travelled = P->fixed_abs - ph.abs_lens_left;
-            const float weight = run ? P->steps[sidx].weight : 0.0f;
+            const float weight = run ? P->work[sidx].step.weight : 0.0f;
             uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
             const bool left_table = save_path_wave(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
                                                    ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth);
@@ -1085,11 +1092,19 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
 }
 
 // meta[1] = largest numPhotons of the bunch (sizes the slices of the unit queue)
-__global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, uint32_t n, uint32_t *meta)
+__global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, uint32_t n, uint32_t *meta, WorkRecord *work,
+                                                         const uint64_t *rng_x, const uint32_t *rng_a)
 {
+    // one pass over the bunch: largest numPhotons (-> slice size) and the work records
     uint32_t m = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t v = steps[i].num_photons;
+        WorkRecord r;
+        r.step = steps[i];
+        r.x = rng_x[i];
+        r.a = rng_a[i];
+        r.done = 0u;
+        work[i] = r;
+        const uint32_t v = r.step.num_photons;
         m = v > m ? v : m;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1212,7 +1227,8 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     }
     {
         const uint32_t sgrid = (P.n_steps + 255u) / 256u;
-        hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue);
+        hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue,
+                           P.work, P.rng_x, P.rng_a);
     }
     hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     hipError_t err = hipGetLastError();

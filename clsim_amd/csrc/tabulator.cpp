@@ -163,7 +163,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), streams * sizeof(DevStep)), "steps");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_slice_done_), streams * sizeof(uint32_t)), "slice counters");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), streams * sizeof(WorkRecord)), "work records");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), streams * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
 }
 
@@ -174,7 +174,7 @@ Tabulator::~Tabulator()
     if (ev_start_) (void)hipEventDestroy(ev_start_);
     if (ev_stop_) (void)hipEventDestroy(ev_stop_);
     (void)hipFree(d_tables_); (void)hipFree(d_len_table_); (void)hipFree(d_bins_); (void)hipFree(d_sq_bins_);
-    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_queue_); (void)hipFree(d_slice_done_);
+    (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_); (void)hipFree(d_steps_); (void)hipFree(d_queue_); (void)hipFree(d_work_);
     if (h_steps_) (void)hipHostFree(h_steps_);
 }
 
@@ -209,10 +209,9 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
     P.rng_a = d_rng_a_;
     P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
     hip_check(hipMemsetAsync(P.queue, 0, 16, stream_), "reset step queue");
-    hip_check(hipMemsetAsync(d_slice_done_, 0, n * sizeof(uint32_t), stream_), "reset slice counters");
     P.k_new = 8;
     P.slices = 0;
-    P.slice_done = d_slice_done_;
+    P.work = d_work_;
     P.tab_bins = d_bins_;
     P.tab_sq_bins = d_sq_bins_;
     {   // I3CLSimReferenceParticle (StepToTableConverter.cxx:64-93)

@@ -65,7 +65,8 @@ private:
     uint64_t *d_rng_x_ = nullptr;
     uint32_t *d_rng_a_ = nullptr;
     DevStep *d_steps_ = nullptr;
-    uint32_t *d_queue_ = nullptr, *d_slice_done_ = nullptr;
+    uint32_t *d_queue_ = nullptr;
+    WorkRecord *d_work_ = nullptr;
     clsimhip_step *h_steps_ = nullptr;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
