@@ -226,6 +226,7 @@ void Converter::setup_device_buffers()
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), max_workitems_ * sizeof(WorkRecord)), "work records");
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
 }
 
@@ -247,6 +248,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     }
     hip_check(hipMemsetAsync(P.queue, 0, 16, stream), "reset step queue");
     P.k_new = k_new_;
+    P.k_search = k_search_;
     P.slices = k_slices_;
     P.work = d_work_;
     P.len_table = d_len_table_;

@@ -58,6 +58,7 @@ struct KParams {
     uint32_t max_hits;
     uint32_t *queue;                    // [0] next unclaimed work unit, [1] max numPhotons (both zeroed before the launch)
     int32_t k_new;                      // lanes that must be waiting before photons are created
+    int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
     WorkRecord *work;                   // per step, filled by scan_steps_kernel (done = slices published so far)
     // TABLE lengths: one 16-byte record per (wavelength bin, layer): {abs[bin], abs[bin+1], sca[bin], sca[bin+1]}

@@ -912,6 +912,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     uint32_t ra = 0;
     uint32_t photons_left = 0;
     uint32_t slice = 0;
+    bool parked = false;       // has a step length and waits for the wave's next DOM search
+    uint32_t *pending = lds_words + P0->table_words + kWavesPerBlock * kStageRecords * kStubWords;     // per lane: that step length
     bool waiting = false;      // holds a unit whose previous slice has not been published yet
     bool last_slice = false;   // the unit ends its step
     bool alive = true;
@@ -921,7 +923,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     ph.layer = 0;
 
     for (;;) {
-        bool need = alive && (ph.abs_lens_left < kEpsilon);
+        bool need = alive && !parked && (ph.abs_lens_left < kEpsilon);
         const uint64_t m_need = __ballot(need);
         const uint64_t m_ready = __ballot(alive && !need);
         if ((m_need | m_ready) == 0ull) break;
@@ -997,16 +999,29 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         }
 
         // ---- one reference loop iteration for the lanes that hold a photon ----
-        const bool run = alive && !need;
+        // A lane runs the layer walk; if its step could reach a string (2 % of the lanes) it parks with the step
+        // length until `k_search` lanes of the wave are parked (or nothing else can advance), and the DOM search runs
+        // for all of them at once: the search costs the wave the same whether 1 or 12 lanes need it.
+        const bool run = alive && !need && !parked;
         float distance = 0.0f;
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
-            if (!TAB && !(distance < free_flight)) {
-                // the search cannot find a DOM closer than the nearest string cylinder: skip it when the step ends before
-                hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+            // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
+            if (!TAB && !(distance < free_flight)) { parked = true; pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance); }
+        }
+        bool advance = run && !parked;
+        if (!TAB) {
+            const uint64_t m_parked = __ballot(parked);
+            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
+                if (parked) {
+                    distance = __builtin_bit_cast(float, pending[threadIdx.x]);
+                    hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    parked = false;
+                    advance = true;
+                }
             }
         }
         if (TAB) {
@@ -1064,7 +1079,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 for (uint32_t k = 0; k < hn; ++k) dst[k] = ring[k];
             }
         }
-        if (run) {
+        if (advance) {
             if (hit) ph.abs_lens_left = 0.0f;                                   // c.cl:741-744
             ph.px += ph.d.x * distance;
             ph.py += ph.d.y * distance;
@@ -1177,7 +1192,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
     const size_t lds_bytes = TAB ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
-                                 : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4;
+                                 : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock) * 4;
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
     static int resident = 0;            // per variant
     if (resident == 0) {
@@ -1223,6 +1238,9 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     {
         const double r = (double)P.n_steps / ((double)grid * kBlock);
         if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : (r < 5.0) ? 12 : 8;
+        // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1M steps: 1 -> 5 is
+        // +6 %), costs when they are scarce (0.4M steps: -14 %)
+        if (P.k_search <= 0) P.k_search = (r < 1.5) ? 1 : (r < 3.0) ? 3 : 5;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0xffffffffull) P.slices = 1;    // 32-bit unit counter
     }
     {
@@ -1286,7 +1304,7 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
     return hipErrorInvalidValue;
 }
 
-size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * kStubWords) * 4; }
+size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock) * 4; }
 int prop_kernel_block_size() { return kBlock; }
 // upper bound of the lanes of one launch (persistent grid: at most 2048 resident threads per CU)
 size_t prop_kernel_max_lanes()

@@ -210,6 +210,7 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
     P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
     hip_check(hipMemsetAsync(P.queue, 0, 16, stream_), "reset step queue");
     P.k_new = 12;
+    P.k_search = 1;
     P.slices = 0;
     P.work = d_work_;
     P.tab_bins = d_bins_;

@@ -155,13 +155,15 @@ def test_double_buffering_pipelines_bunches_with_identical_results():
         assert st["NumKernelCalls"] == len(bunches) and not conv.MorePhotonsAvailable()
 
 
-@pytest.mark.parametrize("slices,k_new", [(1, 8), (3, 8), (16, 8), (64, 1), (7, 64)])
-def test_ragged_bunch_under_every_schedule(slices, k_new, monkeypatch):
+@pytest.mark.parametrize("slices,k_new,k_search", [(1, 8, 1), (3, 8, 5), (16, 8, 64), (64, 1, 2), (7, 64, 13)])
+def test_ragged_bunch_under_every_schedule(slices, k_new, k_search, monkeypatch):
     """Work-unit scheduling must not change results: a bunch whose steps hold 0 ... 1500 photons (empty steps, single
     photons, steps longer than a slice, steps shorter than the slice grid) is cut into `slices` slices per step with
-    photon creation deferred until `k_new` lanes wait, and compared with the oracle, which knows neither."""
+    photon creation deferred until `k_new` lanes wait and the DOM search until `k_search` lanes are parked, and
+    compared with the oracle, which knows none of this."""
     monkeypatch.setenv("CLSIMHIP_SLICES", str(slices))
     monkeypatch.setenv("CLSIMHIP_K_NEW", str(k_new))
+    monkeypatch.setenv("CLSIMHIP_K_SEARCH", str(k_search))
     cfg = common.config("mie")
     steps = common.steps_for(cfg, 2048, seed=77)
     n = len(steps)
