@@ -15,6 +15,8 @@ is executed by the REFERENCE's own Python code:
                              util/GetSpiceLeaAnisotropyTransforms.py) passes to the clsim C++
                              constructors for resources/ice/<model>
   * dom_acceptance.json      python/GetIceCubeDOMAcceptance.py
+  * ppc_wavelength_cdf.txt   resources/scripts/compareToPPCredux/test_ice_models/lea/wv.dat (PPC's cumulative
+                             photon spectrum: DOM acceptance x Cherenkov yield, 265..675 nm), copied as data
   * ice_photonics_<m>.npz    what python/MakeIceCubeMediumPropertiesPhotonics.py passes to the clsim C++
                              constructors for resources/ice/photonics_<m>/*.txt (per-layer FromTable functions)
 
@@ -137,6 +139,9 @@ def main():
     rnd = np.loadtxt(os.path.join(REF, "resources/scripts/compareToPPCredux/test_ice_models/lea/rnd.txt"),
                      usecols=0, dtype=np.uint64)
     np.save(os.path.join(OUT, "mwc_multipliers.npy"), rnd.astype(np.uint32))
+
+    wv = np.loadtxt(os.path.join(REF, "resources/scripts/compareToPPCredux/test_ice_models/lea/wv.dat"))
+    np.savetxt(os.path.join(OUT, "ppc_wavelength_cdf.txt"), wv, fmt="%.8f %.1f")
 
     # ---- 2. reference Python ports of PPC formulas --------------------------
     rng = np.random.Generator(np.random.PCG64(20260101))
