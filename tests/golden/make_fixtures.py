@@ -11,6 +11,8 @@ is executed by the REFERENCE's own Python code:
                              (the reference's Python port of PPC's formula) on seeded unit vectors
   * spice_lea_transforms.npz evaluateVectorTransformationPPCPre/Post() of
                              resources/tests/testSpiceLeaTransforms.py:37-72
+  * vector_transform.npz     calculateDotProducts() of resources/tests/testVectorTransforms.py:52-60 (the reference
+                             test's numpy answer for I3CLSimVectorTransformMatrix) on a seeded random matrix
   * ice_<model>.json         what python/MakeIceCubeMediumProperties.py (+ util/GetIceTiltZShift.py,
                              util/GetSpiceLeaAnisotropyTransforms.py) passes to the clsim C++
                              constructors for resources/ice/<model>
@@ -164,6 +166,12 @@ def main():
     np.savez(os.path.join(OUT, "spice_lea_transforms.npz"), vectors=vec, thx=thx, logk1=k1, logk2=k2,
              pre=np.array([pre(v, azx, azy, ek1, ek2, kz) for v in vec]),
              post=np.array([post(v, azx, azy, ek1, ek2, kz) for v in vec]))
+
+    (dots,) = extract_functions(os.path.join(REF, "resources/tests/testVectorTransforms.py"), ["calculateDotProducts"],
+                                {"numpy": np, "math": math})
+    matrix = rng.uniform(-10., 10., (3, 3))                     # testVectorTransforms.py:16
+    np.savez(os.path.join(OUT, "vector_transform.npz"), matrix=matrix, x=x, y=y, z=z,
+             plain=dots(matrix, x, y, z, renormalize=False), renormalized=dots(matrix, x, y, z, renormalize=True))
 
     # ---- 3. the reference's ice / acceptance loaders -----------------------
     clsim = install_stubs()
