@@ -95,7 +95,7 @@ def tabulator_bench(args, torch, device):
     from clsim_amd import converter as CV
     from clsim_amd import synthetic as S
     from clsim_amd import tabulator as TB
-    n = (min(args.bunch, 1 << 17) // 256) * 256
+    n = ((262144 if args.bunch == (1 << 20) else min(args.bunch, 1 << 19)) // 256) * 256     # >= 4 workgroups per CU
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
     axes = TB.SphericalAxes([TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)])
     ang = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
