@@ -788,8 +788,27 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (have && !oob && j < first_oob[owner])
-                add_to_bin(P, index, o_impact * dm::exp_(-(o_depth + (d / o_length) * o_this)));
+            // Consecutive samples of a segment fall into the same bin 60 % of the time: equal-bin neighbours are summed
+            // in the wave first (segmented scan over the lanes, in double: sums of a few floats are exact there) and
+            // the last lane of each run issues the atomic.  2.5x fewer read-modify-writes on the 670 MB table.
+            const bool commit = have && !oob && (j < first_oob[owner]);
+            const float w = commit ? o_impact * dm::exp_(-(o_depth + (d / o_length) * o_this)) : 0.0f;
+            const uint32_t key = commit ? index : 0xffffffffu;
+            const uint32_t prev_key = (uint32_t)__shfl_up((int)key, 1), next_key = (uint32_t)__shfl_down((int)key, 1);
+            int flag = ((lane == 0u) || (prev_key != key) || !commit) ? 1 : 0;     // first lane of its run
+            double sum = (double)w, sum_sq = (double)w * (double)w;
+            const bool squares = (P->tab_sq_bins != nullptr);
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double up = __shfl_up(sum, off);
+                const double up_sq = squares ? __shfl_up(sum_sq, off) : 0.0;
+                const int up_flag = __shfl_up(flag, off);
+                if ((lane >= (uint32_t)off) && !flag) { sum += up; sum_sq += up_sq; flag = up_flag; }
+            }
+            if (commit && ((lane == 63u) || (next_key != key))) {
+                unsafeAtomicAdd(P->tab_bins + index, sum);
+                if (squares) unsafeAtomicAdd(P->tab_sq_bins + index, sum_sq);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
