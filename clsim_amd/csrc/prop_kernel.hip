@@ -8,14 +8,19 @@
 // with a hand-written kernel whose results are bit-identical for every step and
 // RNG stream, but which is organised for the CDNA4 execution model:
 //
-//  * persistent workgroups (as many as the chip holds) pull steps from a global
-//    queue: a lane that finishes its step takes the next one instead of idling
-//    until the slowest of its 64 neighbours is done.  The RNG stream travels with
-//    the step (propagation_kernel.c.cl:458-461, 911-912), never with the lane;
+//  * persistent workgroups (5-7 per CU, chosen from the bunch size) pull work units
+//    from a global queue: a unit is a slice of a step's photons, handed out
+//    round-robin over the bunch, so that all steps advance together; a lane that
+//    finishes a unit takes the next one instead of idling until the slowest of its
+//    64 neighbours is done.  The RNG stream travels with the step, in a 64-byte
+//    work record (propagation_kernel.c.cl:458-461, 911-912), never with the lane;
 //  * one in-flight photon per lane; the scatter loop is a WAVE-UNIFORM loop
 //    (ballot), so hit records are emitted at a convergent point by the whole wave;
-//  * photon creation -- 1/29 of a lane's iterations but paid by the whole wave
-//    whenever one lane needs it -- is deferred until k_new lanes wait for it;
+//  * rare, heavy phases are batched: photon creation -- 1/29 of a lane's
+//    iterations but paid by the whole wave whenever one lane needs it -- waits
+//    until k_new lanes need it; the DOM search is skipped for steps that end before
+//    the nearest string (proximity map) and the lanes that do need it park until
+//    k_search of them do;
 //  * hit write-out is wave-aggregated: one atomic per wave claims the slots,
 //    records are staged in LDS and written as contiguous dwords by all lanes;
 //  * ice layer records, tilt grid, spectra and the DOM cell/string/layer index are
@@ -41,7 +46,7 @@
 namespace clsimhip {
 
 #ifndef CLSIMHIP_BLOCK
-#define CLSIMHIP_BLOCK 256                       // 4 waves per workgroup, 7 workgroups per CU (70 VGPRs)
+#define CLSIMHIP_BLOCK 256                       // 4 waves per workgroup, up to 7 workgroups per CU (<= 72 VGPRs)
 #define CLSIMHIP_MIN_WAVES 7
 #endif
 constexpr int kBlock = CLSIMHIP_BLOCK;
