@@ -180,3 +180,22 @@ def test_ragged_bunch_under_every_schedule(slices, k_new, k_search, monkeypatch)
     assert np.array_equal(conv.GetRNGState(n), x_o)
     # streams of empty steps are untouched
     assert np.array_equal(x_o[num == 0], np.asarray(x)[:n][num == 0])
+
+
+@pytest.mark.timeout(900)
+def test_full_baseline_bunch_equals_oracle():
+    """BASELINE configs[1] in full: all 1 048 576 steps x 200 photons through the kernel's production schedule
+    (5 workgroups per CU, 12 slices, parked searches) against the oracle run on every host core -- the complete hit
+    multiset and all final RNG states, bit for bit.  (About a minute of oracle time on the GPU box's 256 threads.)"""
+    import os
+    cfg = common.config("mie")
+    n = 1 << 20
+    steps = common.steps_for(cfg, n, seed=1000)
+    x, a = common.streams(n)
+    conv = common.product_converter(cfg, n)
+    ph_d, cnt_d = device_run(conv, steps, capacity=1 << 21)
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=os.cpu_count() or 8)
+    assert cnt_d == cnt_o and cnt_o > 150000
+    assert common.sort_photons(ph_d).tobytes() == common.sort_photons(ph_o).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)
