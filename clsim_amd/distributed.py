@@ -8,8 +8,10 @@ counterpart is independent converters behind a ZeroMQ router
 (private/clsim/I3CLSimServer.cxx:77-137) -- no collective at all.
 
 xGMI is point-to-point (7 links per GPU), so the gather is an all_gather of the
-counts followed by one direct send per peer to the root; a ring would only add
-hops.  The same code runs on CPU tensors over gloo (tests/test_distributed.py).
+counts followed by one direct send per peer to the root, posted as ONE batch
+(ncclGroupStart/End under torch's batch_isend_irecv) so that the 7 transfers run
+on their 7 links at once; a ring would only add hops.  The same code runs on CPU
+tensors over gloo (tests/test_distributed.py).
 """
 import torch
 import torch.distributed as dist
@@ -38,18 +40,19 @@ def gather_hits(photons, count, dst=0, out=None, group=None):
         if out is None or out.shape[0] < total:
             out = torch.empty((total, photons.shape[1]), dtype=photons.dtype, device=photons.device)
         off = 0
-        reqs = []
+        ops = []
         for peer in range(world):
             k = int(c[peer])
             if peer == dst:
                 if k:
                     out[off:off + k].copy_(photons[:k])
             elif k:
-                reqs.append(dist.irecv(out[off:off + k], src=peer, group=group))
+                ops.append(dist.P2POp(dist.irecv, out[off:off + k], peer, group))
             off += k
-        for r in reqs:
+        for r in (dist.batch_isend_irecv(ops) if ops else []):
             r.wait()
         return out[:total], c
     if int(c[rank]):
-        dist.send(photons[:int(c[rank])].contiguous(), dst=dst, group=group)
+        for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, photons[:int(c[rank])].contiguous(), dst, group)]):
+            r.wait()
     return None, c

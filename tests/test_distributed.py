@@ -52,17 +52,21 @@ def _worker(rank, world, port, counts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_gather_hits_two_ranks_gloo():
-    world = 2
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_hits_gloo(world):
+    """world 4: the root posts three receives in one batch, like the 7 of an 8-GPU node."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    counts = [(5, 9), (0, 3), (7, 0), (0, 0), (64, 64)]      # ragged, empty shards, full buffers
+    port = 29500 + (os.getpid() % 2000) + world
+    if world == 2:
+        counts = [(5, 9), (0, 3), (7, 0), (0, 0), (64, 64)]      # ragged, empty shards, full buffers
+    else:
+        counts = [(5, 9, 1, 30), (0, 3, 0, 2), (7, 0, 0, 0), (0, 0, 0, 0), (64, 64, 64, 64)]
     procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in range(world)]
     for p in procs:
         p.join(timeout=30)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
