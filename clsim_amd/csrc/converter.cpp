@@ -291,6 +291,7 @@ void Converter::submit(Slot &s, const Job &job)
     hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
     hip_check(hipEventRecord(s.stop, stream_), "event");
     hip_check(hipMemcpyAsync(s.h_hit_count, s.d_hit_count, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
+    hip_check(hipMemcpyAsync(s.h_hit_count + 1, P.queue + 2, 4, hipMemcpyDeviceToHost, stream_), "download skipped-step counter");
     hip_check(hipEventRecord(s.counted, stream_), "event");
 }
 
@@ -300,6 +301,9 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
 {
     hip_check(hipEventSynchronize(s.counted), "propagation kernel");
     uint32_t hits = *s.h_hit_count;
+    if (s.h_hit_count[1] != 0)
+        std::fprintf(stderr, "clsimhip: %u steps of bunch %u have non-finite position/direction/length/beta and were not propagated\n",
+                     s.h_hit_count[1], s.id);
     if (hits > max_output_photons_) {
         // OpenCL.cxx:1027-1032: logged, truncated
         std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);

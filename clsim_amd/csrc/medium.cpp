@@ -75,6 +75,28 @@ void MediumData::validate() const
 {
     if (num_layers < 1) throw Error(CLSIMHIP_ERR_ARGUMENT, "medium needs at least one layer");
     if (!(layers_height > 0)) throw Error(CLSIMHIP_ERR_ARGUMENT, "layer height must be positive");
+    // A zero, negative, infinite or NaN length turns a photon's absorption budget into NaN, and then the reference's
+    // photon loop never ends (propagation_kernel.c.cl:536, 681-691); on a GPU that is a hang, so it is refused here.
+    auto usable = [](const std::vector<double> &v, bool strictly_positive, const char *what) {
+        for (double x : v)
+            if (!std::isfinite(x) || x < 0. || (strictly_positive && !(x > 0.)))
+                throw Error(CLSIMHIP_ERR_ARGUMENT, std::string(what) + " must be finite and " + (strictly_positive ? "positive" : "non-negative"));
+    };
+    usable(abs_length, true, "absorption lengths"); usable(sca_length, true, "scattering lengths");
+    usable(abs_table, true, "tabulated absorption lengths"); usable(sca_table, true, "tabulated scattering lengths");
+    usable(b400, true, "b400");
+    if (lengths_kind == CLSIMHIP_LENGTHS_ICECUBE && a_dust400.size() == delta_tau.size()) {
+        // AbsLenIceCube.cxx:63-77: the dust term may be negative, the absorptivity as a whole must not be
+        const double lo = (min_wlen > 0. && std::isfinite(min_wlen)) ? min_wlen : 265e-9;
+        const double hi = (max_wlen > lo && std::isfinite(max_wlen)) ? max_wlen : 675e-9;
+        for (size_t l = 0; l < a_dust400.size(); ++l)
+            for (double w : {lo, 0.5 * (lo + hi), hi}) {
+                const double x = w / units::nanometer;
+                const double absorptivity = (D * a_dust400[l] + E) * std::pow(x, -kappa) + A * std::exp(-B / x) * (1. + 0.01 * delta_tau[l]);
+                if (!std::isfinite(absorptivity) || !(absorptivity > 0.))
+                    throw Error(CLSIMHIP_ERR_ARGUMENT, "ice layer " + std::to_string(l) + " has no positive, finite absorptivity");
+            }
+    }
     const size_t nl = static_cast<size_t>(num_layers);
     if (lengths_kind == CLSIMHIP_LENGTHS_CONSTANT) {
         if (abs_length.size() != nl || sca_length.size() != nl)

@@ -1142,6 +1142,15 @@ __global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, u
         r.x = rng_x[i];
         r.a = rng_a[i];
         r.done = 0u;
+        {   // A step with a non-finite field makes the reference's photon loop spin forever (a NaN absorption budget
+            // never drops below EPSILON); here that would hang the GPU.  Such a step propagates no photons and is
+            // counted in meta[2]; its RNG stream is left alone.
+            const float f[8] = {r.step.x, r.step.y, r.step.z, r.step.t, r.step.theta, r.step.phi, r.step.length, r.step.beta};
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) finite = finite && (__builtin_fabsf(f[k]) <= 3.0e38f);
+            if (!finite && r.step.num_photons != 0u) { r.step.num_photons = 0u; atomicAdd(meta + 2, 1u); }
+        }
         work[i] = r;
         const uint32_t v = r.step.num_photons;
         m = v > m ? v : m;

@@ -66,6 +66,15 @@ def test_unsupported_modes_are_refused_at_compile():
     conv.Compile()
 
 
+def test_degenerate_medium_values_are_refused():
+    """Zero / infinite / NaN lengths would turn absorption budgets into NaN (an endless photon loop in the reference)."""
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="finite and positive"):
+            CV.MakeHomogeneousMediumProperties(absLen=bad)
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="finite and positive"):
+            CV.MakeHomogeneousMediumProperties(scaLen=bad)
+
+
 def test_incomplete_configuration_is_refused():
     conv = CV.I3CLSimStepToPhotonConverterHIP(0)
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="WlenGenerators"):

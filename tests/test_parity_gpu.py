@@ -308,3 +308,28 @@ def test_photon_history(entries, name):
     assert longest == entries
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="photon histories"):
         conv.PropagateDevice(1, 256, 1, 1, 1)
+
+
+def test_non_finite_steps_are_skipped_not_spun_on(capfd):
+    """A NaN direction under an anisotropic medium makes the reference's photon loop spin forever (the absorption budget
+    becomes NaN and never drops below EPSILON); on a GPU that is a hang.  Such steps propagate nothing, their streams
+    stay untouched, the rest of the bunch is unaffected."""
+    cfg = common.config("lea")
+    steps = common.steps_for(cfg, 1024, seed=19)
+    n = len(steps)
+    bad = steps.copy()
+    bad["theta"][3] = np.nan
+    bad["x"][100] = np.inf
+    bad["beta"][777] = -np.inf
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    good = bad.copy()
+    good["num"][[3, 100, 777]] = 0
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, good, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    conv = common.product_converter(cfg, n)
+    conv.EnqueueSteps(bad, 1)
+    _, ph_p = conv.GetConversionResult()
+    assert len(ph_p) == cnt_o and common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)
+    assert "3 steps of bunch 1 have non-finite" in capfd.readouterr().err
