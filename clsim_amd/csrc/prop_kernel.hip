@@ -731,7 +731,9 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
     // number of samples and the value d ends with
     uint32_t n = 0;
     float d_end = remainder;
-    if (active) for (; d_end < length; d_end += vstep) ++n;
+    // (the cap only guards the GPU against a walk that cannot advance, d + step == d; the reference's own walk ends
+    // after TABLE_ENTRIES_PER_STREAM = 5000 samples of the whole step)
+    if (active) for (; (d_end < length) && (n < (1u << 16)); d_end += vstep) ++n;
     // exclusive prefix sum over the wave
     uint32_t incl = n;
 #pragma unroll
@@ -749,7 +751,7 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
         if (active) {
             const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
             float d = remainder;
-            for (; d < length; d += vstep) {
+            for (uint32_t taken = 0; (d < length) && (taken < n); d += vstep, ++taken) {
                 uint32_t index;
                 if (sample_bin(P, ref_lds, g, d, index)) { stop = true; break; }
                 add_to_bin(P, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
