@@ -54,7 +54,28 @@ Converter::~Converter()
     (void)hipFree(d_queue_); (void)hipFree(d_work_); (void)hipFree(d_hist_ring_);
 }
 
-void Converter::set_wlen_generators(std::vector<RandomValueData> g) { guard(); compiled_ = false; generators_ = std::move(g); }
+void Converter::set_wlen_generators(std::vector<RandomValueData> g)
+{
+    guard();
+    // a wavelength that is zero, negative or not finite gives a photon lengths of 0/0 = NaN, and a NaN absorption
+    // budget never runs out (propagation_kernel.c.cl:536): refused here rather than spun on by the GPU
+    for (const RandomValueData &r : g) {
+        if (r.kind == CLSIMHIP_RANDOM_CONSTANT) {
+            if (!std::isfinite(r.value) || !(r.value > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "a constant wavelength must be finite and positive");
+        } else {
+            if (!std::isfinite(r.first) || !(r.first > 0.) || !std::isfinite(r.spacing) || !(r.spacing > 0.))
+                throw Error(CLSIMHIP_ERR_ARGUMENT, "a wavelength distribution needs a positive first wavelength and spacing");
+            double sum = 0.;
+            for (double y : r.y) {
+                if (!std::isfinite(y) || y < 0.) throw Error(CLSIMHIP_ERR_ARGUMENT, "wavelength distribution values must be finite and non-negative");
+                sum += y;
+            }
+            if (!(sum > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "a wavelength distribution must not be zero everywhere");
+        }
+    }
+    compiled_ = false;
+    generators_ = std::move(g);
+}
 void Converter::set_wlen_bias(FunctionData b) { guard(); compiled_ = false; bias_ = std::move(b); have_bias_ = true; }
 void Converter::set_medium(MediumData m) { guard(); m.validate(); compiled_ = false; medium_ = std::move(m); have_medium_ = true; }
 void Converter::set_geometry(GeometryInput g) { guard(); compiled_ = false; geometry_ = std::move(g); have_geometry_ = true; }
@@ -302,7 +323,7 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
     hip_check(hipEventSynchronize(s.counted), "propagation kernel");
     uint32_t hits = *s.h_hit_count;
     if (s.h_hit_count[1] != 0)
-        std::fprintf(stderr, "clsimhip: %u steps of bunch %u have non-finite position/direction/length/beta and were not propagated\n",
+        std::fprintf(stderr, "clsimhip: %u steps of bunch %u have non-finite position/direction/length/beta or a source type without spectrum and were not propagated\n",
                      s.h_hit_count[1], s.id);
     if (hits > max_output_photons_) {
         // OpenCL.cxx:1027-1032: logged, truncated

@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
 
 // meta[1] = largest numPhotons of the bunch (sizes the slices of the unit queue)
 __global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, uint32_t n, uint32_t *meta, WorkRecord *work,
-                                                         const uint64_t *rng_x, const uint32_t *rng_a)
+                                                         const uint64_t *rng_x, const uint32_t *rng_a, uint32_t num_generators)
 {
     // one pass over the bunch: largest numPhotons (-> slice size) and the work records
     uint32_t m = 0;
@@ -1151,7 +1151,10 @@ __global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, u
             bool finite = true;
 #pragma unroll
             for (int k = 0; k < 8; ++k) finite = finite && (__builtin_fabsf(f[k]) <= 3.0e38f);
-            if (!finite && r.step.num_photons != 0u) { r.step.num_photons = 0u; atomicAdd(meta + 2, 1u); }
+            // likewise a source type without a wavelength generator: generateWavelength() returns 0 for it
+            // (MediumPropertiesSource.cxx:392-432) and every length of that photon becomes 0/0
+            const bool no_spectrum = (num_generators > 1u) && ((r.step.source_type_and_pad & 0xffu) >= num_generators);
+            if ((!finite || no_spectrum) && r.step.num_photons != 0u) { r.step.num_photons = 0u; atomicAdd(meta + 2, 1u); }
         }
         work[i] = r;
         const uint32_t v = r.step.num_photons;
@@ -1281,7 +1284,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     {
         const uint32_t sgrid = (P.n_steps + 255u) / 256u;
         hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue,
-                           P.work, P.rng_x, P.rng_a);
+                           P.work, P.rng_x, P.rng_a, (uint32_t)P.num_gen);
     }
     hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     hipError_t err = hipGetLastError();

@@ -75,6 +75,15 @@ def test_degenerate_medium_values_are_refused():
             CV.MakeHomogeneousMediumProperties(scaLen=bad)
 
 
+def test_degenerate_wavelength_generators_are_refused():
+    conv = CV.I3CLSimStepToPhotonConverterHIP(0)
+    for gen in (CV.I3CLSimRandomValueConstant(0.0), CV.I3CLSimRandomValueConstant(float("nan")),
+                CV.I3CLSimRandomValueInterpolatedDistribution(3e-7, 1e-8, [0.0, 0.0, 0.0]),
+                CV.I3CLSimRandomValueInterpolatedDistribution(3e-7, 0.0, [1.0, 2.0])):
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
+            conv.SetWlenGenerators([gen])
+
+
 def test_incomplete_configuration_is_refused():
     conv = CV.I3CLSimStepToPhotonConverterHIP(0)
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="WlenGenerators"):

@@ -333,3 +333,19 @@ def test_non_finite_steps_are_skipped_not_spun_on(capfd):
     assert len(ph_p) == cnt_o and common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
     assert np.array_equal(conv.GetRNGState(n), x_o)
     assert "3 steps of bunch 1 have non-finite" in capfd.readouterr().err
+    # a source type without a wavelength generator (the reference's generateWavelength() returns 0 for it)
+    cfg = common.config("flasher")
+    steps = common.steps_for(cfg, 512, seed=20)
+    n = len(steps)
+    bad = steps.copy()
+    bad["sourceType"][7] = 9
+    good = bad.copy()
+    good["num"][7] = 0
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, good, x, a, threads=8)
+    conv = common.product_converter(cfg, n)
+    conv.EnqueueSteps(bad, 2)
+    _, ph_p = conv.GetConversionResult()
+    assert len(ph_p) == cnt_o and np.array_equal(conv.GetRNGState(n), x_o)
+    assert "1 steps of bunch 2" in capfd.readouterr().err
