@@ -25,6 +25,13 @@ class RandomValue(C.Structure):     # clsimhip_random_value
                 ("y", DP), ("value", C.c_double)]
 
 
+class StepRequest(C.Structure):     # clsimhip_step_request
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("time", C.c_float),
+                ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float), ("length", C.c_float),
+                ("pa", C.c_float), ("pb", C.c_float), ("kind", C.c_uint32), ("identifier", C.c_uint32),
+                ("photons_per_step", C.c_uint32), ("num_photons_in_last_step", C.c_uint32), ("num_steps", C.c_uint64)]
+
+
 class Axis(C.Structure):            # clsimhip_axis
     _fields_ = [("kind", C.c_int32), ("min", C.c_double), ("max", C.c_double), ("n_bins", C.c_uint32), ("power", C.c_uint32)]
 
@@ -77,6 +84,7 @@ SYMBOLS = [
     "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_version",
+    "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
     "clsimhip_tabulator_create", "clsimhip_tabulator_destroy", "clsimhip_tabulator_last_error",
     "clsimhip_tabulator_enqueue_steps", "clsimhip_tabulator_finish", "clsimhip_tabulator_get_shape",
     "clsimhip_tabulator_get_bin_content", "clsimhip_tabulator_get_bin_sums", "clsimhip_tabulator_get_bin_edges",
@@ -146,6 +154,9 @@ def load():
         "clsimhip_get_rng_state": (i32, [vp, vp, sz]),
         "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
         "clsimhip_version": (C.c_char_p, []),
+        "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
+        "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),
         "clsimhip_tabulator_create": (i32, [i32, i32, C.POINTER(Axis), sz, i32, vp, C.POINTER(Function), C.POINTER(Polynomial),
                                             dbl, dbl, vp, vp, sz, C.POINTER(vp)]),
         "clsimhip_tabulator_destroy": (None, [vp]),

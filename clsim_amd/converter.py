@@ -411,3 +411,39 @@ def initializeHIP(device, geometry, medium, wavelengthGenerationBias, wavelength
     else:
         conv.Initialize(seed)
     return conv
+
+
+# ---- step producer on the GPU (clsimhip_generate_steps*, csrc/steps_kernel.hip) ----
+REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
+                          ("length", "<f4"), ("pa", "<f4"), ("pb", "<f4"), ("kind", "<u4"), ("identifier", "<u4"),
+                          ("photons_per_step", "<u4"), ("num_photons_in_last_step", "<u4"), ("num_steps", "<u8")])
+STEPS_CASCADE, STEPS_MUON_CASCADE, STEPS_MUON = 0, 1, 2
+
+
+def CountGeneratedSteps(requests, granularity=1):
+    req = np.ascontiguousarray(requests, dtype=REQUEST_DTYPE)
+    steps, padded = C.c_size_t(), C.c_size_t()
+    _check(_lib.load().clsimhip_count_generated_steps(req.ctypes.data_as(C.POINTER(_lib.StepRequest)), len(req), int(granularity),
+                                                      C.byref(steps), C.byref(padded)))
+    return steps.value, padded.value
+
+
+def GenerateSteps(requests, seed, granularity=1, device=0):
+    """Steps of a list of step requests (the reference's CascadeStepData_t / MuonStepData_t queue entries,
+    I3CLSimLightSourceToStepConverterPPC.cxx:524-551, 785-842), generated on the GPU, as a host array."""
+    req = np.ascontiguousarray(requests, dtype=REQUEST_DTYPE)
+    _, padded = CountGeneratedSteps(req, granularity)
+    out = np.zeros(padded, dtype=STEP_DTYPE)
+    got = C.c_size_t()
+    _check(_lib.load().clsimhip_generate_steps(int(device), req.ctypes.data_as(C.POINTER(_lib.StepRequest)), len(req), int(seed),
+                                               int(granularity), out.ctypes.data_as(C.c_void_p), len(out), C.byref(got)))
+    return out
+
+
+def GenerateStepsDevice(requests, seed, d_steps, capacity, granularity=1, device=0, stream=0):
+    """The same into device memory (address d_steps, room for `capacity` steps); returns the padded step count."""
+    req = np.ascontiguousarray(requests, dtype=REQUEST_DTYPE)
+    got = C.c_size_t()
+    _check(_lib.load().clsimhip_generate_steps_device(int(device), req.ctypes.data_as(C.POINTER(_lib.StepRequest)), len(req), int(seed),
+                                                      int(granularity), C.c_void_p(d_steps), int(capacity), C.c_void_p(stream), C.byref(got)))
+    return got.value

@@ -346,6 +346,87 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
 }
 
 
+// ---- step producer ----
+namespace {
+void plan_steps(const clsimhip_step_request *requests, size_t n, size_t granularity, std::vector<uint64_t> &first, uint64_t &real, uint64_t &padded)
+{
+    need(requests, "requests");
+    if (granularity == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "granularity must not be 0");
+    first.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const clsimhip_step_request &q = requests[i];
+        if (q.kind > CLSIMHIP_STEPS_MUON) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown step request kind");
+        if (q.photons_per_step == 0 && q.num_steps > 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "photonsPerStep may not be <= 0!");
+        if (q.kind == CLSIMHIP_STEPS_CASCADE && !(q.pa > 0.f)) throw Error(CLSIMHIP_ERR_ARGUMENT, "cascade shape parameter must be positive");
+        first[i + 1] = first[i] + q.num_steps + (q.num_photons_in_last_step > 0 ? 1 : 0);
+    }
+    real = first[n];
+    padded = ((real + granularity - 1) / granularity) * granularity;
+}
+} // namespace
+
+extern "C" {
+int clsimhip_count_generated_steps(const clsimhip_step_request *requests, size_t n, size_t granularity, size_t *steps_out, size_t *padded_out)
+{
+    return guarded(nullptr, [&] {
+        std::vector<uint64_t> first; uint64_t real = 0, padded = 0;
+        plan_steps(requests, n, granularity, first, real, padded);
+        if (steps_out) *steps_out = static_cast<size_t>(real);
+        if (padded_out) *padded_out = static_cast<size_t>(padded);
+    });
+}
+int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed, size_t granularity,
+                                   void *d_steps, size_t capacity, void *hip_stream, size_t *padded_out)
+{
+    return guarded(nullptr, [&] {
+        need(d_steps, "d_steps");
+        std::vector<uint64_t> first; uint64_t real = 0, padded = 0;
+        plan_steps(requests, n, granularity, first, real, padded);
+        if (padded > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "the requests produce more steps than the buffer holds");
+        if (padded_out) *padded_out = static_cast<size_t>(padded);
+        if (padded == 0) return;
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
+        chk(hipSetDevice(device), "hipSetDevice");
+        hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+        clsimhip_step_request *d_req = nullptr;
+        uint64_t *d_first = nullptr;
+        const size_t nreq = n ? n : 1;
+        chk(hipMalloc(reinterpret_cast<void **>(&d_req), nreq * sizeof(clsimhip_step_request)), "hipMalloc");
+        chk(hipMalloc(reinterpret_cast<void **>(&d_first), (n + 1) * sizeof(uint64_t)), "hipMalloc");
+        if (n) chk(hipMemcpyAsync(d_req, requests, n * sizeof(clsimhip_step_request), hipMemcpyHostToDevice, stream), "upload requests");
+        chk(hipMemcpyAsync(d_first, first.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "upload offsets");
+        chk(launch_generate_steps(d_req, d_first, static_cast<uint32_t>(n ? n : 1), real, padded, seed, d_steps, stream), "step generation kernel launch");
+        // the request copies were made from pageable memory (synchronous w.r.t. the host); free after the kernel
+        chk(hipStreamSynchronize(stream), "step generation kernel");
+        (void)hipFree(d_req); (void)hipFree(d_first);
+    });
+}
+int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed, size_t granularity,
+                            clsimhip_step *steps_out, size_t capacity, size_t *padded_out)
+{
+    return guarded(nullptr, [&] {
+        need(steps_out, "steps_out");
+        std::vector<uint64_t> first; uint64_t real = 0, padded = 0;
+        plan_steps(requests, n, granularity, first, real, padded);
+        if (padded > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "the requests produce more steps than the buffer holds");
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
+        chk(hipSetDevice(device), "hipSetDevice");
+        void *d_steps = nullptr;
+        chk(hipMalloc(&d_steps, std::max<size_t>(padded, 1) * sizeof(clsimhip_step)), "hipMalloc");
+        size_t got = 0;
+        const int rc = clsimhip_generate_steps_device(device, requests, n, seed, granularity, d_steps, padded, nullptr, &got);
+        if (rc != CLSIMHIP_OK) { (void)hipFree(d_steps); throw Error(rc, g_create_error); }
+        chk(hipMemcpy(steps_out, d_steps, padded * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
+        (void)hipFree(d_steps);
+        if (padded_out) *padded_out = static_cast<size_t>(padded);
+    });
+}
+} // extern "C"
+
 // ---- photon table maker ----
 
 int clsimhip_tabulator_create(int device, int axes_kind, const clsimhip_axis *axes, size_t n_axes, int store_squared_weights,

@@ -252,6 +252,37 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
 
 const char *clsimhip_version(void);
 
+/* ---- step producer on the GPU (the arithmetic that is part of the reference tree) ----------
+ * One request = one entry of the reference's step generation queue (CascadeStepData_t / MuonStepData_t,
+ * private/clsim/I3CLSimLightSourceToStepConverterPPC.h): the particle, how many steps of how many photons it was
+ * given (I3CLSimLightSourceToStepConverterPPC.cxx:284-470 computes those from sim-services / GSL / the random
+ * service -- not part of this library), and the longitudinal profile parameters.  Steps are generated like
+ * FillStep/GenerateStep/GenerateStepForMuon (:524-551, :785-842) do, one GPU lane per step. */
+#define CLSIMHIP_STEPS_CASCADE 0        /* CascadeStepData_t: position = pb * Gamma(pa) along the axis, PPC angular profile */
+#define CLSIMHIP_STEPS_MUON_CASCADE 1   /* MuonStepData_t, stepIsCascadeLike: position uniform along `length`, angular profile */
+#define CLSIMHIP_STEPS_MUON 2           /* MuonStepData_t, muon-like: every step is the whole track (length, direction) */
+typedef struct {
+    float x, y, z, time;                /* particle vertex [m, ns] */
+    float dx, dy, dz;                   /* unit direction of flight */
+    float length;                       /* MUON*: track length [m] */
+    float pa, pb;                       /* CASCADE: shower_params.a, shower_params.b [m] (b = 0: no cascade extension) */
+    uint32_t kind;
+    uint32_t identifier;                /* -> I3CLSimStep::identifier */
+    uint32_t photons_per_step;
+    uint32_t num_photons_in_last_step;  /* a last step with this many photons is appended when > 0 */
+    uint64_t num_steps;                 /* steps of photons_per_step photons */
+} clsimhip_step_request;
+/* steps the requests produce; *padded_out = that number rounded up to a multiple of `granularity` (the converter's
+ * workgroup size) with the reference's no-op steps (Async.cxx:240-257) */
+int clsimhip_count_generated_steps(const clsimhip_step_request *requests, size_t n, size_t granularity,
+                                   size_t *steps_out, size_t *padded_out);
+/* generates into device memory d_steps (room for `capacity` steps) on `hip_stream`; asynchronous */
+int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed,
+                                   size_t granularity, void *d_steps, size_t capacity, void *hip_stream, size_t *padded_out);
+/* the same into host memory (synchronous) */
+int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed,
+                            size_t granularity, clsimhip_step *steps_out, size_t capacity, size_t *padded_out);
+
 /* ---- photon table maker -------------------------------------------------------------
  * I3CLSimStepToTableConverter (private/clsim/tabulator/I3CLSimStepToTableConverter.h:44-101): propagates steps with
  * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no

@@ -341,6 +341,32 @@ def propagate(tables, steps, x, a, max_hits=None, threads=1, history=False):
     return out[:min(cnt, max_hits)], cnt, x, it.value
 
 
+REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
+                          ("length", "<f4"), ("pa", "<f4"), ("pb", "<f4"), ("kind", "<u4"), ("identifier", "<u4"),
+                          ("photons_per_step", "<u4"), ("num_photons_in_last_step", "<u4"), ("num_steps", "<u8")])
+assert REQUEST_DTYPE.itemsize == 64
+
+
+def plan_generated_steps(requests, granularity):
+    """first output step of every request, number of real steps, padded number (Async.cxx:240-257)."""
+    first = np.zeros(len(requests) + 1, dtype=np.uint64)
+    for i, q in enumerate(requests):
+        first[i + 1] = first[i] + np.uint64(int(q["num_steps"]) + (1 if q["num_photons_in_last_step"] > 0 else 0))
+    real = int(first[-1])
+    return first, real, ((real + granularity - 1) // granularity) * granularity
+
+
+def generate_steps(requests, seed, granularity=1):
+    """oracle_generate_steps (stepgen_oracle.c)."""
+    L = lib()
+    req = np.ascontiguousarray(requests, dtype=REQUEST_DTYPE)
+    first, real, padded = plan_generated_steps(req, granularity)
+    out = np.zeros(padded, dtype=STEP_DTYPE)
+    L.oracle_generate_steps(req.ctypes.data_as(C.c_void_p), first.ctypes.data_as(C.c_void_p), C.c_uint32(max(len(req), 1)),
+                            C.c_uint64(real), C.c_uint64(padded), C.c_uint64(int(seed)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 ENTRY_DTYPE = np.dtype([("index", np.uint32), ("weight", np.float32)])
 
 
