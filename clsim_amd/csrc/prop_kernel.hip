@@ -483,21 +483,21 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
     float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
     int j = current_layer;
-    if (dz < 0.0f) {
-        while ((j > 0) && (ais < 0.0f) && (aia < 0.0f)) {
-            --j;
-            boundary -= thickness;
+    {
+        // c.cl:643-668 has one loop for photons going down and one for photons going up; a wave holds both kinds, so the
+        // two loops cost it the sum of their longest walks.  One loop with a sign does the same arithmetic (x - y is
+        // x + (-y), a product with +-1 is exact, and (-ais < 0) is (ais > 0) also for signed zeros) in the longer walk only.
+        const bool down = (dz < 0.0f);
+        const float sgn = down ? -1.0f : 1.0f;
+        const int step = down ? -1 : 1;
+        const int last = down ? 0 : (num_layers - 1);
+        const float signed_thickness = sgn * thickness;
+        while ((j != last) && (sgn * ais > 0.0f) && (sgn * aia > 0.0f)) {
+            j += step;
+            boundary += signed_thickness;
             layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
-            ais += 1.0f / sca_len;
-            aia += 1.0f / abs_len;
-        }
-    } else {
-        while ((j < num_layers - 1) && (ais > 0.0f) && (aia > 0.0f)) {
-            ++j;
-            boundary += thickness;
-            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
-            ais -= 1.0f / sca_len;
-            aia -= 1.0f / abs_len;
+            ais -= sgn * (1.0f / sca_len);
+            aia -= sgn * (1.0f / abs_len);
         }
     }
     float distance, to_absorption;
