@@ -67,6 +67,16 @@ class I3CLSimRandomValueInterpolatedDistribution:
         return _lib.RandomValue(0, len(self.y), self.first, self.spacing, _dp(self.y), 0.0)
 
 
+class I3CLSimRandomValueWlenCherenkovNoDispersion:
+    """random_value/I3CLSimRandomValueWlenCherenkovNoDispersion.cxx:40-98: 1/lambda uniform between 1/toWlen and 1/fromWlen."""
+
+    def __init__(self, fromWlen, toWlen):
+        self.fromWlen, self.toWlen = float(fromWlen), float(toWlen)
+
+    def _desc(self):
+        return _lib.RandomValue(2, 0, self.fromWlen, self.toWlen, None, 0.0)
+
+
 class I3CLSimRandomValueConstant:
     def __init__(self, value):
         self.value = float(value)

@@ -192,6 +192,8 @@ int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_va
                 v[i].y.assign(gens[i].y, gens[i].y + gens[i].n);
             } else if (gens[i].kind == CLSIMHIP_RANDOM_CONSTANT) {
                 v[i].value = gens[i].value;
+            } else if (gens[i].kind == CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION) {
+                v[i].first = gens[i].first; v[i].spacing = gens[i].spacing;       // fromWlen, toWlen
             } else
                 throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown random value kind");
         }

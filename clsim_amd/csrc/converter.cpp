@@ -62,6 +62,12 @@ void Converter::set_wlen_generators(std::vector<RandomValueData> g)
     for (const RandomValueData &r : g) {
         if (r.kind == CLSIMHIP_RANDOM_CONSTANT) {
             if (!std::isfinite(r.value) || !(r.value > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "a constant wavelength must be finite and positive");
+        } else if (r.kind == CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION) {
+            // WlenCherenkovNoDispersion.cxx:47-51
+            if (std::isnan(r.first)) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"fromWlen\" argument must not be NaN!");
+            if (std::isnan(r.spacing)) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"toWlen\" argument must not be NaN!");
+            if (r.first > r.spacing) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"fromWlen\" argument must not be greater than \"toWlen\".");
+            if (!(r.first > 0.) || !std::isfinite(r.spacing)) throw Error(CLSIMHIP_ERR_ARGUMENT, "the wavelength range must be positive and finite");
         } else {
             if (!std::isfinite(r.first) || !(r.first > 0.) || !std::isfinite(r.spacing) || !(r.spacing > 0.))
                 throw Error(CLSIMHIP_ERR_ARGUMENT, "a wavelength distribution needs a positive first wavelength and spacing");

@@ -276,6 +276,10 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
 DM float generate_wavelength(KP P, int gen, uint64_t &x, uint32_t a)
 {
     if (P->gen_kind[gen] == 1) return P->gen_value[gen];      // RandomValueConstant
+    if (P->gen_kind[gen] == 2) {                               // WlenCherenkovNoDispersion.cxx:72-92
+        const float u = rng_oc(x, a);
+        return 1.0f / (P->gen_first[gen] + u * P->gen_spacing[gen]);
+    }
     const float r = rng_oc(x, a);
     const uint32_t cum = P->off_gen_ycum[gen], yv = P->off_gen_yv[gen];
     int lo = 1, hi = P->gen_n[gen] - 1;

@@ -292,6 +292,13 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             P.gen_value[k] = to_float_literal(g.value);
             continue;
         }
+        if (g.kind == CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION) {
+            // WlenCherenkovNoDispersion.cxx:72-92: 1.f/(minVal + r * range) with the two literals
+            const double min_val = 1. / g.spacing, range = (1. / g.first) - min_val;
+            P.gen_first[k] = to_float_literal(min_val);
+            P.gen_spacing[k] = to_float_literal(range);
+            continue;
+        }
         // InterpolatedDistribution.cxx:134-175 (InitTables) and :177-234 (WriteTableCode)
         const size_t n = g.y.size();
         if (n < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified for an interpolated distribution.");

@@ -79,6 +79,9 @@ typedef struct {
  * private/clsim/random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:57-74 */
 #define CLSIMHIP_RANDOM_INTERPOLATED 0
 #define CLSIMHIP_RANDOM_CONSTANT 1
+#define CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION 2 /* I3CLSimRandomValueWlenCherenkovNoDispersion(fromWlen, toWlen)
+                                                    (random_value/…WlenCherenkovNoDispersion.cxx:40-98): first = fromWlen,
+                                                    spacing = toWlen */
 typedef struct {
     int32_t kind;
     int32_t n;

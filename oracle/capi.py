@@ -272,6 +272,11 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
             t.gen[k].spacing = fl(gdesc["spacing"])
             t.gen[k].yv = O._ptr("gen%d_yv" % k, yv, C.c_float)
             t.gen[k].ycum = O._ptr("gen%d_ycum" % k, ycum, C.c_float)
+        elif gdesc["kind"] == "nodispersion":                # WlenCherenkovNoDispersion.cxx:72-77
+            min_val = 1.0 / gdesc["to"]
+            t.gen[k].kind = 2
+            t.gen[k].first = fl(min_val)
+            t.gen[k].spacing = fl((1.0 / gdesc["from"]) - min_val)
         else:
             t.gen[k].kind = 1
             t.gen[k].value = fl(gdesc["value"])

@@ -66,7 +66,7 @@ _Static_assert(sizeof(oracle_photon) == 80, "photon size");
 #define ORACLE_MAX_SUBDET 9
 
 typedef struct {
-    int32_t kind;               /* 0 interpolated (const spacing), 1 constant */
+    int32_t kind;               /* 0 interpolated (const spacing), 1 constant, 2 Cherenkov without dispersion */
     int32_t n;
     float first, spacing;       /* literals of InterpolatedDistribution.cxx:250-266 */
     const float *yv;            /* _distYValues */
@@ -348,6 +348,10 @@ static inline float generateWavelength_k(const oracle_tables *T, int kgen, rng_t
 {
     const oracle_wlen_gen *G = &T->gen[kgen];
     if (G->kind == 1) return G->value;
+    if (G->kind == 2) {                             /* WlenCherenkovNoDispersion.cxx:72-92: first = minVal, spacing = range */
+        const float r = rand_oc(rng);
+        return 1.f / (G->first + r * G->spacing);
+    }
     const float randomNumber = rand_oc(rng);
     unsigned int k = 0;
     float this_acu = 0.0f;

@@ -79,9 +79,13 @@ def test_degenerate_wavelength_generators_are_refused():
     conv = CV.I3CLSimStepToPhotonConverterHIP(0)
     for gen in (CV.I3CLSimRandomValueConstant(0.0), CV.I3CLSimRandomValueConstant(float("nan")),
                 CV.I3CLSimRandomValueInterpolatedDistribution(3e-7, 1e-8, [0.0, 0.0, 0.0]),
-                CV.I3CLSimRandomValueInterpolatedDistribution(3e-7, 0.0, [1.0, 2.0])):
+                CV.I3CLSimRandomValueInterpolatedDistribution(3e-7, 0.0, [1.0, 2.0]),
+                CV.I3CLSimRandomValueWlenCherenkovNoDispersion(7e-7, 3e-7),             # WlenCherenkovNoDispersion.cxx:47-51
+                CV.I3CLSimRandomValueWlenCherenkovNoDispersion(float("nan"), 3e-7),
+                CV.I3CLSimRandomValueWlenCherenkovNoDispersion(0.0, 3e-7)):
         with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
             conv.SetWlenGenerators([gen])
+    conv.SetWlenGenerators([CV.I3CLSimRandomValueWlenCherenkovNoDispersion(265e-9, 675e-9)])
 
 
 def test_incomplete_configuration_is_refused():

@@ -111,7 +111,7 @@ def _run_custom(med_o, med_p, geom, gens_o, gens_p, steps, pancake=5.0, max_item
 
 
 @pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1",
-                                  "table_float", "table_with_tilt_and_aniso"])
+                                  "table_float", "table_with_tilt_and_aniso", "no_dispersion_no_bias"])
 def test_other_kernel_variants(kind):
     """Variants of the generated program: PANCAKE_FACTOR undefined (pancake = 1), getTiltZShift_IS_CONSTANT with
     layered ice (carried layer index), a one-layer IceCube medium (un-optimised per-function form, SURVEY 9.7 ii),
@@ -150,6 +150,27 @@ def test_other_kernel_variants(kind):
         med_o = B.load_ppc_ice(ice_dir("spice_lea"), use_tilt_if_available=False)
         med_p = product_medium(directory=ice_dir("spice_lea"), tilt=False)
         _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind == "no_dispersion_no_bias":
+        # generateCherenkovPhotonsWithoutDispersion with a constant bias of 1 (ModuleHelper.cxx:265-275):
+        # I3CLSimRandomValueWlenCherenkovNoDispersion over the medium's wavelength range, constant wavelength bias
+        med_o = B.load_ppc_ice(ice_dir("spice_mie"))
+        med_p = product_medium(directory=ice_dir("spice_mie"))
+        n = len(steps)
+        x, a = common.streams(n)
+        geo = B.build_geometry(geom["string_ids"], geom["dom_ids"], geom["x"], geom["y"], geom["z"], geom["subdetectors"], geom["om_radius"])
+        T = capi.make_tables(med_o, geo, [dict(kind="nodispersion", **{"from": med_o["min_wlen"], "to": med_o["max_wlen"]})],
+                             dict(kind="const", value=1.0), pancake=5.0)
+        ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+        ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+        conv = CV.initializeHIP(0, CV.I3CLSimSimpleGeometry.from_dict(geom), med_p, CV.I3CLSimFunctionConstant(1.0),
+                                [CV.I3CLSimRandomValueWlenCherenkovNoDispersion(med_o["min_wlen"], med_o["max_wlen"])], pancakeFactor=5.0,
+                                approximateNumberOfWorkItems=n, streams=(x, a))
+        conv.EnqueueSteps(steps, 3)
+        _, ph_p = conv.GetConversionResult()
+        assert cnt_o > 5 and len(ph_p) == cnt_o
+        assert common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+        assert np.array_equal(conv.GetRNGState(n), x_o)
+        assert float(ph_p["wavelength"].min()) >= 264e-9 and float(ph_p["wavelength"].max()) <= 676e-9 and np.all(ph_p["weight"] == 1.0)
     elif kind in ("table_float", "table_with_tilt_and_aniso"):
         # per-layer FromTable lengths stored as floats (storeDataAsHalfPrecision=False); and tabulated lengths under
         # the tilt / anisotropy / Mixed scattering objects of SPICE-Lea (no reference loader builds this mix, the classes allow it)
