@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
     ap.add_argument("--photons-per-step", type=int, default=200)
     ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab", "tab5"],
                     help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
                          "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea; tab: the "
                          "table-maker half of configs[4] (point cascade, default spherical axes, SPICE-Mie) -- prints its own line")
@@ -97,7 +97,11 @@ def tabulator_bench(args, torch, device):
     from clsim_amd import tabulator as TB
     n = ((262144 if args.bunch == (1 << 20) else min(args.bunch, 1 << 19)) // 256) * 256     # >= 4 workgroups per CU
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
-    axes = TB.SphericalAxes([TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)])
+    axis_list = [TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)]
+    if args.workload == "tab5":             # fifth axis = cosine of the impact angle (TABULATE_IMPACT_ANGLE), coarser in azimuth
+        axis_list = [TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 12), TB.LinearAxis(-1, 1, 50), TB.PowerAxis(0, 7e3, 105, 2),
+                     TB.LinearAxis(-1, 1, 10)]
+    axes = TB.SphericalAxes(axis_list)
     ang = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
     a = CV.mwc_multipliers(n)
     x = CV.seed_streams(a)
@@ -124,8 +128,9 @@ def tabulator_bench(args, torch, device):
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
            "kernel_ms_per_pass": kernel_ms, "photons_per_pass": photons, "table_bins": tab.n_bins, "occupied_bins": occupied,
            "sum_of_weights_per_pass": (float(sums.sum()) - before) / args.steps,
-           "config": {"workload": "%d steps x %d photons at the origin, spherical axes 200x36x100x105, spice_mie, 42 absorption lengths, "
-                                  "1 m sampling; BASELINE.json configs[4] (tablemaker half)" % (n, args.photons_per_step)}}
+           "config": {"workload": "%d steps x %d photons at the origin, spherical axes %s, spice_mie, 42 absorption lengths, "
+                                  "1 m sampling; BASELINE.json configs[4] (tablemaker half)"
+                                  % (n, args.photons_per_step, "x".join(str(v - 2) for v in tab.shape))}}
     if not args.no_cpu_baseline:
         # path samples are counted by the oracle on a small sample of the same steps (they are the same on both sides)
         from oracle import builders as B
@@ -177,7 +182,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.workload == "tab":
+    if args.workload in ("tab", "tab5"):
         return tabulator_bench(args, torch, local_rank)
     n = (args.bunch // 512) * 512
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----

@@ -163,7 +163,7 @@ def load():
         "clsimhip_tabulator_last_error": (C.c_char_p, [vp]),
         "clsimhip_tabulator_enqueue_steps": (i32, [vp, vp, sz, DP]),
         "clsimhip_tabulator_finish": (i32, [vp]),
-        "clsimhip_tabulator_get_shape": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_tabulator_get_shape": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_tabulator_get_bin_content": (i32, [vp, vp, sz, i32, i32]),
         "clsimhip_tabulator_get_bin_sums": (i32, [vp, vp, sz, i32]),
         "clsimhip_tabulator_get_bin_edges": (i32, [vp, i32, DP, sz]),

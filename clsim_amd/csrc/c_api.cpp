@@ -463,12 +463,13 @@ int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step 
     return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->enqueue_steps(steps, n, reference); });
 }
 int clsimhip_tabulator_finish(clsimhip_tabulator *t) { return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->finish(); }); }
-int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t shape[4])
+int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t *n_dim, size_t shape[5])
 {
     return guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] {
-        need(t, "tabulator"); need(n_bins, "n_bins"); need(shape, "shape");
+        need(t, "tabulator"); need(n_bins, "n_bins"); need(n_dim, "n_dim"); need(shape, "shape");
         *n_bins = t->impl->n_bins();
-        for (size_t i = 0; i < 4; ++i) shape[i] = t->impl->shape()[i];
+        *n_dim = t->impl->shape().size();
+        for (size_t i = 0; i < 5; ++i) shape[i] = i < t->impl->shape().size() ? t->impl->shape()[i] : 0;
     });
 }
 int clsimhip_tabulator_get_bin_content(clsimhip_tabulator *t, float *out, size_t n_bins, int squared, int normalized)
@@ -483,7 +484,7 @@ int clsimhip_tabulator_get_bin_edges(const clsimhip_tabulator *t, int axis, doub
 {
     return guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] {
         need(t, "tabulator"); need(out, "out");
-        if (axis < 0 || axis >= 4) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis out of range");
+        if (axis < 0 || static_cast<size_t>(axis) >= t->impl->axes().size()) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis out of range");
         const AxisData &ax = t->impl->axes()[axis];
         if (cap < ax.n_bins + 1) throw Error(CLSIMHIP_ERR_ARGUMENT, "output buffer too small");
         for (unsigned i = 0; i <= ax.n_bins; ++i) out[i] = ax.bin_edge(i);      // Axis::GetBinEdges (Axis.cxx:62-74)

@@ -136,9 +136,10 @@ struct KParams {
     // stall on every use: the loop's atomics make the compiler reload kernel arguments each trip)
     uint32_t off_tab;
     int32_t tab_axes_kind, tab_full_azimuth;
-    float tab_scale[4], tab_offset[4];  // Axis::GetIndexCode literals
-    int32_t tab_inverse[4], tab_nbins[4];
-    uint32_t tab_stride[4];
+    int32_t tab_ndim;                   // 4, or 5 = TABULATE_IMPACT_ANGLE (fifth axis: cosine of the impact angle)
+    float tab_scale[5], tab_offset[5];  // Axis::GetIndexCode literals
+    int32_t tab_inverse[5], tab_nbins[5];
+    uint32_t tab_stride[5];
     float tab_max0, tab_max3, tab_min_inv_groupvel, tab_tan_thetac, tab_volume_step;
     int32_t ang_n;                      // getAngularAcceptance polynomial (coefficients in the LDS image)
     uint32_t off_ang;

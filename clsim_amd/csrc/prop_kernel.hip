@@ -386,6 +386,7 @@ struct Photon {
     uint64_t rx_start;          // RNG state word when the photon was created
     int layer;                  // carried layer index (getTiltZShift_IS_CONSTANT, c.cl:521-523)
     float tab_remainder, tab_depth;     // TABULATE only: prevStepRemainder, depthPropagated (c.cl:530-534, 563)
+    float tab_wlen;                     // TABULATE only: photonDirAndWlen.w (enters the impact-angle dot product)
 };
 
 struct Birth {                  // propagation_kernel.c.cl:132-184 + :587: what createPhotonFromTrack yields
@@ -446,7 +447,7 @@ DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
     // TABULATE: the first sub-step is drawn between the photon's creation and its (fixed) absorption budget,
     // which draws nothing (c.cl:559-563, 582-588)
     const Birth b = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, ra);
-    if (TAB) { ph.tab_remainder = P->tab_volume_step * rng_oc(rx, ra); ph.tab_depth = 0.0f; }
+    if (TAB) { ph.tab_remainder = P->tab_volume_step * rng_oc(rx, ra); ph.tab_depth = 0.0f; ph.tab_wlen = b.wlen; }
     ph.px = b.x; ph.py = b.y; ph.pz = b.z; ph.pt = b.t;
     ph.d = b.d;
     ph.num_scatters = 0;
@@ -666,19 +667,25 @@ DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float 
 // overflow.  Returns true when the photon left the table (isOutOfBounds): it is dropped (c.cl:781-784).
 // One path sample (the body of the loop of c.cl:256-287): the table bin of the point at distance d along the segment
 // and whether it is out of bounds (isOutOfBounds, Axes.cxx:104-116, 140-151).
-struct Segment { float px, py, pz, pt, dx, dy, dz, igv; };
-DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uint32_t &index)
+// LDS record at off_tab (tabulator.cpp): [0..4] scale, [5..9] offset, [10..14] bins, [15..19] stride, [20..24] sqrt axis,
+// [25] max of axis 0, [26] max of axis 3, [27] min_invGroupVel, [28] tan_thetaC, [29] VOLUME_MODE_STEP, [30] dimensions
+struct Segment { float px, py, pz, pt, dx, dy, dz, igv, wlen; };
+// (x, a): the photon's stream before the two draws of this sample (ANGLE = TABULATE_IMPACT_ANGLE only)
+template <bool ANGLE>
+DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uint64_t x, uint32_t a, uint32_t &index)
 {
     const uint32_t T = P->off_tab;
     auto R = [&](int k) { return __builtin_bit_cast(float, ref_lds[k]); };
     // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
-    const float px = (g.px + d * g.dx) - R(0), py = (g.py + d * g.dy) - R(1), pz = (g.pz + d * g.dz) - R(2);
-    const float pw = (g.pt + d * g.igv) - R(3);
+    const float ax = g.px + d * g.dx, ay = g.py + d * g.dy, az = g.pz + d * g.dz, aw = g.pt + d * g.igv;
+    const float px = ax - R(0), py = ay - R(1), pz = az - R(2);
+    const float pw = aw - R(3);
     const float ux = R(4), uy = R(5), uz = R(6), uw = R(7), qx = R(8), qy = R(9), qz = R(10), qw = R(11);
     const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
     const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
     const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
-    float c0, c1, c2, c3;
+    constexpr int ndim = ANGLE ? 5 : 4;
+    float c0, c1, c2, c3, c4 = 0.0f;
     if (P->tab_axes_kind == 0) {
         c0 = dm::sqrt_(px * px + py * py + pz * pz);
         const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
@@ -690,25 +697,44 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
             c1 = azimuth;
         }
         c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
-        c3 = pw - c0 * ldsf(T + 22u);
-        if ((c3 > ldsf(T + 21u)) || (c0 > ldsf(T + 20u))) return true;
+        c3 = pw - c0 * ldsf(T + 27u);
     } else {
         c0 = n_rho;
         c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
         c2 = R(2) + l * uz;
-        c3 = pw - (l + c0 * ldsf(T + 23u)) * 3.33564095f;
-        if (c3 > ldsf(T + 21u)) return true;
+        c3 = pw - (l + c0 * ldsf(T + 28u)) * 3.33564095f;
+    }
+    if (ANGLE) {
+        // TABULATE_IMPACT_ANGLE (spherical :67-79, cylindrical :61-76): drawn before the bounds check, like the reference
+        const float sina = dm::sqrt_(rng_co(x, a));
+        Vec3 dd = {g.dx, g.dy, g.dz};
+        scatter_direction(dm::sqrt_(1.0f - sina * sina), sina, dd, rng_co(x, a));
+        if (P->tab_axes_kind == 0) {
+            c4 = (c0 > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, px, py, pz, pw) / c0) : 1.0f;
+        } else {
+            // (l - rho*recip(tan_thetaC))*dir, component by component as OpenCL evaluates it
+            const float rt = 1.0f / ldsf(T + 28u);
+            const float kx = ax - (R(0) + (l - rx_ * rt) * ux), ky = ay - (R(1) + (l - ry_ * rt) * uy);
+            const float kz = az - (R(2) + (l - rz_ * rt) * uz), kw = aw - (R(3) + (l - rw_ * rt) * uw);
+            const float cdist = dm::sqrt_(kx * kx + ky * ky + kz * kz);
+            c4 = (cdist > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, kx, ky, kz, kw) / cdist) : 1.0f;
+        }
+    }
+    if (P->tab_axes_kind == 0) {
+        if ((c3 > ldsf(T + 26u)) || (c0 > ldsf(T + 25u))) return true;
+    } else {
+        if (c3 > ldsf(T + 26u)) return true;
     }
     // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
-    const float c[4] = {c0, c1, c2, c3};
+    const float c[5] = {c0, c1, c2, c3, c4};
     index = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float v = ldsu(T + 16u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
-        const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 4u + (uint32_t)k));
+    for (int k = 0; k < ndim; ++k) {
+        const float v = ldsu(T + 20u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
+        const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 5u + (uint32_t)k));
         int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-        b = clampi(b, -1, (int)ldsu(T + 8u + (uint32_t)k)) + 1;
-        index += ldsu(T + 12u + (uint32_t)k) * (uint32_t)b;
+        b = clampi(b, -1, (int)ldsu(T + 10u + (uint32_t)k)) + 1;
+        index += ldsu(T + 15u + (uint32_t)k) * (uint32_t)b;
     }
     return false;
 }
@@ -726,12 +752,16 @@ DM void add_to_bin(KP P, uint32_t index, float w)
 // samples are evaluated 64 at a time by whichever lanes, and a sample is added to the table unless its segment
 // went out of bounds at an earlier sample.  Bins and weights are those of the per-lane walk, bit for bit.
 // Returns true for lanes whose photon left the table.
+template <bool ANGLE>
 DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool active, const Photon &ph, float weight,
-                       float length, float &remainder, float depth, float this_depth)
+                       float length, float &remainder, float depth, float this_depth, uint64_t &rx, uint32_t ra)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const float vstep = ldsf(P->off_tab + 24u);
-    const float impact = active ? weight * angular_acceptance(P, ph.d.z) : 0.0f;
+    const float vstep = ldsf(P->off_tab + 29u);
+    // ANGLE = TABULATE_IMPACT_ANGLE: every sample draws two numbers from the photon's stream (its impact point on the
+    // DOM), the angular acceptance is a table axis instead of a weight (c.cl:246-251)
+    constexpr bool angle_axis = ANGLE;
+    const float impact = active ? (angle_axis ? weight : weight * angular_acceptance(P, ph.d.z)) : 0.0f;
     // number of samples and the value d ends with
     uint32_t n = 0;
     float d_end = remainder;
@@ -747,23 +777,29 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
     const uint32_t first = incl - n;
+    // pool layout: d and owner per sample, plus the stream state before the sample's draws when there is an angle axis
+    // (then the pool holds half as many samples)
+    const uint32_t slots = angle_axis ? (uint32_t)kTabSlots / 2u : (uint32_t)kTabSlots;
+    const uint64_t rx_before = rx;
     bool stop = false;
     if (total == 0u) {
         // nothing to record
-    } else if (total > (uint32_t)kTabSlots) {
+    } else if (total > slots) {
         // (rare) more samples than the pool holds: every lane walks its own segment
         if (active) {
-            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
+            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, ph.tab_wlen};
             float d = remainder;
             for (uint32_t taken = 0; (d < length) && (taken < n); d += vstep, ++taken) {
                 uint32_t index;
-                if (sample_bin(P, ref_lds, g, d, index)) { stop = true; break; }
+                const uint64_t x_sample = rx;
+                if (angle_axis) { (void)rng_co(rx, ra); (void)rng_co(rx, ra); }
+                if (sample_bin<ANGLE>(P, ref_lds, g, d, x_sample, ra, index)) { stop = true; break; }
                 add_to_bin(P, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
             }
             d_end = d;
         }
     } else {
-        uint32_t *slot_d = wave_lds, *slot_owner = wave_lds + kTabSlots;
+        uint32_t *slot_d = wave_lds, *slot_owner = wave_lds + slots, *slot_xlo = wave_lds + 2u * slots, *slot_xhi = wave_lds + 3u * slots;
         int *first_oob = reinterpret_cast<int *>(wave_lds + 2 * kTabSlots);
         first_oob[lane] = 0x7fffffff;
         if (active) {
@@ -771,6 +807,12 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
             for (uint32_t j = 0; j < n; ++j, d += vstep) {
                 slot_d[first + j] = __builtin_bit_cast(uint32_t, d);
                 slot_owner[first + j] = lane | (j << 8);
+                if (angle_axis) {
+                    slot_xlo[first + j] = (uint32_t)rx;
+                    slot_xhi[first + j] = (uint32_t)(rx >> 32);
+                    (void)rng_co(rx, ra);
+                    (void)rng_co(rx, ra);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -788,12 +830,20 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
             g.px = __shfl(ph.px, owner); g.py = __shfl(ph.py, owner); g.pz = __shfl(ph.pz, owner); g.pt = __shfl(ph.pt, owner);
             g.dx = __shfl(ph.d.x, owner); g.dy = __shfl(ph.d.y, owner); g.dz = __shfl(ph.d.z, owner);
             g.igv = __shfl(ph.inv_groupvel, owner);
+            g.wlen = 0.0f;
+            uint64_t x_sample = 0;
+            uint32_t a_sample = 0;
+            if (angle_axis) {
+                g.wlen = __shfl(ph.tab_wlen, owner);
+                a_sample = (uint32_t)__shfl((int)ra, owner);
+                if (have) x_sample = (uint64_t)slot_xlo[slot] | ((uint64_t)slot_xhi[slot] << 32);
+            }
             const float o_length = __shfl(length, owner), o_depth = __shfl(depth, owner), o_this = __shfl(this_depth, owner);
             const float o_impact = __shfl(impact, owner);
             uint32_t index = 0;
             bool oob = false;
             if (have) {
-                oob = sample_bin(P, ref_lds, g, d, index);
+                oob = sample_bin<ANGLE>(P, ref_lds, g, d, x_sample, a_sample, index);
                 if (oob) atomicMin(&first_oob[owner], j);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -829,6 +879,11 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
             if (s_ != 0x7fffffff) {
                 stop = true;
                 d_end = __builtin_bit_cast(float, slot_d[first + (uint32_t)s_]);
+                if (angle_axis) {
+                    // the walk ended at sample s_, whose two draws were made: the stream stands behind them
+                    rx = rx_before;
+                    for (int k = 0; k <= s_; ++k) { (void)rng_co(rx, ra); (void)rng_co(rx, ra); }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -901,7 +956,9 @@ DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
     return born.abs_lens_initial;
 }
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER, bool TAB>
+// TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
+// four-dimensional table maker keeps its register allocation)
+template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
 __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
     // the only kernel argument sits at offset 0 of the kernarg segment
@@ -1016,7 +1073,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
             if (need && !waiting && (photons_left > 0)) {
-                create_photon<MED, TILT, FLASHER, TAB>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER, TAB != 0>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -1060,8 +1117,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             const float travelled = P->fixed_abs - ph.abs_lens_left;
             const float weight = run ? P->work[sidx].step.weight : 0.0f;
             uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
-            const bool left_table = save_path_wave(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
-                                                   ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth);
+            const bool left_table = save_path_wave<TAB == 2>(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
+                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra);
             if (run) {
                 if (left_table) ph.abs_lens_left = 0.0f;
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
@@ -1229,7 +1286,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 }
 
 // ---- host-side launchers (called from converter.cpp) ----
-template <int MED, bool TILT, bool ANISO, bool FLASHER, bool TAB>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -1315,7 +1372,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, false>(P, stream);
+#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, 0>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
@@ -1335,9 +1392,10 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
     if (!v.tabulate || !P.tab_bins || !P.has_fixed_abs) return hipErrorInvalidValue;
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
+    if (P.tab_ndim != 4 && P.tab_ndim != 5) return hipErrorInvalidValue;
     const int key = 4 * v.lengths + (v.tilt ? 2 : 0) + (v.aniso ? 1 : 0);
     switch (key) {
-#define CASE(k, m, t, a) case k: return launch_variant<m, t, a, true, true>(P, stream);
+#define CASE(k, m, t, a) case k: return (P.tab_ndim > 4) ? launch_variant<m, t, a, true, 2>(P, stream) : launch_variant<m, t, a, true, 1>(P, stream);
 #define CASES(m) CASE(4 * m + 0, m, false, false) CASE(4 * m + 1, m, false, true) CASE(4 * m + 2, m, true, false) CASE(4 * m + 3, m, true, true)
     CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
 #undef CASES

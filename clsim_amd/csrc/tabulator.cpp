@@ -60,7 +60,8 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
       reference_area_(reference_area), step_length_(step_length), streams_(streams)
 {
     if (axes_kind_ != CLSIMHIP_AXES_SPHERICAL && axes_kind_ != CLSIMHIP_AXES_CYLINDRICAL) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown axes kind");
-    if (axes_.size() != 4) throw Error(CLSIMHIP_ERR_CONFIG, "only 4-dimensional tables are restated (no TABULATE_IMPACT_ANGLE)");
+    // 4 axes, or 5 = TABULATE_IMPACT_ANGLE (StepToTableConverter.cxx:187-188)
+    if (axes_.size() != 4 && axes_.size() != 5) throw Error(CLSIMHIP_ERR_CONFIG, "a table has 4 axes, or 5 with the impact angle");
     for (const AxisData &ax : axes_) {
         if (ax.n_bins == 0 || !(ax.max > ax.min)) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis needs bins and max > min");
         if (ax.kind == CLSIMHIP_AXIS_POWER && (ax.power < 1 || ax.power > 2))
@@ -88,7 +89,9 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     P.fixed_abs = to_float_literal(kFixedAbsorptionLengths);
     P.tab_axes_kind = axes_kind_;
     P.tab_full_azimuth = (axes_kind_ == CLSIMHIP_AXES_SPHERICAL && axes_[1].max > 180.) ? 1 : 0;     // Axes.cxx:96-97
-    for (size_t k = 0; k < 4; ++k) {
+    P.tab_ndim = static_cast<int32_t>(nd);
+    for (size_t k = 0; k < 5; ++k) { P.tab_scale[k] = P.tab_offset[k] = 0.f; P.tab_inverse[k] = 0; P.tab_nbins[k] = 0; P.tab_stride[k] = 0; }
+    for (size_t k = 0; k < nd; ++k) {
         // Axis::GetIndexCode (Axis.cxx:45-60)
         const AxisData &ax = axes_[k];
         const double scale = ax.n_bins / (ax.inverse(ax.max) - ax.inverse(ax.min));
@@ -111,12 +114,13 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         while (img.size() % 4) img.push_back(0u);
         P.off_tab = static_cast<uint32_t>(img.size());
         auto putf = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); img.push_back(u); };
-        for (int k = 0; k < 4; ++k) putf(P.tab_scale[k]);
-        for (int k = 0; k < 4; ++k) putf(P.tab_offset[k]);
-        for (int k = 0; k < 4; ++k) img.push_back(static_cast<uint32_t>(P.tab_nbins[k]));
-        for (int k = 0; k < 4; ++k) img.push_back(P.tab_stride[k]);
-        for (int k = 0; k < 4; ++k) img.push_back(static_cast<uint32_t>(P.tab_inverse[k]));
+        for (int k = 0; k < 5; ++k) putf(P.tab_scale[k]);
+        for (int k = 0; k < 5; ++k) putf(P.tab_offset[k]);
+        for (int k = 0; k < 5; ++k) img.push_back(static_cast<uint32_t>(P.tab_nbins[k]));
+        for (int k = 0; k < 5; ++k) img.push_back(P.tab_stride[k]);
+        for (int k = 0; k < 5; ++k) img.push_back(static_cast<uint32_t>(P.tab_inverse[k]));
         putf(P.tab_max0); putf(P.tab_max3); putf(P.tab_min_inv_groupvel); putf(P.tab_tan_thetac); putf(P.tab_volume_step);
+        img.push_back(static_cast<uint32_t>(nd));
         while (img.size() % 4) img.push_back(0u);
     }
     {   // getAngularAcceptance: coefficients are appended to the LDS image
@@ -132,8 +136,8 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         tables_.named["getAngularAcceptance"] = angular.coefficients;
     }
     tables_.named["TABULATOR"] = {n_group_, n_phase_, P.tab_min_inv_groupvel, P.tab_tan_thetac, double(n_bins_)};
-    tables_.named["TABULATOR_SCALE"] = {P.tab_scale[0], P.tab_scale[1], P.tab_scale[2], P.tab_scale[3]};
-    tables_.named["TABULATOR_OFFSET"] = {P.tab_offset[0], P.tab_offset[1], P.tab_offset[2], P.tab_offset[3]};
+    tables_.named["TABULATOR_SCALE"] = std::vector<double>(P.tab_scale, P.tab_scale + nd);
+    tables_.named["TABULATOR_OFFSET"] = std::vector<double>(P.tab_offset, P.tab_offset + nd);
 
     for (size_t i = 0; i < streams; ++i)
         if ((x[i] == 0) | ((static_cast<uint32_t>(x[i] >> 32)) >= (a[i] - 1)) | ((static_cast<uint32_t>(x[i])) >= 0xfffffffful))
@@ -282,7 +286,7 @@ void Tabulator::bin_content(float *out, size_t n, bool squared, bool normalized)
     const size_t nd = axes_.size();
     const size_t spatial_stride = strides_[2];
     for (size_t offset = 0; offset < n_bins_; offset += spatial_stride) {
-        size_t idxs[4];
+        size_t idxs[5];
         for (size_t j = 0; j < nd; ++j)
             idxs[j] = static_cast<size_t>(std::min(std::max(static_cast<int>(offset / strides_[j] % shape_[j]) - 1, 0), static_cast<int>(shape_[j]) - 3));
         double norm = bin_volume(idxs) / (step_length_ * reference_area_);

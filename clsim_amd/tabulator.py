@@ -93,9 +93,9 @@ class I3CLSimStepToTableConverterHIP:
         if rc != _lib.OK:
             raise I3CLSimStepToPhotonConverter_exception((self._lib.clsimhip_tabulator_last_error(None) or b"").decode(), rc)
         self._medium = mediumProperties
-        n, shape = C.c_size_t(), (C.c_size_t * 4)()
-        self._call("clsimhip_tabulator_get_shape", C.byref(n), shape)
-        self.n_bins, self.shape = n.value, tuple(shape)
+        n, nd, shape = C.c_size_t(), C.c_size_t(), (C.c_size_t * 5)()
+        self._call("clsimhip_tabulator_get_shape", C.byref(n), C.byref(nd), shape)
+        self.n_bins, self.shape = n.value, tuple(shape)[:nd.value]
 
     def __del__(self):
         try:

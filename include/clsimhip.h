@@ -290,7 +290,8 @@ int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, s
  * I3CLSimStepToTableConverter (private/clsim/tabulator/I3CLSimStepToTableConverter.h:44-101): propagates steps with
  * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no
  * detector, a path sample every `step_length` metres) and fills a table over coordinates relative to a reference
- * particle.  4-dimensional tables (no impact-angle axis), linear and square-root axes. */
+ * particle.  4 axes, or 5 = TABULATE_IMPACT_ANGLE (StepToTableConverter.cxx:187-188: the fifth axis is the cosine of
+ * the impact angle on the DOM, two random numbers per path sample); linear and square-root axes. */
 #define CLSIMHIP_AXIS_LINEAR 0          /* clsim::tabulator::LinearAxis (tabulator/Axis.h:71-80) */
 #define CLSIMHIP_AXIS_POWER 1           /* clsim::tabulator::PowerAxis  (tabulator/Axis.h:82-95) */
 typedef struct {
@@ -324,8 +325,9 @@ const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t);
 int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step *steps, size_t n, const double reference[7]);
 /* Finish() (:287-295): waits until every enqueued bunch is in the table */
 int clsimhip_tabulator_finish(clsimhip_tabulator *t);
-/* number of bins including under-/overflow bins, and the shape (n_bins + 2 per axis) */
-int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t shape[4]);
+/* number of bins including under-/overflow bins, number of axes (4, or 5 with the impact angle), and the shape
+ * (n_bins + 2 per axis; unused entries 0) */
+int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t *n_dim, size_t shape[5]);
 /* binContent_ (squared == 0) or squaredWeights_ as the float image WriteFITSFile stores (:595-686), before
  * (normalized == 0) or after Normalize() (:512-543) */
 int clsimhip_tabulator_get_bin_content(clsimhip_tabulator *t, float *out, size_t n_bins, int squared, int normalized);

@@ -839,7 +839,7 @@ def reference_particle(pos, time, direction):
 
 def tabulator_config(kind, axes, medium, angular_coefficients, step_length=1.0, entries_per_stream=5000):
     """What tabulator/I3CLSimStepToTableConverter.cxx:178-207 and Axes::GenerateBinningCode put into the program."""
-    assert kind in ("spherical", "cylindrical") and len(axes) == 4
+    assert kind in ("spherical", "cylindrical") and len(axes) in (4, 5)     # 5: TABULATE_IMPACT_ANGLE (:187-188)
     shape, strides, n_bins = axes_layout(axes)
     n_group, n_phase = minimum_refractive_index(medium)
     lit = [axis_index_literals(ax) for ax in axes]

@@ -82,8 +82,9 @@ class Tables(C.Structure):
         ("phase_data", FP), ("group_data", FP),
         ("has_fixed_abs", C.c_int32), ("fixed_abs", C.c_float), ("history_n", C.c_int32),
         ("tab_axes_kind", C.c_int32), ("tab_full_azimuth", C.c_int32),
-        ("tab_scale", C.c_float * 4), ("tab_offset", C.c_float * 4), ("tab_inverse", C.c_int32 * 4),
-        ("tab_nbins", C.c_int32 * 4), ("tab_stride", C.c_uint32 * 4),
+        ("tab_ndim", C.c_int32),
+        ("tab_scale", C.c_float * 5), ("tab_offset", C.c_float * 5), ("tab_inverse", C.c_int32 * 5),
+        ("tab_nbins", C.c_int32 * 5), ("tab_stride", C.c_uint32 * 5),
         ("tab_max0", C.c_float), ("tab_max3", C.c_float), ("tab_min_inv_groupvel", C.c_float), ("tab_tan_thetac", C.c_float),
         ("tab_volume_step", C.c_float), ("tab_entries_per_stream", C.c_uint32),
         ("ang_n", C.c_int32), ("ang_coeff", C.c_float * 16), ("ang_has_min", C.c_int32), ("ang_has_max", C.c_int32),
@@ -156,7 +157,8 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
         t.has_fixed_abs, t.fixed_abs = 1, fl(42.0)                           # PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS 42
         t.tab_axes_kind = 0 if tb["kind"] == "spherical" else 1
         t.tab_full_azimuth = 1 if tb["full_azimuth"] else 0
-        for k in range(4):
+        t.tab_ndim = len(tb["axes"])                                         # > 4: TABULATE_IMPACT_ANGLE
+        for k in range(t.tab_ndim):
             t.tab_scale[k], t.tab_offset[k] = tb["scale"][k], tb["offset"][k]
             t.tab_inverse[k], t.tab_nbins[k], t.tab_stride[k] = tb["inverse"][k], tb["axes"][k]["n_bins"], tb["strides"][k]
         t.tab_max0, t.tab_max3 = tb["max0"], tb["max3"]

@@ -143,10 +143,11 @@ typedef struct {
     /* ---- TABULATE (tabulator/I3CLSimStepToTableConverter.cxx:178-207, Axes.cxx, Axis.cxx) ---- */
     int32_t tab_axes_kind;      /* 0 spherical_coordinates.c.cl, 1 cylindrical_coordinates.c.cl */
     int32_t tab_full_azimuth;   /* HAS_FULL_AZIMUTH_EXTENSION */
-    float tab_scale[4], tab_offset[4];  /* Axis::GetIndexCode literals */
-    int32_t tab_inverse[4];     /* inverse transform: 0 identity, 1 sqrt */
-    int32_t tab_nbins[4];
-    uint32_t tab_stride[4];
+    int32_t tab_ndim;           /* 4, or 5 = TABULATE_IMPACT_ANGLE (StepToTableConverter.cxx:187-188) */
+    float tab_scale[5], tab_offset[5];  /* Axis::GetIndexCode literals */
+    int32_t tab_inverse[5];     /* inverse transform: 0 identity, 1 sqrt */
+    int32_t tab_nbins[5];
+    uint32_t tab_stride[5];
     float tab_max0, tab_max3;   /* isOutOfBounds */
     float tab_min_inv_groupvel, tab_tan_thetac;
     float tab_volume_step;      /* VOLUME_MODE_STEP */
@@ -656,8 +657,10 @@ static inline float getAngularAcceptance(const oracle_tables *T, float x)
     for (int i = T->ang_n - 2; i >= 0; --i) r = T->ang_coeff[i] + x * r;     /* c0 + x*(c1 + x*(...)) */
     return r;
 }
-/* spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77 (4 dimensions) */
-static inline void getCoordinates(const oracle_tables *T, const float absPos[4], const oracle_reference *source, float coords[4])
+static void scatterDirectionByAngle(float cosa, float sina, float d[4], float randomNumber);
+/* spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77; dirw is the function's own copy */
+static inline void getCoordinates(const oracle_tables *T, const float absPos[4], float dirw[4], const oracle_reference *source,
+                                  rng_t *rng, float coords[5])
 {
     float pos[4], rho[4];
     for (int k = 0; k < 4; ++k) pos[k] = absPos[k] - source->posAndTime[k];
@@ -686,9 +689,28 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
         coords[2] = source->posAndTime[2] + l * source->dir[2];
         coords[3] = pos[3] - (l + coords[0] * T->tab_tan_thetac) * 3.33564095f;
     }
+    coords[4] = 0.0f;
+    if (T->tab_ndim > 4) {
+        /* TABULATE_IMPACT_ANGLE (spherical :67-79, cylindrical :61-72): impact position randomised over the DOM's
+         * cross-section; dot() runs over all four components (wavelength * time difference included) */
+        const float sina = om_sqrt(rand_co(rng));
+        scatterDirectionByAngle(om_sqrt(1 - sina * sina), sina, dirw, rand_co(rng));
+        if (T->tab_axes_kind == 0) {
+            coords[4] = (coords[0] > 0) ? (dot4(dirw, pos) / coords[0]) : 1;
+        } else {
+            /* cylindrical :70-75: (l - rho*recip(tan_thetaC))*source->dir is evaluated component by component
+             * (scalar - vector, vector * vector), as OpenCL does for this expression */
+            const float recip_tan = 1.f / T->tab_tan_thetac;
+            float cpos[4];
+            for (int k = 0; k < 4; ++k)
+                cpos[k] = absPos[k] - (source->posAndTime[k] + (l - rho[k] * recip_tan) * source->dir[k]);
+            const float cdist = magnitude(cpos);
+            coords[4] = (cdist > 0) ? (dot4(dirw, cpos) / cdist) : 1;
+        }
+    }
 }
 /* Axes.cxx:104-151 */
-static inline int isOutOfBounds(const oracle_tables *T, const float c[4])
+static inline int isOutOfBounds(const oracle_tables *T, const float c[5])
 {
     if (T->tab_axes_kind == 0) return (c[3] > T->tab_max3) || (c[0] > T->tab_max0);
     return (c[3] > T->tab_max3);
@@ -703,10 +725,10 @@ static inline int convert_int_sat_rtn(float v)
     return (int)f;
 }
 /* Axes.cxx:69-90 with Axis.cxx:45-60 */
-static inline uint32_t getBinIndex(const oracle_tables *T, const float c[4])
+static inline uint32_t getBinIndex(const oracle_tables *T, const float c[5])
 {
     uint32_t index = 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < T->tab_ndim; ++k) {
         const float v = T->tab_inverse[k] ? om_sqrt(c[k]) : c[k];
         int b = convert_int_sat_rtn(T->tab_scale[k] * v - T->tab_offset[k]);
         b = imin(imax(b, -1), T->tab_nbins[k]) + 1;
@@ -716,9 +738,11 @@ static inline uint32_t getBinIndex(const oracle_tables *T, const float c[4])
 }
 /* c.cl:228-303 */
 static int savePath(const oracle_tables *T, const oracle_step *step, tab_ctx *tc, const float pos0[4], const float dirw[4],
-                    float thisStepLength, float *prevStepLength, float inv_groupvel, float depth, float thisStepDepth, int *stop)
+                    float thisStepLength, float *prevStepLength, float inv_groupvel, float depth, float thisStepDepth, int *stop,
+                    rng_t *rng)
 {
-    const float impactWeight = step->weight * getAngularAcceptance(T, dirw[2]);
+    /* c.cl:246-251 */
+    const float impactWeight = (T->tab_ndim > 4) ? step->weight : step->weight * getAngularAcceptance(T, dirw[2]);
     float d = *prevStepLength;
     uint32_t offset = *tc->entry_counter;
     for (; d < thisStepLength && offset < T->tab_entries_per_stream; d += T->tab_volume_step, offset++) {
@@ -727,8 +751,9 @@ static int savePath(const oracle_tables *T, const oracle_step *step, tab_ctx *tc
         pos[1] = pos0[1] + d * dirw[1];
         pos[2] = pos0[2] + d * dirw[2];
         pos[3] = pos0[3] + d * inv_groupvel;
-        float coords[4];
-        getCoordinates(T, pos, tc->source, coords);
+        float coords[5];
+        float dir_copy[4] = { dirw[0], dirw[1], dirw[2], dirw[3] };
+        getCoordinates(T, pos, dir_copy, tc->source, rng, coords);
         if (isOutOfBounds(T, coords)) { *stop = 1; break; }
         tc->entries[offset].index = getBinIndex(T, coords);
         tc->entries[offset].weight = impactWeight * om_exp(-(depth + (d / thisStepLength) * thisStepDepth));
@@ -853,7 +878,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         } else {                                                            /* c.cl:755-785 */
             int stop = 0;
             if (!savePath(T, &step, tc, pos, dirw, distancePropagated, &prevStepRemainder, inv_groupvel, depthPropagated,
-                          abs_lens_initial - abs_lens_left - depthPropagated, &stop)) {
+                          abs_lens_initial - abs_lens_left - depthPropagated, &stop, rng)) {
                 tc->photons_left_out = photonsLeftToPropagate;              /* unfinished: restart this photon later */
                 *rng = prev_rng;
                 if (iterations) *iterations += iters;
@@ -914,10 +939,16 @@ void oracle_tabulate(const oracle_tables *T, const oracle_step *steps, uint32_t 
 void oracle_eval_tabulator(const oracle_tables *T, const oracle_reference *source, const float *pos_and_time, int n,
                            float *coords, uint32_t *index, int32_t *out_of_bounds)
 {
+    /* the four geometric coordinates; with a fifth axis the caller supplies direction + wavelength and a stream */
     for (int i = 0; i < n; ++i) {
-        getCoordinates(T, pos_and_time + 4 * i, source, coords + 4 * i);
-        index[i] = getBinIndex(T, coords + 4 * i);
-        out_of_bounds[i] = isOutOfBounds(T, coords + 4 * i);
+        float c[5], dirw[4] = { 0.f, 0.f, 1.f, 0.f };
+        rng_t r = { 1u, 4294967118u };
+        oracle_tables T4 = *T;
+        T4.tab_ndim = 4;
+        getCoordinates(&T4, pos_and_time + 4 * i, dirw, source, &r, c);
+        for (int k = 0; k < 4; ++k) coords[4 * i + k] = c[k];
+        index[i] = getBinIndex(&T4, c);
+        out_of_bounds[i] = isOutOfBounds(&T4, c);
     }
 }
 float oracle_eval_angular_acceptance(const oracle_tables *T, float x) { return getAngularAcceptance(T, x); }

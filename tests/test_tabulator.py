@@ -27,6 +27,13 @@ def axes_pair(kind, small=True):
     elif kind == "spherical360":
         o = [B.power_axis(0, 300, 30, 2), B.linear_axis(0, 360, 24), B.linear_axis(-1, 1, 20), B.power_axis(0, 3e3, 30, 2)]
         p = TB.SphericalAxes([TB.PowerAxis(0, 300, 30, 2), TB.LinearAxis(0, 360, 24), TB.LinearAxis(-1, 1, 20), TB.PowerAxis(0, 3e3, 30, 2)])
+    elif kind == "spherical5":
+        # a fifth axis (cosine of the impact angle) switches TABULATE_IMPACT_ANGLE on (StepToTableConverter.cxx:187-188)
+        o = [B.power_axis(0, 580, 40, 2), B.linear_axis(0, 180, 8), B.linear_axis(-1, 1, 20), B.power_axis(0, 7e3, 21, 2), B.linear_axis(-1, 1, 10)]
+        p = TB.SphericalAxes([TB.PowerAxis(0, 580, 40, 2), TB.LinearAxis(0, 180, 8), TB.LinearAxis(-1, 1, 20), TB.PowerAxis(0, 7e3, 21, 2), TB.LinearAxis(-1, 1, 10)])
+    elif kind == "cylindrical5":
+        o = [B.power_axis(0, 580, 20, 2), B.linear_axis(0, math.pi, 8), B.linear_axis(-8e2, 8e2, 16), B.power_axis(0, 7e3, 21, 2), B.linear_axis(-1, 1, 10)]
+        p = TB.CylindricalAxes([TB.PowerAxis(0, 580, 20, 2), TB.LinearAxis(0, math.pi, 8), TB.LinearAxis(-8e2, 8e2, 16), TB.PowerAxis(0, 7e3, 21, 2), TB.LinearAxis(-1, 1, 10)])
     else:
         o = [B.power_axis(0, 580, 100 // f, 2), B.linear_axis(0, math.pi, (36 if f == 1 else 8)), B.linear_axis(-8e2, 8e2, 80 // f), B.power_axis(0, 7e3, 105 // f, 2)]
         p = TB.CylindricalAxes([TB.PowerAxis(0, 580, 100 // f, 2), TB.LinearAxis(0, math.pi, (36 if f == 1 else 8)), TB.LinearAxis(-8e2, 8e2, 80 // f), TB.PowerAxis(0, 7e3, 105 // f, 2)])
@@ -91,15 +98,17 @@ def test_oracle_tabulator_entries_and_misses():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,ice,step_length", [("spherical", "mie", 1.0), ("cylindrical", "lea", 1.0), ("spherical360", "photonics_mie", 1.0),
-                                                  ("spherical", "lea", 0.2)])
+                                                  ("spherical", "lea", 0.2), ("spherical5", "mie", 1.0), ("cylindrical5", "lea", 1.0),
+                                                  ("spherical5", "lea", 0.2)])
 def test_table_matches_the_oracle(kind, ice, step_length):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
     the reference's in-order float accumulation to float accuracy.  step_length 0.2 m makes most waves exceed the
-    sample pool, i.e. exercises the per-lane walk next to the pooled one."""
+    sample pool, i.e. exercises the per-lane walk next to the pooled one.  The "5" kinds have the impact-angle axis:
+    two random numbers per sample from the photon's own stream, so the final stream states check the draw count."""
     cfg = common.config(ice)
     o, p = axes_pair(kind)
-    okind = "cylindrical" if kind == "cylindrical" else "spherical"
+    okind = "cylindrical" if kind.startswith("cylindrical") else "spherical"
     fine = step_length != 1.0
     tb = B.tabulator_config(okind, o, cfg["med_o"], ANGULAR, step_length=step_length, entries_per_stream=60000)
     bias_o = B.icecube_dom_acceptance()
@@ -129,7 +138,7 @@ def test_table_matches_the_oracle(kind, ice, step_length):
     tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=step_length)
     assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
-    for k in range(4):
+    for k in range(len(o)):
         assert np.array_equal(tab.GetBinEdges(k), B.axis_bin_edges(o[k]))
     assert np.array_equal(tab.GetTable("TABULATOR_SCALE"), np.array(tb["scale"], dtype=np.float64))
     assert np.array_equal(tab.GetTable("TABULATOR_OFFSET"), np.array(tb["offset"], dtype=np.float64))
