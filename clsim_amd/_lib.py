@@ -85,6 +85,9 @@ SYMBOLS = [
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
+    "clsimhip_step_store_create", "clsimhip_step_store_destroy", "clsimhip_step_store_insert", "clsimhip_step_store_size",
+    "clsimhip_step_store_count", "clsimhip_step_store_pop_bunch", "clsimhip_step_store_pop_bunch_filled",
+    "clsimhip_step_store_size_with_dummy_fill",
     "clsimhip_tabulator_create", "clsimhip_tabulator_destroy", "clsimhip_tabulator_last_error",
     "clsimhip_tabulator_enqueue_steps", "clsimhip_tabulator_finish", "clsimhip_tabulator_get_shape",
     "clsimhip_tabulator_get_bin_content", "clsimhip_tabulator_get_bin_sums", "clsimhip_tabulator_get_bin_edges",
@@ -157,6 +160,14 @@ def load():
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
         "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),
+        "clsimhip_step_store_create": (i32, [sz, C.POINTER(vp)]),
+        "clsimhip_step_store_destroy": (None, [vp]),
+        "clsimhip_step_store_insert": (i32, [vp, vp, sz]),
+        "clsimhip_step_store_size": (i32, [vp, C.POINTER(sz)]),
+        "clsimhip_step_store_count": (i32, [vp, u32, C.POINTER(u32)]),
+        "clsimhip_step_store_pop_bunch": (i32, [vp, sz, vp, C.POINTER(sz)]),
+        "clsimhip_step_store_pop_bunch_filled": (i32, [vp, sz, vp, vp]),
+        "clsimhip_step_store_size_with_dummy_fill": (i32, [vp, sz, C.POINTER(sz)]),
         "clsimhip_tabulator_create": (i32, [i32, i32, C.POINTER(Axis), sz, i32, vp, C.POINTER(Function), C.POINTER(Polynomial),
                                             dbl, dbl, vp, vp, sz, C.POINTER(vp)]),
         "clsimhip_tabulator_destroy": (None, [vp]),

@@ -6,6 +6,7 @@
 
 #include "converter.h"
 #include "tabulator.h"
+#include "step_store.h"
 
 using namespace clsimhip;
 
@@ -426,6 +427,52 @@ int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, s
         (void)hipFree(d_steps);
         if (padded_out) *padded_out = static_cast<size_t>(padded);
     });
+}
+} // extern "C"
+
+// ---- step store ----
+struct clsimhip_step_store {
+    clsimhip::StepStore impl;
+    explicit clsimhip_step_store(size_t bins) : impl(bins) {}
+};
+extern "C" {
+int clsimhip_step_store_create(size_t initial_bins, clsimhip_step_store **out)
+{
+    return guarded(nullptr, [&] { need(out, "out"); *out = new clsimhip_step_store(initial_bins); });
+}
+void clsimhip_step_store_destroy(clsimhip_step_store *s) { delete s; }
+int clsimhip_step_store_insert(clsimhip_step_store *s, const clsimhip_step *steps, size_t n)
+{
+    return guarded(nullptr, [&] {
+        need(s, "store"); if (n) need(steps, "steps");
+        for (size_t i = 0; i < n; ++i) s->impl.insert(steps[i]);
+    });
+}
+int clsimhip_step_store_size(const clsimhip_step_store *s, size_t *out)
+{
+    return guarded(nullptr, [&] { need(s, "store"); need(out, "out"); *out = s->impl.size(); });
+}
+int clsimhip_step_store_count(const clsimhip_step_store *s, uint32_t identifier, uint32_t *out)
+{
+    return guarded(nullptr, [&] { need(s, "store"); need(out, "out"); *out = s->impl.count(identifier); });
+}
+int clsimhip_step_store_pop_bunch(clsimhip_step_store *s, size_t size, clsimhip_step *out, size_t *popped)
+{
+    return guarded(nullptr, [&] {
+        need(s, "store"); need(popped, "popped"); if (size) need(out, "out");
+        *popped = s->impl.pop_bunch(size, out);
+    });
+}
+int clsimhip_step_store_pop_bunch_filled(clsimhip_step_store *s, size_t size, clsimhip_step *out, const clsimhip_step *fill)
+{
+    return guarded(nullptr, [&] {
+        need(s, "store"); need(fill, "fill"); if (size) need(out, "out");
+        s->impl.pop_bunch_filled(size, out, *fill);
+    });
+}
+int clsimhip_step_store_size_with_dummy_fill(const clsimhip_step_store *s, size_t granularity, size_t *out)
+{
+    return guarded(nullptr, [&] { need(s, "store"); need(out, "out"); *out = s->impl.size_with_dummy_fill(granularity); });
 }
 } // extern "C"
 

@@ -286,6 +286,25 @@ int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requ
 int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed,
                             size_t granularity, clsimhip_step *steps_out, size_t capacity, size_t *padded_out);
 
+/* ---- step store ------------------------------------------------------------------------
+ * I3CLSimStepStore (public/clsim/I3CLSimStepStore.h:44-320): steps sorted by photon count (one FIFO per count), with
+ * the number of stored steps per identifier; the feeder thread of the reference cuts bunches from it
+ * (I3CLSimLightSourceToStepConverterAsync.cxx:209-273).  Host memory only. */
+typedef struct clsimhip_step_store clsimhip_step_store;
+int clsimhip_step_store_create(size_t initial_bins, clsimhip_step_store **out);
+void clsimhip_step_store_destroy(clsimhip_step_store *s);
+/* insert_copy(step.GetNumPhotons(), step) for n steps (StepStore.h:266-283) */
+int clsimhip_step_store_insert(clsimhip_step_store *s, const clsimhip_step *steps, size_t n);
+int clsimhip_step_store_size(const clsimhip_step_store *s, size_t *out);
+/* count(identifier) (StepStore.h:308-312) */
+int clsimhip_step_store_count(const clsimhip_step_store *s, uint32_t identifier, uint32_t *out);
+/* pop_bunch_to_vector(size, vect): ascending photon count, FIFO within a count; *popped <= size (StepStore.h:163-198) */
+int clsimhip_step_store_pop_bunch(clsimhip_step_store *s, size_t size, clsimhip_step *out, size_t *popped);
+/* pop_bunch_to_vector(size, vect, temp): exactly `size` steps, the remainder copies of *fill (StepStore.h:209-222) */
+int clsimhip_step_store_pop_bunch_filled(clsimhip_step_store *s, size_t size, clsimhip_step *out, const clsimhip_step *fill);
+/* numStepsWithDummyFill (Async.cxx:256): size of the padded last bunch before a barrier */
+int clsimhip_step_store_size_with_dummy_fill(const clsimhip_step_store *s, size_t granularity, size_t *out);
+
 /* ---- photon table maker -------------------------------------------------------------
  * I3CLSimStepToTableConverter (private/clsim/tabulator/I3CLSimStepToTableConverter.h:44-101): propagates steps with
  * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no

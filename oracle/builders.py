@@ -855,3 +855,68 @@ def tabulator_config(kind, axes, medium, angular_coefficients, step_length=1.0, 
                 n_group=n_group, n_phase=n_phase,
                 volume_step=float_literal(step_length), entries_per_stream=int(entries_per_stream),
                 angular=[float(c) for c in angular_coefficients])
+
+
+# ---- step store and bunching (public/clsim/I3CLSimStepStore.h, I3CLSimLightSourceToStepConverterAsync.cxx) ----
+class StepStoreModel:
+    """I3CLSimStepStore restated with plain Python containers (StepStore.h:66-320)."""
+
+    def __init__(self):
+        self.bins = {}                      # photon count -> list (FIFO); the reference's vector of deques
+        self.pending = {}
+        self.n = 0
+
+    def insert_copy(self, step):
+        self.bins.setdefault(int(step["num"]), []).append(step.copy())           # :96-123
+        self.pending[int(step["id"])] = self.pending.get(int(step["id"]), 0) + 1  # :276-281
+        self.n += 1
+
+    def size(self):
+        return self.n
+
+    def count(self, identifier):
+        return self.pending.get(int(identifier), 0)                                # :308-312
+
+    def pop_bunch_to_vector(self, size, fill=None):
+        real = min(size, self.n)                                                   # :163-198
+        out = []
+        for key in sorted(self.bins):
+            q = self.bins[key]
+            while q and len(out) < real:
+                s = q.pop(0)
+                out.append(s)
+                self.pending[int(s["id"])] -= 1                                    # :286-296
+                if self.pending[int(s["id"])] == 0:
+                    del self.pending[int(s["id"])]
+            if len(out) >= real:
+                break
+        self.n -= len(out)
+        if fill is not None:                                                       # :209-222, 298-306
+            out.extend(fill.copy() for _ in range(size - len(out)))
+        return out
+
+
+def bunch_steps_model(sources, max_bunch_size, granularity, no_op):
+    """The feeder thread's flushStepStore/emitStep (Async.cxx:209-273) for a list of (identifier, steps) light sources
+    followed by a barrier: list of (steps, finished identifiers, last)."""
+    store, markers, out = StepStoreModel(), [], []
+
+    def full():
+        while store.size() >= max_bunch_size:                                      # :212-232
+            steps = store.pop_bunch_to_vector(max_bunch_size)
+            finished = []
+            while markers and store.count(markers[0]) == 0:
+                finished.append(markers.pop(0))
+            out.append((steps, finished, False))
+
+    for identifier, steps in sources:
+        markers.append(identifier)
+        for s in steps:
+            store.insert_copy(s)                                                   # emitStep :268-271
+            full()
+    full()
+    n_fill = ((store.size() // granularity) + 1) * granularity if granularity > 1 else store.size()   # :256
+    steps = store.pop_bunch_to_vector(n_fill, fill=no_op)
+    assert store.size() == 0
+    out.append((steps, list(markers), True))                                       # :262-269
+    return out
