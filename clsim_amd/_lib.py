@@ -32,6 +32,16 @@ class StepRequest(C.Structure):     # clsimhip_step_request
                 ("photons_per_step", C.c_uint32), ("num_photons_in_last_step", C.c_uint32), ("num_steps", C.c_uint64)]
 
 
+class Distribution(C.Structure):    # clsimhip_distribution
+    _fields_ = [("kind", C.c_int32), ("value", C.c_float)]
+
+
+class FlasherConfig(C.Structure):   # clsimhip_flasher_config
+    _fields_ = [("polar", Distribution), ("azimuthal", Distribution), ("time_delay", Distribution),
+                ("interpret_in_polar_coordinates", C.c_int32), ("photons_per_step", C.c_uint32),
+                ("max_bunch_size", C.c_uint32), ("bunch_size_granularity", C.c_uint32)]
+
+
 class Axis(C.Structure):            # clsimhip_axis
     _fields_ = [("kind", C.c_int32), ("min", C.c_double), ("max", C.c_double), ("n_bins", C.c_uint32), ("power", C.c_uint32)]
 
@@ -85,6 +95,8 @@ SYMBOLS = [
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
+    "clsimhip_count_flasher_steps", "clsimhip_generate_flasher_steps_device", "clsimhip_generate_flasher_steps",
+    "clsimhip_flasher_time_profile",
     "clsimhip_step_store_create", "clsimhip_step_store_destroy", "clsimhip_step_store_insert", "clsimhip_step_store_size",
     "clsimhip_step_store_count", "clsimhip_step_store_pop_bunch", "clsimhip_step_store_pop_bunch_filled",
     "clsimhip_step_store_size_with_dummy_fill",
@@ -160,6 +172,10 @@ def load():
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
         "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),
+        "clsimhip_count_flasher_steps": (i32, [C.POINTER(FlasherConfig), vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_generate_flasher_steps_device": (i32, [i32, C.POINTER(FlasherConfig), vp, sz, u64, vp, sz, vp, C.POINTER(sz)]),
+        "clsimhip_generate_flasher_steps": (i32, [i32, C.POINTER(FlasherConfig), vp, sz, u64, vp, sz, C.POINTER(sz)]),
+        "clsimhip_flasher_time_profile": (i32, [dbl, vp, vp]),
         "clsimhip_step_store_create": (i32, [sz, C.POINTER(vp)]),
         "clsimhip_step_store_destroy": (None, [vp]),
         "clsimhip_step_store_insert": (i32, [vp, vp, sz]),

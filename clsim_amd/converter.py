@@ -457,3 +457,60 @@ def GenerateStepsDevice(requests, seed, d_steps, capacity, granularity=1, device
     _check(_lib.load().clsimhip_generate_steps_device(int(device), req.ctypes.data_as(C.POINTER(_lib.StepRequest)), len(req), int(seed),
                                                       int(granularity), C.c_void_p(d_steps), int(capacity), C.c_void_p(stream), C.byref(got)))
     return got.value
+
+
+# ---- flasher step producer (I3CLSimLightSourceToStepConverterFlasher) ----
+FLASHER_REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
+                                  ("sigma_polar", "<f4"), ("sigma_azimuthal", "<f4"), ("pulse_width", "<f4"), ("identifier", "<u4"),
+                                  ("source_type", "<u4"), ("num_photons_with_bias", "<u8")])
+assert FLASHER_REQUEST_DTYPE.itemsize == 56
+DIST_CONSTANT, DIST_NORMAL, DIST_UNIFORM, DIST_FLASHER_TIME_PROFILE = 0, 1, 2, 3
+
+
+def FlasherStepConverterConfig(angularProfileDistributionPolar, angularProfileDistributionAzimuthal, timeDelayDistribution,
+                               interpretAngularDistributionsInPolarCoordinates=False, photonsPerStep=400, maxBunchSize=512000,
+                               bunchSizeGranularity=512):
+    """Constructor arguments of I3CLSimLightSourceToStepConverterFlasher (Flasher.h; defaults Flasher.cxx:46-48); a
+    distribution is (kind, value): (DIST_NORMAL, mean), (DIST_CONSTANT, 0), (DIST_UNIFORM, from), (DIST_FLASHER_TIME_PROFILE, 0).
+    python/GetFlasherParameterizationList.py: LEDs = normal(0) / normal(0) / time profile, not polar; standard candles =
+    constant / uniform(0) / normal(2 ns), polar."""
+    c = _lib.FlasherConfig()
+    for name, d in (("polar", angularProfileDistributionPolar), ("azimuthal", angularProfileDistributionAzimuthal), ("time_delay", timeDelayDistribution)):
+        f = getattr(c, name)
+        f.kind, f.value = int(d[0]), float(d[1])
+    c.interpret_in_polar_coordinates = 1 if interpretAngularDistributionsInPolarCoordinates else 0
+    c.photons_per_step, c.max_bunch_size, c.bunch_size_granularity = int(photonsPerStep), int(maxBunchSize), int(bunchSizeGranularity)
+    return c
+
+
+def CountFlasherSteps(config, requests):
+    req = np.ascontiguousarray(requests, dtype=FLASHER_REQUEST_DTYPE)
+    total, real = C.c_size_t(), C.c_size_t()
+    _check(_lib.load().clsimhip_count_flasher_steps(C.byref(config), req.ctypes.data_as(C.c_void_p), len(req), C.byref(total), C.byref(real)))
+    return total.value, real.value
+
+
+def GenerateFlasherSteps(config, requests, seed, device=0):
+    """All steps of the given flasher pulses (MakeSteps called until every pulse is used up), made on the GPU."""
+    req = np.ascontiguousarray(requests, dtype=FLASHER_REQUEST_DTYPE)
+    total, _ = CountFlasherSteps(config, req)
+    out = np.zeros(total, dtype=STEP_DTYPE)
+    n = C.c_size_t()
+    _check(_lib.load().clsimhip_generate_flasher_steps(int(device), C.byref(config), req.ctypes.data_as(C.c_void_p), len(req), int(seed),
+                                                       out.ctypes.data_as(C.c_void_p), total, C.byref(n)))
+    return out[:n.value]
+
+
+def GenerateFlasherStepsDevice(config, requests, seed, d_steps, capacity, device=0, stream=0):
+    req = np.ascontiguousarray(requests, dtype=FLASHER_REQUEST_DTYPE)
+    n = C.c_size_t()
+    _check(_lib.load().clsimhip_generate_flasher_steps_device(int(device), C.byref(config), req.ctypes.data_as(C.c_void_p), len(req), int(seed),
+                                                              C.c_void_p(int(d_steps)), int(capacity), C.c_void_p(int(stream)), C.byref(n)))
+    return n.value
+
+
+def FlasherTimeProfile(pulseWidthNs):
+    """(density, cumulative) tables of the time delay distribution of one pulse width (240 points at 0.5 ns)."""
+    d, c = np.zeros(240, dtype=np.float32), np.zeros(240, dtype=np.float32)
+    _check(_lib.load().clsimhip_flasher_time_profile(float(pulseWidthNs), d.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)))
+    return d, c

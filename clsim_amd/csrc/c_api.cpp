@@ -7,6 +7,7 @@
 #include "converter.h"
 #include "tabulator.h"
 #include "step_store.h"
+#include "flasher.h"
 
 using namespace clsimhip;
 
@@ -426,6 +427,90 @@ int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, s
         chk(hipMemcpy(steps_out, d_steps, padded * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
         (void)hipFree(d_steps);
         if (padded_out) *padded_out = static_cast<size_t>(padded);
+    });
+}
+} // extern "C"
+
+// ---- flasher step producer ----
+extern "C" {
+int clsimhip_count_flasher_steps(const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests, size_t n,
+                                 size_t *steps_out, size_t *real_steps_out)
+{
+    return guarded(nullptr, [&] {
+        need(config, "config"); if (n) need(requests, "requests");
+        std::vector<FlasherPlanEntry> plan; std::vector<double> widths;
+        const uint64_t total = plan_flasher_steps(*config, requests, n, plan, widths);
+        uint64_t real = 0;
+        for (const FlasherPlanEntry &e : plan) real += e.n_real;
+        if (steps_out) *steps_out = static_cast<size_t>(total);
+        if (real_steps_out) *real_steps_out = static_cast<size_t>(real);
+    });
+}
+int clsimhip_flasher_time_profile(double pulse_width_ns, float density[240], float cumulative[240])
+{
+    return guarded(nullptr, [&] {
+        need(density, "density"); need(cumulative, "cumulative");
+        if (!(pulse_width_ns > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "the flasher time profile needs a positive pulse width");
+        std::vector<float> d, c;
+        interpolated_distribution_tables(0.5, flasher_time_profile(pulse_width_ns), d, c);
+        std::copy(d.begin(), d.end(), density); std::copy(c.begin(), c.end(), cumulative);
+    });
+}
+int clsimhip_generate_flasher_steps_device(int device, const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests,
+                                           size_t n, uint64_t seed, void *d_steps, size_t capacity, void *hip_stream, size_t *steps_out)
+{
+    return guarded(nullptr, [&] {
+        need(config, "config"); need(d_steps, "d_steps"); if (n) need(requests, "requests");
+        std::vector<FlasherPlanEntry> plan; std::vector<double> widths;
+        const uint64_t total = plan_flasher_steps(*config, requests, n, plan, widths);
+        if (total > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "the pulses produce more steps than the buffer holds");
+        if (steps_out) *steps_out = static_cast<size_t>(total);
+        if (total == 0) return;
+        std::vector<float> profiles(std::max<size_t>(widths.size(), 1) * 2 * kFlasherProfilePoints, 0.f);
+        for (size_t w = 0; w < widths.size(); ++w) {
+            std::vector<float> d, c;
+            interpolated_distribution_tables(0.5, flasher_time_profile(widths[w]), d, c);
+            std::copy(d.begin(), d.end(), profiles.begin() + w * 2 * kFlasherProfilePoints);
+            std::copy(c.begin(), c.end(), profiles.begin() + (w * 2 + 1) * kFlasherProfilePoints);
+        }
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
+        chk(hipSetDevice(device), "hipSetDevice");
+        hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+        void *d_req = nullptr, *d_plan = nullptr, *d_prof = nullptr;
+        chk(hipMalloc(&d_req, n * sizeof(clsimhip_flasher_request)), "hipMalloc");
+        chk(hipMalloc(&d_plan, n * sizeof(FlasherPlanEntry)), "hipMalloc");
+        chk(hipMalloc(&d_prof, profiles.size() * sizeof(float)), "hipMalloc");
+        chk(hipMemcpyAsync(d_req, requests, n * sizeof(clsimhip_flasher_request), hipMemcpyHostToDevice, stream), "upload pulses");
+        chk(hipMemcpyAsync(d_plan, plan.data(), n * sizeof(FlasherPlanEntry), hipMemcpyHostToDevice, stream), "upload plan");
+        chk(hipMemcpyAsync(d_prof, profiles.data(), profiles.size() * sizeof(float), hipMemcpyHostToDevice, stream), "upload time profiles");
+        chk(launch_generate_flasher_steps(*config, static_cast<const clsimhip_flasher_request *>(d_req), d_plan, static_cast<uint32_t>(n), total, seed,
+                                          static_cast<const float *>(d_prof), d_steps, stream), "flasher step kernel launch");
+        chk(hipStreamSynchronize(stream), "flasher step kernel");
+        (void)hipFree(d_req); (void)hipFree(d_plan); (void)hipFree(d_prof);
+    });
+}
+int clsimhip_generate_flasher_steps(int device, const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests,
+                                    size_t n, uint64_t seed, clsimhip_step *steps_out, size_t capacity, size_t *count_out)
+{
+    return guarded(nullptr, [&] {
+        need(config, "config"); need(steps_out, "steps_out");
+        size_t total = 0;
+        int rc = clsimhip_count_flasher_steps(config, requests, n, &total, nullptr);
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
+        if (total > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "the pulses produce more steps than the buffer holds");
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
+        chk(hipSetDevice(device), "hipSetDevice");
+        void *d_steps = nullptr;
+        chk(hipMalloc(&d_steps, std::max<size_t>(total, 1) * sizeof(clsimhip_step)), "hipMalloc");
+        rc = clsimhip_generate_flasher_steps_device(device, config, requests, n, seed, d_steps, total, nullptr, nullptr);
+        if (rc != CLSIMHIP_OK) { (void)hipFree(d_steps); throw Error(rc, g_create_error); }
+        chk(hipMemcpy(steps_out, d_steps, total * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
+        (void)hipFree(d_steps);
+        if (count_out) *count_out = total;
     });
 }
 } // extern "C"

@@ -21,6 +21,9 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
 int prop_kernel_block_size();
+hipError_t launch_generate_flasher_steps(const clsimhip_flasher_config &cfg, const clsimhip_flasher_request *d_requests, const void *d_plan,
+                                         uint32_t n_requests, uint64_t total, uint64_t seed, const float *d_profiles, void *d_out,
+                                         hipStream_t stream);
 hipError_t launch_generate_steps(const clsimhip_step_request *d_requests, const uint64_t *d_first_step, uint32_t n_requests,
                                  uint64_t total_real, uint64_t total_padded, uint64_t seed, void *d_out, hipStream_t stream);
 hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream);

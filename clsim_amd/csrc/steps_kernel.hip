@@ -169,7 +169,142 @@ __global__ void __launch_bounds__(256) generate_steps_kernel(const clsimhip_step
     out[g] = s;
 }
 
+// ---- flasher pulses: I3CLSimLightSourceToStepConverterFlasher::FillStep (Flasher.cxx:443-545) ----
+struct FlasherPlanEntryDev { uint64_t first_out, n_real; uint32_t last_real, profile; };
+
+// profile tables: [profile][0: density, 1: cumulative][240]
+DS float sample_distribution(const clsimhip_distribution d, float parameter, uint64_t &x, const float *profile)
+{
+    if (d.kind == CLSIMHIP_DIST_CONSTANT) return parameter;                           // Constant.cxx:61-73
+    if (d.kind == CLSIMHIP_DIST_NORMAL) {                                              // NormalDistribution.cxx:68-80
+        const float rnd1 = uniform_oc(x);
+        const float rnd2 = uniform_oc(x);
+        float s, c;
+        dm::sincos_(2.0f * kPiS * rnd2, s, c);
+        return (dm::sqrt_(-2.0f * dm::log_(rnd1)) * s) * parameter + d.value;
+    }
+    if (d.kind == CLSIMHIP_DIST_UNIFORM) return uniform_co(x) * (parameter - d.value) + d.value;   // Uniform.cxx:101-103
+    // InterpolatedDistribution.cxx:236-336 over the pulse shape (x0 = 0, spacing 0.5 ns)
+    const float r = uniform_oc(x);
+    const float *yv = profile, *cum = profile + 240;
+    int lo = 1, hi = 239;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] >= r) hi = mid; else lo = mid + 1;
+    }
+    const int k = lo - 1;
+    const float this_acu = (k == 0) ? 0.0f : cum[k];
+    const float b = yv[k];
+    const float sp = 0.5f;
+    const float x0 = (float)k * sp + 0.0f;
+    const float slope = (yv[k + 1] - b) / sp;
+    const float dy = r - this_acu;
+    if ((b == 0.0f) && (slope == 0.0f)) return x0;
+    else if (b == 0.0f) return x0 + dm::sqrt_(2.0f * dy / slope);
+    else if (slope == 0.0f) return x0 + dy / b;
+    else return x0 + (dm::sqrt_(dy * (2.0f * slope) / (b * b) + 1.0f) - 1.0f) * b / slope;
+}
+
+__global__ void __launch_bounds__(256) generate_flasher_steps_kernel(const clsimhip_flasher_config cfg, const clsimhip_flasher_request *requests,
+                                                                     const FlasherPlanEntryDev *plan, uint32_t n_requests,
+                                                                     uint64_t total, uint64_t seed, const float *profiles, DevStep *out)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= total) return;
+    uint32_t lo = 0, hi = n_requests - 1u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (plan[mid].first_out <= g) lo = mid; else hi = mid - 1u;
+    }
+    const clsimhip_flasher_request q = requests[lo];
+    const FlasherPlanEntryDev e = plan[lo];
+    const uint64_t k = g - e.first_out;
+    DevStep s;
+    if (k >= e.n_real) {
+        // dummy steps (:420-434): theta = phi = 0, the pulse's identifier
+        s.x = s.y = s.z = s.t = 0.0f;
+        s.theta = 0.0f; s.phi = 0.0f; s.length = 0.0f; s.beta = 1.0f;
+        s.num_photons = 0u; s.weight = 0.0f; s.identifier = q.identifier; s.source_type_and_pad = 0u;
+        out[g] = s;
+        return;
+    }
+    uint64_t x = stream_state(seed, g);
+    const float *profile = profiles + (size_t)e.profile * 480u;
+    const float smear_polar = sample_distribution(cfg.polar, q.sigma_polar, x, profile);           // :450-460
+    const float smear_azimuthal = sample_distribution(cfg.azimuthal, q.sigma_azimuthal, x, profile);
+    float dx = q.dx, dy = q.dy, dz = q.dz;
+    {
+        const float r_inv = 1.0f / dm::sqrt_(dx * dx + dy * dy + dz * dz);
+        dx *= r_inv; dy *= r_inv; dz *= r_inv;
+    }
+    if (!cfg.interpret_in_polar_coordinates) {
+        // :468-486: azimuth smeared in the horizontal plane; then the horizontal unit vector is rotated about the
+        // horizontal axis perpendicular to it by (90 deg - polar angle) + smearing (right-handed: zero smearing gives
+        // the pulse's direction back)
+        const float cz = (dz > 1.0f) ? 1.0f : ((dz < -1.0f) ? -1.0f : dz);
+        const float polar = dm::acos_(cz);
+        float azimuth = dm::atan2_(dy, dx);
+        if (azimuth < 0.0f) azimuth += 2.0f * kPiS;
+        const float smeared_azimuth = azimuth + smear_azimuthal;
+        const float lift = (1.5707963267948966f - polar) + smear_polar;
+        float sa, ca, sl, cl;
+        dm::sincos_(smeared_azimuth, sa, ca);
+        dm::sincos_(lift, sl, cl);
+        dx = ca * cl; dy = sa * cl; dz = sl;
+    } else {
+        // :488-541: polar = how far from the old direction, azimuthal = at which orientation around it
+        float sina, cosa, sinb, cosb;
+        dm::sincos_(smear_polar, sina, cosa);
+        dm::sincos_(smear_azimuthal, sinb, cosb);
+        const float t = 1.0f - dz * dz;
+        const float sinth = dm::sqrt_((t > 0.0f) ? t : 0.0f);
+        if (sinth > 0.0f) {
+            const float ox = dx, oy = dy, oz = dz;
+            dx = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina / sinth);
+            dy = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina / sinth);
+            dz = oz * cosa + sina * sinb * sinth;
+        } else {
+            dx = sina * cosb;
+            dy = sina * sinb;
+            dz = cosa * ((dz < 0.0f) ? -1.0f : 1.0f);
+        }
+        const float recip_length = 1.0f / dm::sqrt_(dx * dx + dy * dy + dz * dz);
+        dx *= recip_length; dy *= recip_length; dz *= recip_length;
+    }
+    const float delay = sample_distribution(cfg.time_delay, q.pulse_width, x, profile);           // :544-551
+    s.x = q.x; s.y = q.y; s.z = q.z;
+    s.t = q.time + delay;
+    {   // I3CLSimStep::SetDir
+        const float r_inv = 1.0f / dm::sqrt_(dx * dx + dy * dy + dz * dz);
+        float cz = dz * r_inv;
+        cz = (cz > 1.0f) ? 1.0f : ((cz < -1.0f) ? -1.0f : cz);
+        s.theta = dm::acos_(cz);
+        float phi = dm::atan2_(dy, dx);
+        if (phi < 0.0f) phi += 2.0f * kPiS;
+        s.phi = phi;
+    }
+    s.length = 0.0f;
+    s.beta = 1.0f;
+    s.num_photons = (k + 1u == e.n_real) ? e.last_real : cfg.photons_per_step;
+    s.weight = 1.0f;
+    s.identifier = q.identifier;
+    s.source_type_and_pad = q.source_type & 0xffu;
+    out[g] = s;
+}
+
 } // namespace
+
+hipError_t launch_generate_flasher_steps(const clsimhip_flasher_config &cfg, const clsimhip_flasher_request *d_requests, const void *d_plan,
+                                         uint32_t n_requests, uint64_t total, uint64_t seed, const float *d_profiles, void *d_out,
+                                         hipStream_t stream)
+{
+    if (total == 0) return hipSuccess;
+    const uint64_t blocks = (total + 255u) / 256u;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(generate_flasher_steps_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, cfg, d_requests,
+                       static_cast<const FlasherPlanEntryDev *>(d_plan), n_requests, total, seed, d_profiles, static_cast<DevStep *>(d_out));
+    return hipGetLastError();
+}
 
 hipError_t launch_generate_steps(const clsimhip_step_request *d_requests, const uint64_t *d_first_step, uint32_t n_requests,
                                  uint64_t total_real, uint64_t total_padded, uint64_t seed, void *d_out, hipStream_t stream)

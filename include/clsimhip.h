@@ -286,6 +286,56 @@ int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requ
 int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed,
                             size_t granularity, clsimhip_step *steps_out, size_t capacity, size_t *padded_out);
 
+/* ---- flasher step producer --------------------------------------------------------------
+ * I3CLSimLightSourceToStepConverterFlasher (private/clsim/I3CLSimLightSourceToStepConverterFlasher.cxx): MakeSteps
+ * :329-440 cuts a flasher pulse into steps of photons_per_step photons (zero length, beta 1, weight 1, the pulse's
+ * spectrum as source type) and pads with dummy steps to the bunch granularity; FillStep :443-545 smears every step's
+ * direction and time with three I3CLSimRandomValue distributions whose run-time parameter comes from the pulse.
+ * One GPU lane makes one step, every step has its own MWC stream seeded from (seed, step index) -- the reference
+ * samples with I3RandomService (phys-services, not part of the reference tree) in double precision, so parity is
+ * product = oracle (oracle/stepgen_oracle.c) and distribution tests, as for the cascade/muon producer.
+ * Kept from the reference: a pulse whose photons divide evenly into more than one step loses its last step to a
+ * dummy step (:383-389 with :407-408). */
+#define CLSIMHIP_DIST_CONSTANT 0                /* I3CLSimRandomValueConstant(): the run-time parameter itself */
+#define CLSIMHIP_DIST_NORMAL 1                  /* FixParameter(NormalDistribution(), 0, value): value + parameter * Box-Muller
+                                                   (random_value/I3CLSimRandomValueNormalDistribution.cxx:47-80) */
+#define CLSIMHIP_DIST_UNIFORM 2                 /* Uniform(value, NaN): value + u * (parameter - value) (…Uniform.cxx:77-104) */
+#define CLSIMHIP_DIST_FLASHER_TIME_PROFILE 3    /* python/I3CLSimRandomValueIceCubeFlasherTimeProfile.py: LED pulse shape for
+                                                   the pulse width (parameter), an InterpolatedDistribution of 240 points */
+typedef struct {
+    int32_t kind;
+    float value;                                /* NORMAL: mean; UNIFORM: from */
+} clsimhip_distribution;
+typedef struct {
+    clsimhip_distribution polar;                /* angularProfileDistributionPolar, parameter = sigma_polar */
+    clsimhip_distribution azimuthal;            /* angularProfileDistributionAzimuthal, parameter = sigma_azimuthal */
+    clsimhip_distribution time_delay;           /* timeDelayDistribution, parameter = pulse_width */
+    int32_t interpret_in_polar_coordinates;     /* interpretAngularDistributionsInPolarCoordinates (:497-541) */
+    uint32_t photons_per_step;                  /* photonsPerStep_ (default 400, :46) */
+    uint32_t max_bunch_size;                    /* maxBunchSize_ (default 512000, :47) */
+    uint32_t bunch_size_granularity;            /* bunchSizeGranularity_ (default 512, :48) */
+} clsimhip_flasher_config;
+typedef struct {                                /* one I3CLSimFlasherPulse in the converter's queue (LightSourceData_t) */
+    float x, y, z, time;
+    float dx, dy, dz;                           /* GetDir(), direction of emission */
+    float sigma_polar, sigma_azimuthal;         /* GetAngularEmissionSigmaPolar / Azimuthal [rad] */
+    float pulse_width;                          /* GetPulseWidth [ns] */
+    uint32_t identifier;
+    uint32_t source_type;                       /* spectrumSourceTypeIndex_: wavelength generator of the pulse's spectrum */
+    uint64_t num_photons_with_bias;             /* numPhotonsWithBias (EnqueueLightSource :243-262, computed by the caller) */
+} clsimhip_flasher_request;                     /* 56 bytes */
+/* number of output steps (real + dummy) and of steps that carry photons */
+int clsimhip_count_flasher_steps(const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests, size_t n,
+                                 size_t *steps_out, size_t *real_steps_out);
+/* generates into device memory d_steps (room for `capacity` steps) on `hip_stream` */
+int clsimhip_generate_flasher_steps_device(int device, const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests,
+                                           size_t n, uint64_t seed, void *d_steps, size_t capacity, void *hip_stream, size_t *steps_out);
+/* the same into host memory (synchronous) */
+int clsimhip_generate_flasher_steps(int device, const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests,
+                                    size_t n, uint64_t seed, clsimhip_step *steps_out, size_t capacity, size_t *count_out);
+/* the time delay distribution for one pulse width: 240 densities and cumulative values at 0.5 ns spacing (host only) */
+int clsimhip_flasher_time_profile(double pulse_width_ns, float density[240], float cumulative[240]);
+
 /* ---- step store ------------------------------------------------------------------------
  * I3CLSimStepStore (public/clsim/I3CLSimStepStore.h:44-320): steps sorted by photon count (one FIFO per count), with
  * the number of stored steps per identifier; the feeder thread of the reference cuts bunches from it

@@ -920,3 +920,78 @@ def bunch_steps_model(sources, max_bunch_size, granularity, no_op):
     assert store.size() == 0
     out.append((steps, list(markers), True))                                       # :262-269
     return out
+
+
+# ---- flasher step producer: host logic (I3CLSimLightSourceToStepConverterFlasher.cxx:329-440,
+#      python/I3CLSimRandomValueIceCubeFlasherTimeProfile.py) ----
+FLASHER_PULSE_WIDTH15 = np.array([      # :52-88, the measured LED profile the reference tabulates (1 ns steps)
+    1.18e-03, 2.769e-02, 1.2517e-01, 2.1484e-01, 3.2089e-01, 4.3239e-01, 4.6437e-01, 5.0023e-01, 4.3161e-01, 3.1621e-01, 2.2965e-01,
+    1.3764e-01, 8.774e-02, 7.214e-02, 5.966e-02, 4.797e-02, 4.095e-02, 2.925e-02, 3.081e-02, 2.847e-02, 2.613e-02, 1.834e-02,
+    1.834e-02, 1.99e-02, 1.288e-02, 1.288e-02, 1.288e-02, 1.6e-02, 1.444e-02, 1.678e-02, 7.42e-03, 6.64e-03, 9.76e-03, 1.132e-02,
+    7.42e-03, 9.76e-03, 4.3e-03, 5.86e-03, 7.42e-03, 4.3e-03, 8.2e-03, 5.86e-03, 3.52e-03, 1.96e-03, 2.74e-03, 4.3e-03, 5.08e-03,
+    2.74e-03, 3.52e-03, 4.3e-03, 2.74e-03])
+
+
+def _pulse_narrow(x):
+    """interp1d(kind='linear', bounds_error=False, fill_value=0.) of the adjusted table (:90-91)."""
+    y = (FLASHER_PULSE_WIDTH15 - 0.00118) / 0.49905
+    return np.interp(x, np.arange(51.0), y, left=0.0, right=0.0)
+
+
+def flasher_time_profile(width_ns):
+    """_the_pulse(numpy.linspace(0, 120, 240, endpoint=False), width*2) (:118-155)."""
+    x = np.linspace(0.0, 120.0, 240, endpoint=False)
+    fb = width_ns * 2.0
+    if fb <= 15:
+        return _pulse_narrow(x * (15.0 / fb))
+    plateau = (fb - 15.0) * 59.5 / (124.0 - 15.0)
+    rising = np.log(fb - 12.0) * 1.91 + 5.0
+    rise = _pulse_narrow(np.clip(7.0 * x / rising, 0.0, 7.0))
+    fall = _pulse_narrow(np.maximum(x - rising - plateau + 7.0, 7.0))
+    return np.where(x <= rising, rise, np.where(x <= rising + plateau, 1.0, fall))
+
+
+def interpolated_distribution_tables(spacing, y):
+    """I3CLSimRandomValueInterpolatedDistribution::InitTables (InterpolatedDistribution.cxx:134-175) as float literals."""
+    y = np.asarray(y, dtype=np.float64)
+    acu = np.zeros(len(y))
+    for j in range(1, len(y)):
+        acu[j] = acu[j - 1] + spacing * (y[j] + y[j - 1]) / 2.0
+    total = acu[-1]
+    return (np.array([float_literal(v / total) for v in y], dtype=np.float32),
+            np.array([float_literal(v / total) for v in acu], dtype=np.float32))
+
+
+def flasher_make_steps_model(num_photons_with_bias, photons_per_step, max_bunch_size, granularity):
+    """MakeSteps (Flasher.cxx:329-440) called until the pulse is used up: list of photon counts per output step
+    (0 = dummy step), literally as the reference loops."""
+    out = []
+    left = int(num_photons_with_bias)
+    while True:
+        max_per_result = max_bunch_size * photons_per_step
+        dummies = 0
+        if left >= max_per_result:
+            n_steps, in_last = max_bunch_size, photons_per_step
+            left -= n_steps * photons_per_step
+            done = (left == 0)
+        else:
+            if left <= photons_per_step:
+                n_steps, in_last = 1, left
+            else:
+                n_steps, in_last = left // photons_per_step, left % photons_per_step
+                if in_last > 0:
+                    n_steps += 1
+            done, left = True, 0
+            modulo = n_steps % granularity
+            if modulo > 0:
+                dummies = granularity - modulo
+        steps = []
+        for i in range(n_steps):
+            k = in_last if i == n_steps - 1 else photons_per_step
+            if k == 0:
+                dummies += 1
+                continue
+            steps.append(k)
+        out.extend(steps + [0] * dummies)
+        if done:
+            return out

@@ -374,6 +374,68 @@ def generate_steps(requests, seed, granularity=1):
     return out
 
 
+FLASHER_REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
+                                  ("sigma_polar", "<f4"), ("sigma_azimuthal", "<f4"), ("pulse_width", "<f4"), ("identifier", "<u4"),
+                                  ("source_type", "<u4"), ("num_photons_with_bias", "<u8")])
+FLASHER_PLAN_DTYPE = np.dtype([("first_out", "<u8"), ("n_real", "<u8"), ("last_real", "<u4"), ("profile", "<u4")])
+assert FLASHER_REQUEST_DTYPE.itemsize == 56 and FLASHER_PLAN_DTYPE.itemsize == 24
+DIST_KINDS = {"constant": 0, "normal": 1, "uniform": 2, "flasher_time_profile": 3}
+
+
+class FlasherConfig(C.Structure):
+    _fields_ = [("polar_kind", C.c_int32), ("polar_value", C.c_float), ("azimuthal_kind", C.c_int32), ("azimuthal_value", C.c_float),
+                ("time_kind", C.c_int32), ("time_value", C.c_float), ("polar_coordinates", C.c_int32),
+                ("photons_per_step", C.c_uint32), ("max_bunch_size", C.c_uint32), ("bunch_size_granularity", C.c_uint32)]
+
+
+def flasher_config(polar, azimuthal, time_delay, polar_coordinates=False, photons_per_step=400, max_bunch_size=512000, granularity=512):
+    """(kind, value) pairs as in include/clsimhip.h; the defaults are the reference's (Flasher.cxx:46-48)."""
+    c = FlasherConfig()
+    c.polar_kind, c.polar_value = DIST_KINDS[polar[0]], polar[1]
+    c.azimuthal_kind, c.azimuthal_value = DIST_KINDS[azimuthal[0]], azimuthal[1]
+    c.time_kind, c.time_value = DIST_KINDS[time_delay[0]], time_delay[1]
+    c.polar_coordinates = 1 if polar_coordinates else 0
+    c.photons_per_step, c.max_bunch_size, c.bunch_size_granularity = photons_per_step, max_bunch_size, granularity
+    return c
+
+
+def plan_flasher_steps(cfg, requests):
+    """Bunch plan from the literal MakeSteps model (builders.flasher_make_steps_model) and the time profile tables."""
+    from . import builders as B
+    req = np.ascontiguousarray(requests, dtype=FLASHER_REQUEST_DTYPE)
+    plan = np.zeros(len(req), dtype=FLASHER_PLAN_DTYPE)
+    widths, out, counts = [], 0, []
+    for i, q in enumerate(req):
+        photons = B.flasher_make_steps_model(int(q["num_photons_with_bias"]), cfg.photons_per_step, cfg.max_bunch_size, cfg.bunch_size_granularity)
+        real = [p for p in photons if p > 0]
+        # the kernel lays a pulse out as its real steps followed by its dummy steps; the reference interleaves dummy steps
+        # only at the end of a result, and only the last result of a pulse has any
+        assert all(p > 0 for p in photons[:len(real)]) and all(p == cfg.photons_per_step for p in real[:-1])
+        plan[i] = (out, len(real), real[-1] if real else cfg.photons_per_step, 0)
+        if cfg.time_kind == 3:
+            w = float(q["pulse_width"])
+            if w not in widths:
+                widths.append(w)
+            plan[i]["profile"] = widths.index(w)
+        out += len(photons)
+        counts.append(photons)
+    profiles = np.zeros((max(len(widths), 1), 2, 240), dtype=np.float32)
+    for k, w in enumerate(widths):
+        profiles[k, 0], profiles[k, 1] = B.interpolated_distribution_tables(0.5, B.flasher_time_profile(w))
+    return plan, out, profiles, counts
+
+
+def generate_flasher_steps(cfg, requests, seed):
+    """oracle_generate_flasher_steps (stepgen_oracle.c)."""
+    L = lib()
+    req = np.ascontiguousarray(requests, dtype=FLASHER_REQUEST_DTYPE)
+    plan, total, profiles, _ = plan_flasher_steps(cfg, req)
+    out = np.zeros(total, dtype=STEP_DTYPE)
+    L.oracle_generate_flasher_steps(C.byref(cfg), req.ctypes.data_as(C.c_void_p), plan.ctypes.data_as(C.c_void_p), C.c_uint32(len(req)),
+                                    C.c_uint64(total), C.c_uint64(int(seed)), profiles.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 ENTRY_DTYPE = np.dtype([("index", np.uint32), ("weight", np.float32)])
 
 

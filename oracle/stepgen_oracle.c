@@ -154,3 +154,129 @@ void oracle_generate_steps(const sg_request *requests, const uint64_t *first_ste
         out[g] = s;
     }
 }
+
+/* ---- flasher pulses: clsim_amd/csrc/steps_kernel.hip generate_flasher_steps_kernel, i.e.
+ * I3CLSimLightSourceToStepConverterFlasher::FillStep (Flasher.cxx:443-545) with the reference's OpenCL forms of the
+ * distributions (NormalDistribution.cxx:68-80, Uniform.cxx, Constant.cxx, InterpolatedDistribution.cxx:236-336) ---- */
+typedef struct { int32_t kind; float value; } sg_distribution;
+typedef struct {
+    sg_distribution polar, azimuthal, time_delay;
+    int32_t interpret_in_polar_coordinates;
+    uint32_t photons_per_step, max_bunch_size, bunch_size_granularity;
+} sg_flasher_config;
+typedef struct {
+    float x, y, z, time, dx, dy, dz, sigma_polar, sigma_azimuthal, pulse_width;
+    uint32_t identifier, source_type;
+    uint64_t num_photons_with_bias;
+} sg_flasher_request;
+typedef struct { uint64_t first_out, n_real; uint32_t last_real, profile; } sg_flasher_plan;
+
+static float sample_distribution(sg_distribution d, float parameter, uint64_t *x, const float *profile)
+{
+    if (d.kind == 0) return parameter;
+    if (d.kind == 1) {
+        const float rnd1 = uniform_oc(x);
+        const float rnd2 = uniform_oc(x);
+        float s, c;
+        om_sincos(2.0f * SG_PI * rnd2, &s, &c);
+        return (om_sqrt(-2.0f * om_log(rnd1)) * s) * parameter + d.value;
+    }
+    if (d.kind == 2) return uniform_co(x) * (parameter - d.value) + d.value;
+    const float r = uniform_oc(x);
+    const float *yv = profile, *cum = profile + 240;
+    int k = 0;                                                   /* the reference's linear scan (:262-270) */
+    float this_acu = 0.0f;
+    for (;;) {
+        const float next_acu = cum[k + 1];
+        if (next_acu >= r || k + 1 >= 239) break;
+        this_acu = next_acu;
+        ++k;
+    }
+    const float b = yv[k];
+    const float sp = 0.5f;
+    const float x0 = (float)k * sp + 0.0f;
+    const float slope = (yv[k + 1] - b) / sp;
+    const float dy = r - this_acu;
+    if ((b == 0.0f) && (slope == 0.0f)) return x0;
+    else if (b == 0.0f) return x0 + om_sqrt(2.0f * dy / slope);
+    else if (slope == 0.0f) return x0 + dy / b;
+    else return x0 + (om_sqrt(dy * (2.0f * slope) / (b * b) + 1.0f) - 1.0f) * b / slope;
+}
+
+void oracle_generate_flasher_steps(const sg_flasher_config *cfg, const sg_flasher_request *requests, const sg_flasher_plan *plan,
+                                   uint32_t n_requests, uint64_t total, uint64_t seed, const float *profiles, sg_step *out)
+{
+    uint32_t r = 0;
+    for (uint64_t g = 0; g < total; ++g) {
+        while (r + 1 < n_requests && plan[r + 1].first_out <= g) ++r;
+        const sg_flasher_request q = requests[r];
+        const sg_flasher_plan e = plan[r];
+        const uint64_t k = g - e.first_out;
+        sg_step s;
+        memset(&s, 0, sizeof s);
+        if (k >= e.n_real) {
+            s.dir[3] = 1.0f;
+            s.identifier = q.identifier;
+            out[g] = s;
+            continue;
+        }
+        uint64_t x = stream_state(seed, g);
+        const float *profile = profiles + (size_t)e.profile * 480u;
+        const float smear_polar = sample_distribution(cfg->polar, q.sigma_polar, &x, profile);
+        const float smear_azimuthal = sample_distribution(cfg->azimuthal, q.sigma_azimuthal, &x, profile);
+        float dx = q.dx, dy = q.dy, dz = q.dz;
+        {
+            const float r_inv = 1.0f / om_sqrt(dx * dx + dy * dy + dz * dz);
+            dx *= r_inv; dy *= r_inv; dz *= r_inv;
+        }
+        if (!cfg->interpret_in_polar_coordinates) {
+            const float cz = (dz > 1.0f) ? 1.0f : ((dz < -1.0f) ? -1.0f : dz);
+            const float polar = om_acos(cz);
+            float azimuth = om_atan2(dy, dx);
+            if (azimuth < 0.0f) azimuth += 2.0f * SG_PI;
+            const float smeared_azimuth = azimuth + smear_azimuthal;
+            const float lift = (1.5707963267948966f - polar) + smear_polar;
+            float sa, ca, sl, cl;
+            om_sincos(smeared_azimuth, &sa, &ca);
+            om_sincos(lift, &sl, &cl);
+            dx = ca * cl; dy = sa * cl; dz = sl;
+        } else {
+            float sina, cosa, sinb, cosb;
+            om_sincos(smear_polar, &sina, &cosa);
+            om_sincos(smear_azimuthal, &sinb, &cosb);
+            const float t = 1.0f - dz * dz;
+            const float sinth = om_sqrt((t > 0.0f) ? t : 0.0f);
+            if (sinth > 0.0f) {
+                const float ox = dx, oy = dy, oz = dz;
+                dx = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina / sinth);
+                dy = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina / sinth);
+                dz = oz * cosa + sina * sinb * sinth;
+            } else {
+                dx = sina * cosb;
+                dy = sina * sinb;
+                dz = cosa * ((dz < 0.0f) ? -1.0f : 1.0f);
+            }
+            const float recip_length = 1.0f / om_sqrt(dx * dx + dy * dy + dz * dz);
+            dx *= recip_length; dy *= recip_length; dz *= recip_length;
+        }
+        const float delay = sample_distribution(cfg->time_delay, q.pulse_width, &x, profile);
+        s.pos[0] = q.x; s.pos[1] = q.y; s.pos[2] = q.z;
+        s.pos[3] = q.time + delay;
+        {
+            const float r_inv = 1.0f / om_sqrt(dx * dx + dy * dy + dz * dz);
+            float cz = dz * r_inv;
+            cz = (cz > 1.0f) ? 1.0f : ((cz < -1.0f) ? -1.0f : cz);
+            s.dir[0] = om_acos(cz);
+            float phi = om_atan2(dy, dx);
+            if (phi < 0.0f) phi += 2.0f * SG_PI;
+            s.dir[1] = phi;
+        }
+        s.dir[2] = 0.0f;
+        s.dir[3] = 1.0f;
+        s.numPhotons = (k + 1u == e.n_real) ? e.last_real : cfg->photons_per_step;
+        s.weight = 1.0f;
+        s.identifier = q.identifier;
+        s.sourceType = (uint8_t)(q.source_type & 0xffu);
+        out[g] = s;
+    }
+}
