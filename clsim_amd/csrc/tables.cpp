@@ -490,6 +490,8 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         name("div_ok_cells", flags);
     }
     P.table_words = static_cast<uint32_t>(img.words.size());
+    scalar("lds_image_words", P.table_words);
+    scalar("lds_bytes_per_workgroup", static_cast<double>(prop_kernel_lds_bytes(P.table_words)));
     C.lds_image = std::move(img.words);
     if (prop_kernel_lds_bytes(P.table_words) > prop_kernel_lds_budget())
         throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables do not fit the LDS budget of the propagation kernel");
