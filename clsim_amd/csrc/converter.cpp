@@ -250,7 +250,7 @@ void Converter::setup_device_buffers()
         hip_check(hipEventCreate(&sl.stop), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(&sl.counted, hipEventDisableTiming), "hipEventCreate");
     }
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), static_cast<size_t>(kQueueWords) * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), max_workitems_ * sizeof(WorkRecord)), "work records");
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
@@ -270,10 +270,10 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.max_hits = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffull));
     {   // step queue head for this launch (zeroed in stream order)
         std::lock_guard<std::mutex> lk(ev_mutex_);
-        P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
+        P.queue = d_queue_ + static_cast<size_t>(kQueueWords) * (queue_slot_++ % kQueueSlots);
         last_queue_ = P.queue;
     }
-    hip_check(hipMemsetAsync(P.queue, 0, 16, stream), "reset step queue");
+    hip_check(hipMemsetAsync(P.queue, 0, kQueueWords * sizeof(uint32_t), stream), "reset step queue");
     P.k_new = k_new_;
     P.k_search = k_search_;
     P.slices = k_slices_;

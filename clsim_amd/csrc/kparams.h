@@ -35,6 +35,10 @@ struct DevPhoton {                      // I3CLSimPhoton, 80 B = 20 words
 // One 64-byte line per step: everything a lane needs to take over a slice of the step (the step itself, the state of
 // its RNG stream, the multiplier, how many slices have been published).  Built by scan_steps_kernel at the start of a
 // launch; a hand-off reads and writes this one line instead of four arrays.
+constexpr int kSubQueues = 8;            // sub-queue q hands out the slices of the steps i with i % kSubQueues == q
+constexpr int kQueueHeadStride = 32;     // words between sub-queue heads (128 B)
+constexpr int kQueueWords = 512;         // per launch
+
 struct WorkRecord {
     DevStep step;
     uint64_t x;
@@ -56,7 +60,9 @@ struct KParams {
     DevPhoton *out;
     uint32_t *hit_count;
     uint32_t max_hits;
-    uint32_t *queue;                    // [0] next unclaimed work unit, [1] max numPhotons (both zeroed before the launch)
+    // work queue block of this launch (kQueueWords words, zeroed before the launch): [1] max numPhotons, [2] skipped
+    // steps, [3] debug; the heads of the kSubQueues sub-queues sit on cache lines of their own at [kQueueHeadStride*(q+1)]
+    uint32_t *queue;
     int32_t k_new;                      // lanes that must be waiting before photons are created
     int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)

@@ -54,6 +54,10 @@ constexpr int kMinWavesPerSimd = CLSIMHIP_MIN_WAVES;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStageRecords = 8;                 // hit stubs staged per wave and flush
 constexpr int kStubWords = 16;
+#ifndef CLSIMHIP_PRIO_SHIFT
+#define CLSIMHIP_PRIO_SHIFT 1
+#endif
+constexpr int kPrioShift = CLSIMHIP_PRIO_SHIFT;  // a wave changes its issue priority every 2^kPrioShift loop trips
 constexpr int kTabSlots = 512;                   // TABULATE: path samples one wave pools per loop trip
 constexpr int kTabWaveWords = 2 * kTabSlots + 64;
 constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
@@ -985,15 +989,22 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     // handed out n units earlier, so it practically always has); the photons of a step are still processed
     // in order from one RNG stream, whichever lanes do it.
     const uint32_t n_steps = P0->n_steps;
-    uint32_t slice_photons, total_units;
+    // The queue head is one word that every wave increments: 1.2e8 requests per second is what one address sustains,
+    // and 12 slices of 1M steps in 0.1 s are that many.  So there are kSubQueues heads on cache lines of their own;
+    // sub-queue q hands out the steps i with i % kSubQueues == q -- slice 0 of each, then slice 1 of each ... -- so a
+    // slice's predecessor is always an earlier unit of the same sub-queue.  A wave starts at the sub-queue of its
+    // number and moves on when that one is used up; it is done when it has found them all used up in a row.
+    uint32_t slice_photons, rounds;
     {
         const uint32_t max_photons = P0->queue[1];                 // scan_steps_kernel
         const uint32_t target = (uint32_t)P0->slices;
         slice_photons = (max_photons + target - 1u) / target;
         if (slice_photons == 0u) slice_photons = 1u;
-        const uint32_t rounds = (max_photons + slice_photons - 1u) / slice_photons;
-        total_units = n_steps * (rounds == 0u ? 1u : rounds);
+        rounds = (max_photons + slice_photons - 1u) / slice_photons;
+        if (rounds == 0u) rounds = 1u;
     }
+    uint32_t sub_queue = (blockIdx.x * (uint32_t)kWavesPerBlock + (threadIdx.x >> 6)) % (uint32_t)kSubQueues;     // wave-uniform
+    uint32_t used_up = 0;                                                                                          // in a row
     uint32_t sidx = kNoStep;
     uint64_t rx = 0;
     uint32_t ra = 0;
@@ -1009,40 +1020,73 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.layer = 0;
 
-    for (;;) {
+    // The SIMD's arbiter issues from the oldest wave first, and the kernel is issue bound: left alone, the waves of a SIMD
+    // advance at rates up to 8x apart (measured: trips per wave, p10/p90 = 4.6k/39.6k), so the slow ones stretch the
+    // slice hand-offs and hold the last units of the bunch long after the queue is dry.  Each wave therefore takes
+    // turns at the four issue priorities, offset by its wave slot.
+    const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
+    for (uint32_t trip = 0;; ++trip) {
+        switch (((trip >> kPrioShift) + wave_slot) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
         bool need = alive && !parked && (ph.abs_lens_left < kEpsilon);
         const uint64_t m_need = __ballot(need);
         const uint64_t m_ready = __ballot(alive && !need);
         if ((m_need | m_ready) == 0ull) break;
 
         // ---- new units / new photons, deferred until enough lanes wait for them ----
+        // Photon creation is what is worth batching (k_new lanes), and taking new units goes with it (one atomic on the
+        // queue head per wave and batch).  Handing a finished unit's stream on and looking for the predecessor's must
+        // not wait for that: a wave with few running lanes would sit on finished units while their successors
+        // elsewhere wait, which spreads (every waiting lane is one running lane less).  Finished units are published,
+        // and predecessors polled for, at the latest every fourth trip.
         const uint64_t m_poll = __ballot(need && waiting);
-        if ((m_ready == 0ull) || ((int)__popcll(m_need & ~m_poll) >= fresh_params(P0)->k_new)) {
+        const bool do_create = (m_ready == 0ull) || ((int)__popcll(m_need & ~m_poll) >= fresh_params(P0)->k_new);
+        const bool finished = need && !waiting && (photons_left == 0) && (sidx != kNoStep);
+        const uint64_t m_finished = __ballot(finished);
+        if (do_create || (((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
             const KP P = fresh_params(P0);
-            const bool want_unit = need && (photons_left == 0) && !waiting;
-            const uint64_t m_want = __ballot(want_unit);
-            if (m_want != 0ull) {
-                // next units from the queue: one atomic per wave
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P->queue, (uint32_t)__popcll(m_want));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                WorkRecord *work = P->work;
+            WorkRecord *work = P->work;
+            if (m_finished != 0ull) {
                 // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
                 // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
                 // state first, then the slice counter, both write-through (sc1) so that a lane on another XCD that
                 // sees the counter sees the state
-                if (want_unit && (sidx != kNoStep)) {
+                if (finished) {
                     if (last_slice) P->rng_x[sidx] = rx;
                     else __hip_atomic_store(&work[sidx].x, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (want_unit) {
-                    if ((sidx != kNoStep) && !last_slice) __hip_atomic_store(&work[sidx].done, slice + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t unit = base + (uint32_t)__popcll(m_want & lanes_below);
+                if (finished) {
+                    if (!last_slice) __hip_atomic_store(&work[sidx].done, slice + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sidx = kNoStep;
-                    if (unit < total_units) {
-                        const uint32_t s_new = unit / n_steps;
-                        const uint32_t i_new = unit - s_new * n_steps;
+                }
+            }
+            const bool want_unit = do_create && need && (photons_left == 0) && !waiting;
+            const uint64_t m_want = __ballot(want_unit);
+            if (m_want != 0ull) {
+                // next units from the wave's sub-queue: one atomic per wave
+                const uint32_t n_sub = (n_steps + (uint32_t)kSubQueues - 1u - sub_queue) / (uint32_t)kSubQueues;   // its steps
+                const uint32_t total_sub = n_sub * rounds;
+                const uint32_t count = (uint32_t)__popcll(m_want);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P->queue + kQueueHeadStride * (sub_queue + 1u), count);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t this_queue = sub_queue;
+                if (base + count > total_sub) {                      // (also when the head has run past the end)
+                    sub_queue = (sub_queue + 1u == (uint32_t)kSubQueues) ? 0u : sub_queue + 1u;
+                    ++used_up;
+                } else {
+                    used_up = 0;
+                }
+                if (want_unit) {
+                    const uint32_t unit = base + (uint32_t)__popcll(m_want & lanes_below);
+                    if ((base < total_sub) && (unit < total_sub)) {
+                        const uint32_t s_new = unit / n_sub;
+                        const uint32_t i_new = (unit - s_new * n_sub) * (uint32_t)kSubQueues + this_queue;
                         const uint32_t num = work[i_new].step.num_photons;
                         const uint32_t first = s_new * slice_photons;
                         if (first < num) {                  // otherwise this step is used up: ask again
@@ -1052,8 +1096,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                             photons_left = last_slice ? (num - first) : slice_photons;
                             waiting = true;
                         }
-                    } else {
-                        alive = false;
+                    } else if (used_up >= (uint32_t)kSubQueues) {
+                        alive = false;                              // every sub-queue was found used up: no work is left
                         need = false;
                     }
                 }
@@ -1072,7 +1116,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     waiting = false;
                 }
             }
-            if (need && !waiting && (photons_left > 0)) {
+            if (do_create && need && !waiting && (photons_left > 0)) {
                 create_photon<MED, TILT, FLASHER, TAB != 0>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
@@ -1307,14 +1351,13 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
     }
-    // Grid and slices per step.  The kernel is instruction-issue bound: from 5 waves per SIMD on, more resident waves
-    // add (almost) no throughput, but every resident lane is one more consumer of the same n steps, and a lane that
-    // sees only two or three steps per bunch schedules badly however they are sliced.  Measured on MI355X (200-photon
-    // steps, SPICE-Mie, n = 0.26M ... 4M, 5/6/7 workgroups per CU x 1/6/8/12/16 slices; r = steps per lane):
-    //   * use the largest grid (7, 6, 5 workgroups per CU) that still leaves r >= 4, at least 5 per CU
-    //     (1M steps: 5 per CU 1.71e9 photons/s, 7 per CU 1.49e9; 4M steps: 7 per CU 1.90e9, 5 per CU 1.78e9);
-    //   * r < 1: whole steps (slicing only adds hand-offs); r < 5: 12 slices; else 8.  16 and more slices never pay:
-    //     every configuration with 16 slices stalls at 1.5e9 photons/s, 24 at 1.2e9 (hand-off cost).
+    // Grid and slices per step, from a scan on MI355X (200-photon steps, SPICE-Mie, n = 0.13M ... 4M, 5/6/7 workgroups per
+    // CU x 8/12/16/24 slices x 3/5 parked lanes per DOM search; r = steps per lane):
+    //   * more resident waves hide more latency (4M steps: 7 per CU 2.20e9 photons/s, 6: 2.14e9, 5: 2.03e9), but every
+    //     resident lane is one more consumer of the same n steps and a bunch ends with every lane finishing what it
+    //     holds: the largest grid (7, 6, 5 workgroups per CU) that leaves r >= 2 (0.5M steps: 5 per CU 1.81e9, 7: 1.53e9;
+    //     1M steps: 7 per CU 2.06e9, 5: 1.99e9);
+    //   * 16 slices (12 ... 24 are within 0.5 % of each other everywhere; 8 loses 1-2 %); whole steps for r < 1.
     // CLSIMHIP_GRID / CLSIMHIP_SLICES (converter) override for tuning.
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)resident;
@@ -1326,7 +1369,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         const int floor_per_cu = per_cu < 5 ? per_cu : 5;
         int chosen = floor_per_cu;
         for (int k = per_cu; k >= floor_per_cu; --k)
-            if ((double)P.n_steps / ((double)cus * k * kBlock) >= 4.0) { chosen = k; break; }
+            if ((double)P.n_steps / ((double)cus * k * kBlock) >= 2.0) { chosen = k; break; }
         grid = (uint32_t)(cus * chosen);
     }
     if (const char *e = getenv("CLSIMHIP_GRID")) {
@@ -1336,11 +1379,11 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     if (needed < grid) grid = needed;
     {
         const double r = (double)P.n_steps / ((double)grid * kBlock);
-        if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : (r < 5.0) ? 12 : 8;
-        // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1M steps: 1 -> 5 is
-        // +6 %), costs when they are scarce (0.4M steps: -14 %)
-        if (P.k_search <= 0) P.k_search = (r < 1.5) ? 1 : (r < 3.0) ? 3 : 5;
-        if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0xffffffffull) P.slices = 1;    // 32-bit unit counter
+        if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
+        // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1.5M steps: 3 -> 5 is
+        // +1.6 %), costs when they are scarce (0.8M steps: -1.7 %)
+        if (P.k_search <= 0) P.k_search = (r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
+        if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }
     {
         const uint32_t sgrid = (P.n_steps + 255u) / 256u;

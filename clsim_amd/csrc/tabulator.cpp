@@ -166,7 +166,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         hip_check(hipMemset(d_sq_bins_, 0, n_bins_ * sizeof(double)), "squared weights");
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), streams * sizeof(DevStep)), "steps");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), 4 * kQueueSlots * sizeof(uint32_t)), "step queue");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), static_cast<size_t>(kQueueWords) * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), streams * sizeof(WorkRecord)), "work records");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), streams * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
 }
@@ -211,8 +211,8 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
     P.n_steps = static_cast<uint32_t>(n);
     P.rng_x = d_rng_x_;
     P.rng_a = d_rng_a_;
-    P.queue = d_queue_ + 4 * (queue_slot_++ % kQueueSlots);
-    hip_check(hipMemsetAsync(P.queue, 0, 16, stream_), "reset step queue");
+    P.queue = d_queue_ + static_cast<size_t>(kQueueWords) * (queue_slot_++ % kQueueSlots);
+    hip_check(hipMemsetAsync(P.queue, 0, kQueueWords * sizeof(uint32_t), stream_), "reset step queue");
     P.k_new = 12;
     P.k_search = 1;
     P.slices = 0;
