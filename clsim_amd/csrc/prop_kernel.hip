@@ -9,11 +9,14 @@
 // RNG stream, but which is organised for the CDNA4 execution model:
 //
 //  * persistent workgroups (5-7 per CU, chosen from the bunch size) pull work units
-//    from a global queue: a unit is a slice of a step's photons, handed out
+//    from eight sub-queues: a unit is a slice of a step's photons, handed out
 //    round-robin over the bunch, so that all steps advance together; a lane that
 //    finishes a unit takes the next one instead of idling until the slowest of its
 //    64 neighbours is done.  The RNG stream travels with the step, in a 64-byte
 //    work record (propagation_kernel.c.cl:458-461, 911-912), never with the lane;
+//  * the waves of a SIMD take turns at the issue priorities (s_setprio): the arbiter
+//    alone serves the oldest wave first, which let young waves crawl and hold slices
+//    that others wait for;
 //  * one in-flight photon per lane; the scatter loop is a WAVE-UNIFORM loop
 //    (ballot), so hit records are emitted at a convergent point by the whole wave;
 //  * rare, heavy phases are batched: photon creation -- 1/29 of a lane's
@@ -1026,7 +1029,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     // turns at the four issue priorities, offset by its wave slot.
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
     for (uint32_t trip = 0;; ++trip) {
-        switch (((trip >> kPrioShift) + wave_slot) & 3u) {
+        if (!TAB) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -1047,7 +1050,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         const bool do_create = (m_ready == 0ull) || ((int)__popcll(m_need & ~m_poll) >= fresh_params(P0)->k_new);
         const bool finished = need && !waiting && (photons_left == 0) && (sidx != kNoStep);
         const uint64_t m_finished = __ballot(finished);
-        if (do_create || (((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
+        // (not the table maker: its waves have fp64 atomics in flight, which a poll would have to wait for first)
+        if (do_create || (!TAB && ((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
             const KP P = fresh_params(P0);
             WorkRecord *work = P->work;
             if (m_finished != 0ull) {
