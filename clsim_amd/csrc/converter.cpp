@@ -277,6 +277,12 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.k_new = k_new_;
     P.k_search = k_search_;
     P.slices = k_slices_;
+#ifdef CLSIMHIP_CENSUS
+    if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), 1 << 20), "census");
+    P.census = d_census_;
+    hip_check(hipMemsetAsync(P.census, 0, 1 << 20, stream), "reset census");
+    hip_check(hipMemsetAsync(P.census + 8, 0xff, 8, stream), "reset census");
+#endif
     P.work = d_work_;
     P.len_table = d_len_table_;
     P.prox_map = d_prox_map_;
@@ -554,7 +560,11 @@ void Converter::debug_counters(uint32_t out[4])
     need_init();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "sync");
+#ifdef CLSIMHIP_CENSUS
+    hip_check(hipMemcpy(out, d_census_, 1 << 20, hipMemcpyDeviceToHost), "download census");     // the caller passes 1 MiB
+#else
     if (last_queue_) hip_check(hipMemcpy(out, last_queue_, 16, hipMemcpyDeviceToHost), "download counters");
+#endif
 }
 
 void Converter::get_rng_state(uint64_t *x, size_t count)

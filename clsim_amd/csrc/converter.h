@@ -200,6 +200,9 @@ private:
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
     uint32_t *last_queue_ = nullptr;
+#ifdef CLSIMHIP_CENSUS
+    unsigned long long *d_census_ = nullptr;
+#endif
     int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
     int k_new_ = 12, k_slices_ = 0;              // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)

@@ -66,6 +66,10 @@ struct KParams {
     int32_t k_new;                      // lanes that must be waiting before photons are created
     int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
+#ifdef CLSIMHIP_CENSUS
+    unsigned long long *census;         // analysis build (make EXTRA=-DCLSIMHIP_CENSUS): [0..7] lane-state sums, [8] earliest
+                                        // wave start, [16 + 3w ...] per wave: end time, time the first sub-queue was found dry, trips
+#endif
     WorkRecord *work;                   // per step, filled by scan_steps_kernel (done = slices published so far)
     // TABLE lengths: one 16-byte record per (wavelength bin, layer): {abs[bin], abs[bin+1], sca[bin], sca[bin+1]}
     // at len_table[4*(bin*num_layers + layer)], already de-quantised (80 KB for a 171 x 30 photonics table: HBM/L2)

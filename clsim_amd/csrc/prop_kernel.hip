@@ -1028,6 +1028,11 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     // slice hand-offs and hold the last units of the bunch long after the queue is dry.  Each wave therefore takes
     // turns at the four issue priorities, offset by its wave slot.
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
+#ifdef CLSIMHIP_CENSUS
+    const unsigned long long t_start = wall_clock64();
+    if (lane == 0 && !TAB) atomicMin(fresh_params(P0)->census + 8, t_start);
+    unsigned long long c_trips = 0, t_dry = 0, c_run = 0, c_need = 0, c_wait = 0, c_parked = 0, c_dead = 0, c_phases = 0, c_created = 0;
+#endif
     for (uint32_t trip = 0;; ++trip) {
         if (!TAB) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -1039,6 +1044,14 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         const uint64_t m_need = __ballot(need);
         const uint64_t m_ready = __ballot(alive && !need);
         if ((m_need | m_ready) == 0ull) break;
+#ifdef CLSIMHIP_CENSUS
+        ++c_trips;
+        if (t_dry == 0 && used_up > 0) t_dry = wall_clock64();
+        c_need += __popcll(__ballot(need && !waiting));
+        c_wait += __popcll(__ballot(need && waiting));
+        c_parked += __popcll(__ballot(parked));
+        c_dead += __popcll(__ballot(!alive));
+#endif
 
         // ---- new units / new photons, deferred until enough lanes wait for them ----
         // Photon creation is what is worth batching (k_new lanes), and taking new units goes with it (one atomic on the
@@ -1120,6 +1133,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     waiting = false;
                 }
             }
+#ifdef CLSIMHIP_CENSUS
+            if (do_create) ++c_phases;
+            c_created += __popcll(__ballot(do_create && need && !waiting && (photons_left > 0)));
+#endif
             if (do_create && need && !waiting && (photons_left > 0)) {
                 create_photon<MED, TILT, FLASHER, TAB != 0>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
@@ -1138,6 +1155,9 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         // length until `k_search` lanes of the wave are parked (or nothing else can advance), and the DOM search runs
         // for all of them at once: the search costs the wave the same whether 1 or 12 lanes need it.
         const bool run = alive && !need && !parked;
+#ifdef CLSIMHIP_CENSUS
+        c_run += __popcll(__ballot(run));
+#endif
         float distance = 0.0f;
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
@@ -1239,6 +1259,17 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
         }
     }
+#ifdef CLSIMHIP_CENSUS
+    if (lane == 0 && !TAB) {
+        unsigned long long *d = fresh_params(P0)->census;
+        const uint32_t w = blockIdx.x * (uint32_t)kWavesPerBlock + (threadIdx.x >> 6);
+        d[16 + 3 * w] = wall_clock64();
+        d[16 + 3 * w + 1] = t_dry;
+        d[16 + 3 * w + 2] = c_trips;
+        atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_need); atomicAdd(d + 3, c_wait);
+        atomicAdd(d + 4, c_parked); atomicAdd(d + 5, c_dead); atomicAdd(d + 6, c_phases); atomicAdd(d + 7, c_created);
+    }
+#endif
 }
 
 // meta[1] = largest numPhotons of the bunch (sizes the slices of the unit queue)

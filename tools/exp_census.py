@@ -1,5 +1,12 @@
 #!/usr/bin/env python3
-"""Experiment: when do the waves of prop_kernel see the queue run dry / finish.  ANALYSIS TOOL (instrumented library)."""
+"""Lane-state census and per-wave clocks of prop_kernel.  ANALYSIS TOOL.
+
+Needs the analysis build of the library:
+    make -C clsim_amd/csrc clean && make -C clsim_amd/csrc EXTRA=-DCLSIMHIP_CENSUS     (then rebuild without for the product)
+usage: exp_census.py n:grid:slices ...      (grid in workgroups, 0 = automatic)
+Prints, per configuration: kernel time; fractions of lane trips spent running / waiting for a creation batch / waiting for
+a predecessor slice / parked for the DOM search / without work; photon creation batches; when the waves first found a
+sub-queue used up and when they ended; trips per wave."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,15 +36,17 @@ for spec in sys.argv[1:]:
     buf = np.zeros(1 << 17, dtype=np.uint64)
     lib = _lib.load(); lib.clsimhip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.clsimhip_debug_counters(conv._h, buf.ctypes.data_as(C.c_void_p))
+    trips, run, need, wait, parked, dead, phases, created = (float(v) for v in buf[:8])
+    lanes = 64.0 * trips
     t0 = int(buf[8])
-    nw = (grid if grid else 1280) * 4
-    rec = buf[16:16 + 3 * nw].reshape(nw, 3).astype(np.int64)
-    end = (rec[:, 0] - t0) / 100e3          # ms at 100 MHz
+    rec = buf[16:16 + 3 * ((len(buf) - 16) // 3)].reshape(-1, 3).astype(np.int64)
+    rec = rec[rec[:, 0] > 0]
+    end = (rec[:, 0] - t0) / 100e3                      # ms at 100 MHz
     dry = np.where(rec[:, 1] > 0, (rec[:, 1] - t0) / 100e3, np.nan)
-    trips = rec[:, 2]
     q = lambda a, p: float(np.nanpercentile(a, p))
-    print("run %.1f%% wait-pred %.1f%% |" % (100.0 * buf[1] / (64.0 * buf[0]), 100.0 * buf[3] / (64.0 * buf[0])), end=" ")
-    print("n %d grid %d slices %d: kernel %.1f ms | first dry sub-queue seen: min %.1f p10 %.1f p50 %.1f p90 %.1f | wave end: p1 %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | trips/wave p10 %d p50 %d p90 %d"
-          % (n, grid, sl, ms, np.nanmin(dry), q(dry, 10), q(dry, 50), q(dry, 90), q(end, 1), q(end, 10), q(end, 50), q(end, 90), end.max(),
-             q(trips, 10), q(trips, 50), q(trips, 90)), flush=True)
+    print("n %d grid %d slices %d: %.1f ms | run %.1f%% need %.1f%% wait-pred %.1f%% parked %.1f%% dead %.1f%% | %.3f creation batches per trip, "
+          "%.1f lanes each | first dry sub-queue seen p10 %.1f p50 %.1f | wave end p1 %.1f p50 %.1f p90 %.1f max %.1f ms | trips/wave p10 %d p50 %d p90 %d"
+          % (n, grid, sl, ms, 100 * run / lanes, 100 * need / lanes, 100 * wait / lanes, 100 * parked / lanes, 100 * dead / lanes,
+             phases / trips, created / max(phases, 1), q(dry, 10), q(dry, 50), q(end, 1), q(end, 50), q(end, 90), end.max(),
+             q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
     del conv
