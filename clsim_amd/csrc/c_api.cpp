@@ -21,6 +21,21 @@ struct clsimhip_tabulator {
 namespace {
 thread_local std::string g_create_error;
 
+// device scratch memory of one call, freed on every path out of it
+struct DeviceBuffer {
+    void *p = nullptr;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes, const char *what)
+    {
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) { p = nullptr; throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 template <class F>
 int guarded(clsimhip_converter *c, F &&f)
 {
@@ -334,18 +349,18 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");
         chk(hipSetDevice(device_ordinal), "hipSetDevice");
-        float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-        chk(hipMalloc(reinterpret_cast<void **>(&dx), n * 4 + 16), "hipMalloc");
-        chk(hipMalloc(reinterpret_cast<void **>(&dout), n * 4 + 16), "hipMalloc");
+        DeviceBuffer bx, by, bout;
+        bx.alloc(n * 4 + 16, "hipMalloc"); bout.alloc(n * 4 + 16, "hipMalloc");
+        float *dx = bx.as<float>(), *dy = nullptr, *dout = bout.as<float>();
         chk(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice), "hipMemcpy");
         if (y) {
-            chk(hipMalloc(reinterpret_cast<void **>(&dy), n * 4 + 16), "hipMalloc");
+            by.alloc(n * 4 + 16, "hipMalloc");
+            dy = by.as<float>();
             chk(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice), "hipMemcpy");
         }
         chk(launch_eval_math(what, dx, dy, static_cast<uint32_t>(n), dout, nullptr), "eval_math launch");
         chk(hipDeviceSynchronize(), "eval_math");
         chk(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     });
 }
 
@@ -394,17 +409,17 @@ int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requ
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
         chk(hipSetDevice(device), "hipSetDevice");
         hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-        clsimhip_step_request *d_req = nullptr;
-        uint64_t *d_first = nullptr;
         const size_t nreq = n ? n : 1;
-        chk(hipMalloc(reinterpret_cast<void **>(&d_req), nreq * sizeof(clsimhip_step_request)), "hipMalloc");
-        chk(hipMalloc(reinterpret_cast<void **>(&d_first), (n + 1) * sizeof(uint64_t)), "hipMalloc");
+        DeviceBuffer b_req, b_first;
+        b_req.alloc(nreq * sizeof(clsimhip_step_request), "hipMalloc");
+        b_first.alloc((n + 1) * sizeof(uint64_t), "hipMalloc");
+        clsimhip_step_request *d_req = b_req.as<clsimhip_step_request>();
+        uint64_t *d_first = b_first.as<uint64_t>();
         if (n) chk(hipMemcpyAsync(d_req, requests, n * sizeof(clsimhip_step_request), hipMemcpyHostToDevice, stream), "upload requests");
         chk(hipMemcpyAsync(d_first, first.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream), "upload offsets");
         chk(launch_generate_steps(d_req, d_first, static_cast<uint32_t>(n ? n : 1), real, padded, seed, d_steps, stream), "step generation kernel launch");
         // the request copies were made from pageable memory (synchronous w.r.t. the host); free after the kernel
         chk(hipStreamSynchronize(stream), "step generation kernel");
-        (void)hipFree(d_req); (void)hipFree(d_first);
     });
 }
 int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed, size_t granularity,
@@ -419,13 +434,13 @@ int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, s
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
         chk(hipSetDevice(device), "hipSetDevice");
-        void *d_steps = nullptr;
-        chk(hipMalloc(&d_steps, std::max<size_t>(padded, 1) * sizeof(clsimhip_step)), "hipMalloc");
+        DeviceBuffer b_steps;
+        b_steps.alloc(padded * sizeof(clsimhip_step), "hipMalloc");
+        void *d_steps = b_steps.p;
         size_t got = 0;
         const int rc = clsimhip_generate_steps_device(device, requests, n, seed, granularity, d_steps, padded, nullptr, &got);
-        if (rc != CLSIMHIP_OK) { (void)hipFree(d_steps); throw Error(rc, g_create_error); }
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
         chk(hipMemcpy(steps_out, d_steps, padded * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
-        (void)hipFree(d_steps);
         if (padded_out) *padded_out = static_cast<size_t>(padded);
     });
 }
@@ -478,17 +493,17 @@ int clsimhip_generate_flasher_steps_device(int device, const clsimhip_flasher_co
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
         chk(hipSetDevice(device), "hipSetDevice");
         hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-        void *d_req = nullptr, *d_plan = nullptr, *d_prof = nullptr;
-        chk(hipMalloc(&d_req, n * sizeof(clsimhip_flasher_request)), "hipMalloc");
-        chk(hipMalloc(&d_plan, n * sizeof(FlasherPlanEntry)), "hipMalloc");
-        chk(hipMalloc(&d_prof, profiles.size() * sizeof(float)), "hipMalloc");
+        DeviceBuffer b_req, b_plan, b_prof;
+        b_req.alloc(n * sizeof(clsimhip_flasher_request), "hipMalloc");
+        b_plan.alloc(n * sizeof(FlasherPlanEntry), "hipMalloc");
+        b_prof.alloc(profiles.size() * sizeof(float), "hipMalloc");
+        void *d_req = b_req.p, *d_plan = b_plan.p, *d_prof = b_prof.p;
         chk(hipMemcpyAsync(d_req, requests, n * sizeof(clsimhip_flasher_request), hipMemcpyHostToDevice, stream), "upload pulses");
         chk(hipMemcpyAsync(d_plan, plan.data(), n * sizeof(FlasherPlanEntry), hipMemcpyHostToDevice, stream), "upload plan");
         chk(hipMemcpyAsync(d_prof, profiles.data(), profiles.size() * sizeof(float), hipMemcpyHostToDevice, stream), "upload time profiles");
         chk(launch_generate_flasher_steps(*config, static_cast<const clsimhip_flasher_request *>(d_req), d_plan, static_cast<uint32_t>(n), total, seed,
                                           static_cast<const float *>(d_prof), d_steps, stream), "flasher step kernel launch");
         chk(hipStreamSynchronize(stream), "flasher step kernel");
-        (void)hipFree(d_req); (void)hipFree(d_plan); (void)hipFree(d_prof);
     });
 }
 int clsimhip_generate_flasher_steps(int device, const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests,
@@ -504,12 +519,12 @@ int clsimhip_generate_flasher_steps(int device, const clsimhip_flasher_config *c
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
         chk(hipSetDevice(device), "hipSetDevice");
-        void *d_steps = nullptr;
-        chk(hipMalloc(&d_steps, std::max<size_t>(total, 1) * sizeof(clsimhip_step)), "hipMalloc");
+        DeviceBuffer b_steps;
+        b_steps.alloc(total * sizeof(clsimhip_step), "hipMalloc");
+        void *d_steps = b_steps.p;
         rc = clsimhip_generate_flasher_steps_device(device, config, requests, n, seed, d_steps, total, nullptr, nullptr);
-        if (rc != CLSIMHIP_OK) { (void)hipFree(d_steps); throw Error(rc, g_create_error); }
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
         chk(hipMemcpy(steps_out, d_steps, total * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
-        (void)hipFree(d_steps);
         if (count_out) *count_out = total;
     });
 }
