@@ -283,7 +283,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     hip_check(hipMemsetAsync(P.census, 0, 1 << 20, stream), "reset census");
     hip_check(hipMemsetAsync(P.census + 8, 0xff, 8, stream), "reset census");
 #endif
-    P.work = d_work_;
+    P.work = d_work_ + rng_offset;       // work records live with the stream slots: launches on disjoint slots may overlap
     P.len_table = d_len_table_;
     P.prox_map = d_prox_map_;
     P.hist_ring = d_hist_ring_;
