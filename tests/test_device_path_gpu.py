@@ -185,7 +185,7 @@ def test_ragged_bunch_under_every_schedule(slices, k_new, k_search, monkeypatch)
 @pytest.mark.timeout(900)
 def test_full_baseline_bunch_equals_oracle():
     """BASELINE configs[1] in full: all 1 048 576 steps x 200 photons through the kernel's production schedule
-    (5 workgroups per CU, 12 slices, parked searches) against the oracle run on every host core -- the complete hit
+    (7 workgroups per CU, 16 slices, eight sub-queues, parked searches) against the oracle run on every host core -- the complete hit
     multiset and all final RNG states, bit for bit.  (About a minute of oracle time on the GPU box's 256 threads.)"""
     import os
     cfg = common.config("mie")
