@@ -39,10 +39,12 @@ Converter::~Converter()
     if (ev_stop_) (void)hipEventDestroy(ev_stop_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    if (upload_stream_) (void)hipStreamDestroy(upload_stream_);
     for (Slot &sl : slots_) {
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.stop) (void)hipEventDestroy(sl.stop);
         if (sl.counted) (void)hipEventDestroy(sl.counted);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count); (void)hipFree(sl.d_hist_out);
         if (sl.h_hist) (void)hipHostFree(sl.h_hist);
         if (sl.h_steps) (void)hipHostFree(sl.h_steps);
@@ -200,6 +202,7 @@ void Converter::initialize_with_streams(const uint64_t *x, const uint32_t *a, si
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
     hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
     setup_device_buffers();
@@ -249,6 +252,7 @@ void Converter::setup_device_buffers()
         hip_check(hipEventCreate(&sl.start), "hipEventCreate");
         hip_check(hipEventCreate(&sl.stop), "hipEventCreate");
         hip_check(hipEventCreateWithFlags(&sl.counted, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming), "hipEventCreate");
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), static_cast<size_t>(kQueueWords) * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), max_workitems_ * sizeof(WorkRecord)), "work records");
@@ -316,7 +320,10 @@ void Converter::submit(Slot &s, const Job &job)
     s.generated = 0;
     for (const clsimhip_step &st : job.steps) s.generated += st.num_photons;
     std::memcpy(s.h_steps, job.steps.data(), n * sizeof(clsimhip_step));
-    hip_check(hipMemcpyAsync(s.d_steps, s.h_steps, n * sizeof(DevStep), hipMemcpyHostToDevice, stream_), "upload steps");
+    // the upload has a stream of its own: with double buffering it runs while the previous bunch's kernel does
+    hip_check(hipMemcpyAsync(s.d_steps, s.h_steps, n * sizeof(DevStep), hipMemcpyHostToDevice, upload_stream_), "upload steps");
+    hip_check(hipEventRecord(s.uploaded, upload_stream_), "event");
+    hip_check(hipStreamWaitEvent(stream_, s.uploaded, 0), "wait for the upload");
     hip_check(hipMemsetAsync(s.d_hit_count, 0, 4, stream_), "reset hit counter");
     KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
     P.hist_out = s.d_hist_out;

@@ -188,7 +188,7 @@ private:
         clsimhip_step *h_steps = nullptr;       // pinned staging
         clsimhip_photon *h_photons = nullptr;
         uint32_t *h_hit_count = nullptr;
-        hipEvent_t start = nullptr, stop = nullptr, counted = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr, counted = nullptr, uploaded = nullptr;
         uint32_t id = 0;
         uint64_t generated = 0;
     };
@@ -207,6 +207,7 @@ private:
     int k_new_ = 12, k_slices_ = 0;              // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
     hipStream_t copy_stream_ = nullptr;      // photon download
+    hipStream_t upload_stream_ = nullptr;    // step upload of the next bunch while the previous kernel runs
     hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
 
     // worker + queues (in: capacity 5 like queueToOpenCL_, OpenCL.cxx:77)
