@@ -275,12 +275,19 @@ def main():
         alg_bytes = n * 72.0 + hits_last * 80.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and args.photons_per_step == 200:
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this same command
             # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken)
             with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch")
+                prof = json.load(f)
+            traffic = prof.get("bytes_per_launch")
+            if prof.get("sq_insts_valu_per_launch"):
+                # the operative bound: VALU issue slots (a wave64 operation holds a SIMD for 2 cycles; 1024 SIMDs at 2.4 GHz)
+                valu = {"insts_per_launch": prof["sq_insts_valu_per_launch"], "lane_utilisation": prof.get("valu_lane_utilisation"),
+                        "issue_slot_frac": prof["sq_insts_valu_per_launch"] * 2.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
+                        "source": "profiles/latest_traffic.json (rocprofv3 --pmc pass of this command) x the live kernel time"}
         out = {
             "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -297,7 +304,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "prop_kernel", "avg_kernel_ms": avg_ms, "launches": int(launches),
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / (avg_ms * 1e-3))},
         }
