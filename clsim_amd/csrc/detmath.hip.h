@@ -194,4 +194,21 @@ DM float acos_(float v)
     return (float)atan2_d(s, d);
 }
 
+// Single precision arccosine for the table maker, which takes one per path sample (the binary64 form above costs ~380
+// instructions, this one ~45): |x| <= 0.5: pi/2 - asin(x); else 2 asin(sqrt((1 - |x|)/2)), reflected for x < 0, with the
+// classic degree-4 minimax polynomial for asin on [0, 0.5] (Cephes asinf).  <= 2 ulp (tests/test_oracle.py); the
+// OpenCL the reference runs on allows 4.  |x| > 1 or NaN gives NaN like acos().
+DM float acos_f(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    if (!(ax <= 1.0f)) return u2f(0x7fc00000u);
+    const bool big = ax > 0.5f;
+    const float z = big ? 0.5f * (1.0f - ax) : ax * ax;
+    const float s = big ? sqrt_(z) : ax;
+    const float p = (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f;
+    const float a = s + (s * z) * p;                         // asin(s)
+    if (big) return (x < 0.0f) ? (3.14159265358979f - 2.0f * a) : (2.0f * a);
+    return (x < 0.0f) ? (1.5707963267948966f + a) : (1.5707963267948966f - a);
+}
+
 } // namespace dm

@@ -695,7 +695,7 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
     float c0, c1, c2, c3, c4 = 0.0f;
     if (P->tab_axes_kind == 0) {
         c0 = dm::sqrt_(px * px + py * py + pz * pz);
-        const float azimuth = (n_rho > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
+        const float azimuth = (n_rho > 0.0f) ? dm::acos_f(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
         if (P->tab_full_azimuth) {
             const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
             const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
@@ -707,7 +707,7 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
         c3 = pw - c0 * ldsf(T + 27u);
     } else {
         c0 = n_rho;
-        c1 = (c0 > 0.0f) ? dm::acos_(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
+        c1 = (c0 > 0.0f) ? dm::acos_f(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
         c2 = R(2) + l * uz;
         c3 = pw - (l + c0 * ldsf(T + 28u)) * 3.33564095f;
     }
@@ -1360,6 +1360,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
     case 7: r = dm::rsqrt_(x); break;
     case 8: r = dm::sqrt_(x); break;
     case 9: r = x / y; break;
+    case 10: r = dm::acos_f(x); break;
     default: break;
     }
     out[i] = r;

@@ -669,7 +669,7 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
     if (T->tab_axes_kind == 0) {
         const float n_rho = magnitude(rho);
         coords[0] = magnitude(pos);
-        const float azimuth = (n_rho > 0) ? om_acos(dot4(rho, source->perpDir) / n_rho) / (PI_F / 180) : 0;
+        const float azimuth = (n_rho > 0) ? om_acos_f(dot4(rho, source->perpDir) / n_rho) / (PI_F / 180) : 0;
         if (T->tab_full_azimuth) {
             /* cross(rho, perpDir) . dir */
             const float cx = rho[1] * source->perpDir[2] - rho[2] * source->perpDir[1];
@@ -685,7 +685,7 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
         coords[3] = pos[3] - coords[0] * T->tab_min_inv_groupvel;
     } else {
         coords[0] = magnitude(rho);
-        coords[1] = (coords[0] > 0) ? om_acos(dot4(rho, source->perpDir) / coords[0]) : 0;
+        coords[1] = (coords[0] > 0) ? om_acos_f(dot4(rho, source->perpDir) / coords[0]) : 0;
         coords[2] = source->posAndTime[2] + l * source->dir[2];
         coords[3] = pos[3] - (l + coords[0] * T->tab_tan_thetac) * 3.33564095f;
     }
@@ -1088,6 +1088,7 @@ void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *
         case 7: out[i] = om_rsqrt(x); break;
         case 8: out[i] = om_sqrt(x); break;
         case 9: out[i] = x / y; break;
+        case 10: out[i] = om_acos_f(x); break;
         default: out[i] = 0.0f;
         }
     }

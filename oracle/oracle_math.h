@@ -239,4 +239,18 @@ OM_INLINE float om_acos(float v)
     return (float)om_atan2_d(s, d);
 }
 
+/* single precision arccosine of the table maker's path samples (detmath.hip.h: acos_f): Cephes asinf polynomial */
+OM_INLINE float om_acos_f(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    if (!(ax <= 1.0f)) return om_u2f(0x7fc00000u);
+    const int big = ax > 0.5f;
+    const float z = big ? 0.5f * (1.0f - ax) : ax * ax;
+    const float s = big ? om_sqrt(z) : ax;
+    const float p = (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f;
+    const float a = s + (s * z) * p;
+    if (big) return (x < 0.0f) ? (3.14159265358979f - 2.0f * a) : (2.0f * a);
+    return (x < 0.0f) ? (1.5707963267948966f + a) : (1.5707963267948966f - a);
+}
+
 #endif
