@@ -682,7 +682,9 @@ template <bool ANGLE>
 DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uint64_t x, uint32_t a, uint32_t &index)
 {
     const uint32_t T = P->off_tab;
-    auto R = [&](int k) { return __builtin_bit_cast(float, ref_lds[k]); };
+    (void)ref_lds; (void)T;
+    // wave-uniform constants: scalar loads from the parameter block (they used to be ~36 LDS reads per sample batch)
+    auto R = [&](int k) { return P->tab_ref[k]; };
     // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
     const float ax = g.px + d * g.dx, ay = g.py + d * g.dy, az = g.pz + d * g.dz, aw = g.pt + d * g.igv;
     const float px = ax - R(0), py = ay - R(1), pz = az - R(2);
@@ -704,12 +706,12 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
             c1 = azimuth;
         }
         c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
-        c3 = pw - c0 * ldsf(T + 27u);
+        c3 = pw - c0 * P->tab_min_inv_groupvel;
     } else {
         c0 = n_rho;
         c1 = (c0 > 0.0f) ? dm::acos_f(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
         c2 = R(2) + l * uz;
-        c3 = pw - (l + c0 * ldsf(T + 28u)) * 3.33564095f;
+        c3 = pw - (l + c0 * P->tab_tan_thetac) * 3.33564095f;
     }
     if (ANGLE) {
         // TABULATE_IMPACT_ANGLE (spherical :67-79, cylindrical :61-76): drawn before the bounds check, like the reference
@@ -720,7 +722,7 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
             c4 = (c0 > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, px, py, pz, pw) / c0) : 1.0f;
         } else {
             // (l - rho*recip(tan_thetaC))*dir, component by component as OpenCL evaluates it
-            const float rt = 1.0f / ldsf(T + 28u);
+            const float rt = 1.0f / P->tab_tan_thetac;
             const float kx = ax - (R(0) + (l - rx_ * rt) * ux), ky = ay - (R(1) + (l - ry_ * rt) * uy);
             const float kz = az - (R(2) + (l - rz_ * rt) * uz), kw = aw - (R(3) + (l - rw_ * rt) * uw);
             const float cdist = dm::sqrt_(kx * kx + ky * ky + kz * kz);
@@ -728,20 +730,20 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
         }
     }
     if (P->tab_axes_kind == 0) {
-        if ((c3 > ldsf(T + 26u)) || (c0 > ldsf(T + 25u))) return true;
+        if ((c3 > P->tab_max3) || (c0 > P->tab_max0)) return true;
     } else {
-        if (c3 > ldsf(T + 26u)) return true;
+        if (c3 > P->tab_max3) return true;
     }
     // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
     const float c[5] = {c0, c1, c2, c3, c4};
     index = 0;
 #pragma unroll
     for (int k = 0; k < ndim; ++k) {
-        const float v = ldsu(T + 20u + (uint32_t)k) ? dm::sqrt_(c[k]) : c[k];
-        const float f = __builtin_floorf(ldsf(T + (uint32_t)k) * v - ldsf(T + 5u + (uint32_t)k));
+        const float v = P->tab_inverse[k] ? dm::sqrt_(c[k]) : c[k];
+        const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
         int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-        b = clampi(b, -1, (int)ldsu(T + 10u + (uint32_t)k)) + 1;
-        index += ldsu(T + 15u + (uint32_t)k) * (uint32_t)b;
+        b = clampi(b, -1, P->tab_nbins[k]) + 1;
+        index += P->tab_stride[k] * (uint32_t)b;
     }
     return false;
 }
@@ -964,10 +966,10 @@ DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
 }
 
 // TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
-// four-dimensional table maker keeps its register allocation; with the angle axis 3 waves per SIMD and 168 VGPRs beat 4
-// waves with 25 spilled dwords by 17 %, without it 3 and 4 are equal)
+// four-dimensional table maker keeps its register allocation).  4 waves per SIMD: 86-110 VGPRs, nothing spilled, since
+// the sampling constants are scalar loads from the parameter block
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
-__global__ void __launch_bounds__(kBlock, TAB == 2 ? 3 : TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
+__global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
     // the only kernel argument sits at offset 0 of the kernarg segment
     const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
