@@ -18,3 +18,20 @@ for rep in range(3):
     got = CV.GenerateStepsDevice(req, 5 + rep, buf.data_ptr(), n, granularity=256)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("%d cascade steps in %.2f ms: %.3g steps/s (= %.3g photons/s of work for the propagator)" % (got, dt * 1e3, got / dt, 200 * got / dt))
+
+# flasher pulses: 64 LED pulses of 5e7 photons each (400 per step)
+cfg = CV.FlasherStepConverterConfig((CV.DIST_NORMAL, 0.0), (CV.DIST_NORMAL, 0.0), (CV.DIST_FLASHER_TIME_PROFILE, 0.0), False,
+                                    photonsPerStep=400, maxBunchSize=512000, bunchSizeGranularity=512)
+q = np.zeros(64, dtype=CV.FLASHER_REQUEST_DTYPE)
+for i in range(64):
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    q[i] = (rng.uniform(-400, 400), rng.uniform(-400, 400), rng.uniform(-400, 400), 0.0, d[0], d[1], d[2], 0.17, 0.17,
+            35.0 + (i % 4), i, 1, 50_000_000 + 7 * i)
+total, real = CV.CountFlasherSteps(cfg, q)
+fbuf = torch.zeros((total, 48), dtype=torch.uint8, device=dev)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    got = CV.GenerateFlasherStepsDevice(cfg, q, 11 + rep, fbuf.data_ptr(), total)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("%d flasher steps (%d with photons) in %.2f ms: %.3g steps/s (= %.3g photons/s of work for the propagator)"
+      % (got, real, dt * 1e3, got / dt, 400 * real / dt))
