@@ -15,11 +15,12 @@ struct clsimhip_converter { Converter impl; explicit clsimhip_converter(int dev)
 struct clsimhip_medium { MediumData data; };
 struct clsimhip_tabulator {
     std::unique_ptr<Tabulator> impl;
-    std::string last_error;
 };
 
 namespace {
-thread_local std::string g_create_error;
+// One message per calling thread (like errno): EnqueueSteps and GetConversionResult are called concurrently from
+// several threads per converter (I3CLSimServer.cxx:126-135, 324-331), so a per-object string would be a data race.
+thread_local std::string g_last_error;
 
 // device scratch memory of one call, freed on every path out of it
 struct DeviceBuffer {
@@ -43,10 +44,11 @@ int guarded(clsimhip_converter *c, F &&f)
         f();
         return CLSIMHIP_OK;
     } catch (const Error &e) {
-        if (c) c->impl.last_error = e.what(); else g_create_error = e.what();
+        (void)c;
+        g_last_error = e.what();
         return e.code;
     } catch (const std::exception &e) {
-        if (c) c->impl.last_error = e.what(); else g_create_error = e.what();
+        g_last_error = e.what();
         return CLSIMHIP_ERR_ARGUMENT;
     }
 }
@@ -80,10 +82,11 @@ int guarded_tab(clsimhip_tabulator *t, F &&f)
         f();
         return CLSIMHIP_OK;
     } catch (const Error &e) {
-        if (t) t->last_error = e.what(); else g_create_error = e.what();
+        (void)t;
+        g_last_error = e.what();
         return e.code;
     } catch (const std::exception &e) {
-        if (t) t->last_error = e.what(); else g_create_error = e.what();
+        g_last_error = e.what();
         return CLSIMHIP_ERR_ARGUMENT;
     }
 }
@@ -93,7 +96,7 @@ extern "C" {
 
 const char *clsimhip_version(void) { return "clsimhip 0.1 (gfx950)"; }
 
-const char *clsimhip_last_error(const clsimhip_converter *c) { return c ? c->impl.last_error.c_str() : g_create_error.c_str(); }
+const char *clsimhip_last_error(const clsimhip_converter *c) { (void)c; return g_last_error.c_str(); }
 
 int clsimhip_medium_create(const clsimhip_medium_desc *desc, clsimhip_medium **out)
 {
@@ -195,6 +198,14 @@ int clsimhip_create(int device_ordinal, clsimhip_converter **out)
     return guarded(nullptr, [&] { need(out, "out"); *out = new clsimhip_converter(device_ordinal); });
 }
 void clsimhip_destroy(clsimhip_converter *c) { delete c; }
+int clsimhip_set_device(clsimhip_converter *c, int device_ordinal)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.set_device(device_ordinal); });
+}
+int clsimhip_get_device(const clsimhip_converter *c, int *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.device(); });
+}
 
 int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_value *gens, size_t n)
 {
@@ -348,7 +359,7 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");
-        chk(hipSetDevice(device_ordinal), "hipSetDevice");
+        DeviceGuard on_device(device_ordinal);
         DeviceBuffer bx, by, bout;
         bx.alloc(n * 4 + 16, "hipMalloc"); bout.alloc(n * 4 + 16, "hipMalloc");
         float *dx = bx.as<float>(), *dy = nullptr, *dout = bout.as<float>();
@@ -407,7 +418,7 @@ int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requ
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
-        chk(hipSetDevice(device), "hipSetDevice");
+        DeviceGuard on_device(device);
         hipStream_t stream = static_cast<hipStream_t>(hip_stream);
         const size_t nreq = n ? n : 1;
         DeviceBuffer b_req, b_first;
@@ -433,13 +444,13 @@ int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, s
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
-        chk(hipSetDevice(device), "hipSetDevice");
+        DeviceGuard on_device(device);
         DeviceBuffer b_steps;
         b_steps.alloc(padded * sizeof(clsimhip_step), "hipMalloc");
         void *d_steps = b_steps.p;
         size_t got = 0;
         const int rc = clsimhip_generate_steps_device(device, requests, n, seed, granularity, d_steps, padded, nullptr, &got);
-        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_last_error);
         chk(hipMemcpy(steps_out, d_steps, padded * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
         if (padded_out) *padded_out = static_cast<size_t>(padded);
     });
@@ -491,7 +502,7 @@ int clsimhip_generate_flasher_steps_device(int device, const clsimhip_flasher_co
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
-        chk(hipSetDevice(device), "hipSetDevice");
+        DeviceGuard on_device(device);
         hipStream_t stream = static_cast<hipStream_t>(hip_stream);
         DeviceBuffer b_req, b_plan, b_prof;
         b_req.alloc(n * sizeof(clsimhip_flasher_request), "hipMalloc");
@@ -513,17 +524,17 @@ int clsimhip_generate_flasher_steps(int device, const clsimhip_flasher_config *c
         need(config, "config"); need(steps_out, "steps_out");
         size_t total = 0;
         int rc = clsimhip_count_flasher_steps(config, requests, n, &total, nullptr);
-        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_last_error);
         if (total > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "the pulses produce more steps than the buffer holds");
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
-        chk(hipSetDevice(device), "hipSetDevice");
+        DeviceGuard on_device(device);
         DeviceBuffer b_steps;
         b_steps.alloc(total * sizeof(clsimhip_step), "hipMalloc");
         void *d_steps = b_steps.p;
         rc = clsimhip_generate_flasher_steps_device(device, config, requests, n, seed, d_steps, total, nullptr, nullptr);
-        if (rc != CLSIMHIP_OK) throw Error(rc, g_create_error);
+        if (rc != CLSIMHIP_OK) throw Error(rc, g_last_error);
         chk(hipMemcpy(steps_out, d_steps, total * sizeof(clsimhip_step), hipMemcpyDeviceToHost), "download steps");
         if (count_out) *count_out = total;
     });
@@ -604,7 +615,7 @@ int clsimhip_tabulator_create(int device, int axes_kind, const clsimhip_axis *ax
     });
 }
 void clsimhip_tabulator_destroy(clsimhip_tabulator *t) { delete t; }
-const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t) { return t ? t->last_error.c_str() : g_create_error.c_str(); }
+const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t) { (void)t; return g_last_error.c_str(); }
 int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step *steps, size_t n, const double reference[7])
 {
     return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->enqueue_steps(steps, n, reference); });

@@ -32,14 +32,25 @@ Converter::~Converter()
     if (in_queue_) in_queue_->close();
     if (out_queue_) out_queue_->close();
     if (worker_.joinable()) worker_.join();
+    release_device();
+}
+
+void Converter::release_device()
+{
+    if (!stream_ && !d_tables_ && !d_rng_x_ && !slots_[0].d_steps) return;     // nothing was created
+    int previous = -1;
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
     (void)hipSetDevice(device_);
     for (auto &p : pending_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : free_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    pending_events_.clear(); free_events_.clear();
     if (ev_start_) (void)hipEventDestroy(ev_start_);
     if (ev_stop_) (void)hipEventDestroy(ev_stop_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (upload_stream_) (void)hipStreamDestroy(upload_stream_);
+    ev_start_ = ev_stop_ = nullptr;
+    stream_ = copy_stream_ = upload_stream_ = nullptr;
     for (Slot &sl : slots_) {
         if (sl.start) (void)hipEventDestroy(sl.start);
         if (sl.stop) (void)hipEventDestroy(sl.stop);
@@ -50,10 +61,31 @@ Converter::~Converter()
         if (sl.h_steps) (void)hipHostFree(sl.h_steps);
         if (sl.h_photons) (void)hipHostFree(sl.h_photons);
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
+        sl = Slot();
     }
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
     (void)hipFree(d_queue_); (void)hipFree(d_work_); (void)hipFree(d_hist_ring_);
+    d_tables_ = nullptr; d_dom_tx_ = d_dom_ty_ = nullptr; d_dom_tz_ = nullptr; d_len_table_ = nullptr; d_prox_map_ = nullptr;
+    d_rng_x_ = nullptr; d_rng_a_ = nullptr; d_queue_ = nullptr; d_work_ = nullptr; d_hist_ring_ = nullptr;
+    last_queue_ = nullptr;
+#ifdef CLSIMHIP_CENSUS
+    (void)hipFree(d_census_); d_census_ = nullptr;
+#endif
+    if (previous >= 0) (void)hipSetDevice(previous);
+}
+
+void Converter::set_device(int device)
+{
+    guard();
+    if (device < 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
+    device_ = device;
+}
+
+void Converter::check_worker() const
+{
+    std::lock_guard<std::mutex> lk(fatal_mutex_);
+    if (worker_failed_) throw Error(CLSIMHIP_ERR_DEVICE, "the converter's worker thread stopped after a device error: " + fatal_error_);
 }
 
 void Converter::set_wlen_generators(std::vector<RandomValueData> g)
@@ -199,18 +231,25 @@ void Converter::initialize_with_streams(const uint64_t *x, const uint32_t *a, si
             throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the propagator has no CPU fallback)");
         if (device_ >= count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
     }
-    hip_check(hipSetDevice(device_), "hipSetDevice");
-    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
-    hip_check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate");
-    hip_check(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking), "hipStreamCreate");
-    hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
-    hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
-    setup_device_buffers();
-    hip_check(hipMemcpy(d_rng_x_, x, count * sizeof(uint64_t), hipMemcpyHostToDevice), "upload rng x");
-    hip_check(hipMemcpy(d_rng_a_, a, count * sizeof(uint32_t), hipMemcpyHostToDevice), "upload rng a");
+    // everything below runs with this converter's device current; the caller's current device is restored on return,
+    // and a failure half-way releases what was created (a retry starts from nothing)
+    DeviceGuard on_device(device_);
+    try {
+        hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
+        hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
+        setup_device_buffers();
+        hip_check(hipMemcpy(d_rng_x_, x, count * sizeof(uint64_t), hipMemcpyHostToDevice), "upload rng x");
+        hip_check(hipMemcpy(d_rng_a_, a, count * sizeof(uint32_t), hipMemcpyHostToDevice), "upload rng a");
+    } catch (...) {
+        release_device();
+        throw;
+    }
 
-    in_queue_.reset(new BoundedQueue<Job>(5));
-    out_queue_.reset(new BoundedQueue<Result>(2));
+    in_queue_.reset(new BoundedQueue<Job>(5));          // queueToOpenCL_(5), OpenCL.cxx:77
+    out_queue_.reset(new BoundedQueue<Result>(0));      // queueFromOpenCL_(0): rendezvous, OpenCL.cxx:78
     initialized_ = true;
     worker_ = std::thread([this] { worker(); });
 }
@@ -302,6 +341,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
 void Converter::enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t identifier)
 {
     need_init();
+    check_worker();
     if (!steps) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps pointer is (null)!");
     if (n == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps are empty!");
     if (n > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than maximum number of work items!");
@@ -433,9 +473,18 @@ void Converter::worker()
         }
         if (pending >= 0) finish(slots_[pending], last_done, first);
     } catch (const Error &e) {
-        // the reference's worker log_fatal()s on device errors (OpenCL.cxx:768-774)
+        // The reference's worker log_fatal()s on device errors, which ends the process (OpenCL.cxx:768-774).  A C
+        // library must not take its host down: the error is logged and kept, both queues are closed so that blocked
+        // callers wake up, and every later EnqueueSteps / GetConversionResult returns CLSIMHIP_ERR_DEVICE with this
+        // text (the C++ adapter turns that into the exception / log_fatal of the host framework).
         std::fprintf(stderr, "clsimhip: fatal device error in worker thread: %s\n", e.what());
-        std::abort();
+        {
+            std::lock_guard<std::mutex> lk(fatal_mutex_);
+            fatal_error_ = e.what();
+            worker_failed_ = true;
+        }
+        in_queue_->close();
+        out_queue_->close();
     }
 }
 
@@ -445,7 +494,10 @@ void Converter::get_result(uint32_t *identifier, const clsimhip_photon **photons
     need_init();
     if (!identifier || !photons || !n) throw Error(CLSIMHIP_ERR_ARGUMENT, "output pointers are (null)");
     Result r;
-    if (!out_queue_->get(r)) throw Error(CLSIMHIP_ERR_STATE, "converter is shutting down");
+    if (!out_queue_->get(r)) {
+        check_worker();
+        throw Error(CLSIMHIP_ERR_STATE, "converter is shutting down");
+    }
     *identifier = r.id;
     *n = r.photons->size();
     static const clsimhip_photon empty_sentinel{};
@@ -519,7 +571,7 @@ void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offse
     if (n == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "Steps are empty!");
     if (rng_offset + n > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than maximum number of work items!");
     if (history_entries_) throw Error(CLSIMHIP_ERR_STATE, "photon histories are only delivered through EnqueueSteps/GetConversionResult");
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
         std::lock_guard<std::mutex> lk(ev_mutex_);
@@ -565,7 +617,7 @@ long Converter::get_table(const std::string &name, double *out, size_t cap) cons
 void Converter::debug_counters(uint32_t out[4])
 {
     need_init();
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     hip_check(hipDeviceSynchronize(), "sync");
 #ifdef CLSIMHIP_CENSUS
     hip_check(hipMemcpy(out, d_census_, 1 << 20, hipMemcpyDeviceToHost), "download census");     // the caller passes 1 MiB
@@ -578,7 +630,7 @@ void Converter::get_rng_state(uint64_t *x, size_t count)
 {
     need_init();
     if (!x || count > max_workitems_) throw Error(CLSIMHIP_ERR_ARGUMENT, "bad rng state request");
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     hip_check(hipDeviceSynchronize(), "sync");
     hip_check(hipMemcpy(x, d_rng_x_, count * sizeof(uint64_t), hipMemcpyDeviceToHost), "download rng state");
 }

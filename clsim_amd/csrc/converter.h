@@ -45,7 +45,9 @@ CompiledTables compile_tables(const MediumData &medium, const GeometryInput &geo
                               const std::vector<RandomValueData> &generators, const FunctionData &bias,
                               double pancake_factor);
 
-// bounded blocking queue (I3CLSimQueue.h:48-195)
+// bounded blocking queue (I3CLSimQueue.h:48-195).  Like the reference's, a consumer that waits in get() counts as
+// one free place: with capacity 0 the queue is a rendezvous -- put() returns only once a get() is there to take the
+// item (queueFromOpenCL_, OpenCL.cxx:77-78), so size() / empty() show an item only while it is being handed over.
 template <class T>
 class BoundedQueue {
 public:
@@ -53,42 +55,64 @@ public:
     void put(T v)
     {
         std::unique_lock<std::mutex> lk(m_);
-        not_full_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        cond_.wait(lk, [&] { return q_.size() < cap_ + waiting_ || closed_; });
         if (closed_) return;
         q_.push_back(std::move(v));
-        not_empty_.notify_one();
+        cond_.notify_all();
     }
     bool get(T &out)
     {
         std::unique_lock<std::mutex> lk(m_);
-        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        ++waiting_;                     // I3CLSimQueue.h:85-87: tell the producer that somebody is waiting
+        cond_.notify_all();
+        cond_.wait(lk, [&] { return !q_.empty() || closed_; });
+        --waiting_;
         if (q_.empty()) return false;
         out = std::move(q_.front());
         q_.pop_front();
-        not_full_.notify_one();
+        cond_.notify_all();
         return true;
     }
     // waits at most `us` microseconds; false if nothing arrived (or the queue was closed and is empty)
     bool get_for(T &out, long us)
     {
         std::unique_lock<std::mutex> lk(m_);
-        if (!not_empty_.wait_for(lk, std::chrono::microseconds(us), [&] { return !q_.empty() || closed_; })) return false;
-        if (q_.empty()) return false;
+        ++waiting_;
+        cond_.notify_all();
+        const bool got = cond_.wait_for(lk, std::chrono::microseconds(us), [&] { return !q_.empty() || closed_; });
+        --waiting_;
+        if (!got || q_.empty()) { cond_.notify_all(); return false; }
         out = std::move(q_.front());
         q_.pop_front();
-        not_full_.notify_one();
+        cond_.notify_all();
         return true;
     }
     bool closed() const { std::lock_guard<std::mutex> lk(m_); return closed_; }
     size_t size() const { std::lock_guard<std::mutex> lk(m_); return q_.size(); }
     bool empty() const { return size() == 0; }
-    void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; not_full_.notify_all(); not_empty_.notify_all(); }
+    void close() { std::lock_guard<std::mutex> lk(m_); closed_ = true; cond_.notify_all(); }
 private:
     size_t cap_;
     mutable std::mutex m_;
-    std::condition_variable not_full_, not_empty_;
+    std::condition_variable cond_;
     std::deque<T> q_;
+    size_t waiting_ = 0;
     bool closed_ = false;
+};
+
+// hipSetDevice for the duration of a call made on the CALLER's thread; the caller's current device is restored
+struct DeviceGuard {
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+        const hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+    ~DeviceGuard() { if (previous_ >= 0) (void)hipSetDevice(previous_); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+private:
+    int previous_ = -1;
 };
 
 class Converter {
@@ -135,8 +159,9 @@ public:
     long get_table(const std::string &name, double *out, size_t cap) const;
     void get_rng_state(uint64_t *x, size_t count);
     void debug_counters(uint32_t out[4]);
-
-    std::string last_error;
+    // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
+    void set_device(int device);
+    int device() const { return device_; }
 
 private:
     struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
@@ -149,7 +174,9 @@ private:
     void guard() const { if (initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP already initialized!"); }
     void need_init() const { if (!initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP is not initialized!"); }
     void setup_device_buffers();
+    void release_device();      // frees every device / pinned allocation, stream and event (idempotent)
     void worker();
+    void check_worker() const;  // throws the worker thread's device error, if it has died of one
     void hip_check(hipError_t e, const char *what) const;
     KParams launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream);
 
@@ -214,6 +241,10 @@ private:
     std::unique_ptr<BoundedQueue<Job>> in_queue_;
     std::unique_ptr<BoundedQueue<Result>> out_queue_;
     std::thread worker_;
+    // a device error in the worker thread: kept for the callers (every later call returns CLSIMHIP_ERR_DEVICE with this text)
+    mutable std::mutex fatal_mutex_;
+    std::string fatal_error_;
+    bool worker_failed_ = false;
     mutable std::mutex results_mutex_;
     std::map<const clsimhip_photon *, Result> handed_out_;
 

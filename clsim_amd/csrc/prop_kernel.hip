@@ -41,6 +41,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "detmath.hip.h"
 #include "../../include/clsimhip.h"
@@ -1375,21 +1377,38 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     KParams P = Pin;
     const size_t lds_bytes = TAB ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
                                  : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock) * 4;
-    // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work
-    static int resident = 0;            // per variant
-    if (resident == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess && lds_bytes > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER, TAB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER, TAB>, kBlock, lds_bytes);
+    // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work.
+    // Occupancy, CU count and the function attributes are per (device, variant): one process may drive converters on
+    // several GPUs (the reference's usual model, I3CLSimServer.cxx:77-137) and from several threads.
+    struct Plan { int cus = 0, resident = 0; bool assemble_ready = false; };
+    static std::mutex plan_mutex;
+    static std::map<std::pair<int, size_t>, Plan> plans;     // (device, LDS bytes of the workgroup: the image differs per configuration)
+    int dev = 0;
+    {
+        const hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        if (per_cu < 1) per_cu = 1;
-        resident = cus * per_cu;
     }
+    Plan plan;
+    {
+        std::lock_guard<std::mutex> lk(plan_mutex);
+        Plan &pl = plans[std::make_pair(dev, lds_bytes)];
+        if (pl.resident == 0) {
+            int cus = 0, per_cu = 0;
+            hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess && lds_bytes > 64 * 1024)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER, TAB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e == hipSuccess)
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER, TAB>, kBlock, lds_bytes);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            if (cus < 1) cus = 1;
+            pl.cus = cus;
+            pl.resident = cus * per_cu;
+        }
+        plan = pl;
+    }
+    const int resident = plan.resident;
     // Grid and slices per step, from a scan on MI355X (200-photon steps, SPICE-Mie, n = 0.13M ... 4M, 5/6/7 workgroups per
     // CU x 8/12/16/24 slices x 3/5 parked lanes per DOM search; r = steps per lane):
     //   * more resident waves hide more latency (4M steps: 7 per CU 2.20e9 photons/s, 6: 2.14e9, 5: 2.03e9), but every
@@ -1401,9 +1420,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)resident;
     {
-        int dev = 0, cus = 1;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (cus < 1) cus = 1;
+        const int cus = plan.cus;
         const int per_cu = resident / cus;
         const int floor_per_cu = per_cu < 5 ? per_cu : 5;
         int chosen = floor_per_cu;
@@ -1433,15 +1450,15 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     hipError_t err = hipGetLastError();
     if (err != hipSuccess || TAB) return err;
     // second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
-    static bool assemble_ready = false;
     const size_t image_bytes = (size_t)P.table_words * 4;
-    if (!assemble_ready) {
+    if (!plan.assemble_ready) {
+        std::lock_guard<std::mutex> lk(plan_mutex);
         if (image_bytes > 64 * 1024) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_hits_kernel<FLASHER>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes);
             if (err != hipSuccess) return err;
         }
-        assemble_ready = true;
+        plans[std::make_pair(dev, lds_bytes)].assemble_ready = true;
     }
     hipLaunchKernelGGL((assemble_hits_kernel<FLASHER>), dim3(512), dim3(256), image_bytes, stream, P);
     return hipGetLastError();

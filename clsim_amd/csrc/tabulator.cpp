@@ -147,7 +147,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the tabulator has no CPU fallback)");
     if (device_ < 0 || device_ >= count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipEventCreate(&ev_start_), "hipEventCreate");
     hip_check(hipEventCreate(&ev_stop_), "hipEventCreate");
@@ -189,7 +189,7 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
     if (n == 0) return;
     if (n > streams_) throw Error(CLSIMHIP_ERR_ARGUMENT, "Number of steps is greater than the number of RNG streams!");
     std::lock_guard<std::mutex> lk(mutex_);
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     // the previous bunch still reads the pinned staging buffer and the slice counters
     hip_check(hipStreamSynchronize(stream_), "previous bunch");
     if (pending_event_) {
@@ -242,7 +242,7 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
 void Tabulator::finish()
 {
     std::lock_guard<std::mutex> lk(mutex_);
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceGuard on_device(device_);
     hip_check(hipStreamSynchronize(stream_), "tabulation kernel");
     if (pending_event_) {
         float ms = 0.f;

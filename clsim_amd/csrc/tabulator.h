@@ -45,7 +45,6 @@ public:
     void statistics(double out[8]);
     void get_rng_state(uint64_t *x, size_t count);
     long get_table(const std::string &name, double *out, size_t cap) const;
-    std::string last_error;
 
 private:
     void hip_check(hipError_t e, const char *what) const;

@@ -168,7 +168,16 @@ int clsimhip_seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64
 /* ---- converter life cycle (I3CLSimStepToPhotonConverterOpenCL.cxx:68-388) ---- */
 int clsimhip_create(int device_ordinal, clsimhip_converter **out);
 void clsimhip_destroy(clsimhip_converter *c);
-const char *clsimhip_last_error(const clsimhip_converter *c); /* c may be NULL: last create error */
+/* Text of the last failure of a clsimhip_* call made BY THE CALLING THREAD (thread-local, like errno; `c` is ignored and
+ * may be NULL): the interface is driven by several threads per converter (I3CLSimServer.cxx:126-135, 324-331). */
+const char *clsimhip_last_error(const clsimhip_converter *c);
+/* SetDevice (public/clsim/I3CLSimStepToPhotonConverterOpenCL.h:96-103, OpenCL.cxx:1322-1331; the canonical caller's
+ * first call, I3CLSimModuleHelper.cxx:321): the HIP device ordinal replaces the I3CLSimOpenCLDevice.  Before Initialize. */
+int clsimhip_set_device(clsimhip_converter *c, int device_ordinal);
+int clsimhip_get_device(const clsimhip_converter *c, int *out);
+/* Device errors: a HIP error inside the converter's worker thread is where the reference log_fatal()s and exits
+ * (OpenCL.cxx:768-774).  This library does not end its host: the worker stops, blocked callers wake up, and every
+ * later EnqueueSteps / GetConversionResult returns CLSIMHIP_ERR_DEVICE with the original text. */
 
 /* setters: CLSIMHIP_ERR_STATE once initialized (OpenCL.cxx:1322-1523) */
 int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_value *gens, size_t n);
