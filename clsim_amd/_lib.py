@@ -80,7 +80,7 @@ SYMBOLS = [
     "clsimhip_medium_create_from_photonics", "clsimhip_medium_describe", "clsimhip_medium_destroy",
     "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
     "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
-    "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device",
+    "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device", "clsimhip_uses_pooled_kernel",
     "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
     "clsimhip_set_geometry_from_text_file",
     "clsimhip_set_enable_double_buffering", "clsimhip_set_double_precision", "clsimhip_set_stop_detected_photons",
@@ -135,6 +135,7 @@ def load():
         "clsimhip_last_error": (C.c_char_p, [vp]),
         "clsimhip_set_device": (i32, [vp, i32]),
         "clsimhip_get_device": (i32, [vp, C.POINTER(i32)]),
+        "clsimhip_uses_pooled_kernel": (i32, [vp, C.POINTER(i32)]),
         "clsimhip_set_wlen_generators": (i32, [vp, C.POINTER(RandomValue), sz]),
         "clsimhip_set_wlen_bias": (i32, [vp, C.POINTER(Function)]),
         "clsimhip_set_medium_properties": (i32, [vp, vp]),

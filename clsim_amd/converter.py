@@ -380,6 +380,11 @@ class I3CLSimStepToPhotonConverterHIP:
         self._lib.clsimhip_get_table(self._h, name.encode(), _dp(out), n)
         return out
 
+    def UsesPooledKernel(self):
+        v = C.c_int32()
+        self._call("clsimhip_uses_pooled_kernel", C.byref(v))
+        return bool(v.value)
+
     def GetRNGState(self, count):
         x = np.zeros(count, dtype=np.uint64)
         self._call("clsimhip_get_rng_state", x.ctypes.data_as(C.c_void_p), count)

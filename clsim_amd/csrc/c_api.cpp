@@ -202,6 +202,10 @@ int clsimhip_set_device(clsimhip_converter *c, int device_ordinal)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.set_device(device_ordinal); });
 }
+int clsimhip_uses_pooled_kernel(const clsimhip_converter *c, int *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.uses_pooled_kernel() ? 1 : 0; });
+}
 int clsimhip_get_device(const clsimhip_converter *c, int *out)
 {
     return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.device(); });

@@ -15,6 +15,12 @@ namespace clsimhip {
 static_assert(sizeof(clsimhip_step) == sizeof(DevStep), "step layouts");
 static_assert(sizeof(clsimhip_photon) == sizeof(DevPhoton), "photon layouts");
 constexpr uint32_t kQueueSlots = 256;
+constexpr bool kDefaultPooledKernel = false;
+
+hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
+{
+    return use_pool_ ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
+}
 
 void Converter::hip_check(hipError_t e, const char *what) const
 {
@@ -298,6 +304,13 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_POP")) k_pop_ = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
+    use_pool_ = kDefaultPooledKernel;
+    if (const char *e = std::getenv("CLSIMHIP_KERNEL")) use_pool_ = (std::strcmp(e, "pool") == 0);
+    // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
+    // leaves its pools no LDS
+    if (history_entries_ != 0 || !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()))) use_pool_ = false;
 }
 
 KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)
@@ -320,6 +333,8 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.k_new = k_new_;
     P.k_search = k_search_;
     P.slices = k_slices_;
+    P.k_pop = k_pop_;
+    P.pool_ready = pool_ready_;
 #ifdef CLSIMHIP_CENSUS
     if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), 1 << 20), "census");
     P.census = d_census_;
@@ -368,7 +383,7 @@ void Converter::submit(Slot &s, const Job &job)
     KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
     P.hist_out = s.d_hist_out;
     hip_check(hipEventRecord(s.start, stream_), "event");
-    hip_check(launch_prop_kernel(P, tables_.variant, stream_), "propagation kernel launch");
+    hip_check(launch(P, stream_), "propagation kernel launch");
     hip_check(hipEventRecord(s.stop, stream_), "event");
     hip_check(hipMemcpyAsync(s.h_hit_count, s.d_hit_count, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
     hip_check(hipMemcpyAsync(s.h_hit_count + 1, P.queue + 2, 4, hipMemcpyDeviceToHost, stream_), "download skipped-step counter");
@@ -581,7 +596,7 @@ void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offse
     hip_check(hipMemsetAsync(d_hit_count, 0, 4, stream), "reset hit counter");
     const KParams P = launch_params(d_steps, n, rng_offset, d_photons, capacity, d_hit_count, stream);
     hip_check(hipEventRecord(ev.first, stream), "event");
-    hip_check(launch_prop_kernel(P, tables_.variant, stream), "propagation kernel launch");
+    hip_check(launch(P, stream), "propagation kernel launch");
     hip_check(hipEventRecord(ev.second, stream), "event");
     std::lock_guard<std::mutex> lk(ev_mutex_);
     pending_events_.push_back(ev);

@@ -18,6 +18,9 @@
 namespace clsimhip {
 
 hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
+// pooled scheduling (prop_pool_kernel.hip): same results, propagation without photon histories only
+hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
+bool pool_kernel_fits(uint32_t table_words);
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
 int prop_kernel_block_size();
@@ -162,6 +165,7 @@ public:
     // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
     void set_device(int device);
     int device() const { return device_; }
+    bool uses_pooled_kernel() const { need_init(); return use_pool_; }
 
 private:
     struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
@@ -231,7 +235,10 @@ private:
     unsigned long long *d_census_ = nullptr;
 #endif
     int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
-    int k_new_ = 12, k_slices_ = 0;              // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
+    int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
+    int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)
+    bool use_pool_ = false;                      // CLSIMHIP_KERNEL=pool|classic
+    hipError_t launch(const KParams &P, hipStream_t stream) const;
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
     hipStream_t copy_stream_ = nullptr;      // photon download
     hipStream_t upload_stream_ = nullptr;    // step upload of the next bunch while the previous kernel runs

@@ -66,6 +66,9 @@ struct KParams {
     int32_t k_new;                      // lanes that must be waiting before photons are created
     int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
+    // pooled kernel (prop_pool_kernel.hip): entries of a wave's ring of ready photons, and how many lanes must be
+    // without a photon before the wave services them; k_new is its creation batch there (0 = automatic everywhere)
+    int32_t pool_ready, k_pop;
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *census;         // analysis build (make EXTRA=-DCLSIMHIP_CENSUS): [0..7] lane-state sums, [8] earliest
                                         // wave start, [16 + 3w ...] per wave: end time, time the first sub-queue was found dry, trips

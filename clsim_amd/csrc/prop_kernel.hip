@@ -44,614 +44,9 @@
 #include <map>
 #include <mutex>
 
-#include "detmath.hip.h"
-#include "../../include/clsimhip.h"
-#include "kparams.h"
+#include "prop_device.hip.h"
 
 namespace clsimhip {
-
-#ifndef CLSIMHIP_BLOCK
-#define CLSIMHIP_BLOCK 256                       // 4 waves per workgroup, up to 7 workgroups per CU (<= 72 VGPRs)
-#define CLSIMHIP_MIN_WAVES 7
-#endif
-constexpr int kBlock = CLSIMHIP_BLOCK;
-constexpr int kMinWavesPerSimd = CLSIMHIP_MIN_WAVES;
-constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kStageRecords = 8;                 // hit stubs staged per wave and flush
-constexpr int kStubWords = 16;
-#ifndef CLSIMHIP_PRIO_SHIFT
-#define CLSIMHIP_PRIO_SHIFT 1
-#endif
-constexpr int kPrioShift = CLSIMHIP_PRIO_SHIFT;  // a wave changes its issue priority every 2^kPrioShift loop trips
-constexpr int kTabSlots = 512;                   // TABULATE: path samples one wave pools per loop trip
-constexpr int kTabWaveWords = 2 * kTabSlots + 64;
-constexpr float kEpsilon = 0.00001f;             // propagation_kernel.c.cl:505
-constexpr float kSpeedOfLight = 0.299792458f;    // propagation_kernel.h.cl:148
-constexpr float kPi = 3.14159265359f;            // propagation_kernel.h.cl:150
-constexpr uint32_t kNoStep = 0xffffffffu;
-constexpr int kTiltScalarBins = 6;               // inner tilt bin edges kept as scalars (nd <= 8)
-
-// kernel parameters, read with scalar loads from the constant address space
-typedef const __attribute__((address_space(4))) KParams *KP;
-
-// Makes the parameter pointer opaque to the optimiser at this point, so that the
-// loads that follow stay here (phase-local SGPR live ranges) instead of being
-// hoisted to the kernel entry and spilled.
-DM KP fresh_params(KP p)
-{
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
-
-struct Rec4 { float a, b, c, d; };
-
-DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
-DM uint32_t ldsu(uint32_t i) { return lds_words[i]; }
-DM Rec4 lds_rec4(uint32_t i) { return *reinterpret_cast<const Rec4 *>(&lds_words[i]); }   // i % 4 == 0
-DM uint32_t lds_u16(uint32_t off, uint32_t i)
-{
-    const uint32_t w = lds_words[off + (i >> 1)];
-    return (i & 1) ? (w >> 16) : (w & 0xffffu);
-}
-
-// mwcrng_kernel.cl:12-20: x = lo32(x)*a + hi32(x); u = float_rtz(lo32(x)) / 2^32
-DM float rng_co(uint64_t &x, uint32_t a)
-{
-    x = (x & 0xffffffffull) * (uint64_t)a + (x >> 32);
-    const uint32_t lo = (uint32_t)x;
-    const int drop = 8 - (int)__clz(lo);                    // bits below the 24-bit significand
-    const uint32_t t = (drop > 0) ? ((lo >> drop) << drop) : lo;
-    return (float)t * 2.3283064365386963e-10f;              // exact: t has <= 24 significant bits
-}
-DM float rng_oc(uint64_t &x, uint32_t a) { return 1.0f - rng_co(x, a); }
-
-DM float sqr(float a) { return a * a; }
-// a / b for an invariant divisor b with r = RN(1/b): exact when Compile() proved it (`ok`, wave-uniform)
-DM float div_by(float a, float b, float r, bool ok)
-{
-    if (ok) {
-        const float q = a * r;
-        return dm::fma_(dm::fma_(-b, q, a), r, q);
-    }
-    return a / b;
-}
-DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
-DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
-
-struct Vec3 { float x, y, z; };
-
-// FunctionFromTable.cxx:213-232: interpolation bin and fraction of an equally spaced table
-DM void table_bin_fraction(float start, float step, int n, float wlen, int &bin, float &fraction)
-{
-    const float q = (wlen - start) / step;
-    const float fbin = __builtin_truncf(q);
-    fraction = q - fbin;                                // modf
-    bin = (int)fbin;
-    if ((bin < 0) || ((bin == 0) && (fraction < 0.0f))) { bin = 0; fraction = 0.0f; }
-    else if (bin >= n - 1) { bin = n - 2; fraction = 1.0f; }
-}
-// FunctionFromTable.cxx:279-291 (float data in the LDS image)
-DM float table_value(uint32_t off, float start, float step, int n, float wlen)
-{
-    int bin; float fraction;
-    table_bin_fraction(start, step, n, wlen, bin, fraction);
-    const float a = ldsf(off + (uint32_t)bin), b = ldsf(off + (uint32_t)bin + 1u);
-    return a + (b - a) * fraction;                      // mix
-}
-// RefIndexIceCube.cxx:128-180, or one FromTable function for all layers
-DM float phase_ref_index(KP P, float wlen)
-{
-    if (P->phase_kind == CLSIMHIP_REFINDEX_TABLE) return table_value(P->off_phase, P->phase_start, P->phase_step, P->phase_n, wlen);
-    const float x = wlen / P->micrometer;
-    return P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
-}
-// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163 or a FromTable override
-DM float group_velocity(KP P, float wlen)
-{
-    if (P->group_kind == CLSIMHIP_REFINDEX_TABLE)
-        return P->c_light / table_value(P->off_group, P->group_start, P->group_step, P->group_n, wlen);
-    const float x = wlen / P->micrometer;
-    const float np = P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
-    const float np_corr = P->g[0] + x * (P->g[1] + x * (P->g[2] + x * (P->g[3] + x * P->g[4])));
-    return P->c_light / (np * np_corr);
-}
-
-// Per-photon wavelength factors of the medium functions.  ICECUBE: the three transcendental terms;
-// TABLE: interpolation fraction (sca_pow) and the record index of (bin, layer 0) (abs_pow, as bits).
-struct IceFactors { float sca_pow, abs_pow, abs_exp; };
-
-template <int MED>
-DM IceFactors ice_factors(KP P, float wlen)
-{
-    IceFactors f = {0.0f, 0.0f, 0.0f};
-    if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
-        // _Optimizers.cxx:237-240: powr(wlen*(1/400nm), -alpha)
-        f.sca_pow = dm::powr_(wlen * P->ref_wlen_recip, P->neg_alpha);
-        // _Optimizers.cxx:170-180: powr(x,-kappa), A*exp(-B/x), x = wlen/nm
-        const float x = wlen / P->nanometer;
-        f.abs_pow = dm::powr_(x, P->neg_kappa);
-        f.abs_exp = P->abs_A * dm::exp_(P->neg_B / x);
-    } else if (MED == CLSIMHIP_LENGTHS_TABLE) {
-        int bin;
-        table_bin_fraction(P->len_tab_start, P->len_tab_step, P->len_tab_n, wlen, bin, f.sca_pow);
-        f.abs_pow = __builtin_bit_cast(float, (uint32_t)(bin * P->num_layers));
-    }
-    return f;
-}
-// scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100,
-// FunctionFromTable.cxx:262-291 behind the switch(layer) of MediumPropertiesSource.cxx:89-123)
-template <int MED>
-DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len)
-{
-    if (MED == CLSIMHIP_LENGTHS_TABLE) {
-        const float4 r = *reinterpret_cast<const float4 *>(len_table + 4u * (__builtin_bit_cast(uint32_t, f.abs_pow) + (uint32_t)layer));
-        abs_len = r.x + (r.y - r.x) * f.sca_pow;
-        sca_len = r.z + (r.w - r.z) * f.sca_pow;
-        return;
-    }
-    const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
-    if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
-        sca_len = 1.0f / (r.c * f.sca_pow);
-        abs_len = 1.0f / (r.a * f.abs_pow + f.abs_exp * r.b);
-    } else {
-        sca_len = r.c;
-        abs_len = r.a;
-    }
-}
-
-// HenyeyGreenstein.cxx:69-92
-DM float hg_cos(KP P, float u)
-{
-    const float s = 2.0f * u - 1.0f;
-    const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
-    return clampf(div_by(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, (P->div_ok & 16u) != 0), -1.0f, 1.0f);
-}
-// SimplifiedLiu.cxx:64-88
-DM float liu_cos(KP P, float u) { return clampf(2.0f * dm::powr_(u, P->liu_beta) - 1.0f, -1.0f, 1.0f); }
-// Mixed.cxx:115-157, single random number form
-DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
-{
-    const float rr = rng_co(x, a);
-    const int kind = P->scatter_kind;
-    if (kind == 0) return hg_cos(P, rr);
-    if (kind == 1) return liu_cos(P, rr);
-    const uint32_t ok = P->div_ok;
-    if (rr < P->mix_frac) return liu_cos(P, div_by(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
-    return hg_cos(P, div_by(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
-}
-
-// ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
-DM float abs_len_corr(KP P, const Vec3 &d)
-{
-    const float n0 = (P->an_azx * d.x) + (P->an_azy * d.y);
-    const float n1 = (P->an_mazy * d.x) + (P->an_azx * d.y);
-    const float s0 = n0 * n0, s1 = n1 * n1, s2 = d.z * d.z;
-    // dot(float4,float4) with a zero 4th component: the +0 term cannot change a sum of squares
-    const float nB = (s0 * P->an_rl[0] + s1 * P->an_rl[1]) + s2 * P->an_rl[2];
-    const float An = (s0 * P->an_l[0] + s1 * P->an_l[1]) + s2 * P->an_l[2];
-    return 2.0f / ((P->an_B2 - nB) * An);
-}
-// VectorTransformMatrix.cxx:101-135
-DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renorm, Vec3 &d)
-{
-    const float x = (m[0] * d.x) + (m[1] * d.y) + (m[2] * d.z);
-    const float y = (m[3] * d.x) + (m[4] * d.y) + (m[5] * d.z);
-    const float z = (m[6] * d.x) + (m[7] * d.y) + (m[8] * d.z);
-    d.x = x; d.y = y; d.z = z;
-    if (renorm) {
-        const float norm = dm::rsqrt_(d.x * d.x + d.y * d.y + d.z * d.z);
-        d.x = d.x * norm; d.y = d.y * norm; d.z = d.z * norm;
-    }
-}
-
-// ScalarFieldIceTiltZShift.cxx:145-213.  The distance bin is the first j with
-// nr < dist[j] (last bin otherwise); dist is ascending, so it is counted.
-DM float tilt_z_shift(KP P, float px, float py, float pz)
-{
-    const float z_rescaled = div_by(pz - P->tilt_first_z, P->tilt_dz, P->rcp_tilt_dz, (P->div_ok & 1u) != 0);
-    const int nz = P->tilt_nz, nd = P->tilt_nd;
-    const uint32_t off_dist = P->off_tilt_dist;
-    const int k = clampi((int)__builtin_floorf(z_rescaled), 0, nz - 2);
-    const float fraction_z_above = z_rescaled - (float)k;
-    const float fraction_z_below = 1.0f - fraction_z_above;
-    const float nr = P->tilt_lnx * px + P->tilt_lny * py;
-    int j = 1;
-    if (nd <= kTiltScalarBins + 2) {
-        // inner bin edges live in the parameter block (padded with +inf): compares against SGPRs, no LDS
-#pragma unroll
-        for (int t = 0; t < kTiltScalarBins; ++t) j += (nr >= P->tilt_inner_dist[t]) ? 1 : 0;
-    } else {
-        for (int t = 1; t < nd - 1; ++t) j += (nr >= ldsf(off_dist + t)) ? 1 : 0;
-    }
-    const Rec4 bin = lds_rec4(P->off_tilt_bins + 4u * (uint32_t)j);    // dist[j], dist[j]-dist[j-1], 1/width, proven
-    const float thisDist = bin.a;
-    // the proof bit differs per bin: select, the divide is only executed if some lane's bin lacks the proof
-    const float q = (thisDist - nr) * bin.c;
-    float frac_at_lower = dm::fma_(dm::fma_(-bin.b, q, thisDist - nr), bin.c, q);
-    if (__builtin_bit_cast(uint32_t, bin.d) == 0u) frac_at_lower = (thisDist - nr) / bin.b;
-    const float frac_at_upper = 1.0f - frac_at_lower;
-    const uint32_t lo = P->off_tilt_zcorr + (uint32_t)((j - 1) * nz + k);
-    const uint32_t hi = lo + (uint32_t)nz;
-    const float val_at_lower = (ldsf(lo + 1) * fraction_z_above + ldsf(lo) * fraction_z_below);
-    const float val_at_upper = (ldsf(hi + 1) * fraction_z_above + ldsf(hi) * fraction_z_below);
-    return (val_at_upper * frac_at_upper + val_at_lower * frac_at_lower);
-}
-
-// InterpolatedDistribution.cxx:236-336 (constant spacing).  The reference scans
-// the cumulative table linearly for the first entry >= r; the table is
-// non-decreasing, so a bisection lands on the same bin.
-DM float generate_wavelength(KP P, int gen, uint64_t &x, uint32_t a)
-{
-    if (P->gen_kind[gen] == 1) return P->gen_value[gen];      // RandomValueConstant
-    if (P->gen_kind[gen] == 2) {                               // WlenCherenkovNoDispersion.cxx:72-92
-        const float u = rng_oc(x, a);
-        return 1.0f / (P->gen_first[gen] + u * P->gen_spacing[gen]);
-    }
-    const float r = rng_oc(x, a);
-    const uint32_t cum = P->off_gen_ycum[gen], yv = P->off_gen_yv[gen];
-    int lo = 1, hi = P->gen_n[gen] - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (ldsf(cum + mid) >= r) hi = mid; else lo = mid + 1;
-    }
-    const int k = lo - 1;
-    const float this_acu = (k == 0) ? 0.0f : ldsf(cum + k);
-    const float b = ldsf(yv + k);
-    const float sp = P->gen_spacing[gen];
-    const float x0 = (float)k * sp + P->gen_first[gen];
-    const float slope = (ldsf(yv + k + 1) - b) / sp;
-    const float dy = r - this_acu;
-    if ((b == 0.0f) && (slope == 0.0f)) return x0;
-    else if (b == 0.0f) return x0 + dm::sqrt_(2.0f * dy / slope);
-    else if (slope == 0.0f) return x0 + dy / b;
-    else return x0 + (dm::sqrt_(dy * (2.0f * slope) / (b * b) + 1.0f) - 1.0f) * b / slope;
-}
-
-// FunctionFromTable.cxx:167-300
-DM float wavelength_bias(KP P, float wavelength)
-{
-    if (P->bias_kind == 1) return P->bias_value;
-    const float q = (wavelength - P->bias_start) / P->bias_step;
-    const float fbin = __builtin_truncf(q);
-    float fraction = q - fbin;
-    int ibin = (int)fbin;
-    const int n = P->bias_n;
-    if ((ibin < 0) || ((ibin == 0) && (fraction < 0.0f))) { ibin = 0; fraction = 0.0f; }
-    else if (ibin >= n - 1) { ibin = n - 2; fraction = 1.0f; }
-    const uint32_t off = P->off_bias;
-    const float v0 = ldsf(off + ibin), v1 = ldsf(off + ibin + 1);
-    return v0 + (v1 - v0) * fraction;
-}
-
-// GeometrySource.cxx:685-700
-DM void dom_position(KP P, uint32_t s, uint32_t d, float &x, float &y, float &z)
-{
-    const uint32_t rec = P->off_strings + 8u * s;
-    const uint32_t index = (ldsu(rec + 4) >> 8) + d;
-    int tx, ty;
-    if (P->dom_in_lds) {                // wave-uniform: templates staged in LDS when they fit
-        const uint32_t w = ldsu(P->off_dom_xy + index);
-        tx = (int)(int16_t)(w & 0xffffu);
-        ty = (int)(int16_t)(w >> 16);
-        z = ldsf(P->off_dom_z + index);
-    } else {
-        tx = P->dom_tx[index];
-        ty = P->dom_ty[index];
-        z = P->dom_tz[index];
-    }
-    x = (float)tx * P->dom_mul_x + ldsf(rec + 5);
-    y = (float)ty * P->dom_mul_y + ldsf(rec + 6);
-}
-
-// propagation_kernel.c.cl:83-129
-DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
-{
-    const float b = 2.0f * kPi * u;
-    float sinb, cosb;
-    dm::sincos_(b, sinb, cosb);
-    const float t = 1.0f - d.z * d.z;
-    const float sinth = dm::sqrt_((t > 0.0f) ? t : 0.0f);
-    if (sinth > 0.0f) {
-        const float ox = d.x, oy = d.y, oz = d.z;
-        d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
-        d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
-        d.z = oz * cosa + sina * sinb * sinth;
-    } else {
-        const float sgn = (d.z > 0.0f) ? 1.0f : ((d.z < 0.0f) ? -1.0f : d.z);
-        d.x = sina * cosb;
-        d.y = sina * sinb;
-        d.z = cosa * sgn;
-    }
-    const float recip_length = dm::rsqrt_(sqr(d.x) + sqr(d.y) + sqr(d.z));
-    d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
-}
-
-// propagation_kernel.c.cl:206-223
-DM void sph_dir_from_car(const Vec3 &d, float &theta, float &phi)
-{
-    const float r_inv = dm::rsqrt_(d.x * d.x + d.y * d.y + d.z * d.z);
-    theta = 0.0f;
-    if (__builtin_fabsf(d.z * r_inv) <= 1.0f) theta = dm::acos_(d.z * r_inv);
-    else if (d.z < 0.0f) theta = kPi;
-    if (theta < 0.0f) theta += 2.0f * kPi;
-    phi = dm::atan2_(d.y, d.x);
-    if (phi < 0.0f) phi += 2.0f * kPi;
-}
-
-// Per-lane photon state that the scatter loop touches every iteration.  What only a
-// hit record needs (start position / direction, wavelength, initial absorption budget)
-// is NOT kept: it is a pure function of the step and of the RNG state at the photon's
-// birth, so the rare hit re-derives it from `rx_start` with the very code that created
-// the photon (photon_birth).  7 VGPRs per lane buy an extra wave per SIMD.
-struct Photon {
-    float px, py, pz, pt;       // position, time
-    Vec3 d;                     // direction
-    float inv_groupvel, total_path;
-    float abs_lens_left;
-    uint32_t num_scatters;
-    IceFactors ice;
-    uint64_t rx_start;          // RNG state word when the photon was created
-    int layer;                  // carried layer index (getTiltZShift_IS_CONSTANT, c.cl:521-523)
-    float tab_remainder, tab_depth;     // TABULATE only: prevStepRemainder, depthPropagated (c.cl:530-534, 563)
-    float tab_wlen;                     // TABULATE only: photonDirAndWlen.w (enters the impact-angle dot product)
-};
-
-struct Birth {                  // propagation_kernel.c.cl:132-184 + :587: what createPhotonFromTrack yields
-    float x, y, z, t;
-    Vec3 d;
-    float wlen;
-    float abs_lens_initial;
-};
-
-// c.cl:482-489: direction of a step from its (theta, phi); evaluated once when a lane takes the step
-DM Vec3 step_direction(const DevStep *step_ptr)
-{
-    float sin_t, cos_t, sin_p, cos_p;
-    dm::sincos_(step_ptr->theta, sin_t, cos_t);
-    dm::sincos_(step_ptr->phi, sin_p, cos_p);
-    Vec3 d;
-    d.x = sin_t * cos_p; d.y = sin_t * sin_p; d.z = cos_t;
-    return d;
-}
-
-// propagation_kernel.c.cl:132-184 + :587.  The step record is re-read from HBM/L2 here
-// (48 B every ~30 loop iterations) instead of living in registers.  Consumes the RNG draws
-// of a photon's birth in the reference's order: position, wavelength, azimuth, absorption budget.
-template <bool FLASHER>
-DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra)
-{
-    const DevStep st = *step_ptr;
-    Birth b;
-    const float shift = st.length * rng_co(rx, ra);
-    const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);
-    b.x = st.x + step_dir.x * shift;
-    b.y = st.y + step_dir.y * shift;
-    b.z = st.z + step_dir.z * shift;
-    b.t = st.t + inv_speed * shift;
-    const uint32_t source_type = st.source_type_and_pad & 0xffu;
-    b.d = step_dir;
-    if (!FLASHER || source_type == 0) {
-        const float wavelength = generate_wavelength(P, 0, rx, ra);
-        const float rcp = 1.0f / (st.beta * phase_ref_index(P, wavelength));
-        const float cos_c = (rcp < 1.0f) ? rcp : 1.0f;
-        const float sin_c = dm::sqrt_(1.0f - cos_c * cos_c);
-        b.wlen = wavelength;
-        scatter_direction(cos_c, sin_c, b.d, rng_co(rx, ra));
-    } else {
-        // generateWavelength(number): 0 for an out-of-range generator (MediumPropertiesSource.cxx:392-432)
-        b.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
-    }
-    // c.cl:582-588: a fixed budget draws no random number
-    b.abs_lens_initial = P->has_fixed_abs ? P->fixed_abs : -dm::log_(rng_oc(rx, ra));
-    return b;
-}
-
-// c.cl:546-596
-template <int MED, bool TILT, bool FLASHER, bool TAB>
-DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
-{
-    ph.rx_start = rx;
-    // TABULATE: the first sub-step is drawn between the photon's creation and its (fixed) absorption budget,
-    // which draws nothing (c.cl:559-563, 582-588)
-    const Birth b = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, ra);
-    if (TAB) { ph.tab_remainder = P->tab_volume_step * rng_oc(rx, ra); ph.tab_depth = 0.0f; ph.tab_wlen = b.wlen; }
-    ph.px = b.x; ph.py = b.y; ph.pz = b.z; ph.pt = b.t;
-    ph.d = b.d;
-    ph.num_scatters = 0;
-    ph.total_path = 0.0f;
-    if (!TILT) ph.layer = clampi((int)div_by(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
-    ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
-    ph.abs_lens_left = b.abs_lens_initial;
-    ph.ice = ice_factors<MED>(P, b.wlen);
-}
-
-// propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
-template <int MED, bool TILT, bool ANISO>
-DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
-{
-    const float thickness = P->layer_thickness, bottom = P->layer_bottom;
-    const int num_layers = P->num_layers;
-    const uint32_t off_layers = P->off_layers;
-    const float *len_table = (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr;
-    float effective_z;
-    int current_layer;
-    if (TILT) {
-        effective_z = ph.pz - tilt_z_shift(P, ph.px, ph.py, ph.pz);
-        current_layer = clampi((int)div_by(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, num_layers - 1);
-    } else {
-        effective_z = ph.pz - P->tilt_const;
-        current_layer = ph.layer;
-    }
-    const float dz = ph.d.z;
-    // without anisotropy the factor is the literal 1.f: x*1 and x/1 are exact, so both are skipped
-    const float corr = (ANISO && P->has_abs_corr) ? abs_len_corr(P, ph.d) : 1.0f;
-    if (ANISO) ph.abs_lens_left *= corr;
-    const float lower = ((float)current_layer * thickness) + bottom;
-    float boundary = (dz < 0.0f) ? lower : (lower + thickness);
-    const float sca_step_left = -dm::log_(rng_oc(rx, ra));
-    float sca_len, abs_len;
-    layer_lengths<MED>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len);
-    const float recip_thickness = P->recip_thickness;
-    float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
-    float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
-    int j = current_layer;
-    {
-        // c.cl:643-668 has one loop for photons going down and one for photons going up; a wave holds both kinds, so the
-        // two loops cost it the sum of their longest walks.  One loop with a sign does the same arithmetic (x - y is
-        // x + (-y), a product with +-1 is exact, and (-ais < 0) is (ais > 0) also for signed zeros) in the longer walk only.
-        const bool down = (dz < 0.0f);
-        const float sgn = down ? -1.0f : 1.0f;
-        const int step = down ? -1 : 1;
-        const int last = down ? 0 : (num_layers - 1);
-        const float signed_thickness = sgn * thickness;
-        while ((j != last) && (sgn * ais > 0.0f) && (sgn * aia > 0.0f)) {
-            j += step;
-            boundary += signed_thickness;
-            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
-            ais -= sgn * (1.0f / sca_len);
-            aia -= sgn * (1.0f / abs_len);
-        }
-    }
-    float distance, to_absorption;
-    if ((current_layer == j) || (__builtin_fabsf(dz) < kEpsilon)) {
-        distance = sca_step_left * sca_len;
-        to_absorption = ph.abs_lens_left * abs_len;
-    } else {
-        const float recip_dz = 1.0f / dz;
-        distance = (ais * thickness * sca_len + boundary - effective_z) * recip_dz;
-        to_absorption = (aia * thickness * abs_len + boundary - effective_z) * recip_dz;
-    }
-    if (!TILT) ph.layer = j;
-    if (to_absorption < distance) {
-        distance = to_absorption;
-        ph.abs_lens_left = 0.0f;
-    } else {
-        ph.abs_lens_left = (to_absorption - distance) / abs_len;
-    }
-    if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;
-    return distance;
-}
-
-// ---- DOM search: sparse_collision_kernel.c.cl:27-303, 462-547 (STOP_PHOTONS_ON_DETECTION) ----
-struct Detector {               // wave-uniform values of the search, fetched once per call
-    uint32_t off_strings, off_sets, off_layer_to_om;
-    int max_layers;
-    float string_max_radius_sq, string_max_radius, om_radius_sq, pancake;
-    int has_pancake;
-};
-
-// collision c.cl:27-192
-DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_xy_sqr, const Photon &ph, float &step_len,
-                            bool &hit, uint32_t &hit_string, uint32_t &hit_dom)
-{
-    const Rec4 str = lds_rec4(D.off_strings + 8u * s);      // x, y, maxZ+R, minZ-R
-    const float wx = str.a - ph.px, wy = str.b - ph.py;
-    {
-        const float smin = sqr((ph.px - str.a) * ph.d.y - (ph.py - str.b) * ph.d.x) / dir_len_xy_sqr;
-        if (smin > D.string_max_radius_sq) return;
-    }
-    {
-        // Not in the reference: a conservative early-out.  The test above is about the INFINITE line.
-        // A DOM of this string can only be hit at a point of the segment [0, step_len] that lies within
-        // GEO_STRING_MAX_RADIUS of the string axis in xy (the hit point is inside the oversized sphere,
-        // whose centre is within maxR - OM_RADIUS of the axis).  If the point of the segment closest to
-        // the axis is an END point and that end point is farther away -- with a margin that exceeds the
-        // float error of these few operations by more than an order of magnitude -- every sphere test
-        // of this string fails, so skipping them cannot change the result.
-        const float along = wx * ph.d.x + wy * ph.d.y;          // (axis - start) . dir_xy
-        const float ex = wx - step_len * ph.d.x, ey = wy - step_len * ph.d.y;
-        const float reach = D.string_max_radius + (1e-3f + 9.5367431640625e-7f * (__builtin_fabsf(ph.px) + __builtin_fabsf(ph.py) + __builtin_fabsf(str.a) + __builtin_fabsf(str.b)));
-        const float reach_sq = reach * reach;
-        if ((along <= 0.0f) && (wx * wx + wy * wy > reach_sq)) return;
-        if ((along >= step_len * dir_len_xy_sqr) && (ex * ex + ey * ey > reach_sq)) return;
-    }
-    if ((ph.d.z > 0.0f) && (ph.pz > str.c)) return;
-    if ((ph.d.z < 0.0f) && (ph.pz < str.d)) return;
-    const uint32_t set = ldsu(D.off_strings + 8u * s + 4) & 0xffu;
-    const Rec4 lay = lds_rec4(D.off_sets + 4u * set);        // nlayers (bits), start z, height
-    const float start_z = lay.b, height = lay.c;
-    const int nl = (int)__builtin_bit_cast(uint32_t, lay.a);
-    int low = (int)((ph.pz - start_z) / height);
-    int high = (int)((ph.pz + ph.d.z * step_len - start_z) / height);
-    if (high < low) { const int tmp = low; low = high; high = tmp; }
-    low = clampi(low, 0, nl - 1);
-    high = clampi(high, 0, nl - 1);
-    const uint32_t base = set * (uint32_t)D.max_layers;
-    for (int layer = low; layer <= high; ++layer) {
-        const uint32_t dom = lds_u16(D.off_layer_to_om, base + (uint32_t)layer);
-        if (dom == 0xFFFFu) continue;
-        float dom_x, dom_y, dom_z;
-        dom_position(P, s, dom, dom_x, dom_y, dom_z);
-        const float dx = dom_x - ph.px, dy = dom_y - ph.py, dzz = dom_z - ph.pz;
-        // dot() of float4s whose 4th component is 0: ((x+y)+z); the trailing +0 only matters for -0
-        const float dr2 = (dx * dx + dy * dy) + dzz * dzz;
-        const float urdot = (dx * ph.d.x + dy * ph.d.y) + dzz * ph.d.z;
-        float discr = sqr(urdot) - dr2 + D.om_radius_sq;
-        if (discr < 0.0f) continue;
-        discr = D.has_pancake ? (dm::sqrt_(discr) / D.pancake) : dm::sqrt_(discr);
-        if (urdot + discr < 0.0f) continue;
-        const float smin1 = urdot - discr;
-        if (smin1 < 0.0f) continue;
-        if (smin1 < step_len) {
-            step_len = smin1;
-            hit_string = s;
-            hit_dom = dom;
-            hit = true;
-        }
-    }
-}
-
-// String proximity map (kparams.h): xy distance [m] that a photon at (x, y) can travel before it could touch a DOM
-DM float free_flight_bound(KP P, float x, float y)
-{
-    const int n = P->prox_n;
-    const int ix = clampi((int)((x - P->prox_x0) * P->prox_inv_cell), 0, n - 1);
-    const int iy = clampi((int)((y - P->prox_y0) * P->prox_inv_cell), 0, n - 1);
-    return (float)P->prox_map[iy * n + ix] * 0.25f;
-}
-
-// collision c.cl:194-303 + :462-547
-DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
-{
-    const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
-    if (dir_len_xy_sqr <= 0.0f) return false;
-    Detector D;
-    D.off_strings = P->off_strings; D.off_sets = P->off_sets; D.off_layer_to_om = P->off_layer_to_om;
-    D.max_layers = P->max_layers;
-    D.string_max_radius_sq = P->string_max_radius_sq; D.string_max_radius = P->string_max_radius; D.om_radius_sq = P->om_radius_sq;
-    D.pancake = P->pancake; D.has_pancake = P->has_pancake;
-    const int num_subdet = P->num_subdet;
-    const uint32_t off_subdet = P->off_subdet;
-    bool hit = false;
-    for (int sd = 0; sd < num_subdet; ++sd) {
-        const Rec4 g0 = lds_rec4(off_subdet + 12u * (uint32_t)sd);        // nx, ny (bits), width x, width y
-        const Rec4 g1 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 4u);   // start x, start y, cell offset, proof bits
-        const Rec4 g2 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 8u);   // 1/width x, 1/width y
-        const int nx = (int)__builtin_bit_cast(uint32_t, g0.a), ny = (int)__builtin_bit_cast(uint32_t, g0.b);
-        const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
-        const uint32_t cells = __builtin_bit_cast(uint32_t, g1.c);
-        // all lanes are in the same subdetector here, so the proof bits are wave-uniform
-        const uint32_t proven = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, g1.d));
-        const bool okx = (proven & 1u) != 0, oky = (proven & 2u) != 0;
-        int low_x = (int)div_by(ph.px - sx, wx, g2.a, okx);
-        int low_y = (int)div_by(ph.py - sy, wy, g2.b, oky);
-        int high_x = (int)div_by(ph.px + ph.d.x * step_len - sx, wx, g2.a, okx);
-        int high_y = (int)div_by(ph.py + ph.d.y * step_len - sy, wy, g2.b, oky);
-        if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
-        if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
-        low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);
-        high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
-        for (int cy = low_y; cy <= high_y; ++cy)
-            for (int cx = low_x; cx <= high_x; ++cx) {
-                const uint32_t s = lds_u16(cells, (uint32_t)(cy * nx + cx));
-                if (s == 0xFFFFu) continue;
-                collide_with_string(P, D, s, dir_len_xy_sqr, ph, step_len, hit, hit_string, hit_dom);
-            }
-    }
-    return hit;
-}
 
 // ---------------- TABULATE (c.cl:228-303) ----------------
 // Polynomial.cxx:96-153
@@ -901,70 +296,6 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
     }
     if (active) remainder = d_end - length;
     return stop;
-}
-
-// A detected photon leaves the propagation kernel as a 16-word stub written into its 80-byte output
-// slot; assemble_hits_kernel expands it in place into the I3CLSimPhoton record.  Everything saveHit
-// (propagation_kernel.c.cl:307-404) stores is a function of the stub: the birth of the photon is
-// re-derived from the step and the RNG state at its creation (photon_birth), the rest is arithmetic.
-struct HitStub {
-    float px, py, pz, pt;               // photon at the start of its last segment
-    float dx, dy, dz;
-    float step_len;                     // distance to the DOM along the direction (shortened step)
-    float total_path, abs_lens_left, inv_groupvel;
-    uint32_t num_scatters;
-    uint32_t step_index;
-    uint32_t rx_lo, rx_hi;              // RNG state word at the photon's creation
-    uint32_t string_and_dom;            // string index | DOM index << 16
-};
-static_assert(sizeof(HitStub) == 64, "hit stub");
-
-// propagation_kernel.c.cl:307-404: the 20 words of an I3CLSimPhoton
-template <bool FLASHER>
-DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
-{
-    const DevStep *step_ptr = P->steps + h.step_index;
-    const Vec3 step_dir = step_direction(step_ptr);
-    uint64_t rx = ((uint64_t)h.rx_hi << 32) | (uint64_t)h.rx_lo;
-    const Birth born = photon_birth<FLASHER>(P, step_ptr, step_dir, rx, P->rng_a[h.step_index]);
-    const uint32_t hit_string = h.string_and_dom & 0xffffu, hit_dom = h.string_and_dom >> 16;
-    const Vec3 d = {h.dx, h.dy, h.dz};
-    float dom_x, dom_y, dom_z;
-    dom_position(P, hit_string, hit_dom, dom_x, dom_y, dom_z);
-    if (P->has_pancake) {
-        const float unpancake = P->unpancake;
-        const float qx = h.px - dom_x, qy = h.py - dom_y, qz = h.pz - dom_z;
-        const float parallel = qx * d.x + qy * d.y + qz * d.z;
-        const float nx = qx - parallel * d.x;
-        const float ny = qy - parallel * d.y;
-        const float nz = qz - parallel * d.z;
-        dom_x += unpancake * nx; dom_y += unpancake * ny; dom_z += unpancake * nz;
-    }
-    float theta, phi, stheta, sphi;
-    sph_dir_from_car(d, theta, phi);
-    sph_dir_from_car(born.d, stheta, sphi);
-    const float weight = step_ptr->weight / wavelength_bias(P, born.wlen);
-    rec[0] = dm::f2u(h.px + h.step_len * d.x - dom_x);
-    rec[1] = dm::f2u(h.py + h.step_len * d.y - dom_y);
-    rec[2] = dm::f2u(h.pz + h.step_len * d.z - dom_z);
-    rec[3] = dm::f2u(h.pt + h.step_len * h.inv_groupvel);
-    rec[4] = dm::f2u(theta);
-    rec[5] = dm::f2u(phi);
-    rec[6] = dm::f2u(born.wlen);
-    rec[7] = dm::f2u(h.total_path + h.step_len);
-    rec[8] = h.num_scatters;
-    rec[9] = dm::f2u(weight);
-    rec[10] = step_ptr->identifier;
-    rec[11] = h.string_and_dom;                             // short stringID, ushort omID
-    rec[12] = dm::f2u(born.x);
-    rec[13] = dm::f2u(born.y);
-    rec[14] = dm::f2u(born.z);
-    rec[15] = dm::f2u(born.t);
-    rec[16] = dm::f2u(stheta);
-    rec[17] = dm::f2u(sphi);
-    rec[18] = dm::f2u(1.0f / h.inv_groupvel);
-    rec[19] = dm::f2u(born.abs_lens_initial - h.abs_lens_left);   // c.cl:718: after this step's update
-    return born.abs_lens_initial;
 }
 
 // TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
@@ -1371,6 +702,36 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 }
 
 // ---- host-side launchers (called from converter.cpp) ----
+hipError_t launch_scan_steps(const KParams &P, hipStream_t stream)
+{
+    const uint32_t sgrid = (P.n_steps + 255u) / 256u;
+    hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue,
+                       P.work, P.rng_x, P.rng_a, (uint32_t)P.num_gen);
+    return hipGetLastError();
+}
+
+// second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
+hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream)
+{
+    const size_t image_bytes = (size_t)P.table_words * 4;
+    if (image_bytes > 64 * 1024) {
+        // once per (device, kernel, image size)
+        static std::mutex m;
+        static std::map<std::pair<int, size_t>, int> ready;
+        std::lock_guard<std::mutex> lk(m);
+        int &done = ready[std::make_pair(2 * device + (flasher ? 1 : 0), image_bytes)];
+        if (!done) {
+            const hipError_t err = flasher ? hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_hits_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes)
+                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_hits_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes);
+            if (err != hipSuccess) return err;
+            done = 1;
+        }
+    }
+    if (flasher) hipLaunchKernelGGL((assemble_hits_kernel<true>), dim3(512), dim3(256), image_bytes, stream, P);
+    else hipLaunchKernelGGL((assemble_hits_kernel<false>), dim3(512), dim3(256), image_bytes, stream, P);
+    return hipGetLastError();
+}
+
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
@@ -1380,7 +741,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work.
     // Occupancy, CU count and the function attributes are per (device, variant): one process may drive converters on
     // several GPUs (the reference's usual model, I3CLSimServer.cxx:77-137) and from several threads.
-    struct Plan { int cus = 0, resident = 0; bool assemble_ready = false; };
+    struct Plan { int cus = 0, resident = 0; };
     static std::mutex plan_mutex;
     static std::map<std::pair<int, size_t>, Plan> plans;     // (device, LDS bytes of the workgroup: the image differs per configuration)
     int dev = 0;
@@ -1436,32 +797,18 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     {
         const double r = (double)P.n_steps / ((double)grid * kBlock);
         if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
+        if (P.k_new <= 0) P.k_new = 12;
         // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1.5M steps: 3 -> 5 is
         // +1.6 %), costs when they are scarce (0.8M steps: -1.7 %)
         if (P.k_search <= 0) P.k_search = (r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }
-    {
-        const uint32_t sgrid = (P.n_steps + 255u) / 256u;
-        hipLaunchKernelGGL(scan_steps_kernel, dim3(sgrid < 1024u ? sgrid : 1024u), dim3(256), 0, stream, P.steps, P.n_steps, P.queue,
-                           P.work, P.rng_x, P.rng_a, (uint32_t)P.num_gen);
-    }
+    hipError_t err = launch_scan_steps(P, stream);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
-    hipError_t err = hipGetLastError();
+    err = hipGetLastError();
     if (err != hipSuccess || TAB) return err;
-    // second pass (same stream): stubs -> I3CLSimPhoton records.  Hits are ~1e-3 of the photons.
-    const size_t image_bytes = (size_t)P.table_words * 4;
-    if (!plan.assemble_ready) {
-        std::lock_guard<std::mutex> lk(plan_mutex);
-        if (image_bytes > 64 * 1024) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&assemble_hits_kernel<FLASHER>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes);
-            if (err != hipSuccess) return err;
-        }
-        plans[std::make_pair(dev, lds_bytes)].assemble_ready = true;
-    }
-    hipLaunchKernelGGL((assemble_hits_kernel<FLASHER>), dim3(512), dim3(256), image_bytes, stream, P);
-    return hipGetLastError();
+    return launch_assemble_hits(P, FLASHER, dev, stream);
 }
 
 hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream)

@@ -1,0 +1,517 @@
+// Photon propagator for gfx950 (MI355X), pooled scheduling.
+//
+// Same arithmetic as prop_kernel.hip (every device function is shared, prop_device.hip.h) and the same work
+// units (slices of steps from eight sub-queues, one RNG stream per step handed on through 64-byte work records);
+// what differs is how a wave keeps its 64 lanes busy.
+//
+// The classic kernel holds exactly one photon per lane.  A lane whose photon has died waits until k_new = 12 lanes of
+// the wave are in the same position, then the wave runs photon creation (~900 instructions) for those 12 lanes: 16 %
+// of all issued instructions at 19 % lane use, and 11 % of the lane trips spent waiting for the batch.
+//
+// Here a wave owns U = 64 + R work-unit slots instead of 64, the surplus living in a wave-private LDS pool:
+//   * `ready` ring (R entries x 21 words): photons that have been created and wait for a free lane;
+//   * `pending` list (U entries x 5 words): units whose photon has died and that need their next one created (or whose
+//     predecessor slice has not been published yet).
+// A lane whose photon dies hands its unit to `pending` and takes a photon from `ready` in the same loop trip (a
+// "service" of ~40 instructions, run when k_pop lanes need it), so lanes do not wait for creation; creation runs when
+// the ring has room for a batch, for up to 64 pending units at once and with the results going to the ring.  Waiting
+// for a predecessor slice costs a pending slot, not a lane.  Everything is private to the wave: no locks, no polling
+// of other waves' LDS, wave barriers only (the cross-wave mailbox experiment of round 1 lost to exactly that).
+// The ring is first-in first-out so that no unit -- possibly the predecessor another wave waits for -- is starved.
+//
+// Large workgroups (12 waves share one table image) leave the LDS to the pools: 2 workgroups x 12 waves per CU.
+// Results are bit-identical to the classic kernel for every R, k_pop and creation threshold: a unit's photons are
+// still created and propagated in sequence from its own stream, whichever lanes carry them.
+//
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+#include "prop_device.hip.h"
+
+namespace clsimhip {
+
+#ifndef CLSIMHIP_POOL_BLOCK
+#define CLSIMHIP_POOL_BLOCK 768                 // 12 waves per workgroup, 2 workgroups per CU
+#define CLSIMHIP_POOL_WAVES 6                   // waves per SIMD the register allocation aims at (<= 80 VGPRs)
+#endif
+constexpr int kPoolBlock = CLSIMHIP_POOL_BLOCK;
+constexpr int kPoolWavesPerBlock = kPoolBlock / 64;
+constexpr int kPoolMinWaves = CLSIMHIP_POOL_WAVES;
+constexpr uint32_t kReadyWords = 21;            // odd strides: consecutive entries fall into different LDS banks
+constexpr uint32_t kPendWords = 5;
+constexpr uint32_t kPoolFixedWords = kStageRecords * kStubWords + 64;      // hit stub staging + parked step lengths
+constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // unit flags above the slice number
+
+__host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R) { return kPoolFixedWords + kReadyWords * R + kPendWords * (64u + R); }
+
+template <int MED, bool TILT, bool ANISO, bool FLASHER>
+__global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(const KParams Pvalue)
+{
+    const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Pvalue;
+    {   // stage the table image: one coalesced pass of the workgroup
+        const uint32_t words = P0->table_words;
+        const uint32_t *src = P0->tables;
+        for (uint32_t i = threadIdx.x; i < words; i += kPoolBlock) lds_words[i] = src[i];
+    }
+    const uint32_t R = (uint32_t)P0->pool_ready;
+    const uint32_t U = 64u + R;
+    uint32_t *wave_lds = lds_words + P0->table_words + (threadIdx.x >> 6) * pool_wave_words(R);
+    uint32_t *stage = wave_lds;
+    uint32_t *parked_len = wave_lds + kStageRecords * kStubWords;
+    uint32_t *ready = wave_lds + kPoolFixedWords;
+    uint32_t *pend = ready + kReadyWords * R;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const uint32_t n_steps = P0->n_steps;
+    uint32_t slice_photons, rounds;
+    {
+        const uint32_t max_photons = P0->queue[1];                 // scan_steps_kernel
+        const uint32_t target = (uint32_t)P0->slices;
+        slice_photons = (max_photons + target - 1u) / target;
+        if (slice_photons == 0u) slice_photons = 1u;
+        rounds = (max_photons + slice_photons - 1u) / slice_photons;
+        if (rounds == 0u) rounds = 1u;
+    }
+    // wave-uniform bookkeeping of the U unit slots: each is in a lane, in `ready`, in `pending`, empty or gone
+    uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + (threadIdx.x >> 6)) % (uint32_t)kSubQueues;
+    uint32_t used_up = 0;                       // sub-queues found used up in a row
+    uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_gone = 0;     // n_wait: pending units that wait for a predecessor
+
+    // per lane: the photon it carries and the unit that photon belongs to
+    bool has = false;          // carries a photon
+    bool spent = false;        // that photon has been absorbed or detected
+    bool parked = false;       // has a step length and waits for the wave's next DOM search
+    uint32_t sidx = kNoStep, ra = 0, photons_left = 0, uflags = 0;
+    uint64_t rx = 0;
+    Photon ph;
+    ph.abs_lens_left = 0.0f;
+    ph.layer = 0;
+
+    const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
+#ifdef CLSIMHIP_CENSUS
+    unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0;
+#endif
+    for (uint32_t trip = 0;; ++trip) {
+        switch (((trip >> kPrioShift) + wave_slot) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        const uint64_t m_spent = __ballot(has && spent);
+        const uint64_t m_vacant = __ballot(!has);
+        const uint64_t m_live = __ballot(has && !spent);
+        if ((m_live == 0ull) && (m_spent == 0ull) && (n_gone == U)) break;       // every unit slot has been retired
+#ifdef CLSIMHIP_CENSUS
+        ++c_trips;
+        c_vacant += __popcll(m_vacant | m_spent);
+#endif
+
+        // ---- service: retire the units of spent photons, create photons when the ring has room, hand out ready photons ----
+        const uint32_t n_free = (uint32_t)__popcll(m_spent | m_vacant);
+        if ((n_free != 0u) && ((n_free >= (uint32_t)fresh_params(P0)->k_pop) || (m_live == 0ull))) {
+            const KP P = fresh_params(P0);
+            WorkRecord *work = P->work;
+#ifdef CLSIMHIP_CENSUS
+            ++c_services;
+#endif
+            if (m_spent != 0ull) {
+                const bool mine = has && spent;
+                const bool finished = mine && (photons_left == 0u);
+                const bool next = mine && (photons_left != 0u);
+                const uint64_t m_finished = __ballot(finished), m_next = __ballot(next);
+                if (m_finished != 0ull) {
+                    // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
+                    // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
+                    // state first, then the slice counter, both write-through so that a lane on another XCD that sees
+                    // the counter sees the state
+                    const bool last = (uflags & kFlagLast) != 0u;
+                    if (finished) {
+                        if (last) P->rng_x[sidx] = rx;
+                        else __hip_atomic_store(&work[sidx].x, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (finished && !last)
+                        __hip_atomic_store(&work[sidx].done, (uflags & 0xffffu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    n_empty += (uint32_t)__popcll(m_finished);
+                }
+                if (next) {     // the unit goes to `pending` with its stream where the photon left it
+                    uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_next & lanes_below));
+                    e[0] = sidx; e[1] = (uint32_t)rx; e[2] = (uint32_t)(rx >> 32); e[3] = photons_left; e[4] = uflags;
+                }
+                n_pend += (uint32_t)__popcll(m_next);
+                if (mine) { has = false; spent = false; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+
+            if (used_up >= (uint32_t)kSubQueues) { n_gone += n_empty; n_empty = 0u; }          // the queues are dry: empty slots retire
+
+            // photon creation: when a batch fits the ring, or when lanes would otherwise go without a photon.  A wave
+            // whose pending units all wait for predecessors elsewhere looks again every fourth trip.
+            const uint32_t room = R - n_ready;
+            const uint32_t creatable = (n_pend - n_wait) + ((used_up < (uint32_t)kSubQueues) ? n_empty : 0u);
+            const uint32_t batch = (creatable < room) ? creatable : room;
+            const bool starving = (n_ready < n_free);
+            const bool look_again = starving && (n_wait != 0u) && (room != 0u) && (((trip & 3u) == 0u) || (m_live == 0ull));
+            if (((batch != 0u) && ((batch >= (uint32_t)P->k_new) || starving)) || look_again) {
+#ifdef CLSIMHIP_CENSUS
+                ++c_creations;
+#endif
+                // (a) new units for the empty slots: one atomic per wave and round on the wave's sub-queue
+                for (uint32_t round = 0; (n_empty != 0u) && (used_up < (uint32_t)kSubQueues) && (round < (uint32_t)kSubQueues + 2u); ++round) {
+                    const uint32_t n_sub = (n_steps + (uint32_t)kSubQueues - 1u - sub_queue) / (uint32_t)kSubQueues;   // its steps
+                    const uint32_t total_sub = n_sub * rounds;
+                    const uint32_t count = (n_empty < 64u) ? n_empty : 64u;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P->queue + kQueueHeadStride * (sub_queue + 1u), count);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t this_queue = sub_queue;
+                    if (base + count > total_sub) {                      // (also when the head has run past the end)
+                        sub_queue = (sub_queue + 1u == (uint32_t)kSubQueues) ? 0u : sub_queue + 1u;
+                        ++used_up;
+                    } else {
+                        used_up = 0;
+                    }
+                    bool got = false;
+                    uint32_t i_new = 0, s_new = 0, left = 0, flags = 0;
+                    const uint32_t unit = base + lane;
+                    if ((lane < count) && (base < total_sub) && (unit < total_sub)) {
+                        s_new = unit / n_sub;
+                        i_new = (unit - s_new * n_sub) * (uint32_t)kSubQueues + this_queue;
+                        const uint32_t num = work[i_new].step.num_photons;
+                        const uint32_t first = s_new * slice_photons;
+                        if (first < num) {                  // otherwise this step is used up: the slot stays empty and asks again
+                            got = true;
+                            const bool last = (num - first <= slice_photons);
+                            left = last ? (num - first) : slice_photons;
+                            flags = s_new | (last ? kFlagLast : 0u) | kFlagWaiting;
+                        }
+                    }
+                    const uint64_t m_got = __ballot(got);
+                    if (got) {
+                        uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_got & lanes_below));
+                        e[0] = i_new; e[1] = 0u; e[2] = 0u; e[3] = left; e[4] = flags;
+                    }
+                    const uint32_t n_got = (uint32_t)__popcll(m_got);
+                    n_pend += n_got;
+                    n_empty -= n_got;
+                }
+                if (used_up >= (uint32_t)kSubQueues) { n_gone += n_empty; n_empty = 0u; }      // no work is left anywhere
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // (b) the pending units, 64 at a time: look for the predecessor's state where needed, create the next
+                // photon while the ring has room; what stays is compacted to the front of the list in its order
+                uint32_t kept = 0, created = 0, still_waiting = 0;
+                for (uint32_t c = 0; c < n_pend; c += 64u) {
+                    const bool have = (c + lane) < n_pend;
+                    uint32_t e_sidx = 0, e_left = 0, e_flags = 0;
+                    uint64_t e_rx = 0;
+                    if (have) {
+                        const uint32_t *e = pend + kPendWords * (c + lane);
+                        e_sidx = e[0]; e_rx = (uint64_t)e[1] | ((uint64_t)e[2] << 32); e_left = e[3]; e_flags = e[4];
+                    }
+                    bool waiting = have && ((e_flags & kFlagWaiting) != 0u);
+                    if (waiting) {
+                        WorkRecord *rec = work + e_sidx;
+                        const uint32_t slice = e_flags & 0xffffu;
+                        const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&rec->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CLSIMHIP_CENSUS
+                        ++c_polls;
+#endif
+                        if (published >= slice) {
+                            // c.cl:458-461; slice 0 reads the state left by the previous bunch
+                            e_rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            e_flags &= ~kFlagWaiting;
+                            waiting = false;
+                        }
+                    }
+                    still_waiting += (uint32_t)__popcll(__ballot(waiting));
+                    const bool can = have && !waiting;
+                    const uint64_t m_can = __ballot(can);
+                    const uint32_t slot = created + (uint32_t)__popcll(m_can & lanes_below);
+                    const bool make = can && (slot < (R - n_ready));
+                    if (make) {
+                        const WorkRecord *rec = work + e_sidx;
+                        const uint32_t e_ra = rec->a;
+                        const Vec3 step_dir = step_direction(&rec->step);
+                        Photon born;
+                        born.layer = 0;
+                        create_photon<MED, TILT, FLASHER, false>(P, &rec->step, step_dir, e_rx, e_ra, born);
+                        uint32_t pos = ready_head + n_ready + slot;
+                        if (pos >= R) pos -= R;
+                        if (pos >= R) pos -= R;
+                        uint32_t *q = ready + kReadyWords * pos;
+                        q[0] = dm::f2u(born.px); q[1] = dm::f2u(born.py); q[2] = dm::f2u(born.pz); q[3] = dm::f2u(born.pt);
+                        q[4] = dm::f2u(born.d.x); q[5] = dm::f2u(born.d.y); q[6] = dm::f2u(born.d.z); q[7] = dm::f2u(born.inv_groupvel);
+                        q[8] = dm::f2u(born.abs_lens_left);
+                        q[9] = dm::f2u(born.ice.sca_pow); q[10] = dm::f2u(born.ice.abs_pow); q[11] = dm::f2u(born.ice.abs_exp);
+                        q[12] = (uint32_t)born.rx_start; q[13] = (uint32_t)(born.rx_start >> 32);
+                        q[14] = (uint32_t)born.layer;
+                        q[15] = e_sidx; q[16] = (uint32_t)e_rx; q[17] = (uint32_t)(e_rx >> 32); q[18] = e_ra; q[19] = e_left; q[20] = e_flags;
+                    }
+                    const bool keep = have && !make;
+                    const uint64_t m_keep = __ballot(keep);
+                    // (every lane has read its entry above; the compacted entries land at or before the ones read)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (keep) {
+                        uint32_t *e = pend + kPendWords * (kept + (uint32_t)__popcll(m_keep & lanes_below));
+                        e[0] = e_sidx; e[1] = (uint32_t)e_rx; e[2] = (uint32_t)(e_rx >> 32); e[3] = e_left; e[4] = e_flags;
+                    }
+                    kept += (uint32_t)__popcll(m_keep);
+                    created += (uint32_t)__popcll(__ballot(make));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                n_pend = kept;
+                n_wait = still_waiting;
+                n_ready += created;
+#ifdef CLSIMHIP_CENSUS
+                c_created += created;
+#endif
+            }
+
+            // ready photons for the lanes without one, oldest first
+            if (n_ready != 0u) {
+                const bool want = !has;
+                const uint64_t m_want = __ballot(want);
+                const uint32_t rank = (uint32_t)__popcll(m_want & lanes_below);
+                if (want && (rank < n_ready)) {
+                    uint32_t pos = ready_head + rank;
+                    if (pos >= R) pos -= R;
+                    const uint32_t *q = ready + kReadyWords * pos;
+                    ph.px = dm::u2f(q[0]); ph.py = dm::u2f(q[1]); ph.pz = dm::u2f(q[2]); ph.pt = dm::u2f(q[3]);
+                    ph.d.x = dm::u2f(q[4]); ph.d.y = dm::u2f(q[5]); ph.d.z = dm::u2f(q[6]); ph.inv_groupvel = dm::u2f(q[7]);
+                    ph.abs_lens_left = dm::u2f(q[8]);
+                    ph.ice.sca_pow = dm::u2f(q[9]); ph.ice.abs_pow = dm::u2f(q[10]); ph.ice.abs_exp = dm::u2f(q[11]);
+                    ph.rx_start = (uint64_t)q[12] | ((uint64_t)q[13] << 32);
+                    ph.layer = (int)q[14];
+                    ph.num_scatters = 0;
+                    ph.total_path = 0.0f;
+                    sidx = q[15]; rx = (uint64_t)q[16] | ((uint64_t)q[17] << 32); ra = q[18]; photons_left = q[19]; uflags = q[20];
+                    has = true;
+                    spent = false;
+                }
+                uint32_t taken = (uint32_t)__popcll(m_want);
+                if (taken > n_ready) taken = n_ready;
+                ready_head += taken;
+                if (ready_head >= R) ready_head -= R;
+                n_ready -= taken;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // nothing runnable in this wave: every unit it holds waits for another wave's slice
+            if (__ballot(has) == 0ull) __builtin_amdgcn_s_sleep(16);
+        }
+
+        // ---- one reference loop iteration for the lanes that hold a live photon ----
+        const bool run = has && !spent && !parked;
+#ifdef CLSIMHIP_CENSUS
+        c_run += __popcll(__ballot(run));
+#endif
+        float distance = 0.0f;
+        bool hit = false;
+        uint32_t hit_string = 0, hit_dom = 0;
+        if (run) {
+            const float free_flight = free_flight_bound(fresh_params(P0), ph.px, ph.py);
+            distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
+            // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
+            if (!(distance < free_flight)) { parked = true; parked_len[lane] = __builtin_bit_cast(uint32_t, distance); }
+        }
+        bool advance = run && !parked;
+        {
+            const uint64_t m_parked = __ballot(parked);
+            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
+                if (parked) {
+                    distance = __builtin_bit_cast(float, parked_len[lane]);
+                    hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    parked = false;
+                    advance = true;
+                }
+            }
+        }
+        // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+        const uint64_t hit_mask = __ballot(hit);
+        if (hit_mask != 0ull) {
+            const KP P = fresh_params(P0);
+            const uint32_t total = (uint32_t)__popcll(hit_mask);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(P->hit_count, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
+            const uint32_t max_hits = P->max_hits;
+            uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
+            for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
+                if (hit && rank >= chunk && rank < chunk + kStageRecords) {
+                    uint32_t *st = stage + (rank - chunk) * kStubWords;
+                    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
+                    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
+                    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
+                    st[11] = ph.num_scatters; st[12] = sidx;
+                    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
+                    st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t first = base + chunk;
+                const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
+                // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
+                const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
+                const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
+                uint32_t *dst = out_words + (size_t)first * 20u;
+                // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
+                for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (advance) {
+            if (hit) ph.abs_lens_left = 0.0f;                                   // c.cl:741-744
+            ph.px += ph.d.x * distance;
+            ph.py += ph.d.y * distance;
+            ph.pz += ph.d.z * distance;
+            ph.pt += ph.inv_groupvel * distance;
+            ph.total_path += distance;
+            if (ph.abs_lens_left < kEpsilon) {
+                --photons_left;                                                 // absorbed or detected
+                spent = true;
+            } else {
+                const KP P = fresh_params(P0);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d);
+                const float cos_s = scattering_cos(P, rx, ra);
+                const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
+                scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d);
+                ++ph.num_scatters;
+            }
+        }
+    }
+#ifdef CLSIMHIP_CENSUS
+    if (lane == 0) {
+        unsigned long long *d = fresh_params(P0)->census;
+        atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_services); atomicAdd(d + 3, c_creations);
+        atomicAdd(d + 4, c_created); atomicAdd(d + 5, c_vacant); atomicAdd(d + 6, c_polls);
+    }
+#endif
+}
+
+// ---- host-side launcher (called from launch_prop_kernel) ----
+hipError_t launch_scan_steps(const KParams &P, hipStream_t stream);
+hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream);
+
+template <int MED, bool TILT, bool ANISO, bool FLASHER>
+static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
+{
+    KParams P = Pin;
+    int dev = 0;
+    {
+        const hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+    }
+    // LDS: two workgroups per CU share 160 KB; the image is per workgroup, the rest goes to the waves' pools
+    int R = P.pool_ready;
+    {
+        const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)P.table_words;         // per workgroup
+        const int per_wave = budget_words / kPoolWavesPerBlock;
+        const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
+        if (R <= 0 || R > fit) R = fit;
+        if (R > 64) R = 64;
+        if (R < 4) return hipErrorInvalidValue;            // the caller falls back to the classic kernel for such an image
+        P.pool_ready = R;
+    }
+    const size_t lds_bytes = (size_t)(P.table_words + kPoolWavesPerBlock * pool_wave_words((uint32_t)R)) * 4;
+    struct Plan { int cus = 0, resident = 0; };
+    static std::mutex plan_mutex;
+    static std::map<std::pair<int, size_t>, Plan> plans;
+    Plan plan;
+    {
+        std::lock_guard<std::mutex> lk(plan_mutex);
+        Plan &pl = plans[std::make_pair(dev, lds_bytes)];
+        if (pl.resident == 0) {
+            int cus = 0, per_cu = 0;
+            hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess && lds_bytes > 64 * 1024)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_pool_kernel<MED, TILT, ANISO, FLASHER>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e == hipSuccess)
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_pool_kernel<MED, TILT, ANISO, FLASHER>, kPoolBlock, lds_bytes);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            if (cus < 1) cus = 1;
+            pl.cus = cus;
+            pl.resident = cus * per_cu;
+        }
+        plan = pl;
+    }
+    uint32_t grid = (uint32_t)plan.resident;
+    if (const char *e = getenv("CLSIMHIP_GRID")) {
+        const int g = atoi(e);
+        if (g >= 1 && g <= plan.resident) grid = (uint32_t)g;
+    }
+    // never more unit slots than steps
+    const uint32_t slots_per_group = (uint32_t)kPoolWavesPerBlock * (64u + (uint32_t)R);
+    const uint32_t needed = (P.n_steps + slots_per_group - 1u) / slots_per_group;
+    if (needed < grid) grid = needed;
+    {
+        const double r = (double)P.n_steps / ((double)grid * slots_per_group);
+        if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
+        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (r < 1.5) ? 3 : 5;
+        if (P.k_pop <= 0) P.k_pop = 4;
+        if (P.k_new <= 0 || P.k_new > R) P.k_new = (R > 8) ? R - 4 : R;      // create when the ring is down to its last entries
+        if (P.slices > 0xffff) P.slices = 0xffff;
+        if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
+    }
+    hipError_t err = launch_scan_steps(P, stream);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
+    err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    return launch_assemble_hits(P, FLASHER, dev, stream);
+}
+
+hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
+{
+    if (P.n_steps == 0) return hipSuccess;
+    if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
+    if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
+    if (P.history_n != 0 || v.tabulate) return hipErrorInvalidValue;
+    const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
+    switch (key) {
+#define CASE(k, a, b, c, d) case k: return launch_pool_variant<a, b, c, d>(P, stream);
+#define CASES(m) \
+    CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
+    CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
+    CASE(8 * m + 4, m, true, false, false)  CASE(8 * m + 5, m, true, false, true)  \
+    CASE(8 * m + 6, m, true, true, false)   CASE(8 * m + 7, m, true, true, true)
+    CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
+#undef CASES
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// smallest table image the pooled kernel cannot serve (its waves would get fewer than 4 ring entries)
+bool pool_kernel_fits(uint32_t table_words)
+{
+    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)table_words;
+    const int per_wave = budget_words / kPoolWavesPerBlock;
+    const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
+    return fit >= 8;
+}
+
+} // namespace clsimhip

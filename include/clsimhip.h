@@ -253,6 +253,10 @@ int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_phot
 int clsimhip_kernel_time_ms(clsimhip_converter *c, int reset, double *total_ms, uint64_t *launches);
 
 /* ---- introspection used by the parity tests ---- */
+/* which scheduling the propagation kernel runs with (after Initialize): 1 = per-wave photon pools
+ * (prop_pool_kernel.hip), 0 = one photon per lane (prop_kernel.hip: photon histories, very large table images).
+ * Results do not depend on it.  CLSIMHIP_KERNEL=pool|classic in the environment overrides the default. */
+int clsimhip_uses_pooled_kernel(const clsimhip_converter *c, int *out);
 /* copies the compiled table `name` (e.g. "geoStringPosX", "aDust400") converted to
  * double into out[0..cap); returns the entry count or a negative status */
 long clsimhip_get_table(const clsimhip_converter *c, const char *name, double *out, size_t cap);

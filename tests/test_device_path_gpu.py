@@ -199,3 +199,25 @@ def test_full_baseline_bunch_equals_oracle():
     assert cnt_d == cnt_o and cnt_o > 150000
     assert common.sort_photons(ph_d).tobytes() == common.sort_photons(ph_o).tobytes()
     assert np.array_equal(conv.GetRNGState(n), x_o)
+
+
+@pytest.mark.parametrize("kernel", ["classic", "pool"])
+def test_overflow_keeps_counting(kernel, monkeypatch):
+    """More hits than the output buffer holds: the counter keeps counting, only the first `capacity` arrivals are
+    stored and nothing is written behind them (propagation_kernel.c.cl:329-334), with either scheduling."""
+    monkeypatch.setenv("CLSIMHIP_KERNEL", kernel)
+    cfg = common.config("flasher")
+    n = 2048
+    steps = common.steps_for(cfg, n, seed=3)
+    conv = common.product_converter(cfg, n)
+    assert conv.UsesPooledKernel() == (kernel == "pool")
+    dev = torch.device("cuda", 0)
+    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+    cap = 64
+    out = torch.zeros((cap + 8, 80), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    conv.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) > cap
+    assert int(out[cap:].sum().item()) == 0
+    assert int((out[:cap].sum(dim=1) == 0).sum().item()) == 0

@@ -1,0 +1,96 @@
+"""GPU parity of the pooled propagation kernel (clsim_amd/csrc/prop_pool_kernel.hip, CLSIMHIP_KERNEL=pool): same bar as
+tests/test_parity_gpu.py -- the sorted multiset of 80-byte photon records and the RNG state words left behind are
+BIT-IDENTICAL to the CPU oracle's -- for every ring size, service threshold and creation batch, and equal to the classic
+kernel's output on bunches too large for the oracle."""
+import numpy as np
+import pytest
+
+from oracle import capi
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def pooled(monkeypatch):
+    monkeypatch.setenv("CLSIMHIP_KERNEL", "pool")
+    for k in ("CLSIMHIP_POOL_R", "CLSIMHIP_K_POP", "CLSIMHIP_K_NEW", "CLSIMHIP_SLICES", "CLSIMHIP_K_SEARCH", "CLSIMHIP_GRID"):
+        monkeypatch.delenv(k, raising=False)
+    return monkeypatch
+
+
+@pytest.mark.parametrize("name,n_steps", [("c1", 1000), ("mie", 4096), ("lea", 4096), ("flasher", 2048),
+                                          ("photonics_mie", 4096), ("photonics_wham", 2048)])
+def test_pooled_hit_multiset_bit_exact(pooled, name, n_steps):
+    cfg = common.config(name)
+    steps = common.steps_for(cfg, n_steps, seed=3)
+    n = len(steps)
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    conv = common.product_converter(cfg, n)
+    assert conv.UsesPooledKernel()
+    xo = x_o
+    conv.EnqueueSteps(steps, 77)
+    ident, ph_p = conv.GetConversionResult()
+    assert ident == 77 and cnt_o > 10 and len(ph_p) == cnt_o
+    assert common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o)
+    # the streams carry over to the next bunch (propagation_kernel.c.cl:458-461, 911-912)
+    ph_o2, cnt_o2, x_o2, _ = capi.propagate(T, steps, xo, a, threads=8)
+    conv.EnqueueSteps(steps, 78)
+    _, ph_p2 = conv.GetConversionResult()
+    assert common.sort_photons(capi.replace_indices_with_ids(ph_o2, T.geo)).tobytes() == common.sort_photons(ph_p2).tobytes()
+    assert np.array_equal(conv.GetRNGState(n), x_o2)
+
+
+@pytest.mark.parametrize("ring,k_pop,k_new,slices,k_search", [(4, 1, 1, 1, 1), (8, 64, 8, 3, 5), (34, 4, 30, 16, 5), (17, 2, 64, 7, 64),
+                                                               (64, 16, 1, 64, 2), (33, 7, 12, 16, 13)])
+def test_pooled_ragged_bunch_under_every_schedule(pooled, ring, k_pop, k_new, slices, k_search):
+    """Pool sizes and thresholds must not change results: a bunch whose steps hold 0 ... 1500 photons (empty steps,
+    single photons, steps much longer than a slice), two bunches in a row."""
+    pooled.setenv("CLSIMHIP_POOL_R", str(ring)); pooled.setenv("CLSIMHIP_K_POP", str(k_pop)); pooled.setenv("CLSIMHIP_K_NEW", str(k_new))
+    pooled.setenv("CLSIMHIP_SLICES", str(slices)); pooled.setenv("CLSIMHIP_K_SEARCH", str(k_search))
+    cfg = common.config("mie")
+    n = 2048
+    steps = common.steps_for(cfg, n, seed=17)
+    rng = np.random.default_rng(5)
+    num = rng.integers(0, 400, n)
+    num[rng.random(n) < 0.15] = 0
+    num[rng.random(n) < 0.05] = 1
+    num[rng.random(n) < 0.02] = 1500
+    steps["num"] = num
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg)
+    conv = common.product_converter(cfg, n)
+    assert conv.UsesPooledKernel()
+    xo = x
+    for bunch in range(2):
+        ph_o, cnt_o, xo, _ = capi.propagate(T, steps, xo, a, threads=8)
+        conv.EnqueueSteps(steps, bunch)
+        _, ph_p = conv.GetConversionResult()
+        assert len(ph_p) == cnt_o and cnt_o > 50
+        assert common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes() == common.sort_photons(ph_p).tobytes()
+        assert np.array_equal(conv.GetRNGState(n), xo)
+
+
+@pytest.mark.parametrize("name,n_steps", [("mie", 131072), ("lea", 65536), ("flasher", 32768)])
+def test_pooled_equals_classic_kernel_on_large_bunches(pooled, name, n_steps):
+    """Enough steps to fill every wave's pool on the whole chip (slices, hand-offs between XCDs, full rings): the
+    pooled and the classic kernel produce the same multiset and the same stream states."""
+    cfg = common.config(name)
+    steps = common.steps_for(cfg, n_steps, seed=23)
+    n = len(steps)
+    results = []
+    for kernel in ("classic", "pool"):
+        pooled.setenv("CLSIMHIP_KERNEL", kernel)
+        conv = common.product_converter(cfg, n)
+        assert conv.UsesPooledKernel() == (kernel == "pool")
+        conv.EnqueueSteps(steps, 5)
+        _, ph = conv.GetConversionResult()
+        results.append((common.sort_photons(ph).tobytes(), conv.GetRNGState(n)))
+        del conv
+    assert len(results[0][0]) > 80 * 50
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
