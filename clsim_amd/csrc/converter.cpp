@@ -15,11 +15,15 @@ namespace clsimhip {
 static_assert(sizeof(clsimhip_step) == sizeof(DevStep), "step layouts");
 static_assert(sizeof(clsimhip_photon) == sizeof(DevPhoton), "photon layouts");
 constexpr uint32_t kQueueSlots = 256;
-constexpr bool kDefaultPooledKernel = false;
+// The pooled kernel keeps 64 + R units per wave in flight (about 0.6M on the chip): it wins on bunches that hold more
+// steps than that by a margin (1M steps: +9 %, 4M: +8 %) and loses on smaller ones (0.5M: -17 %), where the classic
+// kernel's smaller grids apply.  Chosen per launch; results do not depend on the choice.
+constexpr size_t kPooledKernelMinSteps = 786432;
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
-    return use_pool_ ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
+    const bool pooled = use_pool_ && (P.n_steps >= pool_min_steps_);
+    return pooled ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
 }
 
 void Converter::hip_check(hipError_t e, const char *what) const
@@ -306,8 +310,13 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_POP")) k_pop_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
-    use_pool_ = kDefaultPooledKernel;
-    if (const char *e = std::getenv("CLSIMHIP_KERNEL")) use_pool_ = (std::strcmp(e, "pool") == 0);
+    use_pool_ = true;
+    pool_min_steps_ = kPooledKernelMinSteps;
+    if (const char *e = std::getenv("CLSIMHIP_KERNEL")) {          // pool / classic: that kernel for every bunch size
+        use_pool_ = (std::strcmp(e, "pool") == 0);
+        pool_min_steps_ = 0;
+    }
+    if (const char *e = std::getenv("CLSIMHIP_POOL_MIN_STEPS")) pool_min_steps_ = static_cast<size_t>(std::max(0ll, std::atoll(e)));
     // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
     // leaves its pools no LDS
     if (history_entries_ != 0 || !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()))) use_pool_ = false;

@@ -165,7 +165,7 @@ public:
     // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
     void set_device(int device);
     int device() const { return device_; }
-    bool uses_pooled_kernel() const { need_init(); return use_pool_; }
+    bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
 
 private:
     struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
@@ -237,7 +237,8 @@ private:
     int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
     int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)
-    bool use_pool_ = false;                      // CLSIMHIP_KERNEL=pool|classic
+    bool use_pool_ = false;                      // pooled kernel allowed (CLSIMHIP_KERNEL=pool|classic forces one)
+    size_t pool_min_steps_ = 0;                  // ... for bunches of at least this many steps
     hipError_t launch(const KParams &P, hipStream_t stream) const;
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
     hipStream_t copy_stream_ = nullptr;      // photon download

@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
 #ifdef CLSIMHIP_CENSUS
-    unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0;
+    if (lane == 0) atomicMin(fresh_params(P0)->census + 8, wall_clock64());
+    unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
 #endif
     for (uint32_t trip = 0;; ++trip) {
         switch (((trip >> kPrioShift) + wave_slot) & 3u) {
@@ -214,6 +215,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 // photon while the ring has room; what stays is compacted to the front of the list in its order
                 uint32_t kept = 0, created = 0, still_waiting = 0;
                 for (uint32_t c = 0; c < n_pend; c += 64u) {
+#ifdef CLSIMHIP_CENSUS
+                    ++c_chunks;
+#endif
                     const bool have = (c + lane) < n_pend;
                     uint32_t e_sidx = 0, e_left = 0, e_flags = 0;
                     uint64_t e_rx = 0;
@@ -322,6 +326,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         const bool run = has && !spent && !parked;
 #ifdef CLSIMHIP_CENSUS
         c_run += __popcll(__ballot(run));
+        c_parked += __popcll(__ballot(parked));
+        if (n_ready == 0u) ++c_empty_ring;
 #endif
         float distance = 0.0f;
         bool hit = false;
@@ -336,6 +342,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         {
             const uint64_t m_parked = __ballot(parked);
             if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
+#ifdef CLSIMHIP_CENSUS
+                ++c_searches;
+#endif
                 if (parked) {
                     distance = __builtin_bit_cast(float, parked_len[lane]);
                     hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
@@ -405,7 +414,12 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     if (lane == 0) {
         unsigned long long *d = fresh_params(P0)->census;
         atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_services); atomicAdd(d + 3, c_creations);
-        atomicAdd(d + 4, c_created); atomicAdd(d + 5, c_vacant); atomicAdd(d + 6, c_polls);
+        atomicAdd(d + 4, c_created); atomicAdd(d + 5, c_vacant); atomicAdd(d + 6, c_polls); atomicAdd(d + 7, c_parked);
+        atomicAdd(d + 9, c_searches); atomicAdd(d + 10, c_chunks); atomicAdd(d + 11, c_empty_ring);
+        const uint32_t w = blockIdx.x * (uint32_t)kPoolWavesPerBlock + (threadIdx.x >> 6);
+        d[16 + 3 * w] = wall_clock64();
+        d[16 + 3 * w + 1] = 0;
+        d[16 + 3 * w + 2] = c_trips;
     }
 #endif
 }

@@ -1,0 +1,8 @@
+// stand-in (tests/stubs/README.md)
+#pragma once
+#include <icetray/I3PointerTypedefs.h>
+class I3FrameObject {
+public:
+    virtual ~I3FrameObject() {}
+};
+I3_POINTER_TYPEDEFS(I3FrameObject);

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Census of the pooled kernel (GPU).  ANALYSIS TOOL.  Needs the analysis build:
+    make -C clsim_amd/csrc clean && make -C clsim_amd/csrc -j EXTRA=-DCLSIMHIP_CENSUS
+usage: exp_pool_census.py spec ...   (spec as in exp_pool_scan.py)"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from clsim_amd import converter as CV, synthetic as S, _lib
+
+ENV = {"kernel": "CLSIMHIP_KERNEL", "R": "CLSIMHIP_POOL_R", "pop": "CLSIMHIP_K_POP", "new": "CLSIMHIP_K_NEW", "slices": "CLSIMHIP_SLICES",
+       "search": "CLSIMHIP_K_SEARCH", "grid": "CLSIMHIP_GRID"}
+medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
+bias = CV.GetIceCubeDOMAcceptance(); gen = CV.makeCherenkovWavelengthGenerator(bias, medium)
+geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
+dev = torch.device("cuda", 0)
+for spec in sys.argv[1:]:
+    kv = dict(item.split("=") for item in spec.split(",") if item)
+    for k, e in ENV.items():
+        os.environ.pop(e, None)
+        if k in kv:
+            os.environ[e] = kv[k]
+    os.environ.setdefault("CLSIMHIP_KERNEL", "pool")
+    n = int(kv.get("n", 1 << 20))
+    conv = CV.initializeHIP(0, geom, medium, bias, [gen], pancakeFactor=5.0, approximateNumberOfWorkItems=n, seed=12345)
+    steps = S.cascade_steps(n, seed=1000)
+    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+    cap = 8 << 20
+    out = torch.empty((cap, 80), dtype=torch.uint8, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    for rep in range(2):
+        conv.KernelTimeMs(reset=True)
+        conv.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ms, _ = conv.KernelTimeMs(reset=True)
+    buf = np.zeros(1 << 17, dtype=np.uint64)
+    lib = _lib.load(); lib.clsimhip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    lib.clsimhip_debug_counters(conv._h, buf.ctypes.data_as(C.c_void_p))
+    trips, run, services, creations, created, vacant, polls, parked = (float(v) for v in buf[:8])
+    searches, chunks, empty_ring = (float(v) for v in buf[9:12])
+    t0 = int(buf[8])
+    rec = buf[16:16 + 3 * ((len(buf) - 16) // 3)].reshape(-1, 3).astype(np.int64)
+    rec = rec[rec[:, 0] > 0]
+    end = (rec[:, 0] - t0) / 100e3
+    q = lambda a, p: float(np.percentile(a, p))
+    lanes = 64.0 * trips
+    print("%s: %.1f ms, %d waves | lanes: run %.1f%% parked %.1f%% without photon %.1f%% | per trip: services %.3f, creation stages %.4f "
+          "(%.1f photons each, %.2f chunks), searches %.3f, ring empty %.1f%% of trips, polls/trip %.3f | wave end p1 %.1f p50 %.1f p99 %.1f max %.1f ms | trips/wave p10 %d p50 %d p90 %d"
+          % (spec, ms, len(rec), 100 * run / lanes, 100 * parked / lanes, 100 * vacant / lanes, services / trips, creations / trips,
+             created / max(creations, 1), chunks / max(creations, 1), searches / trips, 100 * empty_ring / trips, polls / trips,
+             q(end, 1), q(end, 50), q(end, 99), end.max(), q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
+    del conv

@@ -17,7 +17,7 @@ for path in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recur
 for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     acc = defaultdict(lambda: defaultdict(float))
     for row in csv.DictReader(open(path)):
-        if "prop_kernel" not in row["Kernel_Name"]:
+        if "prop_kernel" not in row["Kernel_Name"] and "prop_pool_kernel" not in row["Kernel_Name"]:
             continue
         acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for name, per_dispatch in acc.items():
