@@ -7,14 +7,18 @@
 // private/clsim/I3CLSimModuleHelper.cxx:303-372), with the same names, argument
 // meaning and error behaviour (I3CLSimStepToPhotonConverter_exception).
 //
-// Inside IceTray it derives from the real interface (define
-// CLSIMHIP_WITH_ICETRAY and include the clsim headers first; INTEGRATION.md shows
-// the translation of I3CLSimMediumProperties / I3CLSimSimpleGeometry into the C
-// descriptors).  Stand-alone (this repository's tests) it derives from the
-// minimal interface below, which has the same virtual functions in the same
-// order, and takes the C descriptors directly.
+// Two builds of the same class:
+//  * -DCLSIMHIP_WITH_ICETRAY (inside IceTray): derives from the REAL interface -- the four configuration setters
+//    take I3CLSimRandomValueConstPtr / I3CLSimFunctionConstPtr / I3CLSimMediumPropertiesConstPtr /
+//    I3CLSimSimpleGeometryConstPtr exactly as public/clsim/I3CLSimStepToPhotonConverter.h:91-124 declares them and
+//    translate through I3CLSimStepToPhotonConverterHIPGlue.h; the constructor takes the I3RandomService that seeds the
+//    streams (OpenCL.cxx:68-69), SetDevice takes the HIP device ordinal (OpenCL.h:102 takes an I3CLSimOpenCLDevice).
+//    This repository compiles and runs that build against tests/stubs/ (tests/test_icetray_adapter.py).
+//  * stand-alone (no IceTray headers at all): derives from the minimal interface below, which has the same virtual
+//    functions in the same order, and takes the C descriptors directly.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -23,7 +27,11 @@
 
 #include "../../include/clsimhip.h"
 
-#ifndef CLSIMHIP_WITH_ICETRAY
+#ifdef CLSIMHIP_WITH_ICETRAY
+#include <clsim/I3CLSimStepToPhotonConverter.h>
+#include <phys-services/I3RandomService.h>
+#include "I3CLSimStepToPhotonConverterHIPGlue.h"
+#else
 // ---- stand-alone counterparts of the reference types ----
 typedef clsimhip_step I3CLSimStep;                       // public/clsim/I3CLSimStep.h (48 B blob)
 typedef clsimhip_photon I3CLSimPhoton;                   // public/clsim/I3CLSimPhoton.h (80 B blob)
@@ -78,17 +86,88 @@ struct I3CLSimStepToPhotonConverter {
 };
 #endif
 
+static_assert(sizeof(I3CLSimStep) == sizeof(clsimhip_step), "I3CLSimStep must be the 48-byte record of the C ABI");
+static_assert(sizeof(I3CLSimPhoton) == sizeof(clsimhip_photon), "I3CLSimPhoton must be the 80-byte record of the C ABI");
+
 class I3CLSimStepToPhotonConverterHIP : public I3CLSimStepToPhotonConverter {
 public:
+#ifdef CLSIMHIP_WITH_ICETRAY
+    // I3CLSimStepToPhotonConverterOpenCL(I3RandomServicePtr, bool useNativeMath) (OpenCL.cxx:68-69); there is one math
+    // library here, so the second argument has no counterpart
+    explicit I3CLSimStepToPhotonConverterHIP(I3RandomServicePtr randomService, int device = 0) : handle_(nullptr), seed_(12345), randomService_(randomService)
+    {
+        if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
+    }
+#else
     explicit I3CLSimStepToPhotonConverterHIP(int device = 0, uint64_t seed = 12345) : handle_(nullptr), seed_(seed)
     {
         if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
     }
+#endif
     ~I3CLSimStepToPhotonConverterHIP() override { clsimhip_destroy(handle_); }
     I3CLSimStepToPhotonConverterHIP(const I3CLSimStepToPhotonConverterHIP &) = delete;
     I3CLSimStepToPhotonConverterHIP &operator=(const I3CLSimStepToPhotonConverterHIP &) = delete;
 
-    // ---- interface ----
+    // ---- interface: configuration ----
+#ifdef CLSIMHIP_WITH_ICETRAY
+    void SetWlenGenerators(const std::vector<I3CLSimRandomValueConstPtr> &wlenGenerators) override
+    {
+        std::vector<clsimhip_glue::RandomValueHolder> held(wlenGenerators.size());
+        std::vector<clsimhip_random_value> g(wlenGenerators.size());
+        for (std::size_t i = 0; i < wlenGenerators.size(); ++i) {
+            if (!wlenGenerators[i]) throw I3CLSimStepToPhotonConverter_exception("wavelength generator is (null)!");
+            held[i] = clsimhip_glue::MakeHIPWlenGenerator(*wlenGenerators[i], i);
+            g[i] = held[i].r;
+        }
+        check(clsimhip_set_wlen_generators(handle_, g.data(), g.size()));
+    }
+    void SetWlenBias(I3CLSimFunctionConstPtr wlenBias) override
+    {
+        if (!wlenBias) throw I3CLSimStepToPhotonConverter_exception("wavelength bias is (null)!");
+        const clsimhip_glue::FunctionHolder h = clsimhip_glue::MakeHIPFunction(*wlenBias, "the wavelength bias");
+        check(clsimhip_set_wlen_bias(handle_, &h.f));
+    }
+    void SetMediumProperties(I3CLSimMediumPropertiesConstPtr mediumProperties) override
+    {
+        if (!mediumProperties) throw I3CLSimStepToPhotonConverter_exception("medium properties are (null)!");
+        clsimhip_glue::MediumHolder h;
+        clsimhip_glue::MakeHIPMedium(*mediumProperties, h);
+        check(clsimhip_set_medium_properties(handle_, h.m));
+    }
+    // the seven vectors the reference hands to its geometry code generator (GeometrySource.cxx:88-99)
+    void SetGeometry(I3CLSimSimpleGeometryConstPtr geometry) override
+    {
+        if (!geometry) throw I3CLSimStepToPhotonConverter_exception("geometry is (null)!");
+        const std::vector<std::string> &sub = geometry->GetSubdetectorVector();
+        std::vector<const char *> names;
+        for (const std::string &s : sub) names.push_back(s.c_str());
+        check(clsimhip_set_geometry(handle_, geometry->size(), geometry->GetStringIDVector().data(), geometry->GetDomIDVector().data(),
+                                    geometry->GetPosXVector().data(), geometry->GetPosYVector().data(), geometry->GetPosZVector().data(),
+                                    names.data(), geometry->GetOMRadius()));
+    }
+    // streams seeded from the random service like init_MWC_RNG does (private/opencl/mwcrng_init.h:104-112); the
+    // multipliers are the library's (the same safeprimes the reference reads from its file)
+    void Initialize() override
+    {
+        if (!randomService_) { check(clsimhip_initialize(handle_, seed_)); return; }
+        if (IsInitialized()) throw I3CLSimStepToPhotonConverter_exception("I3CLSimStepToPhotonConverterHIP already initialized!");
+        check(clsimhip_compile(handle_));
+        std::size_t n = 0;
+        check(clsimhip_get_max_num_workitems(handle_, &n));
+        if (n == 0) { n = 1048576; check(clsimhip_set_max_num_workitems(handle_, n)); }
+        std::vector<uint32_t> a(n);
+        std::vector<uint64_t> x(n, 0);
+        check(clsimhip_mwc_multipliers(a.data(), n));
+        for (std::size_t i = 0; i < n; ++i) {
+            while ((x[i] == 0) | ((static_cast<uint32_t>(x[i] >> 32)) >= (a[i] - 1)) | ((static_cast<uint32_t>(x[i])) >= 0xfffffffful)) {
+                x[i] = static_cast<uint32_t>(randomService_->Integer(0xffffffff));
+                x[i] = x[i] << 32;
+                x[i] += static_cast<uint32_t>(randomService_->Integer(0xffffffff));
+            }
+        }
+        check(clsimhip_initialize_with_streams(handle_, x.data(), a.data(), n));
+    }
+#else
     void SetWlenGenerators(const std::vector<clsimhip_random_value> &g) override { check(clsimhip_set_wlen_generators(handle_, g.data(), g.size())); }
     void SetWlenBias(const clsimhip_function &b) override { check(clsimhip_set_wlen_bias(handle_, &b)); }
     void SetMediumProperties(const clsimhip_medium *m) override { check(clsimhip_set_medium_properties(handle_, m)); }
@@ -102,7 +181,10 @@ public:
                                     names.data(), omRadius));
     }
     void Initialize() override { check(clsimhip_initialize(handle_, seed_)); }
+#endif
     void InitializeWithStreams(const std::vector<uint64_t> &x, const std::vector<uint32_t> &a) { check(clsimhip_initialize_with_streams(handle_, x.data(), a.data(), x.size())); }
+
+    // ---- interface: steady state ----
     bool IsInitialized() const override { return clsimhip_is_initialized(handle_) != 0; }
     void EnqueueSteps(I3CLSimStepSeriesConstPtr steps, uint32_t identifier) override
     {
@@ -122,9 +204,9 @@ public:
         const clsimhip_photon *p = nullptr;
         size_t n = 0;
         check(clsimhip_get_conversion_result(handle_, &r.identifier, &p, &n));
-        r.photons = I3CLSimPhotonSeriesPtr(new I3CLSimPhotonSeries(reinterpret_cast<const I3CLSimPhoton *>(p),
-                                                                   reinterpret_cast<const I3CLSimPhoton *>(p) + n));
+        r.photons = I3CLSimPhotonSeriesPtr(new I3CLSimPhotonSeries(n));
         if (n) {
+            std::memcpy(static_cast<void *>(r.photons->data()), p, n * sizeof(clsimhip_photon));
             // I3CLSimPhotonHistory (public/clsim/I3CLSimPhotonHistory.h): per photon the recorded scatter points
             const float *h = nullptr;
             uint32_t entries = 0;
@@ -154,7 +236,8 @@ public:
         return m;
     }
 
-    // ---- concrete setters of the OpenCL converter ----
+    // ---- concrete setters of the OpenCL converter (OpenCL.h:78-258) ----
+    void SetDevice(int hipDeviceOrdinal) { check(clsimhip_set_device(handle_, hipDeviceOrdinal)); }
     void SetEnableDoubleBuffering(bool v) { check(clsimhip_set_enable_double_buffering(handle_, v)); }
     void SetDoublePrecision(bool v) { check(clsimhip_set_double_precision(handle_, v)); }
     void SetStopDetectedPhotons(bool v) { check(clsimhip_set_stop_detected_photons(handle_, v)); }
@@ -170,7 +253,60 @@ public:
     clsimhip_converter *Handle() { return handle_; }
 
 private:
-    void check(int rc) const { if (rc != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(handle_)); }
+    void check(int rc) const
+    {
+        if (rc == CLSIMHIP_OK) return;
+#ifdef CLSIMHIP_WITH_ICETRAY
+        // a device error is where the reference's worker log_fatal()s (OpenCL.cxx:768-774)
+        if (rc == CLSIMHIP_ERR_DEVICE) log_fatal("%s", clsimhip_last_error(handle_));
+#endif
+        throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(handle_));
+    }
     clsimhip_converter *handle_;
     uint64_t seed_;
+#ifdef CLSIMHIP_WITH_ICETRAY
+    I3RandomServicePtr randomService_;
+#endif
 };
+
+#ifdef CLSIMHIP_WITH_ICETRAY
+typedef boost::shared_ptr<I3CLSimStepToPhotonConverterHIP> I3CLSimStepToPhotonConverterHIPPtr;
+
+namespace I3CLSimModuleHelper {
+// initializeOpenCL (private/clsim/I3CLSimModuleHelper.cxx:303-372) with a HIP device ordinal in the place of the
+// I3CLSimOpenCLDevice (its GetApproximateNumberOfWorkItems() becomes an argument): the same calls in the same order
+inline I3CLSimStepToPhotonConverterHIPPtr initializeHIP(int device, uint32_t approximateNumberOfWorkItems, I3RandomServicePtr rng,
+                                                        I3CLSimSimpleGeometryConstPtr geometry, I3CLSimMediumPropertiesConstPtr medium,
+                                                        I3CLSimFunctionConstPtr wavelengthGenerationBias,
+                                                        const std::vector<I3CLSimRandomValueConstPtr> &wavelengthGenerators,
+                                                        bool enableDoubleBuffering, bool doublePrecision, bool stopDetectedPhotons,
+                                                        bool saveAllPhotons, double saveAllPhotonsPrescale, double fixedNumberOfAbsorptionLengths,
+                                                        double pancakeFactor, uint32_t photonHistoryEntries, uint32_t limitWorkgroupSize)
+{
+    I3CLSimStepToPhotonConverterHIPPtr conv(new I3CLSimStepToPhotonConverterHIP(rng));
+    conv->SetDevice(device);
+    conv->SetWlenGenerators(wavelengthGenerators);
+    conv->SetWlenBias(wavelengthGenerationBias);
+    conv->SetMediumProperties(medium);
+    conv->SetGeometry(geometry);
+    conv->SetEnableDoubleBuffering(enableDoubleBuffering);
+    conv->SetDoublePrecision(doublePrecision);
+    conv->SetStopDetectedPhotons(stopDetectedPhotons);
+    conv->SetSaveAllPhotons(saveAllPhotons);
+    conv->SetSaveAllPhotonsPrescale(saveAllPhotonsPrescale);
+    conv->SetFixedNumberOfAbsorptionLengths(fixedNumberOfAbsorptionLengths);
+    conv->SetDOMPancakeFactor(pancakeFactor);
+    conv->SetPhotonHistoryEntries(photonHistoryEntries);
+    conv->Compile();
+    std::size_t maxWorkgroupSize = conv->GetMaxWorkgroupSize();
+    if (limitWorkgroupSize != 0 && limitWorkgroupSize < maxWorkgroupSize) maxWorkgroupSize = limitWorkgroupSize;
+    conv->SetWorkgroupSize(maxWorkgroupSize);
+    const std::size_t workgroupSize = conv->GetWorkgroupSize();
+    std::size_t maxNumWorkitems = (static_cast<std::size_t>(approximateNumberOfWorkItems) / workgroupSize) * workgroupSize;
+    if (maxNumWorkitems == 0) maxNumWorkitems = workgroupSize;
+    conv->SetMaxNumWorkitems(maxNumWorkitems);
+    conv->Initialize();
+    return conv;
+}
+}
+#endif
