@@ -5,12 +5,19 @@ One "step" = one pass of the hot path (the HIP propagation kernel behind the C
 ABI) over one bunch of synthetic I3CLSimSteps that is already resident in HBM.
 N=1 workload = BASELINE.json configs[1]: 1M cascade-like steps x 200 photons,
 SPICE-Mie layered ice with tilt, synthetic 86-string detector, DOM oversize 5.
-N>1: one process per GPU (torch.distributed / RCCL), every rank propagates its
-own bunch of the same size (weak scaling: steps are independent units, no
-data-path collective) and the detected photons are gathered on rank 0 with
-point-to-point RCCL transfers inside the timed region (config C4).
+N>1: one process per GPU, every rank propagates its own bunch of the same size
+(weak scaling: steps are independent units, no data-path collective) and the
+detected photons are gathered on rank 0 inside the timed region (config C4)
+through the C ABI's RCCL gather (clsimhip_gather_hits: counts all-gather + one
+point-to-point transfer per peer); the gather of pass k runs on its own stream
+while the kernel of pass k+1 runs (two photon buffers).  torch.distributed only
+carries the RCCL unique id, the barriers and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the propagation kernel's
+Prints ONE JSON line on rank 0.  At N=1 the line also carries `host_path`: the
+reference's own calling pattern (a producer thread calls EnqueueSteps, the
+consumer GetConversionResult, double buffering on; benchmark.py:300-360) over 8
+bunches, PCIe transfers and index->ID conversion included -- measured after
+and outside the timed region of `value`.  `roofline` prices the propagation kernel's
 algorithmic HBM bytes against the 8 TB/s peak (the kernel is VALU-bound, so the
 fraction is tiny by construction -- see DESIGN.md); `cpu_baseline` times the CPU
 restatement of the reference kernel (oracle/, all host cores) on a bounded
@@ -56,7 +63,6 @@ def cpu_baseline(args, steps_np, seconds):
     from oracle import builders as B
     from oracle import capi
     from clsim_amd import synthetic as S
-    capi.build()
     cores = os.cpu_count() or 1
     g = S.ic86_geometry()
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
@@ -135,7 +141,6 @@ def tabulator_bench(args, torch, device):
         # path samples are counted by the oracle on a small sample of the same steps (they are the same on both sides)
         from oracle import builders as B
         from oracle import capi
-        capi.build()
         cores = os.cpu_count() or 1
         med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
         o_axes = [B.power_axis(0, 580, 200, 2), B.linear_axis(0, 180, 36), B.linear_axis(-1, 1, 100), B.power_axis(0, 7e3, 105, 2)]
@@ -159,8 +164,42 @@ def tabulator_bench(args, torch, device):
     print(json.dumps(out))
 
 
+def host_path_run(CV, args, steps_np, conv, bunches):
+    """The reference's own calling pattern (benchmark.py:300-360): a producer thread enqueues bunches, the consumer takes
+    results; wall clock from the first enqueue to the last result -- host buffers, PCIe transfers, index->ID conversion."""
+    import threading
+    conv.EnqueueSteps(steps_np, 0)          # warm-up bunch
+    conv.GetConversionResult()
+    before = conv.GetStatistics()
+    t0 = time.perf_counter()
+    producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(bunches)])
+    producer.start()
+    hits = 0
+    for _ in range(bunches):
+        _, ph = conv.GetConversionResult()
+        hits += len(ph)
+    producer.join()
+    elapsed = time.perf_counter() - t0
+    st = conv.GetStatistics()
+    photons = int(steps_np["num"].sum()) * bunches
+    device_ns = st["TotalDeviceTime"] - before["TotalDeviceTime"]
+    return {"value": photons / elapsed, "unit": "photons/s", "bunches": bunches, "steps_per_bunch": len(steps_np), "hits": hits,
+            "seconds": elapsed, "device_utilization": device_ns * 1e-9 / elapsed,
+            "device_ns_per_photon": device_ns / photons, "double_buffering": True,
+            "definition": "sum(numPhotons) / wall clock from the first EnqueueSteps to the last GetConversionResult "
+                          "(reference benchmark.py:335-340), outside the timed region of `value`"}
+
+
+WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
+
+
 def main():
     args = parse()
+    if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # the checker's library is built (a `make` child process) BEFORE anything initialises the GPU: a GPU-initialised
+        # process must not spawn build tools under a profiler's preload
+        from oracle import capi
+        capi.build()
     if args.workload == "c3":
         args.ice, args.bunch = "spice_lea", (args.bunch if args.bunch != (1 << 20) else 5 * (1 << 20))   # 10M steps = 2 such bunches:
         # a converter holds at most 6 139 850 streams (all 32-bit safeprime multipliers, OpenCL.cxx:250)
@@ -170,7 +209,7 @@ def main():
     import torch.distributed as dist
     from clsim_amd import converter as CV
     from clsim_amd import synthetic as S
-    from clsim_amd.distributed import gather_hits
+    from clsim_amd.distributed import HitGatherer
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,46 +242,59 @@ def main():
         steps_np = S.cascade_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step)
     photons_per_pass = int(steps_np["num"].sum())
 
-    d_steps = torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)
-    capacity = (4 if args.workload == "c2" else 48) * 1024 * 1024
-    d_photons = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
-    d_count = torch.zeros(1, dtype=torch.int32, device=dev)
-    gathered = torch.empty((capacity if rank == 0 else 1, 80), dtype=torch.uint8, device=dev) if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
-    total_hits = 0
-
     if args.host_path:
-        # the reference's own calling pattern (benchmark.py:300-360): a producer thread enqueues bunches, the
-        # consumer takes results; wall clock from the first enqueue to the last result
-        import threading
-        for _ in range(args.warmup):
-            conv.EnqueueSteps(steps_np, 0)
-            conv.GetConversionResult()
-        t0 = time.perf_counter()
-        producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(args.steps)])
-        producer.start()
-        hits = 0
-        for _ in range(args.steps):
-            _, ph = conv.GetConversionResult()
-            hits += len(ph)
-        producer.join()
-        elapsed = time.perf_counter() - t0
-        st = conv.GetStatistics()
+        hp = host_path_run(CV, args, steps_np, conv, max(args.steps, 1))
         print(json.dumps({"metric": "propagated photons/sec through EnqueueSteps/GetConversionResult (host buffers)",
-                          "value": photons_per_pass * args.steps / elapsed, "unit": "photons/s", "n_gpus": 1, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "hits": hits,
-                          "device_utilization": st["DeviceUtilization"], "device_ns_per_photon": st["AverageDeviceTimePerPhoton"],
-                          "host_ns_per_photon": st["AverageHostTimePerPhoton"], "config": {"workload": args.workload, "steps_per_bunch": n}}))
+                          "value": hp["value"], "unit": "photons/s", "n_gpus": 1, "steps": hp["bunches"], "warmup": 1,
+                          "ms_per_step": 1e3 * hp["seconds"] / hp["bunches"], "host_path": hp,
+                          "config": {"workload": WORKLOAD_NAMES[args.workload], "steps_per_bunch": n}}))
         return
 
+    d_steps = torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)
+    capacity = (4 if args.workload == "c2" else 48) * 1024 * 1024
+    # two photon buffers: with several GPUs the gather of pass k (its own stream) runs while the kernel of pass k+1 does
+    # (CLSIMHIP_BENCH_GATHER=1 runs the gather path in a world of one rank: the multi-GPU code path on a single GPU)
+    use_gather = (world > 1) or (os.environ.get("CLSIMHIP_BENCH_GATHER") == "1")
+    n_buffers = 2 if use_gather else 1
+    d_photons = [torch.empty((capacity, 80), dtype=torch.uint8, device=dev) for _ in range(n_buffers)]
+    d_count = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(n_buffers)]
+    compute = torch.cuda.current_stream()
+    stream = compute.cuda_stream
+    gatherer = gathered = comm_stream = None
+    if use_gather:
+        # detected photons of all ranks on rank 0 through the C ABI (RCCL called from the library; torch.distributed
+        # only distributes the unique id): counts all-gather, then one point-to-point transfer per peer
+        gatherer = HitGatherer.from_process_group(local_rank) if world > 1 else HitGatherer(local_rank, 0, 1, HitGatherer.unique_id())
+        gathered = torch.empty(((capacity if rank == 0 else 1), 80), dtype=torch.uint8, device=dev)
+        comm_stream = torch.cuda.Stream(device=dev)
+    kernel_done = [torch.cuda.Event() for _ in range(n_buffers)]
+    gather_done = [torch.cuda.Event() for _ in range(n_buffers)]
+    state = {"pending": None, "hits": 0, "pass": 0, "overflow": 0}
+
+    def do_gather(b):
+        comm_stream.wait_event(kernel_done[b])
+        counts = gatherer.gather(d_photons[b].data_ptr(), d_count[b].data_ptr(), capacity, 0, gathered.data_ptr(), gathered.shape[0],
+                                 comm_stream.cuda_stream)
+        gather_done[b].record(comm_stream)
+        state["hits"] += int(np.minimum(counts, capacity).sum())
+        state["overflow"] += int((counts > capacity).sum())
+
     def one_pass():
-        nonlocal total_hits
-        conv.PropagateDevice(d_steps.data_ptr(), n, d_photons.data_ptr(), capacity, d_count.data_ptr(), stream=stream)
-        if world > 1:
-            # gather of detected photons on rank 0: counts, then one point-to-point
-            # transfer per peer (7 peers -> 7 distinct xGMI links, no ring)
-            got, c = gather_hits(d_photons, int(d_count.cpu().item()), dst=0, out=gathered)
-            total_hits += int(c.sum())
+        b = state["pass"] % n_buffers
+        state["pass"] += 1
+        if use_gather:
+            compute.wait_event(gather_done[b])          # buffer b is free once its previous gather has left it
+        conv.PropagateDevice(d_steps.data_ptr(), n, d_photons[b].data_ptr(), capacity, d_count[b].data_ptr(), stream=stream)
+        if use_gather:
+            kernel_done[b].record(compute)
+            if state["pending"] is not None:
+                do_gather(state["pending"])             # the previous pass's photons travel while this kernel runs
+            state["pending"] = b
+
+    def flush():
+        if use_gather and state["pending"] is not None:
+            do_gather(state["pending"])
+            state["pending"] = None
 
     def barrier():
         if world > 1:
@@ -251,16 +303,19 @@ def main():
 
     for _ in range(args.warmup):
         one_pass()
+    flush()
     barrier()
     conv.KernelTimeMs(reset=True)
-    total_hits = 0
+    state["hits"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
+    flush()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = conv.KernelTimeMs(reset=True)
-    hits_last = int(d_count.cpu().item())
+    counted_last = int(d_count[(state["pass"] - 1) % n_buffers].cpu().item())
+    hits_last = min(counted_last, capacity)             # the counter keeps counting past the buffer; `capacity` records are stored
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -270,47 +325,68 @@ def main():
     if rank == 0:
         value = photons_per_pass * args.steps * world / elapsed
         avg_ms = kernel_ms / max(launches, 1)
+        pooled = conv.KernelForBunch(n) == "pool"
+        kernel_name = "prop_pool_kernel" if pooled else "prop_kernel"
         # algorithmic HBM bytes per launch: step record + RNG state read and
         # write per step (48 + 12 + 12 B) plus one 80-byte record per detected photon
         alg_bytes = n * 72.0 + hits_last * 80.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         valu = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and args.photons_per_step == 200:
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this same command
-            # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken)
+            # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken).  The file names the kernel and the git
+            # revision it was profiled at: numbers of another kernel are not quoted.
             with open(tpath) as f:
                 prof = json.load(f)
-            traffic = prof.get("bytes_per_launch")
-            if prof.get("sq_insts_valu_per_launch"):
-                # the operative bound: VALU issue slots (a wave64 operation holds a SIMD for 2 cycles; 1024 SIMDs at 2.4 GHz)
-                valu = {"insts_per_launch": prof["sq_insts_valu_per_launch"], "lane_utilisation": prof.get("valu_lane_utilisation"),
-                        "issue_slot_frac": prof["sq_insts_valu_per_launch"] * 2.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
-                        "source": "profiles/latest_traffic.json (rocprofv3 --pmc pass of this command) x the live kernel time"}
+            traffic_source = {"file": "profiles/latest_traffic.json", "kernel": prof.get("kernel"), "git_revision": prof.get("git_revision"),
+                              "profiled_kernel_ms": prof.get("kernel_ms")}
+            if kernel_name + "<" in str(prof.get("kernel")):
+                traffic = prof.get("bytes_per_launch")
+                if prof.get("sq_insts_valu_per_launch"):
+                    # the operative bound: VALU issue slots (a wave64 operation holds a SIMD for 2 cycles; 1024 SIMDs at 2.4 GHz)
+                    valu = {"insts_per_launch": prof["sq_insts_valu_per_launch"], "lane_utilisation": prof.get("valu_lane_utilisation"),
+                            "issue_slot_frac": prof["sq_insts_valu_per_launch"] * 2.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
+                            "source": "rocprofv3 --pmc pass of this command at the revision above x the live kernel time"}
+            else:
+                traffic_source["stale"] = "profiled kernel differs from the one this run launched (%s)" % kernel_name
         out = {
             "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d I3CLSimSteps x %d photons per GPU and pass, %s ice (171 layers%s), synthetic 86-string "
-                                   "detector (5160 DOMs), DOM oversize 5; BASELINE.json configs[%d]" %
-                                   (n, args.photons_per_step, args.ice, " + tilt" if True else "",
-                                    {"c2": 1 if world == 1 else 3, "c3": 2, "c5": 4}[args.workload]),
+            "config": {"workload": "%s: %d steps x %d photons per GPU, %s + tilt, 86 strings, oversize 5" %
+                                   (WORKLOAD_NAMES[args.workload] if world == 1 or args.workload != "c2" else "C4 = BASELINE configs[3] (per-GPU shard of C2 size)",
+                                    n, args.photons_per_step, args.ice),
                        "kind": {"c2": "cascade steps", "c3": "cascade steps", "c5": "flasher steps (405 nm point source at a DOM)"}[args.workload],
+                       "ice_layers": 171, "doms": 5160,
                        "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
-                       "hit_gather": "rccl p2p to rank 0" if world > 1 else "none",
-                       "hits_last_pass_rank0": hits_last},
+                       "hit_gather": "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if world > 1 else "none",
+                       "hits_last_pass_rank0": hits_last, "hit_counter_last_pass_rank0": counted_last,
+                       "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
+                       "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "prop_kernel", "avg_kernel_ms": avg_ms, "launches": int(launches),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "avg_kernel_ms": avg_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / (avg_ms * 1e-3))},
         }
+        if world == 1:
+            # the reference's "actual" metric, outside the timed region of `value`: a second converter with two buffer sets
+            del d_photons, d_count
+            torch.cuda.empty_cache()
+            conv2 = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=True,
+                                     approximateNumberOfWorkItems=n, seed=12345)
+            out["host_path"] = host_path_run(CV, args, steps_np, conv2, 8)
+            del conv2
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
         print(json.dumps(out))
+    if gatherer is not None:
+        gatherer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

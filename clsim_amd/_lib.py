@@ -80,7 +80,8 @@ SYMBOLS = [
     "clsimhip_medium_create_from_photonics", "clsimhip_medium_describe", "clsimhip_medium_destroy",
     "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
     "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
-    "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device", "clsimhip_uses_pooled_kernel",
+    "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device", "clsimhip_uses_pooled_kernel", "clsimhip_kernel_for_bunch",
+    "clsimhip_comm_get_unique_id", "clsimhip_comm_create", "clsimhip_comm_destroy", "clsimhip_gather_hits",
     "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
     "clsimhip_set_geometry_from_text_file",
     "clsimhip_set_enable_double_buffering", "clsimhip_set_double_precision", "clsimhip_set_stop_detected_photons",
@@ -136,6 +137,11 @@ def load():
         "clsimhip_set_device": (i32, [vp, i32]),
         "clsimhip_get_device": (i32, [vp, C.POINTER(i32)]),
         "clsimhip_uses_pooled_kernel": (i32, [vp, C.POINTER(i32)]),
+        "clsimhip_kernel_for_bunch": (i32, [vp, sz, C.POINTER(i32)]),
+        "clsimhip_comm_get_unique_id": (i32, [vp]),
+        "clsimhip_comm_create": (i32, [i32, i32, i32, vp, C.POINTER(vp)]),
+        "clsimhip_comm_destroy": (None, [vp]),
+        "clsimhip_gather_hits": (i32, [vp, vp, vp, sz, i32, vp, sz, vp, vp]),
         "clsimhip_set_wlen_generators": (i32, [vp, C.POINTER(RandomValue), sz]),
         "clsimhip_set_wlen_bias": (i32, [vp, C.POINTER(Function)]),
         "clsimhip_set_medium_properties": (i32, [vp, vp]),

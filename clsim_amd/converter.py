@@ -380,6 +380,12 @@ class I3CLSimStepToPhotonConverterHIP:
         self._lib.clsimhip_get_table(self._h, name.encode(), _dp(out), n)
         return out
 
+    def KernelForBunch(self, n_steps):
+        """'pool' or 'classic': the scheduling the propagation kernel runs with for a bunch of n_steps steps"""
+        v = C.c_int32()
+        self._call("clsimhip_kernel_for_bunch", int(n_steps), C.byref(v))
+        return "pool" if v.value else "classic"
+
     def UsesPooledKernel(self):
         v = C.c_int32()
         self._call("clsimhip_uses_pooled_kernel", C.byref(v))

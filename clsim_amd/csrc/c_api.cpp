@@ -202,9 +202,30 @@ int clsimhip_set_device(clsimhip_converter *c, int device_ordinal)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.set_device(device_ordinal); });
 }
+int clsimhip_comm_get_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES])
+{
+    return guarded(nullptr, [&] { need(id, "id"); comm_unique_id(id); });
+}
+int clsimhip_comm_create(int device_ordinal, int rank, int world_size, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES], clsimhip_comm **out)
+{
+    return guarded(nullptr, [&] { need(out, "out"); *out = reinterpret_cast<clsimhip_comm *>(comm_create(device_ordinal, rank, world_size, id)); });
+}
+void clsimhip_comm_destroy(clsimhip_comm *comm) { comm_destroy(reinterpret_cast<Comm *>(comm)); }
+int clsimhip_gather_hits(clsimhip_comm *comm, const void *d_photons, const void *d_hit_count, size_t capacity, int root,
+                         void *d_gathered, size_t gathered_capacity, uint64_t *counts_out, void *hip_stream)
+{
+    return guarded(nullptr, [&] {
+        comm_gather_hits(reinterpret_cast<Comm *>(comm), d_photons, d_hit_count, capacity, root, d_gathered, gathered_capacity, counts_out,
+                         static_cast<hipStream_t>(hip_stream));
+    });
+}
 int clsimhip_uses_pooled_kernel(const clsimhip_converter *c, int *out)
 {
     return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.uses_pooled_kernel() ? 1 : 0; });
+}
+int clsimhip_kernel_for_bunch(const clsimhip_converter *c, size_t n_steps, int *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.pooled_for(n_steps) ? 1 : 0; });
 }
 int clsimhip_get_device(const clsimhip_converter *c, int *out)
 {

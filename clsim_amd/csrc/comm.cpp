@@ -1,0 +1,181 @@
+// Multi-GPU gather of detected photons behind the C ABI (BASELINE.json: "RCCL gather of hit photons
+// over xGMI").  The propagation itself shards with no exchange -- contiguous step ranges per GPU, every GPU with its
+// own RNG streams and photon buffer -- so the only collective is the gather of the results on one rank:
+//   1. ncclAllGather of the ranks' hit counts (4 bytes each),
+//   2. one point-to-point transfer per peer inside ncclGroupStart/End: 7 peers -> 7 distinct xGMI links, no ring
+//      (a ring all-gather would push every rank's photons over every link).
+// The reference has no counterpart: its multi-device model is a vector of independent converters behind
+// I3CLSimServer (private/clsim/I3CLSimServer.cxx:77-137), results collected by host threads.
+//
+// RCCL is loaded at run time (dlopen), not linked: a host process that already carries an RCCL (PyTorch ships one)
+// keeps its single instance, and a host without multi-GPU use never loads it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "converter.h"
+
+namespace clsimhip {
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    static std::string error;
+    std::call_once(once, [] {
+        std::vector<std::string> names;
+        if (const char *e = std::getenv("CLSIMHIP_RCCL_LIBRARY")) names.push_back(e);
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string &n : names) {
+            r.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { error = std::string("cannot load RCCL: ") + dlerror(); return; }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.handle, name);
+            if (!p && error.empty()) error = std::string("RCCL symbol missing: ") + name;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    if (!error.empty()) throw Error(CLSIMHIP_ERR_DEVICE, error);
+    return r;
+}
+
+void nccl_check(ncclResult_t e, const char *what)
+{
+    if (e != ncclSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + rccl().GetErrorString(e));
+}
+void hip_ok(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+} // namespace
+
+struct Comm {
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    uint32_t *d_counts = nullptr;       // world counts, device
+    uint32_t *h_counts = nullptr;       // pinned
+    hipEvent_t counted = nullptr;
+};
+
+void comm_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == CLSIMHIP_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    nccl_check(rccl().GetUniqueId(&u), "ncclGetUniqueId");
+    std::memcpy(id, &u, sizeof u);
+}
+
+Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES])
+{
+    if (world < 1 || rank < 0 || rank >= world) throw Error(CLSIMHIP_ERR_ARGUMENT, "rank / world size out of range");
+    if (!id) throw Error(CLSIMHIP_ERR_ARGUMENT, "unique id is (null)");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");
+    if (device < 0 || device >= count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device ordinal out of range");
+    DeviceGuard on_device(device);
+    std::unique_ptr<Comm> c(new Comm);
+    c->device = device; c->rank = rank; c->world = world;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    nccl_check(rccl().CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
+    hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_counts), sizeof(uint32_t) * static_cast<size_t>(world)), "hipMalloc");
+    hip_ok(hipHostMalloc(reinterpret_cast<void **>(&c->h_counts), sizeof(uint32_t) * static_cast<size_t>(world), hipHostMallocDefault), "hipHostMalloc");
+    hip_ok(hipEventCreateWithFlags(&c->counted, hipEventDisableTiming), "hipEventCreate");
+    return c.release();
+}
+
+void comm_destroy(Comm *c)
+{
+    if (!c) return;
+    int previous = -1;
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    (void)hipFree(c->d_counts);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->counted) (void)hipEventDestroy(c->counted);
+    if (previous >= 0) (void)hipSetDevice(previous);
+    delete c;
+}
+
+// Blocks the calling thread only until the hit counts are known (the kernel that produced them must have finished
+// anyway); the payload transfers are left running on `stream`.
+void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, size_t capacity, int root, void *d_gathered,
+                      size_t gathered_capacity, uint64_t *counts_out, hipStream_t stream)
+{
+    if (!c) throw Error(CLSIMHIP_ERR_ARGUMENT, "communicator is (null)");
+    if (!d_photons || !d_hit_count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device pointers are (null)");
+    if (root < 0 || root >= c->world) throw Error(CLSIMHIP_ERR_ARGUMENT, "root rank out of range");
+    if (c->rank == root && !d_gathered) throw Error(CLSIMHIP_ERR_ARGUMENT, "the root needs a gather buffer");
+    DeviceGuard on_device(c->device);
+    const Rccl &R = rccl();
+    nccl_check(R.AllGather(d_hit_count, c->d_counts, 1, ncclUint32, c->comm, stream), "ncclAllGather (hit counts)");
+    hip_ok(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t) * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, stream), "download hit counts");
+    hip_ok(hipEventRecord(c->counted, stream), "event");
+    hip_ok(hipEventSynchronize(c->counted), "hit counts");
+    // The kernel's counter keeps counting past the capacity of the photon buffer (propagation_kernel.c.cl:329-334);
+    // a rank sends what it stored.  Every rank clamps every count the same way (equal capacities per rank).
+    std::vector<size_t> stored(static_cast<size_t>(c->world));
+    size_t total = 0;
+    for (int r = 0; r < c->world; ++r) {
+        stored[r] = std::min<size_t>(c->h_counts[r], capacity);
+        if (counts_out) counts_out[r] = c->h_counts[r];
+        total += stored[r];
+    }
+    if (c->rank == root && total > gathered_capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "gather buffer too small for the detected photons of all ranks");
+    constexpr size_t kRecord = sizeof(clsimhip_photon);
+    if (c->world > 1) {
+        nccl_check(R.GroupStart(), "ncclGroupStart");
+        if (c->rank == root) {
+            size_t offset = 0;
+            for (int r = 0; r < c->world; ++r) {
+                if (r != root && stored[r] != 0)
+                    nccl_check(R.Recv(static_cast<uint8_t *>(d_gathered) + offset * kRecord, stored[r] * kRecord, ncclUint8, r, c->comm, stream), "ncclRecv");
+                offset += stored[r];
+            }
+        } else if (stored[c->rank] != 0) {
+            nccl_check(R.Send(d_photons, stored[c->rank] * kRecord, ncclUint8, root, c->comm, stream), "ncclSend");
+        }
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
+    }
+    if (c->rank == root && stored[root] != 0) {
+        size_t offset = 0;
+        for (int r = 0; r < root; ++r) offset += stored[r];
+        hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(d_gathered) + offset * kRecord, d_photons, stored[root] * kRecord, hipMemcpyDeviceToDevice, stream),
+               "copy the root's own photons");
+    }
+}
+
+} // namespace clsimhip

@@ -22,8 +22,7 @@ constexpr size_t kPooledKernelMinSteps = 786432;
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
-    const bool pooled = use_pool_ && (P.n_steps >= pool_min_steps_);
-    return pooled ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
+    return pooled_for(P.n_steps) ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
 }
 
 void Converter::hip_check(hipError_t e, const char *what) const

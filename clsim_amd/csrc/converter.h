@@ -33,6 +33,14 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
 size_t prop_kernel_max_lanes();
 size_t prop_kernel_lds_budget();
 
+// RCCL gather of detected photons (comm.cpp)
+struct Comm;
+void comm_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
+Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
+void comm_destroy(Comm *c);
+void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, size_t capacity, int root, void *d_gathered,
+                      size_t gathered_capacity, uint64_t *counts_out, hipStream_t stream);
+
 // Result of Compile(): kernel parameters without buffer pointers, the LDS image,
 // the DOM templates and the named tables the parity tests read back.
 struct CompiledTables {
@@ -165,6 +173,7 @@ public:
     // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
     void set_device(int device);
     int device() const { return device_; }
+    bool pooled_for(size_t n_steps) const { need_init(); return use_pool_ && n_steps >= pool_min_steps_; }
     bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
 
 private:

@@ -12,9 +12,18 @@ counts followed by one direct send per peer to the root, posted as ONE batch
 (ncclGroupStart/End under torch's batch_isend_irecv) so that the 7 transfers run
 on their 7 links at once; a ring would only add hops.  The same code runs on CPU
 tensors over gloo (tests/test_distributed.py).
+
+The product path is `HitGatherer`: the same gather behind the C ABI (clsimhip_comm_create / clsimhip_gather_hits in
+include/clsimhip.h, RCCL called directly from C++), which is what a C++/IceTray host uses -- it has no torch.
+`gather_hits` below is the same plan on torch tensors; it carries the N>1 logic tests over gloo on CPU.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_range(n_total, rank, world):
@@ -31,6 +40,9 @@ def gather_hits(photons, count, dst=0, out=None, group=None):
     provide a preallocated [>= total, 80] buffer on dst."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    # the kernel's hit counter keeps counting past the buffer's capacity (propagation_kernel.c.cl:329-334): a rank
+    # sends what it stored, and announces that number, so the root's receives match the sends
+    count = min(int(count), int(photons.shape[0]))
     mine = torch.as_tensor([int(count)], dtype=torch.int64, device=photons.device)
     counts = torch.zeros(world, dtype=torch.int64, device=photons.device)
     dist.all_gather_into_tensor(counts, mine, group=group)
@@ -56,3 +68,53 @@ def gather_hits(photons, count, dst=0, out=None, group=None):
         for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, photons[:int(c[rank])].contiguous(), dst, group)]):
             r.wait()
     return None, c
+
+
+class HitGatherer:
+    """RCCL gather of detected photons through the C ABI (one instance per rank / GPU)."""
+
+    def __init__(self, device, rank, world, unique_id):
+        self._lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        rc = self._lib.clsimhip_comm_create(int(device), self.rank, self.world, C.cast(buf, C.c_void_p), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError((self._lib.clsimhip_last_error(None) or b"").decode())
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        if lib.clsimhip_comm_get_unique_id(C.cast(buf, C.c_void_p)) != 0:
+            raise RuntimeError((lib.clsimhip_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        """Rank 0 creates the RCCL unique id, torch.distributed carries it to the other ranks."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(device, rank, world, box[0])
+
+    def gather(self, d_photons, d_hit_count, capacity, root=0, d_gathered=0, gathered_capacity=0, stream=0):
+        """Device pointers (ints).  Returns the ranks' hit counters (numpy uint64); the transfers may still be running
+        on `stream` when this returns."""
+        counts = np.zeros(self.world, dtype=np.uint64)
+        rc = self._lib.clsimhip_gather_hits(self._h, C.c_void_p(d_photons), C.c_void_p(d_hit_count), int(capacity), int(root),
+                                            C.c_void_p(d_gathered), int(gathered_capacity), counts.ctypes.data_as(C.c_void_p), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError((self._lib.clsimhip_last_error(None) or b"").decode())
+        return counts
+
+    def close(self):
+        if self._h:
+            self._lib.clsimhip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

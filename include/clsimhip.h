@@ -252,10 +252,34 @@ int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_phot
  * the last call with reset!=0, measured with HIP events on the launch stream */
 int clsimhip_kernel_time_ms(clsimhip_converter *c, int reset, double *total_ms, uint64_t *launches);
 
+/* ---- multi-GPU: gather of detected photons over RCCL / xGMI (no reference counterpart, the reference
+ * collects the results of its per-device converters with host threads, I3CLSimServer.cxx:77-137) ----
+ * One process (or thread) per GPU: each propagates a contiguous shard of the steps with clsimhip_propagate_device and
+ * its own streams -- no exchange -- then the ranks' photons are gathered on `root`, rank by rank.  RCCL is loaded at
+ * run time (dlopen; CLSIMHIP_RCCL_LIBRARY overrides the name): no link-time dependency. */
+#define CLSIMHIP_UNIQUE_ID_BYTES 128
+typedef struct clsimhip_comm clsimhip_comm;
+/* ncclGetUniqueId: called by one rank; the host application hands the bytes to the others (MPI, ZMQ, a file ...) */
+int clsimhip_comm_get_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
+/* ncclCommInitRank on HIP device `device_ordinal`; collective: every rank of the job calls it */
+int clsimhip_comm_create(int device_ordinal, int rank, int world_size, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES], clsimhip_comm **out);
+void clsimhip_comm_destroy(clsimhip_comm *comm);
+/* Collective.  d_photons / d_hit_count: this rank's photon buffer (`capacity` records) and uint32 hit counter as
+ * clsimhip_propagate_device left them.  On `root`, d_gathered (room for gathered_capacity records) receives rank 0's
+ * photons, then rank 1's ...; counts_out[world_size] (host, every rank, may be NULL) receives the ranks' hit counters
+ * (a rank transfers min(counter, capacity) records).  Ordered after the work already queued on `hip_stream`; returns
+ * once the counts are known -- the transfers (ncclAllGather of the counts, then one ncclSend/ncclRecv per peer in one
+ * group: every peer uses its own xGMI link to the root) may still be running on `hip_stream`. */
+int clsimhip_gather_hits(clsimhip_comm *comm, const void *d_photons, const void *d_hit_count, size_t capacity, int root,
+                         void *d_gathered, size_t gathered_capacity, uint64_t *counts_out, void *hip_stream);
+
 /* ---- introspection used by the parity tests ---- */
-/* which scheduling the propagation kernel runs with (after Initialize): 1 = per-wave photon pools
- * (prop_pool_kernel.hip), 0 = one photon per lane (prop_kernel.hip: photon histories, very large table images).
- * Results do not depend on it.  CLSIMHIP_KERNEL=pool|classic in the environment overrides the default. */
+/* Which scheduling the propagation kernel runs with (after Initialize): 1 = per-wave photon pools
+ * (prop_pool_kernel.hip), 0 = one photon per lane (prop_kernel.hip).  Chosen per launch: pools for bunches large
+ * enough to fill them (>= 786432 steps), never with photon histories or a table image that leaves the pools no LDS.
+ * Results do not depend on it.  CLSIMHIP_KERNEL=pool|classic in the environment forces one for every bunch size
+ * (clsimhip_uses_pooled_kernel then reports 1 / 0), CLSIMHIP_POOL_MIN_STEPS moves the threshold. */
+int clsimhip_kernel_for_bunch(const clsimhip_converter *c, size_t n_steps, int *out);
 int clsimhip_uses_pooled_kernel(const clsimhip_converter *c, int *out);
 /* copies the compiled table `name` (e.g. "geoStringPosX", "aDust400") converted to
  * double into out[0..cap); returns the entry count or a negative status */

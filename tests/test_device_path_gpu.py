@@ -221,3 +221,33 @@ def test_overflow_keeps_counting(kernel, monkeypatch):
     assert int(cnt.item()) > cap
     assert int(out[cap:].sum().item()) == 0
     assert int((out[:cap].sum(dim=1) == 0).sum().item()) == 0
+
+
+def test_rccl_gather_through_the_c_abi_world_of_one():
+    """clsimhip_comm_create / clsimhip_gather_hits (RCCL called from C++, no torch.distributed): a world of one rank
+    exercises the whole path on a single GPU -- unique id, communicator, ncclAllGather of the counts, the root's own
+    copy -- including a counter that ran past the photon buffer's capacity."""
+    from clsim_amd.distributed import HitGatherer
+    cfg = common.config("flasher")
+    n = 2048
+    steps = common.steps_for(cfg, n, seed=3)
+    conv = common.product_converter(cfg, n)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+    gatherer = HitGatherer(0, 0, 1, HitGatherer.unique_id())
+    for cap in (1 << 16, 100):
+        out = torch.zeros((cap, 80), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        gathered = torch.zeros((cap, 80), dtype=torch.uint8, device=dev)
+        conv2 = common.product_converter(cfg, n)
+        conv2.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=stream)
+        counts = gatherer.gather(out.data_ptr(), cnt.data_ptr(), cap, 0, gathered.data_ptr(), cap, stream)
+        torch.cuda.synchronize()
+        hits = int(cnt.item())
+        assert counts.tolist() == [hits] and hits > 1000
+        k = min(hits, cap)
+        assert torch.equal(gathered[:k], out[:k])
+        if k < cap:
+            assert int(gathered[k:].sum().item()) == 0
+    gatherer.close()

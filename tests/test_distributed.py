@@ -45,6 +45,12 @@ def _worker(rank, world, port, counts, q):
                 assert np.array_equal(got.numpy(), exp)
             else:
                 assert got is None
+        # a counter that ran past the buffer's capacity: the stored rows travel, no hang
+        buf = torch.from_numpy(_fake_hits(rank + 100, 64))
+        got, c = gather_hits(buf, 64 + 1000 * (rank + 1), dst=0)
+        assert c.tolist() == [64] * world
+        if rank == 0:
+            assert np.array_equal(got.numpy(), np.concatenate([_fake_hits(r + 100, 64) for r in range(world)], axis=0))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
