@@ -161,7 +161,7 @@ def tabulator_bench(args, torch, device):
         out["cpu_baseline"] = {"value": done / dt, "unit": "photons/s", "cores": cores, "kind": "port",
                                "sample": "%d steps x 8 photons (%d path samples) in %.1f s, %d threads; the reference runs this kernel "
                                          "as ONE work item (StepToTableConverter.cxx:259)" % (m, int(num.sum()), dt, cores)}
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 def host_path_run(CV, args, steps_np, conv, bunches):
@@ -193,8 +193,23 @@ def host_path_run(CV, args, steps_np, conv, bunches):
 WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
+def emit(line):
+    """The one JSON line goes to the process's ORIGINAL stdout (see main)."""
+    os.write(JSON_FD, (line + "\n").encode())
+
+
+JSON_FD = 1
+
+
 def main():
+    global JSON_FD
     args = parse()
+    # Native libraries print banners to the C stdout (RCCL: version / library path at communicator creation, flushed at
+    # exit): file descriptor 1 becomes stderr for everything but the result line, which is written to a duplicate of
+    # the original stdout.
+    sys.stdout.flush()
+    JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         # the checker's library is built (a `make` child process) BEFORE anything initialises the GPU: a GPU-initialised
         # process must not spawn build tools under a profiler's preload
@@ -244,7 +259,7 @@ def main():
 
     if args.host_path:
         hp = host_path_run(CV, args, steps_np, conv, max(args.steps, 1))
-        print(json.dumps({"metric": "propagated photons/sec through EnqueueSteps/GetConversionResult (host buffers)",
+        emit(json.dumps({"metric": "propagated photons/sec through EnqueueSteps/GetConversionResult (host buffers)",
                           "value": hp["value"], "unit": "photons/s", "n_gpus": 1, "steps": hp["bunches"], "warmup": 1,
                           "ms_per_step": 1e3 * hp["seconds"] / hp["bunches"], "host_path": hp,
                           "config": {"workload": WORKLOAD_NAMES[args.workload], "steps_per_bunch": n}}))
@@ -363,7 +378,7 @@ def main():
                        "kind": {"c2": "cascade steps", "c3": "cascade steps", "c5": "flasher steps (405 nm point source at a DOM)"}[args.workload],
                        "ice_layers": 171, "doms": 5160,
                        "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
-                       "hit_gather": "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if world > 1 else "none",
+                       "hit_gather": "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if use_gather else "none",
                        "hits_last_pass_rank0": hits_last, "hit_counter_last_pass_rank0": counted_last,
                        "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
                        "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0)},
@@ -384,7 +399,7 @@ def main():
             del conv2
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if gatherer is not None:
         gatherer.close()
     if world > 1:

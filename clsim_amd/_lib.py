@@ -81,6 +81,8 @@ SYMBOLS = [
     "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
     "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
     "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device", "clsimhip_uses_pooled_kernel", "clsimhip_kernel_for_bunch",
+    "clsimhip_step_series_blob_size", "clsimhip_encode_step_series", "clsimhip_decode_step_series",
+    "clsimhip_photon_series_blob_size", "clsimhip_encode_photon_series", "clsimhip_decode_photon_series", "clsimhip_encode_portable_uint",
     "clsimhip_comm_get_unique_id", "clsimhip_comm_create", "clsimhip_comm_destroy", "clsimhip_gather_hits",
     "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
     "clsimhip_set_geometry_from_text_file",
@@ -138,6 +140,13 @@ def load():
         "clsimhip_get_device": (i32, [vp, C.POINTER(i32)]),
         "clsimhip_uses_pooled_kernel": (i32, [vp, C.POINTER(i32)]),
         "clsimhip_kernel_for_bunch": (i32, [vp, sz, C.POINTER(i32)]),
+        "clsimhip_step_series_blob_size": (i32, [sz, C.POINTER(sz)]),
+        "clsimhip_encode_step_series": (i32, [vp, sz, vp, sz, C.POINTER(sz)]),
+        "clsimhip_decode_step_series": (i32, [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_photon_series_blob_size": (i32, [sz, C.POINTER(sz)]),
+        "clsimhip_encode_photon_series": (i32, [vp, sz, vp, sz, C.POINTER(sz)]),
+        "clsimhip_decode_photon_series": (i32, [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "clsimhip_encode_portable_uint": (i32, [u64, vp, C.POINTER(sz)]),
         "clsimhip_comm_get_unique_id": (i32, [vp]),
         "clsimhip_comm_create": (i32, [i32, i32, i32, vp, C.POINTER(vp)]),
         "clsimhip_comm_destroy": (None, [vp]),

@@ -202,6 +202,34 @@ int clsimhip_set_device(clsimhip_converter *c, int device_ordinal)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.set_device(device_ordinal); });
 }
+int clsimhip_step_series_blob_size(size_t n, size_t *bytes)
+{
+    return guarded(nullptr, [&] { need(bytes, "bytes"); *bytes = series_blob_size(n, sizeof(clsimhip_step)); });
+}
+int clsimhip_encode_step_series(const clsimhip_step *steps, size_t n, uint8_t *out, size_t capacity, size_t *written)
+{
+    return guarded(nullptr, [&] { series_encode(steps, n, sizeof(clsimhip_step), 0u, out, capacity, written); });
+}
+int clsimhip_decode_step_series(const uint8_t *blob, size_t bytes, clsimhip_step *steps_out, size_t capacity, size_t *n, size_t *consumed)
+{
+    return guarded(nullptr, [&] { series_decode(blob, bytes, sizeof(clsimhip_step), 0u, "I3CLSimStep", steps_out, capacity, n, consumed); });
+}
+int clsimhip_photon_series_blob_size(size_t n, size_t *bytes)
+{
+    return guarded(nullptr, [&] { need(bytes, "bytes"); *bytes = series_blob_size(n, sizeof(clsimhip_photon)); });
+}
+int clsimhip_encode_photon_series(const clsimhip_photon *photons, size_t n, uint8_t *out, size_t capacity, size_t *written)
+{
+    return guarded(nullptr, [&] { series_encode(photons, n, sizeof(clsimhip_photon), 0u, out, capacity, written); });
+}
+int clsimhip_decode_photon_series(const uint8_t *blob, size_t bytes, clsimhip_photon *photons_out, size_t capacity, size_t *n, size_t *consumed)
+{
+    return guarded(nullptr, [&] { series_decode(blob, bytes, sizeof(clsimhip_photon), 0u, "I3CLSimPhoton", photons_out, capacity, n, consumed); });
+}
+int clsimhip_encode_portable_uint(uint64_t value, uint8_t out[9], size_t *written)
+{
+    return guarded(nullptr, [&] { need(out, "out"); need(written, "written"); *written = portable_uint_encode(value, out); });
+}
 int clsimhip_comm_get_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES])
 {
     return guarded(nullptr, [&] { need(id, "id"); comm_unique_id(id); });

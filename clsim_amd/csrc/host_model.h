@@ -123,4 +123,12 @@ void mwc_multipliers(uint32_t *out, size_t count);
 void seed_streams(const uint32_t *a, size_t count, uint64_t seed, uint64_t *x);
 bool load_multipliers_from_file(const char *path, uint32_t *a, size_t count);
 
+// wire.cpp: portable-binary-archive payload of I3Vector<I3CLSimStep> / I3Vector<I3CLSimPhoton>
+size_t portable_uint_encode(uint64_t v, uint8_t out[9]);
+size_t portable_uint_decode(const uint8_t *in, size_t bytes, uint64_t *v);
+size_t series_blob_size(size_t n, size_t record);
+void series_encode(const void *records, size_t n, size_t record, unsigned version, uint8_t *out, size_t cap, size_t *written);
+void series_decode(const uint8_t *in, size_t bytes, size_t record, unsigned version, const char *class_name, void *out, size_t cap,
+                   size_t *n_out, size_t *consumed);
+
 } // namespace clsimhip

@@ -252,6 +252,23 @@ int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_phot
  * the last call with reset!=0, measured with HIP events on the launch stream */
 int clsimhip_kernel_time_ms(clsimhip_converter *c, int reset, double *total_ms, uint64_t *launches);
 
+/* ---- wire format of step and photon series ------------------------------------------------
+ * Payload of I3Vector<I3CLSimStep>::serialize / I3Vector<I3CLSimPhoton>::serialize for the portable binary archive
+ * (private/clsim/I3CLSimStep.cxx:111-147, private/clsim/I3CLSimPhoton.cxx:141-168), the messages of I3CLSimServer /
+ * I3CLSimClient (I3CLSimServer.cxx:320, 339, 386, 408): class version (0), number of records, then the records as one
+ * little-endian blob -- from the class version on.  The archive framing around it (stream header, object tracking
+ * records of the shared_ptr and of the I3FrameObject base) belongs to icecube::serialization, which is not part of the
+ * reference tree; integers use that archive's published encoding (count byte + little-endian bytes). */
+int clsimhip_step_series_blob_size(size_t n, size_t *bytes);
+int clsimhip_encode_step_series(const clsimhip_step *steps, size_t n, uint8_t *out, size_t capacity, size_t *written);
+/* *n = number of steps in the blob; steps_out may be NULL to ask for the count; *consumed (may be NULL) = bytes read */
+int clsimhip_decode_step_series(const uint8_t *blob, size_t bytes, clsimhip_step *steps_out, size_t capacity, size_t *n, size_t *consumed);
+int clsimhip_photon_series_blob_size(size_t n, size_t *bytes);
+int clsimhip_encode_photon_series(const clsimhip_photon *photons, size_t n, uint8_t *out, size_t capacity, size_t *written);
+int clsimhip_decode_photon_series(const uint8_t *blob, size_t bytes, clsimhip_photon *photons_out, size_t capacity, size_t *n, size_t *consumed);
+/* the archive's unsigned integer encoding itself (out: up to 9 bytes) */
+int clsimhip_encode_portable_uint(uint64_t value, uint8_t out[9], size_t *written);
+
 /* ---- multi-GPU: gather of detected photons over RCCL / xGMI (no reference counterpart, the reference
  * collects the results of its per-device converters with host threads, I3CLSimServer.cxx:77-137) ----
  * One process (or thread) per GPU: each propagates a contiguous shard of the steps with clsimhip_propagate_device and

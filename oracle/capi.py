@@ -100,10 +100,24 @@ def build():
     subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
 
 
+def use_variant(name):
+    """ANALYSIS ONLY (tools/math_sensitivity.py): switch to another build of the restatement -- "liboracle_libm.so"
+    (glibc math instead of the deterministic header) or "liboracle_libm_mad.so" (+ fused multiply-adds) -- or back to
+    None = the checker.  The parity tests never call this."""
+    global _lib, _variant
+    if name is not None:
+        subprocess.check_call(["make", "-s", "-C", HERE, name])
+    _variant = name
+    _lib = None
+
+
+_variant = None
+
+
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.path.join(HERE, _variant or "liboracle.so")
         if not os.path.exists(path):
             build()
         _lib = C.CDLL(path)

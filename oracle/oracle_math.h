@@ -253,4 +253,29 @@ OM_INLINE float om_acos_f(float x)
     return (x < 0.0f) ? (1.5707963267948966f + a) : (1.5707963267948966f - a);
 }
 
+/* ---- ORACLE_LIBM (analysis build, tools/math_sensitivity.py): a DIFFERENT conforming math library -------------------
+ * The deterministic functions above are this repository's definition of the OpenCL builtins; the reference kernel
+ * runs on whatever the OpenCL runtime provides (a few ulp, unpinned).  With -DORACLE_LIBM the kernel-facing names are
+ * mapped to glibc's single precision functions instead, so that the physics effect of "another conforming math
+ * library" can be measured by comparing two runs of the same restatement.  Never used by the parity tests. */
+#ifdef ORACLE_LIBM
+#include <math.h>
+OM_INLINE float om_libm_log(float x) { return logf(x); }
+OM_INLINE float om_libm_exp(float x) { return expf(x); }
+OM_INLINE float om_libm_powr(float x, float y) { return powf(x, y); }
+OM_INLINE void om_libm_sincos(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
+OM_INLINE float om_libm_sin(float x) { return sinf(x); }
+OM_INLINE float om_libm_cos(float x) { return cosf(x); }
+OM_INLINE float om_libm_atan2(float y, float x) { return atan2f(y, x); }
+OM_INLINE float om_libm_acos(float v) { return acosf(v); }
+#define om_log om_libm_log
+#define om_exp om_libm_exp
+#define om_powr om_libm_powr
+#define om_sincos om_libm_sincos
+#define om_sin om_libm_sin
+#define om_cos om_libm_cos
+#define om_atan2 om_libm_atan2
+#define om_acos om_libm_acos
+#endif
+
 #endif
