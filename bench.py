@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--host-path", action="store_true",
                     help="time EnqueueSteps -> GetConversionResult instead (host buffers, PCIe transfers and the index->ID "
                          "conversion included, double buffering on); NOT the headline value, see DESIGN.md 6")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the host_path object (profile passes: counters then cover the timed launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -389,7 +391,7 @@ def main():
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / (avg_ms * 1e-3))},
         }
-        if world == 1:
+        if world == 1 and not args.no_host_path:
             # the reference's "actual" metric, outside the timed region of `value`: a second converter with two buffer sets
             del d_photons, d_count
             torch.cuda.empty_cache()

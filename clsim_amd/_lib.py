@@ -96,7 +96,7 @@ SYMBOLS = [
     "clsimhip_get_workgroup_size", "clsimhip_get_max_num_workitems", "clsimhip_queue_size",
     "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
-    "clsimhip_eval_math", "clsimhip_version",
+    "clsimhip_eval_math", "clsimhip_check_math_exhaustive", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
     "clsimhip_count_flasher_steps", "clsimhip_generate_flasher_steps_device", "clsimhip_generate_flasher_steps",
     "clsimhip_flasher_time_profile",
@@ -186,6 +186,7 @@ def load():
         "clsimhip_get_table": (C.c_long, [vp, C.c_char_p, DP, sz]),
         "clsimhip_get_rng_state": (i32, [vp, vp, sz]),
         "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
+        "clsimhip_check_math_exhaustive": (i32, [i32, i32, i32, i32, vp, sz]),
         "clsimhip_version": (C.c_char_p, []),
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),

@@ -427,6 +427,24 @@ int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float
         chk(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
     });
 }
+int clsimhip_check_math_exhaustive(int device_ordinal, int what, int exp_lo, int exp_hi, uint32_t *result, size_t result_cap)
+{
+    return guarded(nullptr, [&] {
+        need(result, "result");
+        if (what < 11 || what > 13 || exp_lo < -126 || exp_hi > 127 || exp_lo > exp_hi || result_cap < 1 || result_cap > 4096)
+            throw Error(CLSIMHIP_ERR_CONFIG, "clsimhip_check_math_exhaustive: what in 11..13, -126 <= exp_lo <= exp_hi <= 127, 1 <= result_cap <= 4096");
+        auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");
+        DeviceGuard on_device(device_ordinal);
+        DeviceBuffer buf;
+        buf.alloc(result_cap * 4, "hipMalloc");
+        chk(hipMemset(buf.as<uint32_t>(), 0, result_cap * 4), "hipMemset");
+        chk(launch_check_math(what, exp_lo, exp_hi, buf.as<uint32_t>(), static_cast<uint32_t>(result_cap), nullptr), "check_math launch");
+        chk(hipDeviceSynchronize(), "check_math");
+        chk(hipMemcpy(result, buf.as<uint32_t>(), result_cap * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+    });
+}
 
 
 // ---- step producer ----

@@ -22,6 +22,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
 bool pool_kernel_fits(uint32_t table_words);
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
+hipError_t launch_check_math(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
 int prop_kernel_block_size();
 hipError_t launch_generate_flasher_steps(const clsimhip_flasher_config &cfg, const clsimhip_flasher_request *d_requests, const void *d_plan,

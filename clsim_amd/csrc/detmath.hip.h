@@ -23,8 +23,43 @@ DM float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DM float sqrt_(float a) { return __builtin_sqrtf(a); }
 DM float rsqrt_(float a) { return 1.0f / __builtin_sqrtf(a); }
 DM float rint_(float a) { return __builtin_rintf(a); }
+
 DM uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 DM float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---- correctly rounded 1/x and sqrt(x) for arguments in a known range ----
+// hipcc's IEEE sequences (-fhip-fp32-correctly-rounded-divide-sqrt) carry range scaling (v_div_scale x2, or a scale /
+// unscale pair around v_sqrt), a second quotient refinement and a special-case fix-up: 11 instructions per divide, 16 per
+// square root.  Where the argument is known to be finite and far from the ends of the exponent range the same correctly
+// rounded result takes fewer:
+//   rcp_: v_rcp_f32 (<= 1 ulp) + one Newton step in fma arithmetic.  The step's exact value is (1/x)(1 - d^2) with
+//       d <= 2^-23 the relative error of v_rcp_f32, so it rounds to RN(1/x) unless 1/x lies within 2^-46 of a rounding
+//       boundary, which only a handful of significands can (the classic one: all ones).  Whether any of them is missed
+//       depends on the hardware's v_rcp_f32, so it is not argued, it is TESTED: clsimhip_check_math_exhaustive runs all
+//       2^23 significands x every exponent in [-100, 100] x both signs on the device against the IEEE divide
+//       (tests/test_detmath_gpu.py): gfx950 misses none.  |x| in [2^-100, 2^100]; garbage (never a trap) outside.
+//   sqrt_near_: v_sqrt_f32 (<= 1 ulp) + the compiler's own +-1 ulp residual selection, without the scaling (arguments
+//       >= 2^-96 need none) and without the class fix-up for inf / NaN (finite arguments).  Zero stays zero.
+//       x = 0 or x in [2^-96, 2^100]; same exhaustive test.
+//   rsqrt_near_: their composition (the reference's rsqrt is 1/sqrt here: oracle_math.h).
+// Results are RN(1/x) and RN(sqrt x): the x86 side computes them with the IEEE divide / sqrt.
+DM float rcp_(float x)
+{
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e0 = fma_(-x, r0, 1.0f);
+    return fma_(e0, r0, r0);
+}
+DM float sqrt_near_(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = u2f(f2u(s) - 1u), s_up = u2f(f2u(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x);            // x - s_dn * s <= 0: s is too large, take s_dn
+    const float r_up = fma_(-s_up, s, x);            // x - s_up * s > 0: s is too small, take s_up
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+DM float rsqrt_near_(float x) { return rcp_(sqrt_near_(x)); }
 
 constexpr float LN2_HI = 0.693359375f;
 constexpr float LN2_LO = -2.12194440e-4f;

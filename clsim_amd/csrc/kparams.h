@@ -129,7 +129,7 @@ struct KParams {
     // Compile() proves it per divisor by trying every significand of a; bit set = proven, else the kernel
     // keeps the IEEE divide.  3 VALU instructions instead of ~11.
     float rcp_tilt_dz, rcp_layer_thickness, rcp_mix_frac, rcp_mix_frac_rest, rcp_hg_two_g;
-    uint32_t div_ok;                    // bit 0 tilt_dz, 1 layer_thickness, 2 mix_frac, 3 mix_frac_rest, 4 hg_two_g
+    uint32_t div_ok;                    // bit 0 tilt_dz, 1 layer_thickness, 2 mix_frac, 3 mix_frac_rest, 4 hg_two_g, 5 lengths within [1e-15, 1e15] (dm::rcp_ allowed)
 
     // ---- spectra ----
     int32_t num_gen;

@@ -79,6 +79,10 @@ DM float div_by(float a, float b, float r, bool ok)
     }
     return a / b;
 }
+// 1/x: dm::rcp_ (3 instructions, RN(1/x) for |x| in [2^-100, 2^100]) where Compile() bounded the argument (`fast`,
+// wave-uniform), the IEEE divide otherwise
+DM float rcp_sel(float x, bool fast) { return fast ? dm::rcp_(x) : 1.0f / x; }
+constexpr uint32_t kFastLengths = 32u, kFastMatrices = 64u, kFastAniso = 128u;      // KParams::div_ok bits 5-7
 DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 
@@ -145,7 +149,7 @@ DM IceFactors ice_factors(KP P, float wlen)
 // scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100,
 // FunctionFromTable.cxx:262-291 behind the switch(layer) of MediumPropertiesSource.cxx:89-123)
 template <int MED>
-DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len)
+DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len, bool fast)
 {
     if (MED == CLSIMHIP_LENGTHS_TABLE) {
         const float4 r = *reinterpret_cast<const float4 *>(len_table + 4u * (__builtin_bit_cast(uint32_t, f.abs_pow) + (uint32_t)layer));
@@ -155,8 +159,8 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
     }
     const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
     if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
-        sca_len = 1.0f / (r.c * f.sca_pow);
-        abs_len = 1.0f / (r.a * f.abs_pow + f.abs_exp * r.b);
+        sca_len = rcp_sel(r.c * f.sca_pow, fast);
+        abs_len = rcp_sel(r.a * f.abs_pow + f.abs_exp * r.b, fast);
     } else {
         sca_len = r.c;
         abs_len = r.a;
@@ -193,17 +197,20 @@ DM float abs_len_corr(KP P, const Vec3 &d)
     // dot(float4,float4) with a zero 4th component: the +0 term cannot change a sum of squares
     const float nB = (s0 * P->an_rl[0] + s1 * P->an_rl[1]) + s2 * P->an_rl[2];
     const float An = (s0 * P->an_l[0] + s1 * P->an_l[1]) + s2 * P->an_l[2];
-    return 2.0f / ((P->an_B2 - nB) * An);
+    // RN(2/x) = 2 RN(1/x): a scaling by two is exact
+    const float x = (P->an_B2 - nB) * An;
+    return ((P->div_ok & kFastAniso) != 0u) ? 2.0f * dm::rcp_(x) : 2.0f / x;
 }
 // VectorTransformMatrix.cxx:101-135
-DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renorm, Vec3 &d)
+DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renorm, Vec3 &d, bool fast)
 {
     const float x = (m[0] * d.x) + (m[1] * d.y) + (m[2] * d.z);
     const float y = (m[3] * d.x) + (m[4] * d.y) + (m[5] * d.z);
     const float z = (m[6] * d.x) + (m[7] * d.y) + (m[8] * d.z);
     d.x = x; d.y = y; d.z = z;
     if (renorm) {
-        const float norm = dm::rsqrt_(d.x * d.x + d.y * d.y + d.z * d.z);
+        const float n2 = d.x * d.x + d.y * d.y + d.z * d.z;
+        const float norm = fast ? dm::rsqrt_near_(n2) : dm::rsqrt_(n2);
         d.x = d.x * norm; d.y = d.y * norm; d.z = d.z * norm;
     }
 }
@@ -314,7 +321,7 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     float sinb, cosb;
     dm::sincos_(b, sinb, cosb);
     const float t = 1.0f - d.z * d.z;
-    const float sinth = dm::sqrt_((t > 0.0f) ? t : 0.0f);
+    const float sinth = dm::sqrt_near_((t > 0.0f) ? t : 0.0f);     // 0 or >= 2^-24: |d.z| <= 1 is a float
     if (sinth > 0.0f) {
         const float ox = d.x, oy = d.y, oz = d.z;
         d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
@@ -326,7 +333,7 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
         d.y = sina * sinb;
         d.z = cosa * sgn;
     }
-    const float recip_length = dm::rsqrt_(sqr(d.x) + sqr(d.y) + sqr(d.z));
+    const float recip_length = dm::rsqrt_near_(sqr(d.x) + sqr(d.y) + sqr(d.z));     // a rotated unit vector: ~1
     d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
 }
 
@@ -398,7 +405,7 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
         const float wavelength = generate_wavelength(P, 0, rx, ra);
         const float rcp = 1.0f / (st.beta * phase_ref_index(P, wavelength));
         const float cos_c = (rcp < 1.0f) ? rcp : 1.0f;
-        const float sin_c = dm::sqrt_(1.0f - cos_c * cos_c);
+        const float sin_c = dm::sqrt_near_(1.0f - cos_c * cos_c);
         b.wlen = wavelength;
         scatter_direction(cos_c, sin_c, b.d, rng_co(rx, ra));
     } else {
@@ -437,6 +444,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const int num_layers = P->num_layers;
     const uint32_t off_layers = P->off_layers;
     const float *len_table = (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr;
+    const bool fast = (P->div_ok & kFastLengths) != 0u;
     float effective_z;
     int current_layer;
     if (TILT) {
@@ -454,7 +462,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
     float sca_len, abs_len;
-    layer_lengths<MED>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len);
+    layer_lengths<MED>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, fast);
     const float recip_thickness = P->recip_thickness;
     float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
     float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
@@ -471,9 +479,9 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         while ((j != last) && (sgn * ais > 0.0f) && (sgn * aia > 0.0f)) {
             j += step;
             boundary += signed_thickness;
-            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len);
-            ais -= sgn * (1.0f / sca_len);
-            aia -= sgn * (1.0f / abs_len);
+            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len, fast);
+            ais -= sgn * rcp_sel(sca_len, fast);
+            aia -= sgn * rcp_sel(abs_len, fast);
         }
     }
     float distance, to_absorption;
@@ -481,7 +489,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         distance = sca_step_left * sca_len;
         to_absorption = ph.abs_lens_left * abs_len;
     } else {
-        const float recip_dz = 1.0f / dz;
+        const float recip_dz = dm::rcp_(dz);            // 1e-5 <= |dz| <= 1 on this branch
         distance = (ais * thickness * sca_len + boundary - effective_z) * recip_dz;
         to_absorption = (aia * thickness * abs_len + boundary - effective_z) * recip_dz;
     }

@@ -586,11 +586,11 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     float4 *ring = reinterpret_cast<float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
                     ring[ph.num_scatters % hn] = make_float4(ph.px, ph.py, ph.pz, ph.abs_lens_left);
                 }
-                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
                 const float cos_s = scattering_cos(P, rx, ra);
-                const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
+                const float sin_s = dm::sqrt_near_(1.0f - sqr(cos_s));       // |cos_s| <= 1: 0 or >= 2^-24
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
-                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d);
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
                 ++ph.num_scatters;
             }
         }
@@ -696,9 +696,36 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
     case 8: r = dm::sqrt_(x); break;
     case 9: r = x / y; break;
     case 10: r = dm::acos_f(x); break;
+    case 11: r = dm::rcp_(x); break;
+    case 12: r = dm::sqrt_near_(x); break;
+    case 13: r = dm::rsqrt_near_(x); break;
     default: break;
     }
     out[i] = r;
+}
+
+// Exhaustive proof runs for the range-restricted operations of detmath.hip.h: every significand (2^23) x every binary
+// exponent in [exp_lo, exp_hi], both signs for the reciprocal, against the IEEE operation.  what: 11 rcp_, 12 sqrt_near_,
+// 13 rsqrt_near_.
+// result[0] = mismatches, result[1..] = bit patterns of the first few mismatching arguments.
+__global__ void check_math_kernel(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;        // significand bits
+    if (m >= (1u << 23)) return;
+    for (int e = exp_lo; e <= exp_hi; ++e) {
+        const uint32_t bits = ((uint32_t)(e + 127) << 23) | m;
+        for (int sign = 0; sign < ((what == 11) ? 2 : 1); ++sign) {
+            const float x = dm::u2f(bits | ((uint32_t)sign << 31));
+            float want, got;
+            if (what == 11) { want = 1.0f / x; got = dm::rcp_(x); }
+            else if (what == 12) { want = __builtin_sqrtf(x); got = dm::sqrt_near_(x); }
+            else { want = 1.0f / __builtin_sqrtf(x); got = dm::rsqrt_near_(x); }
+            if (dm::f2u(want) != dm::f2u(got)) {
+                const uint32_t k = atomicAdd(result, 1u);
+                if (k + 1u < result_cap) result[k + 1u] = dm::f2u(x);
+            }
+        }
+    }
 }
 
 // ---- host-side launchers (called from converter.cpp) ----
@@ -861,6 +888,12 @@ size_t prop_kernel_max_lanes()
 }
 // LDS bytes one workgroup may use so that the intended number of workgroups fits the CU's 160 KB
 size_t prop_kernel_lds_budget() { return (size_t)(160 * 1024) / (size_t)((kMinWavesPerSimd * 256) / kBlock) - 1024; }
+
+hipError_t launch_check_math(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap, hipStream_t stream)
+{
+    hipLaunchKernelGGL(check_math_kernel, dim3((1u << 23) / 256), dim3(256), 0, stream, what, exp_lo, exp_hi, result, result_cap);
+    return hipGetLastError();
+}
 
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream)
 {

@@ -401,11 +401,11 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 spent = true;
             } else {
                 const KP P = fresh_params(P0);
-                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
                 const float cos_s = scattering_cos(P, rx, ra);
-                const float sin_s = dm::sqrt_(1.0f - sqr(cos_s));
+                const float sin_s = dm::sqrt_near_(1.0f - sqr(cos_s));       // |cos_s| <= 1: 0 or >= 2^-24
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
-                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d);
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
                 ++ph.num_scatters;
             }
         }

@@ -221,6 +221,25 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.an_azx = to_float_literal(azx); P.an_azy = to_float_literal(azy); P.an_mazy = to_float_literal(-azy);
         P.an_B2 = to_float_literal(B2);
         name("anisotropy", {P.an_l[0], P.an_l[1], P.an_l[2], P.an_rl[0], P.an_rl[1], P.an_rl[2], P.an_azx, P.an_azy, P.an_mazy, P.an_B2});
+        // div_ok bit 7: the divisor (B2 - nB) * An of the correction factor stays far inside the exponent range.  For a
+        // unit direction nB and An are convex combinations of the 1/l_i and of the l_i, so the divisor lies between
+        // (B2 - max 1/l) * min l and (B2 - min 1/l) * max l.
+        const double rl_lo = std::min({1. / l1, 1. / l2, 1. / l3}), rl_hi = std::max({1. / l1, 1. / l2, 1. / l3});
+        const double x_lo = (B2 - rl_hi) * std::min({l1, l2, l3}), x_hi = (B2 - rl_lo) * std::max({l1, l2, l3});
+        if (x_lo > 1e-10 && x_hi < 1e10 && std::isfinite(x_hi)) P.div_ok |= 128u;
+    }
+    {   // div_ok bit 6: renormalisation after the direction transforms may use dm::rsqrt_near_: |M d|^2 of a unit d lies
+        // within [sigma_min^2, sigma_max^2], sigma_max <= |M|_F, sigma_min >= |det M| / |M|_F^2
+        bool ok = true;
+        for (int which = 0; which < 2; ++which) {
+            if (!(which ? (m.has_post && m.post_renorm) : (m.has_pre && m.pre_renorm))) continue;
+            const double *M = which ? m.post : m.pre;
+            double fro2 = 0.;
+            for (int i = 0; i < 9; ++i) fro2 += M[i] * M[i];
+            const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+            if (!(fro2 < 1e16) || !(std::abs(det) / fro2 > 1e-8)) ok = false;
+        }
+        if (ok) P.div_ok |= 64u;
     }
     P.has_pre = m.has_pre ? 1 : 0; P.pre_renorm = m.pre_renorm ? 1 : 0;
     P.has_post = m.has_post ? 1 : 0; P.post_renorm = m.post_renorm ? 1 : 0;
@@ -318,6 +337,36 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         const std::string prefix = "_generateWavelength_" + std::to_string(k);
         name(prefix + "distYValues", as_doubles(yv));
         name(prefix + "distYCumulativeValues", as_doubles(ycum));
+    }
+    {   // div_ok bit 5: every scattering / absorption length a photon can meet is far inside the exponent range, so the
+        // kernel may form the reciprocals of the layer walk (1/(b400 * ...), 1/length) with dm::rcp_ -- v_rcp_f32 + one
+        // Newton step, RN(1/x) for every x in [2^-100, 2^100] (tests/test_detmath_gpu.py runs all of them) -- instead
+        // of the IEEE divide sequence.  Bounds in double over the wavelengths the generators can produce (widened 2x).
+        double w_lo = 1e300, w_hi = 0.;
+        for (const RandomValueData &g : generators) {
+            double a = g.value, b = g.value;
+            if (g.kind == CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION) { a = std::min(g.first, g.spacing); b = std::max(g.first, g.spacing); }
+            else if (g.kind != CLSIMHIP_RANDOM_CONSTANT) { a = g.first - g.spacing; b = g.first + g.spacing * static_cast<double>(g.y.size()); }
+            w_lo = std::min(w_lo, a); w_hi = std::max(w_hi, b);
+        }
+        w_lo *= 0.5; w_hi *= 2.;
+        double len_lo = 1e300, len_hi = 0.;
+        auto see = [&](double len) { if (!(len > 0.) || !std::isfinite(len)) { len_lo = 0.; return; } len_lo = std::min(len_lo, len); len_hi = std::max(len_hi, len); };
+        if (!(w_lo > 0.) || !std::isfinite(w_hi)) len_lo = 0.;
+        else if (m.lengths_kind == CLSIMHIP_LENGTHS_TABLE) { for (double v : m.abs_table) see(v); for (double v : m.sca_table) see(v); }
+        else if (m.lengths_kind == CLSIMHIP_LENGTHS_CONSTANT) { for (double v : m.abs_length) see(v); for (double v : m.sca_length) see(v); }
+        else {
+            const int grid = 64;
+            for (int i = 0; i <= grid; ++i) {
+                const double w = w_lo * std::pow(w_hi / w_lo, static_cast<double>(i) / grid), x = w / units::nanometer;
+                for (size_t l = 0; l < m.b400.size(); ++l) {
+                    see(1. / (m.b400[l] * std::pow(w / (400. * units::nanometer), -m.alpha)));
+                    see(1. / ((m.D * m.a_dust400[l] + m.E) * std::pow(x, -m.kappa) + m.A * std::exp(-m.B / x) * (1. + 0.01 * m.delta_tau[l])));
+                }
+            }
+        }
+        if (len_lo > 1e-15 && len_hi < 1e15) P.div_ok |= 32u;
+        scalar("length_bounds_lo", len_lo); scalar("length_bounds_hi", len_hi);
     }
     P.bias_kind = bias.kind;
     if (bias.kind == CLSIMHIP_FUNCTION_TABLE) {

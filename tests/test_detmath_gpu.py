@@ -67,3 +67,24 @@ def test_binary_functions_bit_exact(oracle_lib):
     assert np.array_equal(bits(device_eval(6, x, y)), bits(capi.eval_math(6, x, y)))        # atan2
     d = rng.uniform(1e-3, 1e3, N).astype(np.float32) * np.where(rng.random(N) < 0.5, -1, 1).astype(np.float32)
     assert np.array_equal(bits(device_eval(9, x, d)), bits(capi.eval_math(9, x, d)))        # IEEE divide
+
+
+def check_exhaustive(what, exp_lo, exp_hi, cap=64):
+    lib = _lib.load()
+    res = np.zeros(cap, dtype=np.uint32)
+    rc = lib.clsimhip_check_math_exhaustive(0, what, exp_lo, exp_hi, res.ctypes.data_as(C.c_void_p), cap)
+    assert rc == 0, lib.clsimhip_last_error(None)
+    return int(res[0]), res[1:1 + min(int(res[0]), cap - 1)].view(np.float32)
+
+
+@pytest.mark.parametrize("what,exp_lo,exp_hi", [(11, -100, 100), (12, -96, 100), (13, -96, 100)])
+def test_range_restricted_operations_equal_the_ieee_ones_on_every_input(what, exp_lo, exp_hi):
+    """dm::rcp_ / dm::sqrt_near_ / dm::rsqrt_near_ (detmath.hip.h) against the IEEE divide and sqrt
+    on the device: ALL 2^23 significands x every exponent of the admitted range (both signs for the reciprocal)."""
+    bad, first = check_exhaustive(what, exp_lo, exp_hi)
+    assert bad == 0, "%d mismatches, first arguments %s" % (bad, [float.hex(float(v)) for v in first[:8]])
+
+
+def test_square_root_of_zero_stays_zero():
+    x = np.array([0.0, 1.0, 4.0, 2.0, 5.9604645e-8], dtype=np.float32)
+    assert np.array_equal(bits(device_eval(12, x)), bits(np.sqrt(x)))

@@ -1,0 +1,104 @@
+"""GPU: BASELINE configs[2] (C3) and configs[4] (C5, flasher half) at their production bunch sizes -- the launch
+geometry bench.py measures (5 242 880 cascade steps x 200 photons on SPICE-Lea; 2 621 440 flasher steps x 400 photons
+from a point source at a DOM, 48 Mi-record photon buffer).  Pattern of test_baseline_size_properties: the whole bunch
+runs once on each of two converters (determinism: the multiset of all 80-byte records through an order-independent
+64-bit checksum computed on the device, and every final stream state), and the records of the first 2048 steps are
+pulled out of the big launch and compared bit for bit with the oracle run on those steps alone."""
+import numpy as np
+import pytest
+import torch
+
+from clsim_amd import synthetic as S
+from clsim_amd.synthetic import PHOTON_DTYPE
+from oracle import capi
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def big_run(conv, d_steps, n, capacity):
+    dev = d_steps.device
+    d_out = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    conv.PropagateDevice(d_steps.data_ptr(), n, d_out.data_ptr(), capacity, d_cnt.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cnt = int(d_cnt.item())
+    assert cnt <= capacity, "photon buffer overflow: %d > %d" % (cnt, capacity)
+    return d_out[:cnt], cnt
+
+
+def multiset_checksum(records):
+    """Order-independent checksum of n x 80-byte records: per record a 64-bit mix of its 10 quadwords, summed mod 2^64."""
+    q = records.view(torch.int64)                                    # n x 10
+    mult = torch.tensor([0x9E3779B97F4A7C15 - (1 << 64), 0x3C6EF372FE94F82B, 0x5BD1E9955BD1E995, 0x2545F4914F6CDD1D,
+                         0x1B873593CC9E2D51, 0x27D4EB2F165667C5, 0x165667B19E3779F9, 0x7FB5D329728EA185,
+                         0x0AEF17502108EF2F, 0x62A9D9ED799705F5], dtype=torch.int64, device=records.device)
+    h = (q * mult).sum(dim=1)
+    h = (h ^ (h >> 29)) * 0x3C79AC492BA7B653
+    h = h ^ (h >> 32)
+    return int(h.sum().item()), int((h * h).sum().item())
+
+
+def prefix_records(records, m):
+    ids = records.view(torch.int32)[:, 10]                            # I3CLSimPhoton.identifier
+    sub = records[(ids >= 0) & (ids < m)].cpu().numpy()
+    return np.frombuffer(sub.tobytes(), dtype=PHOTON_DTYPE).copy()
+
+
+def check_at_size(cfg, steps, capacity, hit_fraction_range, m=2048):
+    n = len(steps)
+    dev = torch.device("cuda", 0)
+    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+    x, a = common.streams(n)
+    conv = common.product_converter(cfg, n)
+    rec1, cnt1 = big_run(conv, d_steps, n, capacity)
+    x1 = conv.GetRNGState(n)
+    sum1 = multiset_checksum(rec1)
+    sub = prefix_records(rec1, m)
+    string_ok = bool((rec1.view(torch.int16)[:, 22] < 86).all()) and bool((rec1.view(torch.int16)[:, 22] >= 0).all())
+    dom_ok = bool((rec1.view(torch.int16)[:, 23] < 60).all())
+    del rec1
+    torch.cuda.empty_cache()
+    # determinism across converters (and across queue schedules: the order lanes take units in is not reproducible)
+    conv_b = common.product_converter(cfg, n)
+    rec2, cnt2 = big_run(conv_b, d_steps, n, capacity)
+    assert cnt1 == cnt2
+    assert multiset_checksum(rec2) == sum1
+    assert np.array_equal(x1, conv_b.GetRNGState(n))
+    del rec2
+    torch.cuda.empty_cache()
+    live = steps["num"] > 0
+    assert np.all(x1[live] != x[live])                               # every stream with photons advanced
+    photons = float(steps["num"].sum())
+    assert hit_fraction_range[0] < cnt1 / photons < hit_fraction_range[1], cnt1 / photons
+    assert string_ok and dom_ok
+    # the first m steps inside the big launch == the oracle on those steps alone
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps[:m], x[:m], a[:m], threads=16)
+    assert len(sub) == cnt_o
+    assert common.sort_photons(sub).tobytes() == common.sort_photons(ph_o).tobytes()
+    assert np.array_equal(x1[:m], x_o)
+    return cnt1
+
+
+@pytest.mark.timeout(900)
+def test_c3_spice_lea_production_bunch():
+    """bench.py --workload c3: one of the two 5 242 880-step bunches of BASELINE configs[2] (tilt + anisotropy + direction
+    transforms), 1.05e9 photons; about 11 steps per resident lane."""
+    cfg = common.config("lea")
+    n = 5 * (1 << 20)
+    steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
+    check_at_size(cfg, steps, capacity=8 << 20, hit_fraction_range=(2e-4, 3e-3))
+
+
+@pytest.mark.timeout(900)
+def test_c5_flasher_production_bunch():
+    """bench.py --workload c5: 2 621 440 flasher steps x 400 photons (1.05e9 photons), 405 nm, point source at a DOM near
+    the detector centre; ~1.6 % of the photons are detected (1.3 GB of records in a 48 Mi-record buffer)."""
+    cfg = common.config("flasher")
+    g = cfg["geom"]
+    k = int(np.argmin(np.abs(g["x"]) + np.abs(g["y"]) + np.abs(g["z"] + 100.0)))
+    n = 2621440
+    steps = S.flasher_steps(n, seed=1000, photons_per_step=400, position=(float(g["x"][k]), float(g["y"][k]), float(g["z"][k])))
+    check_at_size(cfg, steps, capacity=48 << 20, hit_fraction_range=(5e-3, 5e-2))

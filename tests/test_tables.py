@@ -85,6 +85,10 @@ def test_invariant_divisors_are_proven():
         conv.Compile()
         ok = int(conv.GetTable("div_ok")[0])
         assert ok & 0b11110 == 0b11110
+        assert ok & 32          # every length the generators' wavelengths can meet is bounded: dm::rcp_ in the layer walk
+        assert ok & 64          # direction transforms (if any) are well conditioned: dm::rsqrt_near_ in the renormalisation
+        if name == "lea":
+            assert ok & 128     # anisotropy divisor bounded
         if name != "c1":
             assert ok & 1
         assert all(int(v) == 3 for v in conv.GetTable("div_ok_cells"))

@@ -11,9 +11,9 @@ from clsim_amd import converter as CV, synthetic as S, _lib
 
 ENV = {"kernel": "CLSIMHIP_KERNEL", "R": "CLSIMHIP_POOL_R", "pop": "CLSIMHIP_K_POP", "new": "CLSIMHIP_K_NEW", "slices": "CLSIMHIP_SLICES",
        "search": "CLSIMHIP_K_SEARCH", "grid": "CLSIMHIP_GRID"}
-medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
-bias = CV.GetIceCubeDOMAcceptance(); gen = CV.makeCherenkovWavelengthGenerator(bias, medium)
-geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
+bias = CV.GetIceCubeDOMAcceptance()
+g86 = S.ic86_geometry()
+geom = CV.I3CLSimSimpleGeometry.from_dict(g86)
 dev = torch.device("cuda", 0)
 for spec in sys.argv[1:]:
     kv = dict(item.split("=") for item in spec.split(",") if item)
@@ -23,10 +23,18 @@ for spec in sys.argv[1:]:
             os.environ[e] = kv[k]
     os.environ.setdefault("CLSIMHIP_KERNEL", "pool")
     n = int(kv.get("n", 1 << 20))
-    conv = CV.initializeHIP(0, geom, medium, bias, [gen], pancakeFactor=5.0, approximateNumberOfWorkItems=n, seed=12345)
-    steps = S.cascade_steps(n, seed=1000)
+    workload = kv.get("workload", "c2")           # bench.py's workloads: c2 (SPICE-Mie), c3 (SPICE-Lea), c5 (flasher steps at a DOM)
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie" if workload == "c2" else "spice_lea"))
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, medium)]
+    if workload == "c5":
+        gens.append(CV.I3CLSimRandomValueConstant(405e-9))
+        k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))
+        steps = S.flasher_steps(n, seed=1000, photons_per_step=400, position=(float(g86["x"][k]), float(g86["y"][k]), float(g86["z"][k])))
+    else:
+        steps = S.cascade_steps(n, seed=1000)
+    conv = CV.initializeHIP(0, geom, medium, bias, gens, pancakeFactor=5.0, approximateNumberOfWorkItems=n, seed=12345)
     d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
-    cap = 8 << 20
+    cap = (48 if workload == "c5" else 8) << 20
     out = torch.empty((cap, 80), dtype=torch.uint8, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     for rep in range(2):
         conv.KernelTimeMs(reset=True)
@@ -44,9 +52,10 @@ for spec in sys.argv[1:]:
     end = (rec[:, 0] - t0) / 100e3
     q = lambda a, p: float(np.percentile(a, p))
     lanes = 64.0 * trips
-    print("%s: %.1f ms, %d waves | lanes: run %.1f%% parked %.1f%% without photon %.1f%% | per trip: services %.3f, creation stages %.4f "
+    photons = float(steps["num"].sum())
+    print("%s: %.1f ms, %d waves | lane trips with a live photon per photon %.2f, wave trips per 64 photons %.2f | lanes: run %.1f%% parked %.1f%% without photon %.1f%% | per trip: services %.3f, creation stages %.4f "
           "(%.1f photons each, %.2f chunks), searches %.3f, ring empty %.1f%% of trips, polls/trip %.3f | wave end p1 %.1f p50 %.1f p99 %.1f max %.1f ms | trips/wave p10 %d p50 %d p90 %d"
-          % (spec, ms, len(rec), 100 * run / lanes, 100 * parked / lanes, 100 * vacant / lanes, services / trips, creations / trips,
+          % (spec, ms, len(rec), (run + parked) / photons, trips * 64.0 / photons, 100 * run / lanes, 100 * parked / lanes, 100 * vacant / lanes, services / trips, creations / trips,
              created / max(creations, 1), chunks / max(creations, 1), searches / trips, 100 * empty_ring / trips, polls / trips,
              q(end, 1), q(end, 50), q(end, 99), end.max(), q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
     del conv

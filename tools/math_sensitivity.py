@@ -50,7 +50,7 @@ def main():
             ph = ph.copy(); ph["id"] += np.uint32(s * n)          # step identity across seeds
             hits.append(ph); states.append(x_after); trips += it
         runs[variant or "deterministic"] = (np.concatenate(hits), np.concatenate(states), trips)
-        print("%s: %d hits, %d loop trips" % (variant or "deterministic", len(runs[variant or "deterministic"][0]), trips), flush=True)
+        print("%s: %d hits, %d loop trips" % (variant or "deterministic", len(runs[variant or "deterministic"][0]), trips), file=sys.stderr, flush=True)
     capi.use_variant(None)
     photons = seeds * n * 200
     base_h, base_x, base_t = runs["deterministic"]
@@ -76,7 +76,34 @@ def main():
         ks_t = ks_2samp(base_h["t"] - base_h["st"], h["t"] - h["st"])
         ks_s = ks_2samp(base_h["numScatters"].astype(float), h["numScatters"].astype(float))
         ks_w = ks_2samp(base_h["wavelength"], h["wavelength"])
+        # the north star's bar: the same photons detected by the same DOMs, floats within 1e-5 relative.  A hit is
+        # identified by (step, DOM, number of scatters, wavelength bits): the wavelength is drawn before any transcendental
+        # of the walk and is the same bits in all builds unless an earlier photon of the step changed its draw count
+        def keyed(hh):
+            k = np.zeros(len(hh), dtype=[("id", "u4"), ("dom", "i8"), ("ns", "u4"), ("w", "u4")])
+            k["id"], k["dom"], k["ns"], k["w"] = hh["id"], dom_index(hh), hh["numScatters"], hh["wavelength"].view(np.uint32)
+            o = np.argsort(k, order=("id", "dom", "ns", "w"), kind="stable")
+            return k[o], hh[o]
+        ka, ha = keyed(base_h); kb, hb = keyed(h)
+        _, ia, ib = np.intersect1d(ka.view(np.dtype((np.void, ka.dtype.itemsize))), kb.view(np.dtype((np.void, kb.dtype.itemsize))), return_indices=True)
+        ma, mb = ha[ia], hb[ib]
+        def rel(f, scale=None):
+            a_, b_ = ma[f].astype(np.float64), mb[f].astype(np.float64)
+            den = np.maximum(np.abs(a_), 1e-30) if scale is None else scale
+            return float(np.max(np.abs(a_ - b_) / den)) if len(a_) else 0.0
+        def quant(f):
+            a_, b_ = ma[f].astype(np.float64), mb[f].astype(np.float64)
+            r = np.abs(a_ - b_) / np.maximum(np.abs(a_), 1e-30)
+            return {"identical": float(np.mean(r == 0)), "median": float(np.median(r)), "p99": float(np.quantile(r, 0.99)), "within_1e-5": float(np.mean(r <= 1e-5))}
+        matched = {"same_step_dom_scatters_wavelength": float(len(ia)) / len(base_h),
+                   "rel_diff_time": quant("t"), "rel_diff_cherenkov_dist": quant("cherenkovDist"),
+                   "max_rel_diff_time": rel("t"), "max_rel_diff_wavelength": rel("wavelength"), "max_rel_diff_weight": rel("weight"),
+                   "max_rel_diff_dist_in_abs_lens": rel("distInAbsLens"), "max_rel_diff_cherenkov_dist": rel("cherenkovDist"),
+                   # hit position is relative to the DOM centre (|r| = 0.16510 m * oversize): differences relative to that radius
+                   "max_diff_position_over_radius": max(rel("x", 0.8255), rel("y", 0.8255), rel("z", 0.8255)),
+                   "max_abs_diff_theta_phi_rad": max(rel("theta", 1.0), rel("phi", 1.0))}
         out["variants"][name] = {
+            "matched_hits": matched,
             "hits": int(len(h)), "hits_rel_diff": (len(h) - len(base_h)) / len(base_h), "hits_poisson_sigma": (len(h) - len(base_h)) / np.sqrt(len(h) + len(base_h)),
             "loop_trips_rel_diff": (t - base_t) / base_t,
             "steps_with_identical_final_stream_state": same_stream,
