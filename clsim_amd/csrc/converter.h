@@ -50,6 +50,8 @@ struct CompiledTables {
     std::vector<uint32_t> lds_image;
     std::vector<float> len_table;       // KParams::len_table (TABLE lengths)
     std::vector<uint8_t> prox_map;      // KParams::prox_map
+    std::vector<uint32_t> dom_prox;     // KParams::dom_prox
+    std::vector<float> dom_centres;     // KParams::dom_centres (4 floats per DOM)
     GeoTables geo;
     std::map<std::string, std::vector<double>> named;
 };
@@ -214,6 +216,8 @@ private:
     int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
     float *d_len_table_ = nullptr;
     uint8_t *d_prox_map_ = nullptr;
+    uint32_t *d_dom_prox_ = nullptr;
+    float *d_dom_centres_ = nullptr;
     float *d_hist_ring_ = nullptr;           // per resident lane: the last history_entries_ scatter points
     float *d_dom_tz_ = nullptr;
     uint64_t *d_rng_x_ = nullptr;

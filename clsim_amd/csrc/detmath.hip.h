@@ -151,6 +151,13 @@ DM float powr_(float x, float y)
     return exp_hl(ph, pl);
 }
 
+// powr(x, y) for x in [0, 1], y > 0 with y |log x| <= 2 (oracle_math.h: om_powr_unit): single-word logarithm
+DM float powr_unit_(float x, float y)
+{
+    if (x == 0.0f) return 0.0f;
+    return exp_(y * log_(x));
+}
+
 constexpr float PIO2_1 = 0x1.921fb6p+0f;
 constexpr float PIO2_2 = -0x1.777a5cp-25f;
 constexpr float PIO2_3 = -0x1.ee59dap-50f;

@@ -91,6 +91,18 @@ struct KParams {
     const uint8_t *prox_map;
     int32_t prox_n;
     float prox_x0, prox_y0, prox_inv_cell;
+    // DOM proximity map, the second level of the search filter: dprox_nz x dprox_ny x dprox_nx words (cubic cells) over
+    // the bounding box of the DOMs.  A word names the DOM nearest to the cell (bits 0-15: index into dom_centres, 0xffff =
+    // none within 64 m) and carries in bits 16-23, in 0.25 m units, a proven lower bound of the 3D distance from anywhere
+    // in the cell to the sphere of any OTHER DOM.  The kernel takes the exact distance to the named DOM's sphere and the
+    // stored bound for the rest: a step shorter than both cannot touch a DOM.  Consulted only by lanes whose step reaches a
+    // string cylinder: most of them pass between two DOMs of the string (17 m apart, 0.8 m radius), and photons born
+    // at a DOM (flashers) spend their lives within metres of it.  <= 64 MB in HBM, the words in use L2 / MALL resident.
+    const uint32_t *dom_prox;
+    const float4 *dom_centres;          // x, y, z of every DOM as dom_position() reconstructs it, w = 0
+    int32_t dprox_nx, dprox_ny, dprox_nz;
+    float dprox_x0, dprox_y0, dprox_z0, dprox_inv_cell;
+    float dprox_radius;                 // OM radius + safety
     const int16_t *dom_tx;              // DOM templates stay in HBM/L2 (41 KB for IC86)
     const int16_t *dom_ty;
     const float *dom_tz;

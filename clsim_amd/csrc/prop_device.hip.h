@@ -59,13 +59,19 @@ DM uint32_t lds_u16(uint32_t off, uint32_t i)
 }
 
 // mwcrng_kernel.cl:12-20: x = lo32(x)*a + hi32(x); u = float_rtz(lo32(x)) / 2^32
+// convert_float_rtz keeps the 24 leading bits of the word: v_cvt_f32_u32 does exactly that with the wave's single precision
+// rounding mode set to "toward zero" (MODE.FP_ROUND bits 1:0 = 3) for that one instruction -- two scalar instructions in
+// place of the seven vector ones that mask the low bits away by hand (count leading zeros, shift, compare, select, and).
 DM float rng_co(uint64_t &x, uint32_t a)
 {
     x = (x & 0xffffffffull) * (uint64_t)a + (x >> 32);
     const uint32_t lo = (uint32_t)x;
-    const int drop = 8 - (int)__clz(lo);                    // bits below the 24-bit significand
-    const uint32_t t = (drop > 0) ? ((lo >> drop) << drop) : lo;
-    return (float)t * 2.3283064365386963e-10f;              // exact: t has <= 24 significant bits
+    float t;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_f32_u32_e32 %0, %1\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=v"(t) : "v"(lo));
+    return t * 2.3283064365386963e-10f;              // exact: a power of two
 }
 DM float rng_oc(uint64_t &x, uint32_t a) { return 1.0f - rng_co(x, a); }
 
@@ -175,7 +181,13 @@ DM float hg_cos(KP P, float u)
     return clampf(div_by(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, (P->div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
-DM float liu_cos(KP P, float u) { return clampf(2.0f * dm::powr_(u, P->liu_beta) - 1.0f, -1.0f, 1.0f); }
+DM float liu_cos(KP P, float u)
+{
+    const float beta = P->liu_beta;
+    // beta <= 0.09 (mean cosine >= 0.835, wave-uniform): beta |log u| <= 2 for u >= 2^-32, the single-word logarithm form
+    const float p = (beta <= 0.09f) ? dm::powr_unit_(u, beta) : dm::powr_(u, beta);
+    return clampf(2.0f * p - 1.0f, -1.0f, 1.0f);
+}
 // Mixed.cxx:115-157, single random number form
 DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
 {
@@ -580,6 +592,28 @@ DM float free_flight_bound(KP P, float x, float y)
     const int ix = clampi((int)((x - P->prox_x0) * P->prox_inv_cell), 0, n - 1);
     const int iy = clampi((int)((y - P->prox_y0) * P->prox_inv_cell), 0, n - 1);
     return (float)P->prox_map[iy * n + ix] * 0.25f;
+}
+
+// DOM proximity map (kparams.h): distance [m] that a photon at (x, y, z) can travel in any direction before it could touch
+// a DOM: the exact distance to the sphere of the DOM named by the cell (shortened by 1e-5 of itself for the float
+// arithmetic), the cell's stored bound for all others
+DM float dom_free_flight_bound(KP P, float x, float y, float z)
+{
+    const float inv = P->dprox_inv_cell;
+    const int nx = P->dprox_nx, ny = P->dprox_ny;
+    const int ix = clampi((int)((x - P->dprox_x0) * inv), 0, nx - 1);
+    const int iy = clampi((int)((y - P->dprox_y0) * inv), 0, ny - 1);
+    const int iz = clampi((int)((z - P->dprox_z0) * inv), 0, P->dprox_nz - 1);
+    const uint32_t w = P->dom_prox[((size_t)iz * (size_t)ny + (size_t)iy) * (size_t)nx + (size_t)ix];
+    float bound = (float)((w >> 16) & 0xffu) * 0.25f;
+    const uint32_t id = w & 0xffffu;
+    if (id != 0xffffu) {
+        const float4 c = P->dom_centres[id];
+        const float ex = x - c.x, ey = y - c.y, ez = z - c.z;
+        const float near = dm::sqrt_((ex * ex + ey * ey) + ez * ez) * 0.99999f - P->dprox_radius;
+        bound = (near < bound) ? near : bound;
+    }
+    return bound;
 }
 
 // collision c.cl:194-303 + :462-547

@@ -501,7 +501,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
-            if (!TAB && !(distance < free_flight)) { parked = true; pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance); }
+            if (!TAB && !(distance < free_flight) && !(distance < dom_free_flight_bound(fresh_params(P0), ph.px, ph.py, ph.pz))) {
+                parked = true;
+                pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance);
+            }
         }
         bool advance = run && !parked;
         if (!TAB) {
@@ -699,6 +702,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
     case 11: r = dm::rcp_(x); break;
     case 12: r = dm::sqrt_near_(x); break;
     case 13: r = dm::rsqrt_near_(x); break;
+    case 14: r = dm::powr_unit_(x, y); break;
     default: break;
     }
     out[i] = r;

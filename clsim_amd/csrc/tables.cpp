@@ -511,6 +511,81 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         name("string_proximity_map", as_doubles(C.prox_map));
         name("STRING_PROXIMITY_GRID", {double(n), P.prox_x0, P.prox_y0, P.prox_inv_cell, reach});
     }
+    {   // DOM proximity map (kparams.h), the second level of the search filter.  Everything in double, rounded towards
+        // "search anyway".  Cubic cells; at most 256 per axis (64 MB); border cells reach to infinity.
+        int n_max = 256;
+        if (const char *e = std::getenv("CLSIMHIP_DOM_PROX_N")) n_max = std::max(4, std::min(512, std::atoi(e)));
+        const size_t n_doms = G.dom_tx.size();
+        if (n_doms >= 0xffffu) throw Error(CLSIMHIP_ERR_CONFIG, "more than 65534 DOMs");     // (GEO_MAX_DOM_INDEX is a ushort in the reference too)
+        std::vector<double> dx(n_doms), dy(n_doms), dz(n_doms);
+        C.dom_centres.assign(4 * n_doms, 0.f);
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int s = 0; s < G.num_strings; ++s) {
+            const size_t first = G.dom_start[s], last = (s + 1 < G.num_strings) ? G.dom_start[s + 1] : n_doms;
+            for (size_t i = first; i < last; ++i) {
+                // the position the kernel reconstructs (dom_position), same float operations
+                const float fx = static_cast<float>(G.dom_tx[i]) * G.dom_mul_x + G.dom_meanx[s];
+                const float fy = static_cast<float>(G.dom_ty[i]) * G.dom_mul_y + G.dom_meany[s];
+                C.dom_centres[4 * i] = fx; C.dom_centres[4 * i + 1] = fy; C.dom_centres[4 * i + 2] = G.dom_tz[i];
+                dx[i] = fx; dy[i] = fy; dz[i] = G.dom_tz[i];
+                const double p[3] = {dx[i], dy[i], dz[i]};
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+            }
+        }
+        const double margin = 30., range = 63.75;                   // a byte in 0.25 m units
+        double extent = 0.;
+        for (int k = 0; k < 3; ++k) { lo[k] -= margin; hi[k] += margin; extent = std::max(extent, hi[k] - lo[k]); }
+        const double cell = std::max(extent / n_max, 1.0);
+        P.dprox_inv_cell = static_cast<float>(1. / cell);
+        P.dprox_x0 = static_cast<float>(lo[0]); P.dprox_y0 = static_cast<float>(lo[1]); P.dprox_z0 = static_cast<float>(lo[2]);
+        const double cellf = 1. / double(P.dprox_inv_cell);
+        const double o[3] = {double(P.dprox_x0), double(P.dprox_y0), double(P.dprox_z0)};
+        int nn[3];
+        for (int k = 0; k < 3; ++k) nn[k] = std::max(1, std::min(n_max, static_cast<int>(std::ceil((hi[k] - o[k]) / cellf))));
+        P.dprox_nx = nn[0]; P.dprox_ny = nn[1]; P.dprox_nz = nn[2];
+        // cell the kernel computes for a point: (int)((x - x0) * inv_cell) in float; each cell is grown by `slack` for
+        // that arithmetic
+        const double slack = 1e-3 * cellf + 1e-5 * (std::fabs(o[0]) + std::fabs(o[1]) + std::fabs(o[2]) + n_max * cellf);
+        const double radius = double(G.om_radius) + 0.05;            // DOM sphere + safety
+        P.dprox_radius = static_cast<float>(radius);
+        const size_t cells = static_cast<size_t>(nn[0]) * nn[1] * nn[2];
+        // per cell: quantised bound of the nearest DOM with its index, and of the second nearest
+        std::vector<uint8_t> q1(cells, 255), q2(cells, 255);
+        std::vector<uint16_t> id1(cells, 0xffffu);
+        auto axis_gap = [&](int k, int i, double a) {                // distance along axis k from coordinate a to (grown) cell i
+            const double r0 = (i == 0) ? -INFINITY : o[k] + i * cellf - slack, r1 = (i == nn[k] - 1) ? INFINITY : o[k] + (i + 1) * cellf + slack;
+            return std::max(std::max(r0 - a, a - r1), 0.);
+        };
+        for (size_t d = 0; d < n_doms; ++d) {
+            const double p[3] = {dx[d], dy[d], dz[d]};
+            int i0[3], i1[3];
+            for (int k = 0; k < 3; ++k) {
+                i0[k] = std::max(0, static_cast<int>(std::floor((p[k] - range - radius - slack - o[k]) / cellf)) - 1);
+                i1[k] = std::min(nn[k] - 1, static_cast<int>(std::floor((p[k] + range + radius + slack - o[k]) / cellf)) + 1);
+            }
+            for (int iz = i0[2]; iz <= i1[2]; ++iz) {
+                const double gz = axis_gap(2, iz, p[2]);
+                for (int iy = i0[1]; iy <= i1[1]; ++iy) {
+                    const double gy = axis_gap(1, iy, p[1]);
+                    const size_t row = (static_cast<size_t>(iz) * nn[1] + iy) * nn[0];
+                    for (int ix = i0[0]; ix <= i1[0]; ++ix) {
+                        const double gx = axis_gap(0, ix, p[0]);
+                        const double bound = (std::sqrt(gx * gx + gy * gy + gz * gz) - radius) / 1.00001;
+                        const double q = std::floor(bound / 0.25);
+                        const uint8_t v = static_cast<uint8_t>(q < 0. ? 0. : (q > 255. ? 255. : q));
+                        const size_t c = row + ix;
+                        if (v < q1[c]) { q2[c] = q1[c]; q1[c] = v; id1[c] = static_cast<uint16_t>(d); }
+                        else if (v < q2[c]) q2[c] = v;
+                    }
+                }
+            }
+        }
+        C.dom_prox.resize(cells);
+        // a cell without a named DOM keeps the bound of its nearest one (255 = nothing within range) in the same place
+        for (size_t c = 0; c < cells; ++c)
+            C.dom_prox[c] = static_cast<uint32_t>(id1[c]) | (static_cast<uint32_t>(id1[c] == 0xffffu ? q1[c] : q2[c]) << 16);
+        name("DOM_PROXIMITY_GRID", {double(nn[0]), double(nn[1]), double(nn[2]), P.dprox_x0, P.dprox_y0, P.dprox_z0, P.dprox_inv_cell, radius});
+    }
     scalar("NUM_STRINGS", G.num_strings); scalar("OM_RADIUS", G.om_radius);
     scalar("GEO_STRING_MAX_RADIUS", G.string_max_radius);
     scalar("GEO_LAYER_STRINGSET_NUM", G.num_sets); scalar("GEO_LAYER_STRINGSET_MAX_NUM_LAYERS", G.max_layers);

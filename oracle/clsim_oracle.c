@@ -283,6 +283,8 @@ static inline float hg_cos(const oracle_tables *T, float rnd_co)
 /* SimplifiedLiu.cxx:64-88 */
 static inline float liu_cos(const oracle_tables *T, float rnd_co)
 {
+    /* beta * 22.2 <= 2 (u >= 2^-32): the single-word logarithm form; otherwise the general powr */
+    if (T->liu_beta <= 0.09f) return clampf(2.0f * om_powr_unit(rnd_co, T->liu_beta) - 1.0f, -1.0f, 1.0f);
     return clampf(2.0f * om_powr(rnd_co, T->liu_beta) - 1.0f, -1.0f, 1.0f);
 }
 /* Mixed.cxx:115-157 (single random number form) */
@@ -1089,6 +1091,7 @@ void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *
         case 8: out[i] = om_sqrt(x); break;
         case 9: out[i] = x / y; break;
         case 10: out[i] = om_acos_f(x); break;
+        case 14: out[i] = om_powr_unit(x, y); break;
         default: out[i] = 0.0f;
         }
     }

@@ -31,6 +31,10 @@ int main(void)
     SCAN("powr(x,-1.0841) [265,675]", 265.0, 675.0, N, om_powr(x, -1.084106802940f), pow((double)x, (double)-1.084106802940f));
     SCAN("powr(x,-0.8986) [.6,1.7]", 0.6, 1.7, N, om_powr(x, -0.898608505726f), pow((double)x, (double)-0.898608505726f));
     SCAN("powr(x,0.0526) (0,1]", 1e-9, 1.0, N, om_powr(x, 0.0526315793f), pow((double)x, (double)0.0526315793f));
+    SCAN("powr_unit(x,0.0526) (0,1]", 2.3283064e-10, 1.0, N, om_powr_unit(x, 0.0526315793f), pow((double)x, (double)0.0526315793f));
+    SCAN("powr_unit(x,0.0526) (0,1e-4]", 2.3283064e-10, 1e-4, N, om_powr_unit(x, 0.0526315793f), pow((double)x, (double)0.0526315793f));
+    SCAN("powr_unit(x,0.09) (0,1]", 2.3283064e-10, 1.0, N, om_powr_unit(x, 0.09f), pow((double)x, (double)0.09f));
+    SCAN("powr_unit(x,0.09) (0,1e-6]", 2.3283064e-10, 1e-6, N, om_powr_unit(x, 0.09f), pow((double)x, (double)0.09f));
     SCAN("sin [0,2pi]", 0.0, 6.2831855, N, om_sin(x), sin((double)x));
     SCAN("cos [0,2pi]", 0.0, 6.2831855, N, om_cos(x), cos((double)x));
     SCAN("sin [-100,100]", -100.0, 100.0, N, om_sin(x), sin((double)x));

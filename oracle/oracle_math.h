@@ -253,6 +253,17 @@ OM_INLINE float om_acos_f(float x)
     return (x < 0.0f) ? (1.5707963267948966f + a) : (1.5707963267948966f - a);
 }
 
+/* powr(x, y) for x in [0, 1] and 0 < y with y * |log x| <= 2: the scattering angle of the simplified Liu function,
+ * 2 u^beta - 1 with beta = (1 - g)/(1 + g) ~ 0.05 (I3CLSimRandomValueSimplifiedLiu.cxx:84) -- once per scatter, where the
+ * hi+lo logarithm of om_powr is not needed: |y log x| <= 1.2 for u >= 2^-32, so the rounding of log x (0.82 ulp) and of
+ * the product enter exp with an absolute error below 2^-23 and the result stays within 3 ulp (mathcheck.c: 1.94 ulp at
+ * beta = 0.0526, 2.84 at 0.09; OpenCL allows powr 16).  x = 0 gives 0. */
+OM_INLINE float om_powr_unit(float x, float y)
+{
+    if (x == 0.0f) return 0.0f;
+    return om_exp(y * om_log(x));
+}
+
 /* ---- ORACLE_LIBM (analysis build, tools/math_sensitivity.py): a DIFFERENT conforming math library -------------------
  * The deterministic functions above are this repository's definition of the OpenCL builtins; the reference kernel
  * runs on whatever the OpenCL runtime provides (a few ulp, unpinned).  With -DORACLE_LIBM the kernel-facing names are
@@ -271,6 +282,7 @@ OM_INLINE float om_libm_acos(float v) { return acosf(v); }
 #define om_log om_libm_log
 #define om_exp om_libm_exp
 #define om_powr om_libm_powr
+#define om_powr_unit om_libm_powr
 #define om_sincos om_libm_sincos
 #define om_sin om_libm_sin
 #define om_cos om_libm_cos

@@ -58,6 +58,17 @@ def test_powr_bit_exact(oracle_lib, lo, hi, ys):
         assert np.array_equal(bits(device_eval(4, x, y)), bits(capi.eval_math(4, x, y)))
 
 
+def test_powr_unit_bit_exact(oracle_lib):
+    """the scattering-angle power u^beta (single-word logarithm form), u a uniform in [0, 1) incl. 0 and the smallest draw"""
+    rng = np.random.Generator(np.random.PCG64(78))
+    x = rng.uniform(0.0, 1.0, N).astype(np.float32)
+    x[:5] = [0.0, 2.3283064e-10, 1.0, 0.99999994, 5.9604645e-8]
+    x[5:N // 2] = np.exp(rng.uniform(np.log(2.3283064e-10), 0.0, N // 2 - 5)).astype(np.float32)
+    for yv in (0.0526315793, 0.0526315789, 0.09, 0.01):
+        y = np.full(N, yv, dtype=np.float32)
+        assert np.array_equal(bits(device_eval(14, x, y)), bits(capi.eval_math(14, x, y)))
+
+
 def test_binary_functions_bit_exact(oracle_lib):
     rng = np.random.Generator(np.random.PCG64(5))
     x = rng.uniform(-5.0, 5.0, N).astype(np.float32)

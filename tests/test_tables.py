@@ -213,3 +213,49 @@ def test_string_proximity_map_is_a_lower_bound():
         true -= g["om_radius"]
         assert np.all(bound <= np.maximum(true, 0.0)), name
         assert (bound > 0).mean() > 0.5          # and it is useful: most of the volume is free flight
+
+
+def test_dom_proximity_map_is_a_lower_bound():
+    """Second level of the search filter (prop_device.hip.h: dom_free_flight_bound): a cell names its nearest DOM and stores
+    a bound for all others; min(exact distance to the named DOM's sphere, stored bound) must never exceed the true 3D
+    distance from the point to the surface of the nearest DOM sphere -- and should be close to it."""
+    for name in ("mie", "c1"):
+        cfg = common.config(name)
+        conv = common.product_converter(cfg, 512, initialize=False)
+        conv.Compile()
+        nx, ny, nz, x0, y0, z0, inv_cell, radius = conv.GetTable("DOM_PROXIMITY_GRID")
+        nx, ny, nz = int(nx), int(ny), int(nz)
+        words = conv.GetTable("dom_proximity_map").astype(np.uint32).reshape(nz, ny, nx)
+        centres = conv.GetTable("dom_centres").reshape(-1, 4)[:, :3]
+        g = cfg["geom"]
+        doms = np.stack([g["x"], g["y"], g["z"]], axis=1)
+        assert len(centres) == len(doms)
+        # the kernel's DOM positions are the geometry's, up to the int16 template quantisation
+        assert np.abs(np.sort(centres, axis=0) - np.sort(doms, axis=0)).max() < 0.02
+        rng = np.random.Generator(np.random.PCG64(11))
+        lo, hi = doms.min(axis=0) - 150.0, doms.max(axis=0) + 150.0
+        pts = rng.uniform(lo, hi, size=(30000, 3))
+        near = rng.integers(0, len(doms), size=30000)                   # and points close to DOMs, at every scale
+        pts = np.concatenate([pts, doms[near] + rng.normal(0, 1.0, size=(30000, 3)) * rng.choice([0.5, 3.0, 12.0], size=(30000, 1))])
+        pf = pts.astype(np.float32)
+        idx = []
+        for k, (o, n) in enumerate(((x0, nx), (y0, ny), (z0, nz))):
+            idx.append(np.clip(((pf[:, k] - np.float32(o)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1))   # the kernel's arithmetic
+        w = words[idx[2], idx[1], idx[0]]
+        ident = (w & 0xffff).astype(np.int64)
+        bound = ((w >> 16) & 0xff) * 0.25
+        named = ident != 0xffff
+        assert ident[named].max() < len(doms)
+        exact = np.sqrt(((pf[named].astype(np.float64) - centres[ident[named]]) ** 2).sum(axis=1)) * 0.99999 - radius
+        bound[named] = np.minimum(bound[named], exact)
+        true = np.full(len(pts), np.inf)
+        for k in range(0, len(doms), 128):
+            d = np.sqrt(((pf[:, None, :].astype(np.float64) - centres[None, k:k + 128, :]) ** 2).sum(axis=2))
+            true = np.minimum(true, d.min(axis=1))
+        true -= g["om_radius"]
+        assert np.all(bound <= np.maximum(true, 0.0) + 1e-9), name
+        if name == "mie":
+            close = true < 30.0
+            assert np.median((true - bound)[close]) < 0.1         # near a DOM the bound is the exact distance (minus the safety)
+            inside = np.all((pts[:30000] > doms.min(axis=0)) & (pts[:30000] < doms.max(axis=0)), axis=1)
+            assert (bound[:30000][inside] > 3.0).mean() > 0.9     # and it is useful: a few metres of free flight nearly everywhere
