@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
     ap.add_argument("--photons-per-step", type=int, default=200)
     ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab", "tab5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab", "tab5", "benchmark"],
                     help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
                          "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea; tab: the "
                          "table-maker half of configs[4] (point cascade, default spherical axes, SPICE-Mie) -- prints its own line")
+    ap.add_argument("--events-per-pass", type=int, default=2, help="--workload benchmark: 40 TeV electrons per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="time EnqueueSteps -> GetConversionResult instead (host buffers, PCIe transfers and the index->ID "
@@ -192,6 +193,77 @@ def host_path_run(CV, args, steps_np, conv, bunches):
                           "(reference benchmark.py:335-340), outside the timed region of `value`"}
 
 
+def benchmark_workload(args, torch, device):
+    """The reference's own benchmark (resources/scripts/benchmark.py:142-147, 300-316): 40 TeV electrons at the origin pointing
+    down, SPICE-Lea, DOM oversize 5, UnshadowedFraction 0.95.  Particle -> step requests on the host (PPC front end,
+    csrc/lightsource.cpp), steps born in HBM (steps_kernel.hip) and propagated there; nothing visits the host.  One pass =
+    `--events-per-pass` events (2 x 2.56M steps = 1.02e9 photons); the steps of every pass are generated inside the timed region."""
+    from clsim_amd import converter as CV
+    from clsim_amd import synthetic as S
+    dev = torch.device("cuda", device)
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_lea"))
+    bias = CV.GetIceCubeDOMAcceptance(efficiency=0.95)
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, medium)]
+    geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
+    ppc = CV.I3CLSimLightSourceToStepConverterPPC()
+    ppc.SetWlenBias(bias); ppc.SetMediumProperties(medium); ppc.SetRandomSeed(12345); ppc.Initialize()
+    passes = args.warmup + args.steps
+    per_pass = max(1, args.events_per_pass)
+    requests, counts, photons = [], [], []
+    for k in range(passes):
+        ev = np.zeros(per_pass, dtype=CV.PARTICLE_DTYPE)
+        ev["type"] = CV.ParticleType.EMinus
+        ev["energy"] = 40.0e3
+        ev["dz"] = -1.0
+        ev["length"] = np.nan
+        ev["identifier"] = np.arange(k * per_pass, (k + 1) * per_pass, dtype=np.uint32)
+        req = ppc.EnqueueLightSources(ev)
+        requests.append(req)
+        counts.append(CV.CountGeneratedSteps(req, granularity=512)[1])
+        photons.append(int((req["num_steps"] * req["photons_per_step"] + req["num_photons_in_last_step"]).sum()))
+    n_max = max(counts)
+    conv = CV.initializeHIP(device, geom, medium, bias, gens, pancakeFactor=5.0, approximateNumberOfWorkItems=n_max, seed=12345)
+    if conv.GetMaxNumWorkitems() < n_max:
+        raise SystemExit("events-per-pass too large: %d steps for %d RNG streams" % (n_max, conv.GetMaxNumWorkitems()))
+    capacity = 16 * 1024 * 1024
+    d_steps = torch.empty((n_max, 48), dtype=torch.uint8, device=dev)
+    d_photons = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_pass(k):
+        n = CV.GenerateStepsDevice(requests[k], 777 + k, d_steps.data_ptr(), n_max, granularity=512, device=device, stream=stream)
+        conv.PropagateDevice(d_steps.data_ptr(), n, d_photons.data_ptr(), capacity, d_count.data_ptr(), stream=stream)
+
+    for k in range(args.warmup):
+        one_pass(k)
+    torch.cuda.synchronize()
+    conv.KernelTimeMs(reset=True)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, passes):
+        one_pass(k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = conv.KernelTimeMs(reset=True)
+    hits = int(d_count.cpu().item())
+    total = sum(photons[args.warmup:])
+    n_last = counts[-1]
+    avg_ms = kernel_ms / max(launches, 1)
+    alg_bytes = n_last * 72.0 + min(hits, capacity) * 80.0
+    emit(json.dumps({
+        "metric": "propagated photons/sec (whole node)", "value": total / elapsed, "unit": "photons/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "reference benchmark.py: %d x 40 TeV e- at the origin pointing down per pass, spice_lea + tilt, 86 strings, oversize 5" % per_pass,
+                   "kind": "particles -> step requests (host) -> steps born in HBM -> propagated; step generation inside the timed region",
+                   "photons_per_meter_of_track": ppc.MeanPhotonsPerMeter(0), "steps_last_pass": n_last, "photons_last_pass": photons[-1],
+                   "hits_last_pass": hits, "shower_parameters": "restated from the published parameterisation (parity unpinned)"},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "prop_pool_kernel" if conv.KernelForBunch(n_last) == "pool" else "prop_kernel", "avg_kernel_ms": avg_ms,
+                     "launches": int(launches), "algorithmic_bytes_per_launch": alg_bytes}}))
+
+
 WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
@@ -240,6 +312,8 @@ def main():
 
     if args.workload in ("tab", "tab5"):
         return tabulator_bench(args, torch, local_rank)
+    if args.workload == "benchmark":
+        return benchmark_workload(args, torch, local_rank)
     n = (args.bunch // 512) * 512
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))

@@ -32,6 +32,11 @@ class StepRequest(C.Structure):     # clsimhip_step_request
                 ("photons_per_step", C.c_uint32), ("num_photons_in_last_step", C.c_uint32), ("num_steps", C.c_uint64)]
 
 
+class PPCConfig(C.Structure):       # clsimhip_ppc_config
+    _fields_ = [("photons_per_step", C.c_uint32), ("high_photons_per_step", C.c_uint32), ("use_high_photons_per_step_from", C.c_double),
+                ("use_cascade_extension", C.c_int32), ("reserved", C.c_int32), ("medium_density", C.c_double), ("seed", C.c_uint64)]
+
+
 class Distribution(C.Structure):    # clsimhip_distribution
     _fields_ = [("kind", C.c_int32), ("value", C.c_float)]
 
@@ -98,6 +103,7 @@ SYMBOLS = [
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_check_math_exhaustive", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
+    "clsimhip_ppc_create", "clsimhip_ppc_destroy", "clsimhip_ppc_photons_per_meter", "clsimhip_ppc_enqueue", "clsimhip_shower_parameters",
     "clsimhip_count_flasher_steps", "clsimhip_generate_flasher_steps_device", "clsimhip_generate_flasher_steps",
     "clsimhip_flasher_time_profile",
     "clsimhip_step_store_create", "clsimhip_step_store_destroy", "clsimhip_step_store_insert", "clsimhip_step_store_size",
@@ -188,6 +194,11 @@ def load():
         "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
         "clsimhip_check_math_exhaustive": (i32, [i32, i32, i32, i32, vp, sz]),
         "clsimhip_version": (C.c_char_p, []),
+        "clsimhip_ppc_create": (i32, [vp, C.POINTER(Function), C.POINTER(PPCConfig), C.POINTER(vp)]),
+        "clsimhip_ppc_destroy": (None, [vp]),
+        "clsimhip_ppc_photons_per_meter": (i32, [vp, i32, C.POINTER(C.c_double)]),
+        "clsimhip_ppc_enqueue": (i32, [vp, vp, sz, C.POINTER(StepRequest), sz, C.POINTER(sz)]),
+        "clsimhip_shower_parameters": (i32, [i32, C.c_double, C.c_double, C.POINTER(C.c_double)]),
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
         "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),

@@ -470,6 +470,92 @@ def GenerateStepsDevice(requests, seed, d_steps, capacity, granularity=1, device
     return got.value
 
 
+# ---- particle -> step requests (I3CLSimLightSourceToStepConverterPPC front end, csrc/lightsource.cpp) ----
+PARTICLE_DTYPE = np.dtype([("type", "<i4"), ("shape", "<i4"), ("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("time", "<f8"),
+                           ("dx", "<f8"), ("dy", "<f8"), ("dz", "<f8"), ("energy", "<f8"), ("length", "<f8"),
+                           ("identifier", "<u4"), ("reserved", "<u4")])
+assert PARTICLE_DTYPE.itemsize == 88
+
+
+class ParticleType:
+    """I3Particle::ParticleType values (dataclasses): PDG codes and IceCube's codes for stochastic losses"""
+    Gamma, EMinus, EPlus, MuMinus, MuPlus, TauMinus, TauPlus = 22, 11, -11, 13, -13, 15, -15
+    Pi0, PiPlus, PiMinus, K0_Long, KPlus, KMinus, K0_Short = 111, 211, -211, 130, 321, -321, 310
+    PPlus, PMinus, Neutron = 2212, -2212, 2112
+    Brems, DeltaE, PairProd, NuclInt, Hadrons = -2000001001, -2000001002, -2000001003, -2000001004, -2000001006
+
+
+SHAPE_OTHER, SHAPE_CASCADE_SEGMENT = 0, 1
+
+
+class I3CLSimLightSourceToStepConverterPPC:
+    """Front end of the reference's converter (private/clsim/I3CLSimLightSourceToStepConverterPPC.cxx:51-132, 188-470): particles in,
+    step requests out; GenerateSteps / GenerateStepsDevice make the steps on the GPU."""
+
+    def __init__(self, photonsPerStep=200, highPhotonsPerStep=2000, useHighPhotonsPerStepStartingFromNumPhotons=1.0e9):
+        if photonsPerStep <= 0 or highPhotonsPerStep <= 0:
+            raise I3CLSimStepToPhotonConverter_exception("photonsPerStep may not be <= 0!")
+        self._cfg = _lib.PPCConfig(int(photonsPerStep), int(highPhotonsPerStep), float(useHighPhotonsPerStepStartingFromNumPhotons), 1, 0, 0.9216, 0)
+        self._bias = self._medium = self._h = None
+        self._lib = _lib.load()
+
+    def SetUseCascadeExtension(self, v):
+        self._cfg.use_cascade_extension = int(bool(v))
+
+    def SetWlenBias(self, wlenBias):
+        self._bias = wlenBias
+
+    def SetMediumProperties(self, mediumProperties, density=0.9216):
+        self._medium = mediumProperties
+        self._cfg.medium_density = float(density)
+
+    def SetRandomSeed(self, seed):
+        self._cfg.seed = int(seed)
+
+    def Initialize(self):
+        if self._bias is None:
+            raise I3CLSimStepToPhotonConverter_exception("WlenBias not set!")
+        if self._medium is None:
+            raise I3CLSimStepToPhotonConverter_exception("MediumProperties not set!")
+        h = C.c_void_p()
+        d = self._bias._desc()
+        _check(self._lib.clsimhip_ppc_create(self._medium._h, C.byref(d), C.byref(self._cfg), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.clsimhip_ppc_destroy(self._h)
+        except Exception:
+            pass
+
+    def IsInitialized(self):
+        return self._h is not None
+
+    def MeanPhotonsPerMeter(self, layer=0):
+        v = C.c_double()
+        _check(self._lib.clsimhip_ppc_photons_per_meter(self._h, int(layer), C.byref(v)))
+        return v.value
+
+    def EnqueueLightSources(self, particles):
+        """particles: array of PARTICLE_DTYPE -> array of REQUEST_DTYPE (one per cascade, two per muon / tau)"""
+        if self._h is None:
+            raise I3CLSimStepToPhotonConverter_exception("I3CLSimLightSourceToStepConverterPPC is not initialized!")
+        p = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+        out = np.zeros(2 * len(p), dtype=REQUEST_DTYPE)
+        n = C.c_size_t()
+        _check(self._lib.clsimhip_ppc_enqueue(self._h, p.ctypes.data_as(C.c_void_p), len(p), out.ctypes.data_as(C.POINTER(_lib.StepRequest)),
+                                              len(out), C.byref(n)))
+        return out[:n.value]
+
+
+def ShowerParameters(particleType, energy, density=0.9216):
+    """(a, b [m], emScale, emScaleSigma) of I3SimConstants::ShowerParameters as restated in csrc/lightsource.cpp"""
+    out = (C.c_double * 4)()
+    _check(_lib.load().clsimhip_shower_parameters(int(particleType), float(energy), float(density), out))
+    return tuple(out)
+
+
 # ---- flasher step producer (I3CLSimLightSourceToStepConverterFlasher) ----
 FLASHER_REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
                                   ("sigma_polar", "<f4"), ("sigma_azimuthal", "<f4"), ("pulse_width", "<f4"), ("identifier", "<u4"),

@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "converter.h"
+#include "lightsource.h"
 #include "tabulator.h"
 #include "step_store.h"
 #include "flasher.h"
@@ -175,6 +176,50 @@ int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const 
         std::memcpy(y_out, g.y.data(), g.y.size() * sizeof(double));
         if (first_out) *first_out = g.first;
         if (spacing_out) *spacing_out = g.spacing;
+    });
+}
+struct clsimhip_ppc_converter { std::unique_ptr<clsimhip::PPCConverter> impl; };
+int clsimhip_ppc_create(const clsimhip_medium *medium, const clsimhip_function *wavelength_bias, const clsimhip_ppc_config *config,
+                        clsimhip_ppc_converter **out)
+{
+    return guarded(nullptr, [&] {
+        need(medium, "medium"); need(wavelength_bias, "wavelength_bias"); need(out, "out");
+        PPCConfig c;
+        if (config) {
+            c.photons_per_step = config->photons_per_step; c.high_photons_per_step = config->high_photons_per_step;
+            c.use_high_photons_per_step_from = config->use_high_photons_per_step_from;
+            c.use_cascade_extension = config->use_cascade_extension != 0;
+            c.density = config->medium_density; c.seed = config->seed;
+        }
+        std::unique_ptr<clsimhip_ppc_converter> p(new clsimhip_ppc_converter);
+        p->impl.reset(new PPCConverter(medium->data, function_from(wavelength_bias), c));
+        *out = p.release();
+    });
+}
+void clsimhip_ppc_destroy(clsimhip_ppc_converter *p) { delete p; }
+int clsimhip_ppc_photons_per_meter(const clsimhip_ppc_converter *p, int layer, double *out)
+{
+    return guarded(nullptr, [&] { need(p, "converter"); need(out, "out"); *out = p->impl->mean_photons_per_meter(layer); });
+}
+int clsimhip_ppc_enqueue(const clsimhip_ppc_converter *p, const clsimhip_particle *particles, size_t n,
+                         clsimhip_step_request *requests_out, size_t capacity, size_t *n_out)
+{
+    return guarded(nullptr, [&] {
+        need(p, "converter"); need(n_out, "n_out");
+        if (n) need(particles, "particles");
+        std::vector<clsimhip_step_request> v;
+        v.reserve(2 * n);
+        for (size_t i = 0; i < n; ++i) p->impl->enqueue(particles[i], v);
+        *n_out = v.size();
+        if (requests_out) std::copy(v.begin(), v.begin() + static_cast<std::ptrdiff_t>(std::min(capacity, v.size())), requests_out);
+    });
+}
+int clsimhip_shower_parameters(int32_t particle_type, double energy_gev, double density_g_cm3, double out[4])
+{
+    return guarded(nullptr, [&] {
+        need(out, "out");
+        const ShowerParameters s = shower_parameters(particle_type, energy_gev, density_g_cm3);
+        out[0] = s.a; out[1] = s.b; out[2] = s.em_scale; out[3] = s.em_scale_sigma;
     });
 }
 int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count)

@@ -344,6 +344,73 @@ int clsimhip_generate_steps_device(int device, const clsimhip_step_request *requ
 int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed,
                             size_t granularity, clsimhip_step *steps_out, size_t capacity, size_t *padded_out);
 
+/* ---- particle -> step requests: the front end of I3CLSimLightSourceToStepConverterPPC ----------
+ * private/clsim/I3CLSimLightSourceToStepConverterPPC.cxx, Initialize :94-132 (photon yield per metre of track,
+ * ConverterUtils.cxx:44-105) and EnqueueLightSource :188-470: 5.21 m of Cherenkov-radiating track per GeV (scaled with the
+ * density), the electromagnetic fraction of hadronic showers with its fluctuation, a Poisson (Gaussian above 1e7) number
+ * of photons, the split into steps of photonsPerStep (highPhotonsPerStep above a threshold) photons; muons and taus as
+ * a bare track plus the average secondary light (1 + max(0, 0.1880 + 0.0206 ln E)).  Host only.
+ * NOT part of the reference tree and therefore restated from published sources, PARITY UNPINNED:
+ * I3SimConstants::ShowerParameters (sim-services), the random service's Gaus / Poisson (phys-services / GSL), and
+ * gsl_integration_qag.  Particle types are I3Particle::ParticleType values (dataclasses): PDG codes, and IceCube's own
+ * codes for stochastic losses. */
+#define CLSIMHIP_PARTICLE_GAMMA 22
+#define CLSIMHIP_PARTICLE_EMINUS 11
+#define CLSIMHIP_PARTICLE_EPLUS (-11)
+#define CLSIMHIP_PARTICLE_MUMINUS 13
+#define CLSIMHIP_PARTICLE_MUPLUS (-13)
+#define CLSIMHIP_PARTICLE_TAUMINUS 15
+#define CLSIMHIP_PARTICLE_TAUPLUS (-15)
+#define CLSIMHIP_PARTICLE_PI0 111
+#define CLSIMHIP_PARTICLE_PIPLUS 211
+#define CLSIMHIP_PARTICLE_PIMINUS (-211)
+#define CLSIMHIP_PARTICLE_K0_LONG 130
+#define CLSIMHIP_PARTICLE_KPLUS 321
+#define CLSIMHIP_PARTICLE_KMINUS (-321)
+#define CLSIMHIP_PARTICLE_K0_SHORT 310
+#define CLSIMHIP_PARTICLE_PPLUS 2212
+#define CLSIMHIP_PARTICLE_PMINUS (-2212)
+#define CLSIMHIP_PARTICLE_NEUTRON 2112
+#define CLSIMHIP_PARTICLE_BREMS (-2000001001)
+#define CLSIMHIP_PARTICLE_DELTAE (-2000001002)
+#define CLSIMHIP_PARTICLE_PAIRPROD (-2000001003)
+#define CLSIMHIP_PARTICLE_NUCLINT (-2000001004)
+#define CLSIMHIP_PARTICLE_HADRONS (-2000001006)
+#define CLSIMHIP_SHAPE_OTHER 0
+#define CLSIMHIP_SHAPE_CASCADE_SEGMENT 1        /* I3Particle::CascadeSegment: steps spread uniformly over `length` (:342-357) */
+typedef struct {
+    int32_t type;                       /* CLSIMHIP_PARTICLE_* / any PDG code (unknown codes are treated as hadrons, :272-279) */
+    int32_t shape;                      /* CLSIMHIP_SHAPE_* */
+    double x, y, z, time;               /* [m, ns] */
+    double dx, dy, dz;                  /* unit direction */
+    double energy;                      /* [GeV] */
+    double length;                      /* [m]; NaN: unknown (muons then get 2000 m, :377-380) */
+    uint32_t identifier;                /* -> I3CLSimStep::identifier of its steps */
+    uint32_t reserved;
+} clsimhip_particle;
+typedef struct {
+    uint32_t photons_per_step;          /* photonsPerStep (200) */
+    uint32_t high_photons_per_step;     /* highPhotonsPerStep (2000) */
+    double use_high_photons_per_step_from;  /* useHighPhotonsPerStepStartingFromNumPhotons (1e9) */
+    int32_t use_cascade_extension;      /* UseCascadeExtension (on) */
+    int32_t reserved;
+    double medium_density;              /* g/cm3; I3CLSimMediumProperties::GetMediumDensity(), 0.9216 for the IceCube media */
+    uint64_t seed;                      /* of this library's generator (in the place of the I3RandomService) */
+} clsimhip_ppc_config;
+typedef struct clsimhip_ppc_converter clsimhip_ppc_converter;
+/* SetWlenBias + SetMediumProperties + Initialize */
+int clsimhip_ppc_create(const clsimhip_medium *medium, const clsimhip_function *wavelength_bias, const clsimhip_ppc_config *config,
+                        clsimhip_ppc_converter **out);
+void clsimhip_ppc_destroy(clsimhip_ppc_converter *p);
+/* meanPhotonsPerMeterInLayer_[layer] (beta = 1, after the wavelength bias) */
+int clsimhip_ppc_photons_per_meter(const clsimhip_ppc_converter *p, int layer, double *out);
+/* EnqueueLightSource for n particles: one request per cascade, two per muon / tau (muon-like, then cascade-like steps),
+ * ready for clsimhip_generate_steps[_device].  *n_out = requests the particles need; at most `capacity` are written. */
+int clsimhip_ppc_enqueue(const clsimhip_ppc_converter *p, const clsimhip_particle *particles, size_t n,
+                         clsimhip_step_request *requests_out, size_t capacity, size_t *n_out);
+/* I3SimConstants::ShowerParameters as restated here: out = {a, b [m], emScale, emScaleSigma} */
+int clsimhip_shower_parameters(int32_t particle_type, double energy_gev, double density_g_cm3, double out[4]);
+
 /* ---- flasher step producer --------------------------------------------------------------
  * I3CLSimLightSourceToStepConverterFlasher (private/clsim/I3CLSimLightSourceToStepConverterFlasher.cxx): MakeSteps
  * :329-440 cuts a flasher pulse into steps of photons_per_step photons (zero length, beta 1, weight 1, the pulse's
