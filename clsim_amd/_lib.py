@@ -100,6 +100,7 @@ SYMBOLS = [
     "clsimhip_release_result",
     "clsimhip_get_workgroup_size", "clsimhip_get_max_num_workitems", "clsimhip_queue_size",
     "clsimhip_more_photons_available", "clsimhip_get_statistics", "clsimhip_propagate_device",
+    "clsimhip_set_concurrent_device_launches",
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_check_math_exhaustive", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
@@ -187,6 +188,7 @@ def load():
         "clsimhip_more_photons_available": (i32, [vp, C.POINTER(i32)]),
         "clsimhip_get_statistics": (i32, [vp, DP]),
         "clsimhip_propagate_device": (i32, [vp, vp, sz, sz, vp, sz, vp, vp]),
+        "clsimhip_set_concurrent_device_launches": (i32, [vp, i32]),
         "clsimhip_replace_indices_with_ids": (i32, [vp, vp, sz]),
         "clsimhip_kernel_time_ms": (i32, [vp, i32, DP, C.POINTER(u64)]),
         "clsimhip_get_table": (C.c_long, [vp, C.c_char_p, DP, sz]),

@@ -362,6 +362,10 @@ class I3CLSimStepToPhotonConverterHIP:
         self._call("clsimhip_propagate_device", C.c_void_p(d_steps), int(n), int(rng_offset), C.c_void_p(d_photons),
                    int(capacity), C.c_void_p(d_hit_count), C.c_void_p(stream))
 
+    def SetConcurrentDeviceLaunches(self, k):
+        """k device-path launches in flight on k streams (disjoint rng_offset ranges): each sizes its grid for 1/k of the chip"""
+        self._call("clsimhip_set_concurrent_device_launches", int(k))
+
     def ReplaceIndicesWithIDs(self, photons):
         photons = np.ascontiguousarray(photons, dtype=PHOTON_DTYPE)
         self._call("clsimhip_replace_indices_with_ids", photons.ctypes.data_as(C.c_void_p), len(photons))

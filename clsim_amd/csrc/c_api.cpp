@@ -247,6 +247,10 @@ int clsimhip_set_device(clsimhip_converter *c, int device_ordinal)
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.set_device(device_ordinal); });
 }
+int clsimhip_set_concurrent_device_launches(clsimhip_converter *c, int k)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.set_concurrent_device_launches(k); });
+}
 int clsimhip_step_series_blob_size(size_t n, size_t *bytes)
 {
     return guarded(nullptr, [&] { need(bytes, "bytes"); *bytes = series_blob_size(n, sizeof(clsimhip_step)); });

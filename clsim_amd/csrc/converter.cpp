@@ -25,6 +25,12 @@ hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
     return pooled_for(P.n_steps) ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
 }
 
+void Converter::set_concurrent_device_launches(int k)
+{
+    if (k < 1 || k > 16) throw Error(CLSIMHIP_ERR_ARGUMENT, "concurrent device launches: 1 ... 16");
+    concurrent_launches_ = k;
+}
+
 void Converter::hip_check(hipError_t e, const char *what) const
 {
     if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
@@ -345,6 +351,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.slices = k_slices_;
     P.k_pop = k_pop_;
     P.pool_ready = pool_ready_;
+    P.chip_share = concurrent_launches_;
 #ifdef CLSIMHIP_CENSUS
     if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), 1 << 20), "census");
     P.census = d_census_;

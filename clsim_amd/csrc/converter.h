@@ -176,7 +176,10 @@ public:
     // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
     void set_device(int device);
     int device() const { return device_; }
-    bool pooled_for(size_t n_steps) const { need_init(); return use_pool_ && n_steps >= pool_min_steps_; }
+    // the pooled kernel pays from ~3 steps per unit slot on: a launch that owns 1/k of the chip reaches that with 1/k of the steps
+    bool pooled_for(size_t n_steps) const { need_init(); return use_pool_ && n_steps * static_cast<size_t>(concurrent_launches_) >= pool_min_steps_; }
+    void set_concurrent_device_launches(int k);
+    int concurrent_device_launches() const { return concurrent_launches_; }
     bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
 
 private:
@@ -244,6 +247,7 @@ private:
     WorkRecord *d_work_ = nullptr;           // per step: work record (kparams.h), rebuilt by every launch
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight
     uint32_t queue_slot_ = 0;
+    int concurrent_launches_ = 1;            // device path: launches the caller keeps in flight side by side (chip share of each)
     uint32_t *last_queue_ = nullptr;
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *d_census_ = nullptr;

@@ -69,6 +69,7 @@ struct KParams {
     // pooled kernel (prop_pool_kernel.hip): entries of a wave's ring of ready photons, and how many lanes must be
     // without a photon before the wave services them; k_new is its creation batch there (0 = automatic everywhere)
     int32_t pool_ready, k_pop;
+    int32_t chip_share;                 // launch geometry only: this launch may fill 1/chip_share of the chip (0, 1: all of it)
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *census;         // analysis build (make EXTRA=-DCLSIMHIP_CENSUS): [0..7] lane-state sums, [8] earliest
                                         // wave start, [16 + 3w ...] per wave: end time, time the first sub-queue was found dry, trips

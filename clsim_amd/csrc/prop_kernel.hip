@@ -812,8 +812,10 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)resident;
     {
-        const int cus = plan.cus;
-        const int per_cu = resident / cus;
+        // concurrent launches of one converter (clsimhip_set_concurrent_device_launches): each takes its share of the CUs
+        const int share = (P.chip_share > 1) ? P.chip_share : 1;
+        const int cus = (plan.cus / share > 0) ? plan.cus / share : 1;
+        const int per_cu = resident / plan.cus;
         const int floor_per_cu = per_cu < 5 ? per_cu : 5;
         int chosen = floor_per_cu;
         for (int k = per_cu; k >= floor_per_cu; --k)

@@ -477,6 +477,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         plan = pl;
     }
     uint32_t grid = (uint32_t)plan.resident;
+    if (P.chip_share > 1) grid = (grid / (uint32_t)P.chip_share > 0u) ? grid / (uint32_t)P.chip_share : 1u;      // concurrent launches share the chip
     if (const char *e = getenv("CLSIMHIP_GRID")) {
         const int g = atoi(e);
         if (g >= 1 && g <= plan.resident) grid = (uint32_t)g;

@@ -246,6 +246,13 @@ int clsimhip_get_statistics(const clsimhip_converter *c, double out[8]);
  * bunch = rng_offset + i).  String/DOM fields hold INDICES.  Asynchronous. */
 int clsimhip_propagate_device(clsimhip_converter *c, const void *d_steps, size_t n, size_t rng_offset,
                               void *d_photons, size_t capacity, void *d_hit_count, void *stream);
+/* Small bunches: a launch is a persistent grid sized for the whole chip, and a bunch of a few 10^5 steps leaves most lanes
+ * with less than one step.  A caller that has several such bunches keeps k of them in flight instead -- k calls of
+ * clsimhip_propagate_device on k different HIP streams, over disjoint RNG stream ranges [rng_offset, rng_offset + n) and
+ * with output buffers of their own -- after telling the converter so: every launch then sizes its grid for 1/k of the
+ * chip and they run side by side (work records and queue heads are per stream range and per launch).  Results do not
+ * depend on k.  1 <= k <= 16, default 1; may be changed between launches. */
+int clsimhip_set_concurrent_device_launches(clsimhip_converter *c, int k);
 /* index -> ID translation on the device records' host copy (OpenCL.cxx:1565-1600) */
 int clsimhip_replace_indices_with_ids(const clsimhip_converter *c, clsimhip_photon *photons, size_t n);
 /* average duration (ms) of the propagation kernel over the launches recorded since

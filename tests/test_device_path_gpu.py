@@ -68,6 +68,41 @@ def test_sharding_invariance():
         assert np.array_equal(conv2.GetRNGState(n), x_whole)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "pool"])
+def test_bunches_side_by_side_on_several_streams(kernel, monkeypatch):
+    """clsimhip_set_concurrent_device_launches: four bunches in flight on four HIP streams (disjoint RNG stream ranges, output
+    buffers of their own, each launch sized for a quarter of the chip) give what one launch over all the steps gives."""
+    cfg = common.config("mie")
+    k, m = 4, 8192
+    steps = common.steps_for(cfg, k * m, seed=21)
+    n = len(steps)
+    conv = common.product_converter(cfg, n)
+    whole, cnt = device_run(conv, steps, capacity=1 << 16)
+    x_whole = conv.GetRNGState(n)
+    dev = torch.device("cuda", 0)
+    if kernel == "pool":
+        monkeypatch.setenv("CLSIMHIP_KERNEL", "pool")
+    for _ in range(1):
+        conv2 = common.product_converter(cfg, n)
+        conv2.SetConcurrentDeviceLaunches(k)
+        d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+        outs = [torch.zeros((1 << 15, 80), dtype=torch.uint8, device=dev) for _ in range(k)]
+        cnts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(k)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        torch.cuda.synchronize()
+        bounds = [0, 5000, 5000 + 12288, 5000 + 12288 + 256, n]             # ragged bunches
+        for j in range(k):
+            lo, hi = bounds[j], bounds[j + 1]
+            conv2.PropagateDevice(d_steps.data_ptr() + 48 * lo, hi - lo, outs[j].data_ptr(), 1 << 15, cnts[j].data_ptr(),
+                                  stream=streams[j].cuda_stream, rng_offset=lo)
+        torch.cuda.synchronize()
+        parts = [np.frombuffer(outs[j][:int(cnts[j].item())].cpu().numpy().tobytes(), dtype=PHOTON_DTYPE) for j in range(k)]
+        allp = np.concatenate(parts)
+        assert len(allp) == cnt
+        assert common.sort_photons(allp).tobytes() == common.sort_photons(whole).tobytes()
+        assert np.array_equal(conv2.GetRNGState(n), x_whole)
+
+
 def test_baseline_size_properties():
     """BASELINE configs[1] size (1M steps x 200 photons, SPICE-Mie, 86 strings): determinism across
     converters, every stream advanced, hit fraction and record sanity; the first 2048 steps are
