@@ -617,8 +617,12 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     scalar("lds_image_words", P.table_words);
     scalar("lds_bytes_per_workgroup", static_cast<double>(prop_kernel_lds_bytes(P.table_words)));
     C.lds_image = std::move(img.words);
-    if (prop_kernel_lds_bytes(P.table_words) > prop_kernel_lds_budget())
-        throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables do not fit the LDS budget of the propagation kernel");
+    // An image beyond the budget of seven workgroups per CU (a detector of several hundred strings) is not refused: the
+    // launchers ask the runtime how many workgroups of that size a CU holds and run with fewer (the DOM templates, the
+    // largest table, already stay in HBM/L2 then).  Only an image that does not fit a CU's 160 KB even once is.
+    if (prop_kernel_lds_bytes(P.table_words) > static_cast<size_t>(159 * 1024))
+        throw Error(CLSIMHIP_ERR_CONFIG, "medium / geometry tables (" + std::to_string(prop_kernel_lds_bytes(P.table_words)) +
+                                             " bytes) do not fit the 160 KB of LDS of a compute unit");
     return C;
 }
 

@@ -67,6 +67,25 @@ def ic86_geometry(seed=86, jitter=0.3):
                 om_radius=DOM_RADIUS * OVERSIZE)
 
 
+def large_detector_geometry(side=24, spacing=125.0, doms=60, seed=5, jitter=0.3):
+    """side x side strings on a triangular grid (576 strings, 34 560 DOMs by default): a detector whose string records
+    alone exceed the LDS budget of seven workgroups per CU -- the kernels then run with fewer workgroups per CU."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sid, did, xs, ys, zs, sub = [], [], [], [], [], []
+    s = 0
+    for i in range(side):
+        for j in range(side):
+            s += 1
+            x0 = (i - side / 2 + 0.5 * (j % 2)) * spacing
+            y0 = (j - side / 2) * spacing * math.sqrt(3.0) / 2.0
+            for d in range(doms):
+                sid.append(s); did.append(d + 1); sub.append("IceCube")
+                xs.append(x0 + jitter * rng.standard_normal()); ys.append(y0 + jitter * rng.standard_normal())
+                zs.append(500.0 - 17.0 * d)
+    return dict(string_ids=np.array(sid, dtype=np.int32), dom_ids=np.array(did, dtype=np.uint32),
+                x=np.array(xs), y=np.array(ys), z=np.array(zs), subdetectors=sub, om_radius=DOM_RADIUS * OVERSIZE)
+
+
 def cascade_steps(n, seed=1, photons_per_step=200, radius=500.0, half_height=500.0, vertex=None, pad_to=1):
     """Cascade-like steps: 1 mm long, beta 1, weight 1, isotropic directions;
     vertices uniform in a cylinder (or a fixed vertex).  Padded with

@@ -5,6 +5,7 @@ float), and so are the RNG state words left behind."""
 import numpy as np
 import pytest
 
+from clsim_amd import synthetic as S
 from oracle import capi
 from tests import common
 
@@ -370,3 +371,29 @@ def test_non_finite_steps_are_skipped_not_spun_on(capfd):
     _, ph_p = conv.GetConversionResult()
     assert len(ph_p) == cnt_o and np.array_equal(conv.GetRNGState(n), x_o)
     assert "1 steps of bunch 2" in capfd.readouterr().err
+
+
+def test_detector_of_576_strings_runs_with_fewer_workgroups_per_cu():
+    """A table image beyond the budget of seven workgroups per CU (tables.cpp: compile_tables): both kernels run with
+    what fits and stay bit-identical to the oracle."""
+    import os
+    cfg = common.config("mie")
+    cfg["geom"] = S.large_detector_geometry()
+    steps = S.cascade_steps(4096, seed=17, radius=1400.0)
+    x, a = common.streams(len(steps))
+    T = common.oracle_tables(cfg)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    assert cnt_o > 100
+    for kernel in ("classic", "pool"):
+        os.environ["CLSIMHIP_KERNEL"] = kernel
+        try:
+            conv = common.product_converter(cfg, len(steps))
+        finally:
+            del os.environ["CLSIMHIP_KERNEL"]
+        assert conv.GetTable("lds_bytes_per_workgroup")[0] > 160 * 1024 / 7
+        conv.EnqueueSteps(steps, 5)
+        ident, ph_p = conv.GetConversionResult()
+        assert ident == 5 and len(ph_p) == cnt_o, kernel
+        assert common.sort_photons(ph_p).tobytes() == common.sort_photons(ph_o).tobytes(), kernel
+        assert np.array_equal(conv.GetRNGState(len(steps)), x_o), kernel

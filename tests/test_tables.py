@@ -259,3 +259,17 @@ def test_dom_proximity_map_is_a_lower_bound():
             assert np.median((true - bound)[close]) < 0.1         # near a DOM the bound is the exact distance (minus the safety)
             inside = np.all((pts[:30000] > doms.min(axis=0)) & (pts[:30000] < doms.max(axis=0)), axis=1)
             assert (bound[:30000][inside] > 3.0).mean() > 0.9     # and it is useful: a few metres of free flight nearly everywhere
+
+
+def test_a_detector_beyond_the_lds_budget_of_seven_workgroups_compiles():
+    """576 strings: the table image (string records 18 KB + ice + cells) no longer fits seven workgroups per CU; Compile()
+    accepts it (the launchers run fewer workgroups per CU) and the geometry tables still equal the independent builder's."""
+    from clsim_amd import synthetic as S
+    cfg = common.config("mie")
+    cfg["geom"] = S.large_detector_geometry()
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    assert conv.GetTable("lds_bytes_per_workgroup")[0] > 160 * 1024 / 7
+    T = common.oracle_tables(cfg)
+    assert int(conv.GetTable("NUM_STRINGS")[0]) == 576
+    assert np.array_equal(conv.GetTable("geoStringPosX").astype(np.float32), np.asarray(T.geo["str_x"], dtype=np.float32))
