@@ -89,6 +89,18 @@ DM float div_by(float a, float b, float r, bool ok)
 // wave-uniform), the IEEE divide otherwise
 DM float rcp_sel(float x, bool fast) { return fast ? dm::rcp_(x) : 1.0f / x; }
 constexpr uint32_t kFastLengths = 32u, kFastMatrices = 64u, kFastAniso = 128u;      // KParams::div_ok bits 5-7
+// FAST (template parameter of the pooled kernel): Compile() found the standard configuration with every proof in hand
+// (KVariant::fast) -- mixed Liu / Henyey-Greenstein scattering with beta <= 0.09, every invariant divisor proven, lengths
+// and transforms bounded, tilt bins on scalars -- so the wave-uniform tests of those facts, two scalar branches each, are
+// compiled out of the loop.  A scalar instruction costs the kernel as much as a vector one.
+template <bool FAST>
+DM float div_by_t(float a, float b, float r, bool ok)
+{
+    if (FAST) { const float q = a * r; return dm::fma_(dm::fma_(-b, q, a), r, q); }
+    return div_by(a, b, r, ok);
+}
+template <bool FAST>
+DM float rcp_t(float x, bool fast) { return FAST ? dm::rcp_(x) : rcp_sel(x, fast); }
 DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 
@@ -154,7 +166,7 @@ DM IceFactors ice_factors(KP P, float wlen)
 }
 // scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100,
 // FunctionFromTable.cxx:262-291 behind the switch(layer) of MediumPropertiesSource.cxx:89-123)
-template <int MED>
+template <int MED, bool FAST = false>
 DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len, bool fast)
 {
     if (MED == CLSIMHIP_LENGTHS_TABLE) {
@@ -165,8 +177,8 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
     }
     const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
     if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
-        sca_len = rcp_sel(r.c * f.sca_pow, fast);
-        abs_len = rcp_sel(r.a * f.abs_pow + f.abs_exp * r.b, fast);
+        sca_len = rcp_t<FAST>(r.c * f.sca_pow, fast);
+        abs_len = rcp_t<FAST>(r.a * f.abs_pow + f.abs_exp * r.b, fast);
     } else {
         sca_len = r.c;
         abs_len = r.a;
@@ -174,33 +186,39 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
 }
 
 // HenyeyGreenstein.cxx:69-92
+template <bool FAST = false>
 DM float hg_cos(KP P, float u)
 {
     const float s = 2.0f * u - 1.0f;
     const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
-    return clampf(div_by(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, (P->div_ok & 16u) != 0), -1.0f, 1.0f);
+    return clampf(div_by_t<FAST>(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, FAST || (P->div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
+template <bool FAST = false>
 DM float liu_cos(KP P, float u)
 {
     const float beta = P->liu_beta;
     // beta <= 0.09 (mean cosine >= 0.835, wave-uniform): beta |log u| <= 2 for u >= 2^-32, the single-word logarithm form
-    const float p = (beta <= 0.09f) ? dm::powr_unit_(u, beta) : dm::powr_(u, beta);
+    const float p = (FAST || beta <= 0.09f) ? dm::powr_unit_(u, beta) : dm::powr_(u, beta);
     return clampf(2.0f * p - 1.0f, -1.0f, 1.0f);
 }
 // Mixed.cxx:115-157, single random number form
+template <bool FAST = false>
 DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
 {
     const float rr = rng_co(x, a);
-    const int kind = P->scatter_kind;
-    if (kind == 0) return hg_cos(P, rr);
-    if (kind == 1) return liu_cos(P, rr);
-    const uint32_t ok = P->div_ok;
-    if (rr < P->mix_frac) return liu_cos(P, div_by(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
-    return hg_cos(P, div_by(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
+    if (!FAST) {
+        const int kind = P->scatter_kind;
+        if (kind == 0) return hg_cos(P, rr);
+        if (kind == 1) return liu_cos(P, rr);
+    }
+    const uint32_t ok = FAST ? 0xffu : P->div_ok;
+    if (rr < P->mix_frac) return liu_cos<FAST>(P, div_by_t<FAST>(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
+    return hg_cos<FAST>(P, div_by_t<FAST>(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
 }
 
 // ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
+template <bool FAST = false>
 DM float abs_len_corr(KP P, const Vec3 &d)
 {
     const float n0 = (P->an_azx * d.x) + (P->an_azy * d.y);
@@ -211,7 +229,7 @@ DM float abs_len_corr(KP P, const Vec3 &d)
     const float An = (s0 * P->an_l[0] + s1 * P->an_l[1]) + s2 * P->an_l[2];
     // RN(2/x) = 2 RN(1/x): a scaling by two is exact
     const float x = (P->an_B2 - nB) * An;
-    return ((P->div_ok & kFastAniso) != 0u) ? 2.0f * dm::rcp_(x) : 2.0f / x;
+    return (FAST || (P->div_ok & kFastAniso) != 0u) ? 2.0f * dm::rcp_(x) : 2.0f / x;
 }
 // VectorTransformMatrix.cxx:101-135
 DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renorm, Vec3 &d, bool fast)
@@ -229,9 +247,10 @@ DM void apply_matrix(const __attribute__((address_space(4))) float *m, int renor
 
 // ScalarFieldIceTiltZShift.cxx:145-213.  The distance bin is the first j with
 // nr < dist[j] (last bin otherwise); dist is ascending, so it is counted.
+template <bool FAST = false>
 DM float tilt_z_shift(KP P, float px, float py, float pz)
 {
-    const float z_rescaled = div_by(pz - P->tilt_first_z, P->tilt_dz, P->rcp_tilt_dz, (P->div_ok & 1u) != 0);
+    const float z_rescaled = div_by_t<FAST>(pz - P->tilt_first_z, P->tilt_dz, P->rcp_tilt_dz, (P->div_ok & 1u) != 0);
     const int nz = P->tilt_nz, nd = P->tilt_nd;
     const uint32_t off_dist = P->off_tilt_dist;
     const int k = clampi((int)__builtin_floorf(z_rescaled), 0, nz - 2);
@@ -239,7 +258,7 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     const float fraction_z_below = 1.0f - fraction_z_above;
     const float nr = P->tilt_lnx * px + P->tilt_lny * py;
     int j = 1;
-    if (nd <= kTiltScalarBins + 2) {
+    if (FAST || nd <= kTiltScalarBins + 2) {
         // inner bin edges live in the parameter block (padded with +inf): compares against SGPRs, no LDS
 #pragma unroll
         for (int t = 0; t < kTiltScalarBins; ++t) j += (nr >= P->tilt_inner_dist[t]) ? 1 : 0;
@@ -251,7 +270,7 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     // the proof bit differs per bin: select, the divide is only executed if some lane's bin lacks the proof
     const float q = (thisDist - nr) * bin.c;
     float frac_at_lower = dm::fma_(dm::fma_(-bin.b, q, thisDist - nr), bin.c, q);
-    if (__builtin_bit_cast(uint32_t, bin.d) == 0u) frac_at_lower = (thisDist - nr) / bin.b;
+    if (!FAST && __builtin_bit_cast(uint32_t, bin.d) == 0u) frac_at_lower = (thisDist - nr) / bin.b;
     const float frac_at_upper = 1.0f - frac_at_lower;
     const uint32_t lo = P->off_tilt_zcorr + (uint32_t)((j - 1) * nz + k);
     const uint32_t hi = lo + (uint32_t)nz;
@@ -430,7 +449,7 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
 }
 
 // c.cl:546-596
-template <int MED, bool TILT, bool FLASHER, bool TAB>
+template <int MED, bool TILT, bool FLASHER, bool TAB, bool FAST = false>
 DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
 {
     ph.rx_start = rx;
@@ -442,39 +461,39 @@ DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
     ph.d = b.d;
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
-    if (!TILT) ph.layer = clampi((int)div_by(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
+    if (!TILT) ph.layer = clampi((int)div_by_t<FAST>(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
     ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
     ph.abs_lens_left = b.abs_lens_initial;
     ph.ice = ice_factors<MED>(P, b.wlen);
 }
 
 // propagation_kernel.c.cl:598-696: distance to the next scatter / absorption through the layers
-template <int MED, bool TILT, bool ANISO>
+template <int MED, bool TILT, bool ANISO, bool FAST = false>
 DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
 {
     const float thickness = P->layer_thickness, bottom = P->layer_bottom;
     const int num_layers = P->num_layers;
     const uint32_t off_layers = P->off_layers;
     const float *len_table = (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr;
-    const bool fast = (P->div_ok & kFastLengths) != 0u;
+    const bool fast = FAST || (P->div_ok & kFastLengths) != 0u;
     float effective_z;
     int current_layer;
     if (TILT) {
-        effective_z = ph.pz - tilt_z_shift(P, ph.px, ph.py, ph.pz);
-        current_layer = clampi((int)div_by(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, num_layers - 1);
+        effective_z = ph.pz - tilt_z_shift<FAST>(P, ph.px, ph.py, ph.pz);
+        current_layer = clampi((int)div_by_t<FAST>(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, num_layers - 1);
     } else {
         effective_z = ph.pz - P->tilt_const;
         current_layer = ph.layer;
     }
     const float dz = ph.d.z;
     // without anisotropy the factor is the literal 1.f: x*1 and x/1 are exact, so both are skipped
-    const float corr = (ANISO && P->has_abs_corr) ? abs_len_corr(P, ph.d) : 1.0f;
+    const float corr = (ANISO && P->has_abs_corr) ? abs_len_corr<FAST>(P, ph.d) : 1.0f;
     if (ANISO) ph.abs_lens_left *= corr;
     const float lower = ((float)current_layer * thickness) + bottom;
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
     float sca_len, abs_len;
-    layer_lengths<MED>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, fast);
+    layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, fast);
     const float recip_thickness = P->recip_thickness;
     float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
     float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
@@ -491,9 +510,9 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         while ((j != last) && (sgn * ais > 0.0f) && (sgn * aia > 0.0f)) {
             j += step;
             boundary += signed_thickness;
-            layer_lengths<MED>(off_layers, len_table, ph.ice, j, sca_len, abs_len, fast);
-            ais -= sgn * rcp_sel(sca_len, fast);
-            aia -= sgn * rcp_sel(abs_len, fast);
+            layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, j, sca_len, abs_len, fast);
+            ais -= sgn * rcp_t<FAST>(sca_len, fast);
+            aia -= sgn * rcp_t<FAST>(abs_len, fast);
         }
     }
     float distance, to_absorption;
@@ -617,6 +636,7 @@ DM float dom_free_flight_bound(KP P, float x, float y, float z)
 }
 
 // collision c.cl:194-303 + :462-547
+template <bool FAST = false>
 DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
 {
     const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
@@ -637,12 +657,12 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
         const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
         const uint32_t cells = __builtin_bit_cast(uint32_t, g1.c);
         // all lanes are in the same subdetector here, so the proof bits are wave-uniform
-        const uint32_t proven = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, g1.d));
+        const uint32_t proven = FAST ? 3u : (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, g1.d));
         const bool okx = (proven & 1u) != 0, oky = (proven & 2u) != 0;
-        int low_x = (int)div_by(ph.px - sx, wx, g2.a, okx);
-        int low_y = (int)div_by(ph.py - sy, wy, g2.b, oky);
-        int high_x = (int)div_by(ph.px + ph.d.x * step_len - sx, wx, g2.a, okx);
-        int high_y = (int)div_by(ph.py + ph.d.y * step_len - sy, wy, g2.b, oky);
+        int low_x = (int)div_by_t<FAST>(ph.px - sx, wx, g2.a, okx);
+        int low_y = (int)div_by_t<FAST>(ph.py - sy, wy, g2.b, oky);
+        int high_x = (int)div_by_t<FAST>(ph.px + ph.d.x * step_len - sx, wx, g2.a, okx);
+        int high_y = (int)div_by_t<FAST>(ph.py + ph.d.y * step_len - sy, wy, g2.b, oky);
         if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
         if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
         low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);

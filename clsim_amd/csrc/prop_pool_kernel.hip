@@ -34,6 +34,8 @@
 
 namespace clsimhip {
 
+#define CLSIMHIP_STR2(x) #x
+#define CLSIMHIP_STR(x) CLSIMHIP_STR2(x)
 #ifndef CLSIMHIP_POOL_BLOCK
 #define CLSIMHIP_POOL_BLOCK 768                 // 12 waves per workgroup, 2 workgroups per CU
 #define CLSIMHIP_POOL_WAVES 6                   // waves per SIMD the register allocation aims at (<= 80 VGPRs)
@@ -48,7 +50,7 @@ constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // uni
 
 __host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R) { return kPoolFixedWords + kReadyWords * R + kPendWords * (64u + R); }
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST>
 __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(const KParams Pvalue)
 {
     const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -106,6 +108,12 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
+#ifdef CLSIMHIP_EXP_SALU        // experiment: marginal cost of scalar / vector instructions (tools/exp_issue_cost.sh)
+        { uint32_t dummy = trip; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_SALU) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : : "scc"); if (dummy == 0xdeadbeefu) ++n_gone; }
+#endif
+#ifdef CLSIMHIP_EXP_VALU
+        { uint32_t dummy = lane; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_VALU) "\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(dummy)); if (dummy == 0xdeadbeefu) ++n_gone; }
+#endif
         const uint64_t m_spent = __ballot(has && spent);
         const uint64_t m_vacant = __ballot(!has);
         const uint64_t m_live = __ballot(has && !spent);
@@ -251,7 +259,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         const Vec3 step_dir = step_direction(&rec->step);
                         Photon born;
                         born.layer = 0;
-                        create_photon<MED, TILT, FLASHER, false>(P, &rec->step, step_dir, e_rx, e_ra, born);
+                        create_photon<MED, TILT, FLASHER, false, FAST>(P, &rec->step, step_dir, e_rx, e_ra, born);
                         uint32_t pos = ready_head + n_ready + slot;
                         if (pos >= R) pos -= R;
                         if (pos >= R) pos -= R;
@@ -334,7 +342,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
             const float free_flight = free_flight_bound(fresh_params(P0), ph.px, ph.py);
-            distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
+            distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
             if (!(distance < free_flight) && !(distance < dom_free_flight_bound(fresh_params(P0), ph.px, ph.py, ph.pz))) {
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #endif
                 if (parked) {
                     distance = __builtin_bit_cast(float, parked_len[lane]);
-                    hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
                     parked = false;
                     advance = true;
                 }
@@ -405,11 +413,11 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 spent = true;
             } else {
                 const KP P = fresh_params(P0);
-                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
-                const float cos_s = scattering_cos(P, rx, ra);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
+                const float cos_s = scattering_cos<FAST>(P, rx, ra);
                 const float sin_s = dm::sqrt_near_(1.0f - sqr(cos_s));       // |cos_s| <= 1: 0 or >= 2^-24
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
-                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
                 ++ph.num_scatters;
             }
         }
@@ -432,7 +440,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 hipError_t launch_scan_steps(const KParams &P, hipStream_t stream);
 hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream);
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST>
 static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -459,15 +467,15 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     Plan plan;
     {
         std::lock_guard<std::mutex> lk(plan_mutex);
-        Plan &pl = plans[std::make_pair(dev, lds_bytes)];
+        Plan &pl = plans[std::make_pair(dev, lds_bytes)];        // (per instantiation: the map is a static of this template)
         if (pl.resident == 0) {
             int cus = 0, per_cu = 0;
             hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (e == hipSuccess && lds_bytes > 64 * 1024)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_pool_kernel<MED, TILT, ANISO, FLASHER>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e == hipSuccess)
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_pool_kernel<MED, TILT, ANISO, FLASHER>, kPoolBlock, lds_bytes);
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>, kPoolBlock, lds_bytes);
             if (e != hipSuccess) return e;
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 1;
@@ -500,7 +508,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     }
     hipError_t err = launch_scan_steps(P, stream);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
     return launch_assemble_hits(P, FLASHER, dev, stream);
@@ -513,8 +521,11 @@ hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     if (P.history_n != 0 || v.tabulate) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
+    // CLSIMHIP_NO_FAST=1: the generic instantiation also where Compile() found every proof (tests compare the two)
+    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
+    const bool fast = v.fast && !(no_fast && no_fast[0] == '1');
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return launch_pool_variant<a, b, c, d>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_pool_variant<a, b, c, d, true>(P, stream) : launch_pool_variant<a, b, c, d, false>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \

@@ -613,6 +613,22 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         for (size_t k = 0; k < G.cells.size(); ++k) flags.push_back(subdet[12 * k + 7]);
         name("div_ok_cells", flags);
     }
+    {   // KVariant::fast (prop_device.hip.h: FAST): the standard configuration with every proof in hand
+        bool fast = (m.scatter_kind == CLSIMHIP_SCATTER_MIXED) && (P.liu_beta <= 0.09f) && ((P.div_ok & (2u | 4u | 8u | 16u | 32u | 64u)) == (2u | 4u | 8u | 16u | 32u | 64u));
+        if (m.has_aniso && !(P.div_ok & 128u)) fast = false;
+        if (m.has_tilt) {
+            if (!(P.div_ok & 1u) || m.tilt_distances.size() > 8) fast = false;      // kTiltScalarBins + 2
+            for (size_t j = 1; j < m.tilt_distances.size(); ++j) {
+                float rcp = 0.f;
+                const float lo = to_float_literal(m.tilt_distances[j - 1]), hi = to_float_literal(m.tilt_distances[j]);
+                if (!division_by_reciprocal_is_exact(hi - lo, rcp)) fast = false;
+            }
+        }
+        for (size_t k = 0; k < G.cells.size(); ++k)
+            if (subdet[12 * k + 7] != 3u) fast = false;
+        C.variant.fast = fast;
+        scalar("fast_variant", fast ? 1. : 0.);
+    }
     P.table_words = static_cast<uint32_t>(img.words.size());
     scalar("lds_image_words", P.table_words);
     scalar("lds_bytes_per_workgroup", static_cast<double>(prop_kernel_lds_bytes(P.table_words)));

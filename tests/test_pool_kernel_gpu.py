@@ -94,3 +94,20 @@ def test_pooled_equals_classic_kernel_on_large_bunches(pooled, name, n_steps):
     assert len(results[0][0]) > 80 * 50
     assert results[0][0] == results[1][0]
     assert np.array_equal(results[0][1], results[1][1])
+
+
+@pytest.mark.parametrize("name,n_steps", [("mie", 65536), ("lea", 32768), ("flasher", 16384)])
+def test_specialised_and_generic_instantiations_agree(pooled, name, n_steps, monkeypatch):
+    """KVariant::fast: the instantiation with the wave-uniform proof tests compiled out against the generic one
+    (CLSIMHIP_NO_FAST=1) on the same bunch"""
+    cfg = common.config(name)
+    steps = common.steps_for(cfg, n_steps, seed=31)
+    out = []
+    for no_fast in ("0", "1"):
+        monkeypatch.setenv("CLSIMHIP_NO_FAST", no_fast)
+        conv = common.product_converter(cfg, len(steps))
+        assert int(conv.GetTable("fast_variant")[0]) == 1
+        conv.EnqueueSteps(steps, 1)
+        _, ph = conv.GetConversionResult()
+        out.append((common.sort_photons(ph).tobytes(), conv.GetRNGState(len(steps)).tobytes()))
+    assert out[0] == out[1]

@@ -89,6 +89,8 @@ def test_invariant_divisors_are_proven():
         assert ok & 64          # direction transforms (if any) are well conditioned: dm::rsqrt_near_ in the renormalisation
         if name == "lea":
             assert ok & 128     # anisotropy divisor bounded
+        # mixed scattering with every proof in hand: the pooled kernel's instantiation without the run-time tests of those facts
+        assert int(conv.GetTable("fast_variant")[0]) == 1
         if name != "c1":
             assert ok & 1
         assert all(int(v) == 3 for v in conv.GetTable("div_ok_cells"))
