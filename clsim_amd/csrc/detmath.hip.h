@@ -151,11 +151,21 @@ DM float powr_(float x, float y)
     return exp_hl(ph, pl);
 }
 
-// powr(x, y) for x in [0, 1], y > 0 with y |log x| <= 2 (oracle_math.h: om_powr_unit): single-word logarithm
+// powr(x, y) for x in [0, 1], y > 0 with y |log x| <= 2 (oracle_math.h: om_powr_unit): single-word logarithm.  Without
+// branches: the argument of exp lies in [-2, 0], where exp_hl's range tests never fire, and x = 0 (whose logarithm is
+// finite garbage here) is put right by a select at the end.
 DM float powr_unit_(float x, float y)
 {
-    if (x == 0.0f) return 0.0f;
-    return exp_(y * log_(x));
+    const float hi = y * log_(x);
+    const float k = rint_(hi * LOG2E);
+    float r = fma_(-k, LN2_HI, hi);
+    r = fma_(-k, LN2_LO, r);
+    r = r + 0.0f;
+    const float z = r * r;
+    float p = fma_(z, exp_poly(r), r);
+    p = p + 1.0f;
+    const float v = u2f(f2u(p) + ((uint32_t)(int32_t)k << 23));
+    return (x == 0.0f) ? 0.0f : v;
 }
 
 constexpr float PIO2_1 = 0x1.921fb6p+0f;

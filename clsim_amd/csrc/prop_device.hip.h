@@ -345,7 +345,9 @@ DM void dom_position(KP P, uint32_t s, uint32_t d, float &x, float &y, float &z)
     y = (float)ty * P->dom_mul_y + ldsf(rec + 6);
 }
 
-// propagation_kernel.c.cl:83-129
+// propagation_kernel.c.cl:83-129.  The reference branches on sinth > 0; a direction exactly along z is so rare that the
+// wave takes the general formulas for all lanes (a division by zero there yields a value that is thrown away) and visits
+// the special case only when a ballot says some lane needs it.
 DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
 {
     const float b = 2.0f * kPi * u;
@@ -353,16 +355,16 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     dm::sincos_(b, sinb, cosb);
     const float t = 1.0f - d.z * d.z;
     const float sinth = dm::sqrt_near_((t > 0.0f) ? t : 0.0f);     // 0 or >= 2^-24: |d.z| <= 1 is a float
-    if (sinth > 0.0f) {
-        const float ox = d.x, oy = d.y, oz = d.z;
-        d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
-        d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
-        d.z = oz * cosa + sina * sinb * sinth;
-    } else {
-        const float sgn = (d.z > 0.0f) ? 1.0f : ((d.z < 0.0f) ? -1.0f : d.z);
-        d.x = sina * cosb;
-        d.y = sina * sinb;
-        d.z = cosa * sgn;
+    const float ox = d.x, oy = d.y, oz = d.z;
+    d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
+    d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
+    d.z = oz * cosa + sina * sinb * sinth;
+    const bool along_z = !(sinth > 0.0f);
+    if (__ballot(along_z) != 0ull) {
+        const float sgn = (oz > 0.0f) ? 1.0f : ((oz < 0.0f) ? -1.0f : oz);
+        d.x = along_z ? sina * cosb : d.x;
+        d.y = along_z ? sina * sinb : d.y;
+        d.z = along_z ? cosa * sgn : d.z;
     }
     const float recip_length = dm::rsqrt_near_(sqr(d.x) + sqr(d.y) + sqr(d.z));     // a rotated unit vector: ~1
     d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
@@ -629,7 +631,8 @@ DM float dom_free_flight_bound(KP P, float x, float y, float z)
     if (id != 0xffffu) {
         const float4 c = P->dom_centres[id];
         const float ex = x - c.x, ey = y - c.y, ez = z - c.z;
-        const float near = dm::sqrt_((ex * ex + ey * ey) + ez * ez) * 0.99999f - P->dprox_radius;
+        // a bound, not a result: the hardware square root (1 ulp) under the 1e-5 margin
+        const float near = __builtin_amdgcn_sqrtf((ex * ex + ey * ey) + ez * ez) * 0.99999f - P->dprox_radius;
         bound = (near < bound) ? near : bound;
     }
     return bound;

@@ -102,11 +102,13 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
 #endif
     for (uint32_t trip = 0;; ++trip) {
-        switch (((trip >> kPrioShift) + wave_slot) & 3u) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
+        if ((trip & ((1u << kPrioShift) - 1u)) == 0u) {            // the priority changes every 2^kPrioShift trips
+            switch (((trip >> kPrioShift) + wave_slot) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
         }
 #ifdef CLSIMHIP_EXP_SALU        // experiment: marginal cost of scalar / vector instructions (tools/exp_issue_cost.sh)
         { uint32_t dummy = trip; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_SALU) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : : "scc"); if (dummy == 0xdeadbeefu) ++n_gone; }
