@@ -92,7 +92,7 @@ struct KParams {
     const uint8_t *prox_map;
     int32_t prox_n;
     float prox_x0, prox_y0, prox_inv_cell;
-    // DOM proximity map, the second level of the search filter: dprox_nz x dprox_ny x dprox_nx words (cubic cells) over
+    // DOM proximity map, the second level of the search filter: dprox_nx x dprox_ny x dprox_nz words (cubic cells, z fastest) over
     // the bounding box of the DOMs.  A word names the DOM nearest to the cell (bits 0-15: index into dom_centres, 0xffff =
     // none within 64 m) and carries in bits 16-23, in 0.25 m units, a proven lower bound of the 3D distance from anywhere
     // in the cell to the sphere of any OTHER DOM.  The kernel takes the exact distance to the named DOM's sphere and the

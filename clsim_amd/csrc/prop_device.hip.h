@@ -621,11 +621,11 @@ DM float free_flight_bound(KP P, float x, float y)
 DM float dom_free_flight_bound(KP P, float x, float y, float z)
 {
     const float inv = P->dprox_inv_cell;
-    const int nx = P->dprox_nx, ny = P->dprox_ny;
-    const int ix = clampi((int)((x - P->dprox_x0) * inv), 0, nx - 1);
+    const int ny = P->dprox_ny, nz = P->dprox_nz;
+    const int ix = clampi((int)((x - P->dprox_x0) * inv), 0, P->dprox_nx - 1);
     const int iy = clampi((int)((y - P->dprox_y0) * inv), 0, ny - 1);
-    const int iz = clampi((int)((z - P->dprox_z0) * inv), 0, P->dprox_nz - 1);
-    const uint32_t w = P->dom_prox[((size_t)iz * (size_t)ny + (size_t)iy) * (size_t)nx + (size_t)ix];
+    const int iz = clampi((int)((z - P->dprox_z0) * inv), 0, nz - 1);
+    const uint32_t w = P->dom_prox[((size_t)ix * (size_t)ny + (size_t)iy) * (size_t)nz + (size_t)iz];      // z runs fastest
     float bound = (float)((w >> 16) & 0xffu) * 0.25f;
     const uint32_t id = w & 0xffffu;
     if (id != 0xffffu) {

@@ -498,13 +498,17 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     if (needed < grid) grid = needed;
     {
         const double r = (double)P.n_steps / ((double)grid * slots_per_group);
+        // (1M steps: 8 slices 2.76e9 photons/s, 12: 2.84, 16: 2.84, 24: 2.85, 32: 2.87; fabric traffic 18.6 / 19.2 / 20.7 GB per
+        // launch at 12 / 16 / 32 slices: the last per cent of speed is not worth a tenth more traffic)
         if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
         // lanes parked per DOM search: with the two-level proximity filter about 1 % of the lanes need one per trip (cascade
         // steps: 3 parked lanes 2.55e9 photons/s, 1: 2.49, 5: 2.53, 8: 2.27 at 1M steps); photons born at a DOM need one on
         // most trips whatever the filter (flasher steps: 5 parked lanes 1.30e9, 3: 1.24, 1: 1.20)
         if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 5 : 3);
         if (P.k_pop <= 0) P.k_pop = 4;
-        if (P.k_new <= 0 || P.k_new > R) P.k_new = (R > 8) ? R - 4 : R;      // create when the ring is down to its last entries
+        // create when the ring is down to its last entry: the batches are what makes creation cheap per photon
+        // (ring of 34: threshold 20 2.76e9 photons/s, 26: 2.81, 30: 2.84, 33: 2.85)
+        if (P.k_new <= 0 || P.k_new > R) P.k_new = (R > 8) ? R - 1 : R;
         if (P.slices > 0xffff) P.slices = 0xffff;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }

@@ -563,17 +563,19 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
                 i0[k] = std::max(0, static_cast<int>(std::floor((p[k] - range - radius - slack - o[k]) / cellf)) - 1);
                 i1[k] = std::min(nn[k] - 1, static_cast<int>(std::floor((p[k] + range + radius + slack - o[k]) / cellf)) + 1);
             }
-            for (int iz = i0[2]; iz <= i1[2]; ++iz) {
-                const double gz = axis_gap(2, iz, p[2]);
+            // z runs fastest: the lanes that get here are near a string, and a string's cells are then a few contiguous
+            // columns (about 1 KB each) that stay in the L2 instead of one cache line per cell
+            for (int ix = i0[0]; ix <= i1[0]; ++ix) {
+                const double gx = axis_gap(0, ix, p[0]);
                 for (int iy = i0[1]; iy <= i1[1]; ++iy) {
                     const double gy = axis_gap(1, iy, p[1]);
-                    const size_t row = (static_cast<size_t>(iz) * nn[1] + iy) * nn[0];
-                    for (int ix = i0[0]; ix <= i1[0]; ++ix) {
-                        const double gx = axis_gap(0, ix, p[0]);
+                    const size_t row = (static_cast<size_t>(ix) * nn[1] + iy) * nn[2];
+                    for (int iz = i0[2]; iz <= i1[2]; ++iz) {
+                        const double gz = axis_gap(2, iz, p[2]);
                         const double bound = (std::sqrt(gx * gx + gy * gy + gz * gz) - radius) / 1.00001;
                         const double q = std::floor(bound / 0.25);
                         const uint8_t v = static_cast<uint8_t>(q < 0. ? 0. : (q > 255. ? 255. : q));
-                        const size_t c = row + ix;
+                        const size_t c = row + iz;
                         if (v < q1[c]) { q2[c] = q1[c]; q1[c] = v; id1[c] = static_cast<uint16_t>(d); }
                         else if (v < q2[c]) q2[c] = v;
                     }

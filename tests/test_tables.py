@@ -227,7 +227,7 @@ def test_dom_proximity_map_is_a_lower_bound():
         conv.Compile()
         nx, ny, nz, x0, y0, z0, inv_cell, radius = conv.GetTable("DOM_PROXIMITY_GRID")
         nx, ny, nz = int(nx), int(ny), int(nz)
-        words = conv.GetTable("dom_proximity_map").astype(np.uint32).reshape(nz, ny, nx)
+        words = conv.GetTable("dom_proximity_map").astype(np.uint32).reshape(nx, ny, nz)        # z runs fastest
         centres = conv.GetTable("dom_centres").reshape(-1, 4)[:, :3]
         g = cfg["geom"]
         doms = np.stack([g["x"], g["y"], g["z"]], axis=1)
@@ -243,7 +243,7 @@ def test_dom_proximity_map_is_a_lower_bound():
         idx = []
         for k, (o, n) in enumerate(((x0, nx), (y0, ny), (z0, nz))):
             idx.append(np.clip(((pf[:, k] - np.float32(o)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1))   # the kernel's arithmetic
-        w = words[idx[2], idx[1], idx[0]]
+        w = words[idx[0], idx[1], idx[2]]
         ident = (w & 0xffff).astype(np.int64)
         bound = ((w >> 16) & 0xff) * 0.25
         named = ident != 0xffff
