@@ -105,6 +105,7 @@ SYMBOLS = [
     "clsimhip_eval_math", "clsimhip_check_math_exhaustive", "clsimhip_version",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
     "clsimhip_ppc_create", "clsimhip_ppc_destroy", "clsimhip_ppc_photons_per_meter", "clsimhip_ppc_enqueue", "clsimhip_shower_parameters",
+    "clsimhip_flasher_correction_factor", "clsimhip_flasher_enqueue",
     "clsimhip_count_flasher_steps", "clsimhip_generate_flasher_steps_device", "clsimhip_generate_flasher_steps",
     "clsimhip_flasher_time_profile",
     "clsimhip_step_store_create", "clsimhip_step_store_destroy", "clsimhip_step_store_insert", "clsimhip_step_store_size",
@@ -201,6 +202,8 @@ def load():
         "clsimhip_ppc_photons_per_meter": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "clsimhip_ppc_enqueue": (i32, [vp, vp, sz, C.POINTER(StepRequest), sz, C.POINTER(sz)]),
         "clsimhip_shower_parameters": (i32, [i32, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+        "clsimhip_flasher_correction_factor": (i32, [C.POINTER(Function), C.c_double, C.POINTER(Function), C.c_double, C.c_double, C.POINTER(C.c_double)]),
+        "clsimhip_flasher_enqueue": (i32, [C.c_double, u64, vp, sz, vp, sz, C.POINTER(sz)]),
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
         "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),

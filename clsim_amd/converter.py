@@ -568,6 +568,36 @@ assert FLASHER_REQUEST_DTYPE.itemsize == 56
 DIST_CONSTANT, DIST_NORMAL, DIST_UNIFORM, DIST_FLASHER_TIME_PROFILE = 0, 1, 2, 3
 
 
+FLASHER_PULSE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
+                                ("sigma_polar", "<f4"), ("sigma_azimuthal", "<f4"), ("pulse_width", "<f4"), ("identifier", "<u4"),
+                                ("source_type", "<u4"), ("num_photons_no_bias", "<f8")])
+assert FLASHER_PULSE_DTYPE.itemsize == 56
+
+
+def FlasherPhotonNumberCorrectionFactor(wlenBias, spectrumNoBias=None, peakWavelength=None, fromWlen=265e-9, toWlen=675e-9):
+    """PhotonNumberCorrectionFactorAfterBias (ConverterUtils.cxx:113-214): spectrumNoBias = I3CLSimFunctionFromTable, or None with
+    peakWavelength for an I3CLSimFunctionDeltaPeak"""
+    v = C.c_double()
+    b = wlenBias._desc()
+    if spectrumNoBias is None:
+        _check(_lib.load().clsimhip_flasher_correction_factor(None, float(peakWavelength), C.byref(b), float(fromWlen), float(toWlen), C.byref(v)))
+    else:
+        sp = spectrumNoBias._desc()
+        _check(_lib.load().clsimhip_flasher_correction_factor(C.byref(sp), 0.0, C.byref(b), float(fromWlen), float(toWlen), C.byref(v)))
+    return v.value
+
+
+def EnqueueFlasherPulses(pulses, correctionFactor, seed=0):
+    """I3CLSimLightSourceToStepConverterFlasher::EnqueueLightSource (Flasher.cxx:214-265) for an array of FLASHER_PULSE_DTYPE:
+    the converter's queue entries (FLASHER_REQUEST_DTYPE) with the photon numbers after bias drawn"""
+    p = np.ascontiguousarray(pulses, dtype=FLASHER_PULSE_DTYPE)
+    out = np.zeros(len(p), dtype=FLASHER_REQUEST_DTYPE)
+    n = C.c_size_t()
+    _check(_lib.load().clsimhip_flasher_enqueue(float(correctionFactor), int(seed), p.ctypes.data_as(C.c_void_p), len(p),
+                                                out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+    return out[:n.value]
+
+
 def FlasherStepConverterConfig(angularProfileDistributionPolar, angularProfileDistributionAzimuthal, timeDelayDistribution,
                                interpretAngularDistributionsInPolarCoordinates=False, photonsPerStep=400, maxBunchSize=512000,
                                bunchSizeGranularity=512):

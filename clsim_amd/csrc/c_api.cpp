@@ -214,6 +214,32 @@ int clsimhip_ppc_enqueue(const clsimhip_ppc_converter *p, const clsimhip_particl
         if (requests_out) std::copy(v.begin(), v.begin() + static_cast<std::ptrdiff_t>(std::min(capacity, v.size())), requests_out);
     });
 }
+int clsimhip_flasher_correction_factor(const clsimhip_function *spectrum_no_bias, double peak_wavelength,
+                                       const clsimhip_function *wavelength_bias, double from_wavelength, double to_wavelength, double *out)
+{
+    return guarded(nullptr, [&] {
+        need(wavelength_bias, "wavelength_bias"); need(out, "out");
+        const FunctionData bias = function_from(wavelength_bias);
+        if (spectrum_no_bias) {
+            const FunctionData spectrum = function_from(spectrum_no_bias);
+            *out = flasher_correction_factor(&spectrum, 0., bias, from_wavelength, to_wavelength);
+        } else {
+            *out = flasher_correction_factor(nullptr, peak_wavelength, bias, from_wavelength, to_wavelength);
+        }
+    });
+}
+int clsimhip_flasher_enqueue(double correction_factor, uint64_t seed, const clsimhip_flasher_pulse *pulses, size_t n,
+                             clsimhip_flasher_request *requests_out, size_t capacity, size_t *n_out)
+{
+    return guarded(nullptr, [&] {
+        need(n_out, "n_out");
+        if (n) need(pulses, "pulses");
+        std::vector<clsimhip_flasher_request> v;
+        flasher_enqueue(correction_factor, seed, pulses, n, v);
+        *n_out = v.size();
+        if (requests_out) std::copy(v.begin(), v.begin() + static_cast<std::ptrdiff_t>(std::min(capacity, v.size())), requests_out);
+    });
+}
 int clsimhip_shower_parameters(int32_t particle_type, double energy_gev, double density_g_cm3, double out[4])
 {
     return guarded(nullptr, [&] {

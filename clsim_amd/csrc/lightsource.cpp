@@ -61,10 +61,10 @@ struct Rng {                                            // counter-based: splitm
     }
 };
 
-// :322-330 and its three repetitions: Poisson below a mean of 1e7 photons, a non-negative Gaussian above
-uint64_t draw_photons(Rng &rng, double mean)
+// :322-330 and its three repetitions: Poisson below a mean of 1e7 photons (flashers: 1e6), a non-negative Gaussian above
+uint64_t draw_photons(Rng &rng, double mean, double gauss_above = 1e7)
 {
-    if (mean > 1e7) {
+    if (mean > gauss_above) {
         double n = 0.;
         do { n = rng.gauss(mean, std::sqrt(mean)); } while (n < 0.);
         if (n > static_cast<double>(std::numeric_limits<uint64_t>::max())) throw Error(CLSIMHIP_ERR_ARGUMENT, "Too many photons for counter. internal limitation.");
@@ -232,6 +232,51 @@ void PPCConverter::enqueue(const clsimhip_particle &particle, std::vector<clsimh
         r.photons_per_step = static_cast<uint32_t>(use);
         r.num_steps = from_cascades / use;
         r.num_photons_in_last_step = static_cast<uint32_t>(r.num_steps % use);      // :455, as written
+        out.push_back(r);
+    }
+}
+
+// PhotonNumberCorrectionFactorAfterBias (ConverterUtils.cxx:113-214): the bias at the peak for a delta-peak spectrum, else
+// the ratio of the spectrum's integral with and without the bias over [from_wlen, to_wlen] (the reference: two
+// gsl_integration_qag calls to 1e-5; here the same fixed Gauss-Legendre rule as for the Cherenkov yield)
+double flasher_correction_factor(const FunctionData *spectrum, double peak_wavelength, const FunctionData &bias, double from_wlen, double to_wlen)
+{
+    if (!spectrum) return bias.eval(peak_wavelength);
+    static const double node[8] = {-0.9602898564975363, -0.7966664774136267, -0.5255324099163290, -0.1834346424956498,
+                                   0.1834346424956498, 0.5255324099163290, 0.7966664774136267, 0.9602898564975363};
+    static const double weight[8] = {0.1012285362903763, 0.2223810344533745, 0.3137066458778873, 0.3626837833783620,
+                                     0.3626837833783620, 0.3137066458778873, 0.2223810344533745, 0.1012285362903763};
+    if (!(to_wlen > from_wlen)) throw Error(CLSIMHIP_ERR_ARGUMENT, "empty wavelength range");
+    const int panels = 4096;
+    const double h = (to_wlen - from_wlen) / panels;
+    double with = 0., without = 0.;
+    for (int i = 0; i < panels; ++i)
+        for (int k = 0; k < 8; ++k) {
+            const double w = from_wlen + (i + 0.5) * h + 0.5 * h * node[k];
+            const double v = spectrum->eval(w);
+            without += weight[k] * v;
+            with += weight[k] * v * bias.eval(w);
+        }
+    if (!(without > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "flasher spectrum integrates to zero");
+    return with / without;
+}
+
+// I3CLSimLightSourceToStepConverterFlasher::EnqueueLightSource (Flasher.cxx:214-265): pulses without photons are skipped
+void flasher_enqueue(double correction, uint64_t seed, const clsimhip_flasher_pulse *pulses, size_t n, std::vector<clsimhip_flasher_request> &out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const clsimhip_flasher_pulse &p = pulses[i];
+        if (!(p.num_photons_no_bias > 0.)) continue;
+        const double with_bias = p.num_photons_no_bias * correction;
+        if (!(with_bias > 0.)) continue;
+        Rng rng{seed ^ (0xD1B54A32D192ED03ull * (static_cast<uint64_t>(p.identifier) + 1ull))};
+        const uint64_t photons = draw_photons(rng, with_bias, 1e6);             // :237-253
+        if (photons == 0) continue;
+        clsimhip_flasher_request r{};
+        r.x = p.x; r.y = p.y; r.z = p.z; r.time = p.time; r.dx = p.dx; r.dy = p.dy; r.dz = p.dz;
+        r.sigma_polar = p.sigma_polar; r.sigma_azimuthal = p.sigma_azimuthal; r.pulse_width = p.pulse_width;
+        r.identifier = p.identifier; r.source_type = p.source_type;
+        r.num_photons_with_bias = photons;
         out.push_back(r);
     }
 }

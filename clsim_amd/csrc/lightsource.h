@@ -37,4 +37,9 @@ private:
     std::vector<double> photons_per_meter_;
 };
 
+// ConverterUtils.cxx:113-214; spectrum == nullptr: delta peak at peak_wavelength
+double flasher_correction_factor(const FunctionData *spectrum, double peak_wavelength, const FunctionData &bias, double from_wlen, double to_wlen);
+// Flasher.cxx:214-265
+void flasher_enqueue(double correction, uint64_t seed, const clsimhip_flasher_pulse *pulses, size_t n, std::vector<clsimhip_flasher_request> &out);
+
 } // namespace clsimhip

@@ -456,6 +456,24 @@ typedef struct {                                /* one I3CLSimFlasherPulse in th
     uint32_t source_type;                       /* spectrumSourceTypeIndex_: wavelength generator of the pulse's spectrum */
     uint64_t num_photons_with_bias;             /* numPhotonsWithBias (EnqueueLightSource :243-262, computed by the caller) */
 } clsimhip_flasher_request;                     /* 56 bytes */
+/* The converter's front end (Initialize :120-159, EnqueueLightSource :214-265): photons after the wavelength bias =
+ * GetNumberOfPhotonsNoBias() x PhotonNumberCorrectionFactorAfterBias (ConverterUtils.cxx:113-214: the bias at the peak for a
+ * delta-peak spectrum -- spectrum_no_bias NULL, peak_wavelength used -- else the ratio of the spectrum's integrals with and
+ * without bias over [from, to]), then Poisson, or a non-negative Gaussian above 1e6; pulses that end up without photons
+ * are skipped.  The random numbers are this library's (one counter-based stream per identifier), as for clsimhip_ppc_*. */
+typedef struct {
+    float x, y, z, time;
+    float dx, dy, dz;
+    float sigma_polar, sigma_azimuthal;
+    float pulse_width;
+    uint32_t identifier;
+    uint32_t source_type;
+    double num_photons_no_bias;                 /* I3CLSimFlasherPulse::GetNumberOfPhotonsNoBias() */
+} clsimhip_flasher_pulse;
+int clsimhip_flasher_correction_factor(const clsimhip_function *spectrum_no_bias, double peak_wavelength,
+                                       const clsimhip_function *wavelength_bias, double from_wavelength, double to_wavelength, double *out);
+int clsimhip_flasher_enqueue(double correction_factor, uint64_t seed, const clsimhip_flasher_pulse *pulses, size_t n,
+                             clsimhip_flasher_request *requests_out, size_t capacity, size_t *n_out);
 /* number of output steps (real + dummy) and of steps that carry photons */
 int clsimhip_count_flasher_steps(const clsimhip_flasher_config *config, const clsimhip_flasher_request *requests, size_t n,
                                  size_t *steps_out, size_t *real_steps_out);

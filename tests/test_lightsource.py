@@ -216,3 +216,57 @@ def test_benchmark_event_born_and_propagated_on_the_device(ppc):
     ph_o, cnt_o, x_o, _ = capi.propagate(common.oracle_tables(cfg), steps, x, a, threads=8)
     assert cnt == cnt_o and common.sort_photons(ph).tobytes() == common.sort_photons(ph_o).tobytes()
     assert np.array_equal(conv.GetRNGState(n), x_o)
+
+
+def test_flasher_front_end():
+    """I3CLSimLightSourceToStepConverterFlasher Initialize / EnqueueLightSource (Flasher.cxx:120-159, 214-265): photons after
+    bias = photons x correction factor (bias at the peak for a delta peak, ratio of integrals for a tabulated spectrum),
+    Poisson below 1e6 and Gaussian above, empty pulses skipped."""
+    bias = CV.GetIceCubeDOMAcceptance()
+    ob = B.icecube_dom_acceptance()
+
+    def acceptance(w):
+        q = (w - ob["start"]) / ob["step"]
+        i = int(np.clip(math.floor(q), 0, len(ob["values"]) - 2))
+        f = min(max(q - i, 0.0), 1.0)
+        return ob["values"][i] * (1 - f) + ob["values"][i + 1] * f
+
+    c405 = CV.FlasherPhotonNumberCorrectionFactor(bias, peakWavelength=405e-9)
+    assert c405 == pytest.approx(acceptance(405e-9), rel=1e-12)
+    # a tabulated LED-like spectrum: Gaussian around 400 nm, sigma 15 nm, on a 2 nm grid
+    grid = 300e-9 + 2e-9 * np.arange(151)
+    spec = np.exp(-0.5 * ((grid - 400e-9) / 15e-9) ** 2)
+    table = CV.I3CLSimFunctionFromTable(grid[0], 2e-9, spec)
+    got = CV.FlasherPhotonNumberCorrectionFactor(bias, spectrumNoBias=table, fromWlen=300e-9, toWlen=600e-9)
+
+    def sp(w):
+        q = (w - grid[0]) / 2e-9
+        i = int(np.clip(math.floor(q), 0, len(spec) - 2))
+        f = min(max(q - i, 0.0), 1.0)
+        return spec[i] * (1 - f) + spec[i + 1] * f
+
+    edges = np.linspace(300e-9, 600e-9, 151)
+    num = sum(integrate.quad(lambda w: sp(w) * acceptance(w), a, b, epsrel=1e-10)[0] for a, b in zip(edges[:-1], edges[1:]))
+    den = sum(integrate.quad(sp, a, b, epsrel=1e-10)[0] for a, b in zip(edges[:-1], edges[1:]))
+    assert got == pytest.approx(num / den, rel=1e-6)
+
+    n = 6000
+    pulses = np.zeros(n, dtype=CV.FLASHER_PULSE_DTYPE)
+    pulses["dz"] = 1.0
+    pulses["identifier"] = np.arange(n)
+    pulses["source_type"] = 1
+    pulses["pulse_width"] = 70.0
+    pulses["num_photons_no_bias"] = 2.0e5
+    pulses["num_photons_no_bias"][:10] = [0.0, -5.0, 1e-9, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]      # skipped (the third: Poisson gives 0)
+    req = CV.EnqueueFlasherPulses(pulses, c405, seed=3)
+    assert len(req) == n - 10 and np.array_equal(req["identifier"], np.arange(10, n))
+    assert np.all(req["pulse_width"] == 70.0) and np.all(req["source_type"] == 1)
+    mean = 2.0e5 * c405
+    z = (req["num_photons_with_bias"].astype(np.float64) - mean) / math.sqrt(mean)
+    assert abs(z.mean()) < 4 / math.sqrt(n) and abs(z.var() - 1.0) < 0.1
+    # above 1e6 photons after bias: Gaussian
+    pulses["num_photons_no_bias"] = 5.0e9
+    req = CV.EnqueueFlasherPulses(pulses[:2000], c405, seed=4)
+    mean = 5.0e9 * c405
+    z = (req["num_photons_with_bias"].astype(np.float64) - mean) / math.sqrt(mean)
+    assert abs(z.mean()) < 0.1 and abs(z.std() - 1.0) < 0.06
