@@ -128,6 +128,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C clsim_amd/csrc); the HIP propagator has no fallback path" % LIB_PATH)
+    # A process that also uses PyTorch must load torch's HIP runtime BEFORE this library pulls in /opt/rocm's: with the
+    # order reversed torch finds "No HIP GPUs" (two copies of libamdhip64 with one SONAME).  The tests and bench.py use
+    # torch for device buffers, so it is imported here when it is installed; the library itself does not need it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, sz, u32, u64, i32, dbl = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_double
     sig = {

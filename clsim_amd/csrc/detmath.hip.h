@@ -168,6 +168,17 @@ DM float powr_unit_(float x, float y)
     return (x == 0.0f) ? 0.0f : v;
 }
 
+// cbrt and pow with a fractional exponent for the table maker's power axes (oracle_math.h: om_cbrt, om_pow_frac)
+DM float cbrt_(float x)
+{
+    const float ax = x < 0.0f ? -x : x;
+    if (ax == 0.0f) return x;
+    float r = powr_(ax, 0.333333343f);
+    r = fma_(r, -9.934107e-09f * log_(ax), r);              // the exponent's second word: 1/3 - RN(1/3)
+    return x < 0.0f ? -r : r;
+}
+DM float pow_frac_(float x, float y) { return (x < 0.0f) ? u2f(0x7fc00000u) : powr_(x, y); }
+
 constexpr float PIO2_1 = 0x1.921fb6p+0f;
 constexpr float PIO2_2 = -0x1.777a5cp-25f;
 constexpr float PIO2_3 = -0x1.ee59dap-50f;

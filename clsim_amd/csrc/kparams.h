@@ -164,7 +164,8 @@ struct KParams {
     int32_t tab_axes_kind, tab_full_azimuth;
     int32_t tab_ndim;                   // 4, or 5 = TABULATE_IMPACT_ANGLE (fifth axis: cosine of the impact angle)
     float tab_scale[5], tab_offset[5];  // Axis::GetIndexCode literals
-    int32_t tab_inverse[5], tab_nbins[5];
+    int32_t tab_inverse[5], tab_nbins[5];       // tab_inverse: the axis' power (0, 1: identity, 2: sqrt, 3: cbrt, above: pow(x, tab_inv_exp))
+    float tab_inv_exp[5];                       // ToFloatString(1./power), Axis.cxx:168
     uint32_t tab_stride[5];
     float tab_max0, tab_max3, tab_min_inv_groupvel, tab_tan_thetac, tab_volume_step;
     int32_t ang_n;                      // getAngularAcceptance polynomial (coefficients in the LDS image)

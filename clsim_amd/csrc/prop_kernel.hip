@@ -136,7 +136,8 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
     index = 0;
 #pragma unroll
     for (int k = 0; k < ndim; ++k) {
-        const float v = P->tab_inverse[k] ? dm::sqrt_(c[k]) : c[k];
+        const int pw = P->tab_inverse[k];           // wave-uniform
+        const float v = (pw <= 1) ? c[k] : (pw == 2) ? dm::sqrt_(c[k]) : (pw == 3) ? dm::cbrt_(c[k]) : dm::pow_frac_(c[k], P->tab_inv_exp[k]);
         const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
         int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
         b = clampi(b, -1, P->tab_nbins[k]) + 1;
@@ -703,6 +704,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
     case 12: r = dm::sqrt_near_(x); break;
     case 13: r = dm::rsqrt_near_(x); break;
     case 14: r = dm::powr_unit_(x, y); break;
+    case 15: r = dm::cbrt_(x); break;
     default: break;
     }
     out[i] = r;

@@ -64,8 +64,8 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     if (axes_.size() != 4 && axes_.size() != 5) throw Error(CLSIMHIP_ERR_CONFIG, "a table has 4 axes, or 5 with the impact angle");
     for (const AxisData &ax : axes_) {
         if (ax.n_bins == 0 || !(ax.max > ax.min)) throw Error(CLSIMHIP_ERR_ARGUMENT, "axis needs bins and max > min");
-        if (ax.kind == CLSIMHIP_AXIS_POWER && (ax.power < 1 || ax.power > 2))
-            throw Error(CLSIMHIP_ERR_CONFIG, "only linear and square-root (power 2) axes are restated");
+        if (ax.kind == CLSIMHIP_AXIS_POWER && ax.power < 1)
+            throw Error(CLSIMHIP_ERR_CONFIG, "a power axis needs a power >= 1");
     }
     if (!x || !a || streams == 0 || streams % 256 != 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "RNG streams: need a non-zero multiple of 256");
     if (angular.coefficients.size() > 64) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many polynomial coefficients");
@@ -90,7 +90,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     P.tab_axes_kind = axes_kind_;
     P.tab_full_azimuth = (axes_kind_ == CLSIMHIP_AXES_SPHERICAL && axes_[1].max > 180.) ? 1 : 0;     // Axes.cxx:96-97
     P.tab_ndim = static_cast<int32_t>(nd);
-    for (size_t k = 0; k < 5; ++k) { P.tab_scale[k] = P.tab_offset[k] = 0.f; P.tab_inverse[k] = 0; P.tab_nbins[k] = 0; P.tab_stride[k] = 0; }
+    for (size_t k = 0; k < 5; ++k) { P.tab_scale[k] = P.tab_offset[k] = 0.f; P.tab_inverse[k] = 0; P.tab_inv_exp[k] = 1.f; P.tab_nbins[k] = 0; P.tab_stride[k] = 0; }
     for (size_t k = 0; k < nd; ++k) {
         // Axis::GetIndexCode (Axis.cxx:45-60)
         const AxisData &ax = axes_[k];
@@ -98,7 +98,8 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         const double offset = scale * ax.inverse(ax.min);
         P.tab_scale[k] = to_float_literal(scale);
         P.tab_offset[k] = to_float_literal(offset);
-        P.tab_inverse[k] = (ax.kind == CLSIMHIP_AXIS_POWER && ax.power == 2) ? 1 : 0;
+        P.tab_inverse[k] = (ax.kind == CLSIMHIP_AXIS_POWER) ? static_cast<int32_t>(ax.power) : 0;
+        P.tab_inv_exp[k] = (ax.kind == CLSIMHIP_AXIS_POWER) ? to_float_literal(1. / ax.power) : 1.f;
         P.tab_nbins[k] = static_cast<int32_t>(ax.n_bins);
         P.tab_stride[k] = static_cast<uint32_t>(strides_[k]);
     }

@@ -510,14 +510,15 @@ int clsimhip_step_store_size_with_dummy_fill(const clsimhip_step_store *s, size_
  * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no
  * detector, a path sample every `step_length` metres) and fills a table over coordinates relative to a reference
  * particle.  4 axes, or 5 = TABULATE_IMPACT_ANGLE (StepToTableConverter.cxx:187-188: the fifth axis is the cosine of
- * the impact angle on the DOM, two random numbers per path sample); linear and square-root axes. */
+ * the impact angle on the DOM, two random numbers per path sample); linear and power axes (inverse transform: sqrt, cbrt,
+ * pow(x, 1/power), tabulator/Axis.cxx:150-171). */
 #define CLSIMHIP_AXIS_LINEAR 0          /* clsim::tabulator::LinearAxis (tabulator/Axis.h:71-80) */
 #define CLSIMHIP_AXIS_POWER 1           /* clsim::tabulator::PowerAxis  (tabulator/Axis.h:82-95) */
 typedef struct {
     int32_t kind;
     double min, max;
     uint32_t n_bins;                    /* without the under-/overflow bins every axis gets (Axes.cxx:51-64) */
-    uint32_t power;                     /* POWER: 1 or 2 */
+    uint32_t power;                     /* POWER: >= 1 (2: square-root spacing, 3: cube-root ...) */
 } clsimhip_axis;
 #define CLSIMHIP_AXES_SPHERICAL 0       /* SphericalAxes: r, azimuth [deg], cos(polar), delay time (spherical_coordinates.c.cl) */
 #define CLSIMHIP_AXES_CYLINDRICAL 1     /* CylindricalAxes: rho, azimuth [rad], z, delay time (cylindrical_coordinates.c.cl) */

@@ -844,11 +844,12 @@ def tabulator_config(kind, axes, medium, angular_coefficients, step_length=1.0, 
     n_group, n_phase = minimum_refractive_index(medium)
     lit = [axis_index_literals(ax) for ax in axes]
     for ax in axes:
-        assert ax["kind"] == "linear" or ax["power"] in (1, 2), "only linear and sqrt axes are restated"
+        assert ax["kind"] == "linear" or ax["power"] >= 1
     return dict(kind=kind, axes=axes, shape=shape, strides=strides, n_bins=n_bins,
                 full_azimuth=(kind == "spherical" and axes[1]["max"] > 180.0),
                 scale=[l[0] for l in lit], offset=[l[1] for l in lit],
-                inverse=[1 if (ax["kind"] == "power" and ax["power"] == 2) else 0 for ax in axes],
+                inverse=[(ax["power"] if ax["kind"] == "power" else 0) for ax in axes],
+                inv_exp=[(float_literal(1.0 / ax["power"]) if ax["kind"] == "power" else 1.0) for ax in axes],
                 max0=float_literal(axes[0]["max"]), max3=float_literal(axes[3]["max"]),
                 min_inv_groupvel=float_literal(n_group / C_LIGHT),
                 tan_thetac=float_literal(math.sqrt(n_phase * n_phase - 1.0)),

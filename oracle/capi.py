@@ -83,7 +83,7 @@ class Tables(C.Structure):
         ("has_fixed_abs", C.c_int32), ("fixed_abs", C.c_float), ("history_n", C.c_int32),
         ("tab_axes_kind", C.c_int32), ("tab_full_azimuth", C.c_int32),
         ("tab_ndim", C.c_int32),
-        ("tab_scale", C.c_float * 5), ("tab_offset", C.c_float * 5), ("tab_inverse", C.c_int32 * 5),
+        ("tab_scale", C.c_float * 5), ("tab_offset", C.c_float * 5), ("tab_inverse", C.c_int32 * 5), ("tab_inv_exp", C.c_float * 5),
         ("tab_nbins", C.c_int32 * 5), ("tab_stride", C.c_uint32 * 5),
         ("tab_max0", C.c_float), ("tab_max3", C.c_float), ("tab_min_inv_groupvel", C.c_float), ("tab_tan_thetac", C.c_float),
         ("tab_volume_step", C.c_float), ("tab_entries_per_stream", C.c_uint32),
@@ -175,6 +175,7 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
         for k in range(t.tab_ndim):
             t.tab_scale[k], t.tab_offset[k] = tb["scale"][k], tb["offset"][k]
             t.tab_inverse[k], t.tab_nbins[k], t.tab_stride[k] = tb["inverse"][k], tb["axes"][k]["n_bins"], tb["strides"][k]
+            t.tab_inv_exp[k] = tb["inv_exp"][k]
         t.tab_max0, t.tab_max3 = tb["max0"], tb["max3"]
         t.tab_min_inv_groupvel, t.tab_tan_thetac = tb["min_inv_groupvel"], tb["tan_thetac"]
         t.tab_volume_step, t.tab_entries_per_stream = tb["volume_step"], tb["entries_per_stream"]

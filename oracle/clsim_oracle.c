@@ -145,7 +145,8 @@ typedef struct {
     int32_t tab_full_azimuth;   /* HAS_FULL_AZIMUTH_EXTENSION */
     int32_t tab_ndim;           /* 4, or 5 = TABULATE_IMPACT_ANGLE (StepToTableConverter.cxx:187-188) */
     float tab_scale[5], tab_offset[5];  /* Axis::GetIndexCode literals */
-    int32_t tab_inverse[5];     /* inverse transform: 0 identity, 1 sqrt */
+    int32_t tab_inverse[5];     /* inverse transform: the axis' power (0, 1 identity, 2 sqrt, 3 cbrt, above pow(x, tab_inv_exp)) */
+    float tab_inv_exp[5];       /* ToFloatString(1./power), Axis.cxx:168 */
     int32_t tab_nbins[5];
     uint32_t tab_stride[5];
     float tab_max0, tab_max3;   /* isOutOfBounds */
@@ -731,7 +732,8 @@ static inline uint32_t getBinIndex(const oracle_tables *T, const float c[5])
 {
     uint32_t index = 0;
     for (int k = 0; k < T->tab_ndim; ++k) {
-        const float v = T->tab_inverse[k] ? om_sqrt(c[k]) : c[k];
+        const int pw = T->tab_inverse[k];
+        const float v = (pw <= 1) ? c[k] : (pw == 2) ? om_sqrt(c[k]) : (pw == 3) ? om_cbrt(c[k]) : om_pow_frac(c[k], T->tab_inv_exp[k]);
         int b = convert_int_sat_rtn(T->tab_scale[k] * v - T->tab_offset[k]);
         b = imin(imax(b, -1), T->tab_nbins[k]) + 1;
         index += T->tab_stride[k] * (uint32_t)b;
@@ -1092,6 +1094,7 @@ void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *
         case 9: out[i] = x / y; break;
         case 10: out[i] = om_acos_f(x); break;
         case 14: out[i] = om_powr_unit(x, y); break;
+        case 15: out[i] = om_cbrt(x); break;
         default: out[i] = 0.0f;
         }
     }

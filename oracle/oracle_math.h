@@ -264,6 +264,20 @@ OM_INLINE float om_powr_unit(float x, float y)
     return om_exp(y * om_log(x));
 }
 
+/* cbrt(x) and pow(x, y) for the table maker's power axes (tabulator/Axis.cxx:150-171: inverse transform cbrt(x) for power
+ * 3, pow(x, 1/power) above): cbrt through the hi+lo logarithm with the exponent RN(1/3), corrected for the exponent's
+ * second word (1e-8 |ln x| relative otherwise): <= 1.5 ulp (OpenCL: cbrt 2 ulp), odd symmetry as the builtin; pow of
+ * a negative base with a non-integer exponent is NaN as in OpenCL. */
+OM_INLINE float om_cbrt(float x)
+{
+    const float ax = x < 0.0f ? -x : x;
+    if (ax == 0.0f) return x;
+    float r = om_powr(ax, 0.333333343f);
+    r = om_fma(r, -9.934107e-09f * om_log(ax), r);          /* the exponent's second word: 1/3 - RN(1/3) */
+    return x < 0.0f ? -r : r;
+}
+OM_INLINE float om_pow_frac(float x, float y) { return (x < 0.0f) ? om_u2f(0x7fc00000u) : om_powr(x, y); }
+
 /* ---- ORACLE_LIBM (analysis build, tools/math_sensitivity.py): a DIFFERENT conforming math library -------------------
  * The deterministic functions above are this repository's definition of the OpenCL builtins; the reference kernel
  * runs on whatever the OpenCL runtime provides (a few ulp, unpinned).  With -DORACLE_LIBM the kernel-facing names are
@@ -283,6 +297,8 @@ OM_INLINE float om_libm_acos(float v) { return acosf(v); }
 #define om_exp om_libm_exp
 #define om_powr om_libm_powr
 #define om_powr_unit om_libm_powr
+#define om_cbrt cbrtf
+#define om_pow_frac powf
 #define om_sincos om_libm_sincos
 #define om_sin om_libm_sin
 #define om_cos om_libm_cos

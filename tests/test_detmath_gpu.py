@@ -35,7 +35,8 @@ N = 1 << 21
 
 @pytest.mark.parametrize("what,lo,hi", [
     (0, 5.9604645e-8, 1.0), (0, 1e-30, 1e30), (1, -30.0, 0.0), (1, -90.0, 90.0), (2, 0.0, 6.2831855), (3, 0.0, 6.2831855),
-    (2, -1000.0, 1000.0), (3, -1000.0, 1000.0), (5, -1.0, 1.0), (7, 1e-8, 4.0), (8, 0.0, 1e6), (10, -1.0, 1.0), (10, -1.0000005, 1.0000005)])
+    (2, -1000.0, 1000.0), (3, -1000.0, 1000.0), (5, -1.0, 1.0), (7, 1e-8, 4.0), (8, 0.0, 1e6), (10, -1.0, 1.0), (10, -1.0000005, 1.0000005),
+    (15, 0.0, 600.0), (15, -7e3, 7e3)])
 def test_unary_functions_bit_exact(oracle_lib, what, lo, hi):
     rng = np.random.Generator(np.random.PCG64(1000 + what))
     if lo > 0 and hi / lo > 1e6:

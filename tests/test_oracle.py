@@ -182,3 +182,14 @@ def test_oracle_edge_cases(oracle_lib):
     assert cnt0 == 0 and it0 == 0 and np.array_equal(x0, x[:512])
     tiny = capi.propagate(T, steps[:512], x, a, max_hits=3)        # overflow: counter runs on, 3 stored
     assert tiny[1] == cnt and len(tiny[0]) == 3
+
+
+def test_cube_root_of_the_power_axes_is_within_opencl_bounds(oracle_lib):
+    """om_cbrt (tabulator power axes with power 3, Axis.cxx:164-165): <= 2 ulp like OpenCL's cbrt, odd, exact at 0"""
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = np.concatenate([rng.uniform(-7e3, 7e3, 200000), np.exp(rng.uniform(np.log(1e-6), np.log(1e6), 200000))]).astype(np.float32)
+    got = capi.eval_math(15, x).astype(np.float64)
+    want = np.cbrt(x.astype(np.float64))
+    ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(got - want) / ulp) <= 2.0
+    assert capi.eval_math(15, np.array([0.0, 8.0, -27.0], dtype=np.float32)).tolist() == [0.0, 2.0, -3.0]

@@ -31,6 +31,10 @@ def axes_pair(kind, small=True):
         # a fifth axis (cosine of the impact angle) switches TABULATE_IMPACT_ANGLE on (StepToTableConverter.cxx:187-188)
         o = [B.power_axis(0, 580, 40, 2), B.linear_axis(0, 180, 8), B.linear_axis(-1, 1, 20), B.power_axis(0, 7e3, 21, 2), B.linear_axis(-1, 1, 10)]
         p = TB.SphericalAxes([TB.PowerAxis(0, 580, 40, 2), TB.LinearAxis(0, 180, 8), TB.LinearAxis(-1, 1, 20), TB.PowerAxis(0, 7e3, 21, 2), TB.LinearAxis(-1, 1, 10)])
+    elif kind == "spherical_cuberoot":
+        # power 3 (inverse transform cbrt) and power 4 (pow(x, 0.25)): tabulator/Axis.cxx:150-171
+        o = [B.power_axis(0, 580, 40, 3), B.linear_axis(0, 180, 8), B.linear_axis(-1, 1, 20), B.power_axis(0, 7e3, 30, 4)]
+        p = TB.SphericalAxes([TB.PowerAxis(0, 580, 40, 3), TB.LinearAxis(0, 180, 8), TB.LinearAxis(-1, 1, 20), TB.PowerAxis(0, 7e3, 30, 4)])
     elif kind == "cylindrical5":
         o = [B.power_axis(0, 580, 20, 2), B.linear_axis(0, math.pi, 8), B.linear_axis(-8e2, 8e2, 16), B.power_axis(0, 7e3, 21, 2), B.linear_axis(-1, 1, 10)]
         p = TB.CylindricalAxes([TB.PowerAxis(0, 580, 20, 2), TB.LinearAxis(0, math.pi, 8), TB.LinearAxis(-8e2, 8e2, 16), TB.PowerAxis(0, 7e3, 21, 2), TB.LinearAxis(-1, 1, 10)])
@@ -99,7 +103,7 @@ def test_oracle_tabulator_entries_and_misses():
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,ice,step_length", [("spherical", "mie", 1.0), ("cylindrical", "lea", 1.0), ("spherical360", "photonics_mie", 1.0),
                                                   ("spherical", "lea", 0.2), ("spherical5", "mie", 1.0), ("cylindrical5", "lea", 1.0),
-                                                  ("spherical5", "lea", 0.2)])
+                                                  ("spherical5", "lea", 0.2), ("spherical_cuberoot", "mie", 1.0)])
 def test_table_matches_the_oracle(kind, ice, step_length):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
