@@ -18,7 +18,8 @@ out = torch.empty((cap, 80), dtype=torch.uint8, device=dev); cnt = torch.zeros(1
 
 
 def run(cfg, steps, env):
-    for k in ("CLSIMHIP_GRID", "CLSIMHIP_SLICES", "CLSIMHIP_K_NEW", "CLSIMHIP_K_SEARCH"):
+    for k in ("CLSIMHIP_GRID", "CLSIMHIP_SLICES", "CLSIMHIP_K_NEW", "CLSIMHIP_K_SEARCH", "CLSIMHIP_KERNEL", "CLSIMHIP_POOL_R", "CLSIMHIP_K_POP",
+              "CLSIMHIP_NO_FAST"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in env.items()})
     n = len(steps)
@@ -47,6 +48,9 @@ for case in range(cases):
         steps["num"][rng.integers(0, n, 5)] = 3000
     env = dict(CLSIMHIP_GRID=int(rng.integers(1, 1793)), CLSIMHIP_SLICES=int(rng.choice([1, 2, 3, 5, 16, 33, 64])),
                CLSIMHIP_K_NEW=int(rng.choice([1, 4, 12, 40, 64])), CLSIMHIP_K_SEARCH=int(rng.choice([1, 3, 5, 20])))
+    if case % 2:        # the pooled kernel: ring size, service threshold, specialised or generic instantiation
+        env.update(CLSIMHIP_KERNEL="pool", CLSIMHIP_POOL_R=int(rng.choice([4, 7, 16, 34])), CLSIMHIP_K_POP=int(rng.choice([1, 4, 17, 64])),
+                   CLSIMHIP_NO_FAST=int(rng.integers(0, 2)), CLSIMHIP_GRID=int(rng.integers(1, 513)))
     ref = run(cfg, steps, dict(CLSIMHIP_GRID=64, CLSIMHIP_SLICES=1, CLSIMHIP_K_NEW=1, CLSIMHIP_K_SEARCH=1))
     got = run(cfg, steps, env)
     assert got[2] == ref[2] and got[0] == ref[0] and got[1] == ref[1], (case, name, n, env)
