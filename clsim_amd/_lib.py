@@ -106,6 +106,9 @@ SYMBOLS = [
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
     "clsimhip_ppc_create", "clsimhip_ppc_destroy", "clsimhip_ppc_photons_per_meter", "clsimhip_ppc_enqueue", "clsimhip_shower_parameters",
     "clsimhip_flasher_correction_factor", "clsimhip_flasher_enqueue",
+    "clsimhip_feeder_create", "clsimhip_feeder_destroy", "clsimhip_feeder_enqueue_light_source", "clsimhip_feeder_enqueue_steps",
+    "clsimhip_feeder_enqueue_barrier", "clsimhip_feeder_barrier_active", "clsimhip_feeder_more_steps_available",
+    "clsimhip_feeder_get_conversion_result", "clsimhip_feeder_release_result",
     "clsimhip_count_flasher_steps", "clsimhip_generate_flasher_steps_device", "clsimhip_generate_flasher_steps",
     "clsimhip_flasher_time_profile",
     "clsimhip_step_store_create", "clsimhip_step_store_destroy", "clsimhip_step_store_insert", "clsimhip_step_store_size",
@@ -211,6 +214,15 @@ def load():
         "clsimhip_shower_parameters": (i32, [i32, C.c_double, C.c_double, C.POINTER(C.c_double)]),
         "clsimhip_flasher_correction_factor": (i32, [C.POINTER(Function), C.c_double, C.POINTER(Function), C.c_double, C.c_double, C.POINTER(C.c_double)]),
         "clsimhip_flasher_enqueue": (i32, [C.c_double, u64, vp, sz, vp, sz, C.POINTER(sz)]),
+        "clsimhip_feeder_create": (i32, [vp, i32, u64, sz, sz, sz, C.POINTER(vp)]),
+        "clsimhip_feeder_destroy": (None, [vp]),
+        "clsimhip_feeder_enqueue_light_source": (i32, [vp, vp]),
+        "clsimhip_feeder_enqueue_steps": (i32, [vp, u32, vp, sz]),
+        "clsimhip_feeder_enqueue_barrier": (i32, [vp]),
+        "clsimhip_feeder_barrier_active": (i32, [vp, C.POINTER(C.c_int)]),
+        "clsimhip_feeder_more_steps_available": (i32, [vp, C.POINTER(C.c_int)]),
+        "clsimhip_feeder_get_conversion_result": (i32, [vp, C.c_double, C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]),
+        "clsimhip_feeder_release_result": (i32, [vp, vp]),
         "clsimhip_count_generated_steps": (i32, [C.POINTER(StepRequest), sz, sz, C.POINTER(sz), C.POINTER(sz)]),
         "clsimhip_generate_steps_device": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, vp, C.POINTER(sz)]),
         "clsimhip_generate_steps": (i32, [i32, C.POINTER(StepRequest), sz, u64, sz, vp, sz, C.POINTER(sz)]),

@@ -2,10 +2,13 @@
 // catches clsimhip::Error, stores the text for clsimhip_last_error() and returns
 // the status code; nothing C++ crosses the boundary.
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "converter.h"
 #include "lightsource.h"
+#include "feeder.h"
 #include "tabulator.h"
 #include "step_store.h"
 #include "flasher.h"
@@ -247,6 +250,70 @@ int clsimhip_shower_parameters(int32_t particle_type, double energy_gev, double 
         const ShowerParameters s = shower_parameters(particle_type, energy_gev, density_g_cm3);
         out[0] = s.a; out[1] = s.b; out[2] = s.em_scale; out[3] = s.em_scale_sigma;
     });
+}
+struct clsimhip_feeder {
+    std::unique_ptr<clsimhip::Feeder> impl;
+    std::mutex m;
+    std::map<const clsimhip_step *, clsimhip::Feeder::Result> handed_out;
+};
+static const clsimhip_step g_empty_bunch{};
+int clsimhip_feeder_create(const clsimhip_ppc_converter *ppc, int device, uint64_t seed, size_t max_bunch_size,
+                           size_t bunch_size_granularity, size_t queue_depth, clsimhip_feeder **out)
+{
+    return guarded(nullptr, [&] {
+        need(out, "out");
+        std::unique_ptr<clsimhip_feeder> f(new clsimhip_feeder);
+        f->impl.reset(new Feeder(ppc ? ppc->impl.get() : nullptr, device, seed, max_bunch_size, bunch_size_granularity, queue_depth));
+        *out = f.release();
+    });
+}
+void clsimhip_feeder_destroy(clsimhip_feeder *f) { delete f; }
+int clsimhip_feeder_enqueue_light_source(clsimhip_feeder *f, const clsimhip_particle *particle)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); need(particle, "particle"); f->impl->enqueue_light_source(*particle); });
+}
+int clsimhip_feeder_enqueue_steps(clsimhip_feeder *f, uint32_t identifier, const clsimhip_step *steps, size_t n)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); if (n) need(steps, "steps"); f->impl->enqueue_steps(identifier, steps, n); });
+}
+int clsimhip_feeder_enqueue_barrier(clsimhip_feeder *f)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); f->impl->enqueue_barrier(); });
+}
+int clsimhip_feeder_barrier_active(const clsimhip_feeder *f, int *out)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); need(out, "out"); *out = f->impl->barrier_active() ? 1 : 0; });
+}
+int clsimhip_feeder_more_steps_available(const clsimhip_feeder *f, int *out)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); need(out, "out"); *out = f->impl->more_steps_available() ? 1 : 0; });
+}
+int clsimhip_feeder_get_conversion_result(clsimhip_feeder *f, double timeout_ms, int *got, const clsimhip_step **steps, size_t *n,
+                                          const uint32_t **finished, size_t *n_finished, int *barrier_was_reset)
+{
+    return guarded(nullptr, [&] {
+        need(f, "feeder"); need(got, "got"); need(steps, "steps"); need(n, "n"); need(finished, "finished"); need(n_finished, "n_finished");
+        need(barrier_was_reset, "barrier_was_reset");
+        Feeder::Result r;
+        *got = 0; *steps = nullptr; *n = 0; *finished = nullptr; *n_finished = 0; *barrier_was_reset = 0;
+        if (!f->impl->get_result(timeout_ms, r)) return;
+        *got = 1;
+        *n = r.steps->size();
+        *n_finished = r.finished.size();
+        *barrier_was_reset = r.last_before_barrier ? 1 : 0;
+        std::lock_guard<std::mutex> lk(f->m);
+        // the key is the step array itself; an empty bunch gets an address of its own
+        if (r.steps->empty()) r.steps->push_back(g_empty_bunch);
+        const clsimhip_step *key = r.steps->data();
+        Feeder::Result &kept = f->handed_out[key];
+        kept = std::move(r);
+        *steps = key;
+        *finished = kept.finished.empty() ? nullptr : kept.finished.data();
+    });
+}
+int clsimhip_feeder_release_result(clsimhip_feeder *f, const clsimhip_step *steps)
+{
+    return guarded(nullptr, [&] { need(f, "feeder"); std::lock_guard<std::mutex> lk(f->m); f->handed_out.erase(steps); });
 }
 int clsimhip_mwc_multipliers(uint32_t *a_out, size_t count)
 {

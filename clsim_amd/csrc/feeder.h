@@ -1,0 +1,59 @@
+// Feeder: the worker thread of I3CLSimLightSourceToStepConverterAsync (private/clsim/I3CLSimLightSourceToStepConverterAsync.cxx
+// WorkerThread_impl :178-392, EnqueueLightSource / EnqueueBarrier / GetConversionResultWithBarrierInfo :470-600).
+#pragma once
+#include <atomic>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "converter.h"
+#include "lightsource.h"
+#include "step_store.h"
+
+namespace clsimhip {
+
+class Feeder {
+public:
+    struct Result {                         // the tuple the reference puts on queueFromGeant4_ (:222, :268)
+        std::unique_ptr<std::vector<clsimhip_step>> steps;
+        std::vector<uint32_t> finished;     // light sources whose steps have all left the store
+        bool last_before_barrier = false;
+    };
+    // ppc may be null: the feeder then only accepts light sources that come with their steps (enqueue_steps)
+    Feeder(const PPCConverter *ppc, int device, uint64_t seed, size_t max_bunch_size, size_t granularity, size_t queue_depth);
+    ~Feeder();
+    void enqueue_light_source(const clsimhip_particle &particle);
+    void enqueue_steps(uint32_t identifier, const clsimhip_step *steps, size_t n);      // a source whose steps the caller made (a propagator's output)
+    void enqueue_barrier();
+    bool barrier_active() const { return barrier_enqueued_.load(); }
+    bool more_steps_available() const { return !out_->empty(); }
+    // false on timeout (timeout_ms < 0: wait for ever)
+    bool get_result(double timeout_ms, Result &out);
+    std::string worker_error() const;
+
+private:
+    struct Item {
+        bool barrier = false, has_particle = false;
+        clsimhip_particle particle{};
+        uint32_t identifier = 0;
+        std::vector<clsimhip_step> steps;
+    };
+    void worker();
+    void flush(bool reset_barrier);
+    void insert_and_flush(const clsimhip_step *steps, size_t n);
+
+    const PPCConverter *ppc_;
+    int device_;
+    uint64_t seed_;
+    size_t max_bunch_, granularity_;
+    std::unique_ptr<BoundedQueue<Item>> in_;
+    std::unique_ptr<BoundedQueue<Result>> out_;
+    StepStore store_{0};
+    std::deque<uint32_t> markers_;
+    std::atomic<bool> barrier_enqueued_{false};
+    std::thread thread_;
+    mutable std::mutex error_mutex_;
+    std::string error_;
+};
+
+} // namespace clsimhip

@@ -117,3 +117,88 @@ class StepBuncher:
         self.markers.clear()
         out.append((steps, finished, True))
         return out
+
+
+class I3CLSimLightSourceToStepConverterAsync:
+    """The reference's asynchronous light-source converter (private/clsim/I3CLSimLightSourceToStepConverterAsync.cxx) over
+    the C ABI's feeder (clsimhip_feeder_*, csrc/feeder.cpp): a worker thread turns light sources into steps (PPC front end
+    + GPU step producer, or steps the caller supplies), runs them through the step store and hands out bunches."""
+
+    def __init__(self, maxQueueItems=10):
+        self._lib = _lib.load()
+        self._depth = int(maxQueueItems)
+        self._max_bunch, self._granularity, self._ppc, self._seed, self._device = 512000, 512, None, 0, 0
+        self._h = None
+
+    def SetBunchSizeGranularity(self, num):
+        if num <= 0:
+            raise I3CLSimStepToPhotonConverter_exception("BunchSizeGranularity of 0 is invalid!")
+        self._granularity = int(num)
+
+    def SetMaxBunchSize(self, num):
+        if num <= 0:
+            raise I3CLSimStepToPhotonConverter_exception("MaxBunchSize of 0 is invalid!")
+        self._max_bunch = int(num)
+
+    def SetLightSourceParameterization(self, ppc, seed=0, device=0):
+        """the converter that parameterises particles (clsim_amd.converter.I3CLSimLightSourceToStepConverterPPC, initialised)"""
+        self._ppc, self._seed, self._device = ppc, int(seed), int(device)
+
+    def Initialize(self):
+        h = C.c_void_p()
+        ppc = self._ppc._h if self._ppc is not None else None
+        rc = self._lib.clsimhip_feeder_create(ppc, self._device, self._seed, self._max_bunch, self._granularity, self._depth, C.byref(h))
+        self._check(rc)
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.clsimhip_feeder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise I3CLSimStepToPhotonConverter_exception((self._lib.clsimhip_last_error(None) or b"").decode() or ("status %d" % rc), rc)
+
+    def IsInitialized(self):
+        return self._h is not None
+
+    def EnqueueLightSource(self, particle):
+        """particle: one record of clsim_amd.converter.PARTICLE_DTYPE (its identifier travels with it)"""
+        p = np.ascontiguousarray(particle).reshape(1)
+        self._check(self._lib.clsimhip_feeder_enqueue_light_source(self._h, p.ctypes.data_as(C.c_void_p)))
+
+    def EnqueueSteps(self, identifier, steps):
+        st = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+        self._check(self._lib.clsimhip_feeder_enqueue_steps(self._h, int(identifier), st.ctypes.data_as(C.c_void_p), len(st)))
+
+    def EnqueueBarrier(self):
+        self._check(self._lib.clsimhip_feeder_enqueue_barrier(self._h))
+
+    def BarrierActive(self):
+        v = C.c_int()
+        self._check(self._lib.clsimhip_feeder_barrier_active(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def MoreStepsAvailable(self):
+        v = C.c_int()
+        self._check(self._lib.clsimhip_feeder_more_steps_available(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def GetConversionResultWithBarrierInfoAndMarkers(self, timeout_ms=-1.0):
+        """(steps, finished identifiers, barrierWasReset), or None on timeout"""
+        got, n, nf, reset = C.c_int(), C.c_size_t(), C.c_size_t(), C.c_int()
+        steps, fin = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.clsimhip_feeder_get_conversion_result(self._h, float(timeout_ms), C.byref(got), C.byref(steps), C.byref(n),
+                                                                    C.byref(fin), C.byref(nf), C.byref(reset)))
+        if not got.value:
+            return None
+        out = np.zeros(n.value, dtype=STEP_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, steps.value, n.value * STEP_DTYPE.itemsize)
+        finished = list(np.ctypeslib.as_array(C.cast(fin, C.POINTER(C.c_uint32)), shape=(nf.value,)).copy()) if nf.value else []
+        self._check(self._lib.clsimhip_feeder_release_result(self._h, steps))
+        return out, [int(v) for v in finished], bool(reset.value)

@@ -505,6 +505,31 @@ int clsimhip_step_store_pop_bunch_filled(clsimhip_step_store *s, size_t size, cl
 /* numStepsWithDummyFill (Async.cxx:256): size of the padded last bunch before a barrier */
 int clsimhip_step_store_size_with_dummy_fill(const clsimhip_step_store *s, size_t granularity, size_t *out);
 
+/* ---- feeder: the worker thread of I3CLSimLightSourceToStepConverterAsync ----------------------
+ * private/clsim/I3CLSimLightSourceToStepConverterAsync.cxx: EnqueueLightSource / EnqueueBarrier / BarrierActive /
+ * MoreStepsAvailable / GetConversionResultWithBarrierInfo (:470-600) in front of WorkerThread_impl (:178-392): light sources
+ * are converted one after the other (the PPC front end above + the GPU step producer take the place of the
+ * parameterisation), their steps go through the step store, and bunches of max_bunch_size steps come out in ascending
+ * photon count, each with the identifiers of the light sources that have completely left the store; the barrier flushes
+ * the rest, padded with no-op steps to ((size / granularity) + 1) * granularity.  Queues of `queue_depth` entries (10 in
+ * the reference) on both sides; one thread per feeder. */
+typedef struct clsimhip_feeder clsimhip_feeder;
+/* ppc may be NULL (only clsimhip_feeder_enqueue_steps is then accepted); it must outlive the feeder */
+int clsimhip_feeder_create(const clsimhip_ppc_converter *ppc, int device, uint64_t seed, size_t max_bunch_size,
+                           size_t bunch_size_granularity, size_t queue_depth, clsimhip_feeder **out);
+void clsimhip_feeder_destroy(clsimhip_feeder *f);
+int clsimhip_feeder_enqueue_light_source(clsimhip_feeder *f, const clsimhip_particle *particle);
+/* a light source whose steps the caller made itself (the role of an I3CLSimLightSourcePropagator, e.g. Geant4) */
+int clsimhip_feeder_enqueue_steps(clsimhip_feeder *f, uint32_t identifier, const clsimhip_step *steps, size_t n);
+int clsimhip_feeder_enqueue_barrier(clsimhip_feeder *f);
+int clsimhip_feeder_barrier_active(const clsimhip_feeder *f, int *out);
+int clsimhip_feeder_more_steps_available(const clsimhip_feeder *f, int *out);
+/* GetConversionResultWithBarrierInfoAndMarkers: waits up to timeout_ms (< 0: for ever; *got = 0 on timeout).  *steps (n
+ * records) and *finished (n_finished identifiers) stay valid until clsimhip_feeder_release_result(f, *steps). */
+int clsimhip_feeder_get_conversion_result(clsimhip_feeder *f, double timeout_ms, int *got, const clsimhip_step **steps, size_t *n,
+                                          const uint32_t **finished, size_t *n_finished, int *barrier_was_reset);
+int clsimhip_feeder_release_result(clsimhip_feeder *f, const clsimhip_step *steps);
+
 /* ---- photon table maker -------------------------------------------------------------
  * I3CLSimStepToTableConverter (private/clsim/tabulator/I3CLSimStepToTableConverter.h:44-101): propagates steps with
  * the TABULATE variant of propKernel (propagation_kernel.c.cl:228-303, 755-785: fixed 42 absorption lengths, no

@@ -923,6 +923,40 @@ def bunch_steps_model(sources, max_bunch_size, granularity, no_op):
     return out
 
 
+def feeder_model(items, max_bunch_size, granularity, no_op):
+    """The feeder thread's main loop with a parameterisation (Async.cxx:340-392 with getStepsFromParameterization :282-315 and
+    flushStepStore :209-273).  items: (identifier, steps) light sources and None for a barrier.  The parameterisation hands
+    its steps over in bunches of at most max_bunch_size; each is inserted whole, then the store is flushed; the marker of a
+    light source is pushed AFTER its conversion (:388).  Returns the list of (steps, finished identifiers, last)."""
+    store, markers, out = StepStoreModel(), [], []
+
+    def flush(reset_barrier):
+        while store.size() >= max_bunch_size:
+            steps = store.pop_bunch_to_vector(max_bunch_size)
+            finished = []
+            while markers and store.count(markers[0]) == 0:
+                finished.append(markers.pop(0))
+            out.append((steps, finished, False))
+        if reset_barrier:
+            n_fill = ((store.size() // granularity) + 1) * granularity if granularity > 1 else store.size()
+            steps = store.pop_bunch_to_vector(n_fill, fill=no_op)
+            assert store.size() == 0
+            out.append((steps, list(markers), True))
+            del markers[:]
+
+    for item in items:
+        flush(item is None)
+        if item is None:
+            continue
+        identifier, steps = item
+        for lo in range(0, len(steps), max_bunch_size):
+            for s in steps[lo:lo + max_bunch_size]:
+                store.insert_copy(s)
+            flush(False)
+        markers.append(identifier)
+    return out
+
+
 # ---- flasher step producer: host logic (I3CLSimLightSourceToStepConverterFlasher.cxx:329-440,
 #      python/I3CLSimRandomValueIceCubeFlasherTimeProfile.py) ----
 FLASHER_PULSE_WIDTH15 = np.array([      # :52-88, the measured LED profile the reference tabulates (1 ns steps)
