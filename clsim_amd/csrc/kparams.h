@@ -95,8 +95,8 @@ struct KParams {
     // DOM proximity map, the second level of the search filter: dprox_nx x dprox_ny x dprox_nz words (cubic cells, z fastest) over
     // the bounding box of the DOMs.  A word names the DOM nearest to the cell (bits 0-15: index into dom_centres, 0xffff =
     // none within 64 m) and carries in bits 16-23, in 0.25 m units, a proven lower bound of the 3D distance from anywhere
-    // in the cell to the sphere of any OTHER DOM.  The kernel takes the exact distance to the named DOM's sphere and the
-    // stored bound for the rest: a step shorter than both cannot touch a DOM.  Consulted only by lanes whose step reaches a
+    // in the cell to the sphere of any OTHER DOM.  A step shorter than that bound can only touch the named DOM, and does
+    // so only if the segment comes within its radius (prop_device.hip.h: dom_search_needed).  Consulted only by lanes whose step reaches a
     // string cylinder: most of them pass between two DOMs of the string (17 m apart, 0.8 m radius), and photons born
     // at a DOM (flashers) spend their lives within metres of it.  <= 64 MB in HBM, the words in use L2 / MALL resident.
     const uint32_t *dom_prox;

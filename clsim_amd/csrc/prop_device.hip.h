@@ -615,27 +615,33 @@ DM float free_flight_bound(KP P, float x, float y)
     return (float)P->prox_map[iy * n + ix] * 0.25f;
 }
 
-// DOM proximity map (kparams.h): distance [m] that a photon at (x, y, z) can travel in any direction before it could touch
-// a DOM: the exact distance to the sphere of the DOM named by the cell (shortened by 1e-5 of itself for the float
-// arithmetic), the cell's stored bound for all others
-DM float dom_free_flight_bound(KP P, float x, float y, float z)
+// Second and third level of the search filter (kparams.h: DOM proximity map), for a lane whose step of length `len` reaches a
+// string cylinder.  The cell names the nearest DOM and bounds the distance to every other one: a step at least that long
+// goes to the full search.  Otherwise only the named DOM is within reach, and the full search -- whatever its own pruning
+// does -- can report nothing but a hit on that DOM, which requires the segment to touch its sphere (a pancaked DOM lies
+// inside it).  So the segment's closest approach to the DOM centre is taken here, against the radius plus 6 cm (5 cm of the
+// map's safety, 1 cm for this arithmetic in single precision at coordinates of a few hundred metres): farther away, the
+// search would find nothing and is skipped; closer, the lane goes to the full search, which decides.  Conservative in one
+// direction only, so no bit of the result depends on it.  Photons born at a DOM (flashers) spend their lives within metres
+// of it: nearly all of their steps pass this sphere by.
+DM bool dom_search_needed(KP P, const Photon &ph, float len)
 {
     const float inv = P->dprox_inv_cell;
     const int ny = P->dprox_ny, nz = P->dprox_nz;
-    const int ix = clampi((int)((x - P->dprox_x0) * inv), 0, P->dprox_nx - 1);
-    const int iy = clampi((int)((y - P->dprox_y0) * inv), 0, ny - 1);
-    const int iz = clampi((int)((z - P->dprox_z0) * inv), 0, nz - 1);
+    const int ix = clampi((int)((ph.px - P->dprox_x0) * inv), 0, P->dprox_nx - 1);
+    const int iy = clampi((int)((ph.py - P->dprox_y0) * inv), 0, ny - 1);
+    const int iz = clampi((int)((ph.pz - P->dprox_z0) * inv), 0, nz - 1);
     const uint32_t w = P->dom_prox[((size_t)ix * (size_t)ny + (size_t)iy) * (size_t)nz + (size_t)iz];      // z runs fastest
-    float bound = (float)((w >> 16) & 0xffu) * 0.25f;
+    const float others = (float)((w >> 16) & 0xffu) * 0.25f;
+    if (!(len < others)) return true;
     const uint32_t id = w & 0xffffu;
-    if (id != 0xffffu) {
-        const float4 c = P->dom_centres[id];
-        const float ex = x - c.x, ey = y - c.y, ez = z - c.z;
-        // a bound, not a result: the hardware square root (1 ulp) under the 1e-5 margin
-        const float near = __builtin_amdgcn_sqrtf((ex * ex + ey * ey) + ez * ez) * 0.99999f - P->dprox_radius;
-        bound = (near < bound) ? near : bound;
-    }
-    return bound;
+    if (id == 0xffffu) return false;
+    const float4 c = P->dom_centres[id];
+    const float wx = c.x - ph.px, wy = c.y - ph.py, wz = c.z - ph.pz;
+    const float along = clampf((wx * ph.d.x + wy * ph.d.y) + wz * ph.d.z, 0.0f, len);
+    const float qx = wx - along * ph.d.x, qy = wy - along * ph.d.y, qz = wz - along * ph.d.z;
+    const float reach = P->dprox_radius + 0.01f;
+    return !((qx * qx + qy * qy) + qz * qz > reach * reach);
 }
 
 // collision c.cl:194-303 + :462-547

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
-            if (!TAB && !(distance < free_flight) && !(distance < dom_free_flight_bound(fresh_params(P0), ph.px, ph.py, ph.pz))) {
+            if (!TAB && !(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
                 parked = true;
                 pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance);
             }

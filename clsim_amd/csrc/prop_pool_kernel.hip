@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
-            if (!(distance < free_flight) && !(distance < dom_free_flight_bound(fresh_params(P0), ph.px, ph.py, ph.pz))) {
+            if (!(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
                 parked = true;
                 parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
             }
