@@ -118,6 +118,7 @@ SYMBOLS = [
     "clsimhip_tabulator_enqueue_steps", "clsimhip_tabulator_finish", "clsimhip_tabulator_get_shape",
     "clsimhip_tabulator_get_bin_content", "clsimhip_tabulator_get_bin_sums", "clsimhip_tabulator_get_bin_edges",
     "clsimhip_tabulator_get_statistics", "clsimhip_tabulator_get_rng_state", "clsimhip_tabulator_get_table",
+    "clsimhip_tabulator_write_fits_file",
 ]
 
 _lib = None
@@ -251,6 +252,7 @@ def load():
         "clsimhip_tabulator_get_statistics": (i32, [vp, DP]),
         "clsimhip_tabulator_get_rng_state": (i32, [vp, vp, sz]),
         "clsimhip_tabulator_get_table": (C.c_long, [vp, C.c_char_p, DP, sz]),
+        "clsimhip_tabulator_write_fits_file": (i32, [vp, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), sz]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

@@ -869,6 +869,22 @@ int clsimhip_tabulator_get_rng_state(clsimhip_tabulator *t, uint64_t *x, size_t 
 {
     return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->get_rng_state(x, count); });
 }
+int clsimhip_tabulator_write_fits_file(clsimhip_tabulator *t, const char *path, const char *const *keys, const int32_t *is_int,
+                                       const int64_t *int_values, const double *double_values, size_t n_keys)
+{
+    return guarded_tab(t, [&] {
+        need(t, "tabulator"); need(path, "path");
+        std::vector<Tabulator::HeaderEntry> header;
+        for (size_t i = 0; i < n_keys; ++i) {
+            need(keys, "keys"); need(is_int, "is_int"); need(keys[i], "key");
+            Tabulator::HeaderEntry e{keys[i], is_int[i] != 0, 0, 0.};
+            if (e.is_int) { need(int_values, "int_values"); e.i = int_values[i]; }
+            else { need(double_values, "double_values"); e.d = double_values[i]; }
+            header.push_back(e);
+        }
+        t->impl->write_fits_file(path, header);
+    });
+}
 long clsimhip_tabulator_get_table(const clsimhip_tabulator *t, const char *name, double *out, size_t cap)
 {
     long n = -1;

@@ -1,5 +1,9 @@
 // See tabulator.h.  Host logic restated from private/clsim/tabulator/ (file:line at each function).
 #include "tabulator.h"
+#include "lightsource.h"
+
+#include <cstdio>
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -79,6 +83,13 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     n_bins_ = strides_[0] * shape_[0];
     if (n_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
 
+    {   // spectralBiasFactor_ (StepToTableConverter.cxx:142-152): photons of a bare Cherenkov spectrum between 300 and 600 nm per
+        // photon drawn from the acceptance-weighted spectrum (ConverterUtils.cxx:44-105; lightsource.cpp)
+        FunctionData one;
+        one.kind = CLSIMHIP_FUNCTION_CONSTANT;
+        one.value = 1.;
+        spectral_bias_factor_ = photons_per_meter(medium, one, 300e-9, 600e-9) / photons_per_meter(medium, wavelength_acceptance, medium.min_wlen, medium.max_wlen);
+    }
     // StepToTableConverter.cxx:126-141: generator 0 = Cherenkov spectrum biased with the wavelength acceptance
     std::vector<RandomValueData> gens(1, make_cherenkov_generator(wavelength_acceptance, medium));
     tables_ = compile_tables(medium, GeometryInput(), gens, wavelength_acceptance, 1.0);
@@ -319,6 +330,118 @@ long Tabulator::get_table(const std::string &name, double *out, size_t cap) cons
     const size_t n = it->second.size();
     if (out) std::memcpy(out, it->second.data(), std::min(n, cap) * sizeof(double));
     return static_cast<long>(n);
+}
+
+// ---- WriteFITSFile (StepToTableConverter.cxx:545-686) without cfitsio ----------------------------------------------
+// A FITS file is a sequence of 2880-byte blocks: header units of 80-character cards ("KEYWORD = value"), data units of
+// big-endian numbers.  cfitsio writes the image with the axis counts reversed ("like PyFITS does", :553-561), long
+// keyword names through the HIERARCH convention (:621), the squared weights as an IMAGE extension "ERRORS" and one
+// double IMAGE extension "EDGESi" per axis.  Same structure, keywords and values here; card comments are omitted.
+namespace {
+
+struct FitsWriter {
+    FILE *f = nullptr;
+    size_t in_block = 0;
+    explicit FitsWriter(const std::string &path)
+    {
+        f = std::fopen(path.c_str(), "wbx");                // fits_create_diskfile refuses to overwrite, so does "x"
+        if (!f) throw Error(CLSIMHIP_ERR_IO, "Could not create " + path);
+    }
+    ~FitsWriter() { if (f) std::fclose(f); }
+    void raw(const void *p, size_t n)
+    {
+        if (std::fwrite(p, 1, n, f) != n) throw Error(CLSIMHIP_ERR_IO, "write failed");
+        in_block = (in_block + n) % 2880;
+    }
+    void pad(char c)
+    {
+        static const std::string zeros(2880, '\0'), blanks(2880, ' ');
+        if (in_block) raw((c == ' ' ? blanks : zeros).data(), 2880 - in_block);
+    }
+    void card(const std::string &text)
+    {
+        std::string c = text.substr(0, 80);
+        c.resize(80, ' ');
+        raw(c.data(), 80);
+    }
+    void key_logical(const char *k, bool v) { char b[81]; std::snprintf(b, sizeof b, "%-8s= %20s", k, v ? "T" : "F"); card(b); }
+    void key_int(const char *k, long long v) { char b[81]; std::snprintf(b, sizeof b, "%-8s= %20lld", k, v); card(b); }
+    void key_string(const char *k, const std::string &v) { char b[96]; std::snprintf(b, sizeof b, "%-8s= '%-8s'", k, v.c_str()); card(b); }
+    void hierarch_int(const std::string &k, long long v) { char b[128]; std::snprintf(b, sizeof b, "HIERARCH %s = %lld", k.c_str(), v); card(b); }
+    void hierarch_double(const std::string &k, double v) { char b[128]; std::snprintf(b, sizeof b, "HIERARCH %s = %.15G", k.c_str(), v); card(b); }
+    void end_header() { card("END"); pad(' '); }
+    template <class T, class U>
+    void data(const std::vector<T> &v)
+    {
+        static_assert(sizeof(T) == sizeof(U), "size");
+        std::vector<unsigned char> out(v.size() * sizeof(T));
+        for (size_t i = 0; i < v.size(); ++i) {
+            U bits;
+            std::memcpy(&bits, &v[i], sizeof(T));
+            for (size_t b = 0; b < sizeof(T); ++b) out[i * sizeof(T) + b] = static_cast<unsigned char>(bits >> (8 * (sizeof(T) - 1 - b)));
+        }
+        raw(out.data(), out.size());
+        pad('\0');
+    }
+};
+
+} // namespace
+
+void Tabulator::write_fits_file(const std::string &path, const std::vector<HeaderEntry> &header)
+{
+    finish();
+    const size_t nd = shape_.size();
+    std::vector<float> content(n_bins_);
+    bin_content(content.data(), n_bins_, false, true);          // this->Normalize() (:608)
+    FitsWriter w(path);
+    auto image_axes = [&](int bitpix, const std::vector<size_t> &shape) {
+        w.key_int("BITPIX", bitpix);
+        w.key_int("NAXIS", static_cast<long long>(shape.size()));
+        for (size_t k = 0; k < shape.size(); ++k) {             // reversed: the last axis varies fastest in memory (:553-556)
+            char name[16];
+            std::snprintf(name, sizeof name, "NAXIS%zu", k + 1);
+            w.key_int(name, static_cast<long long>(shape[shape.size() - 1 - k]));
+        }
+    };
+    w.key_logical("SIMPLE", true);
+    image_axes(-32, shape_);
+    w.key_logical("EXTEND", true);
+    {   // header keywords (:613-642): what only the converter knows, then the caller's
+        double st[8];
+        statistics(st);
+        w.hierarch_double("_i3_n_photons", spectral_bias_factor_ * st[1]);      // spectralBiasFactor_ * sumOfPhotonWeights_
+        w.hierarch_double("_i3_n_group", n_group_);
+        w.hierarch_double("_i3_n_phase", n_phase_);
+        for (const HeaderEntry &e : header) {
+            if (e.key == "n_photons" || e.key == "n_group" || e.key == "n_phase") continue;      // overwritten by the converter (:614-616)
+            if (e.is_int) w.hierarch_int("_i3_" + e.key, e.i);
+            else w.hierarch_double("_i3_" + e.key, e.d);
+        }
+    }
+    w.end_header();
+    w.data<float, uint32_t>(content);
+    if (squared_) {                                             // :647-651
+        std::vector<float> sq(n_bins_);
+        bin_content(sq.data(), n_bins_, true, true);
+        w.key_string("XTENSION", "IMAGE");
+        image_axes(-32, shape_);
+        w.key_int("PCOUNT", 0);
+        w.key_int("GCOUNT", 1);
+        w.key_string("EXTNAME", "ERRORS");
+        w.end_header();
+        w.data<float, uint32_t>(sq);
+    }
+    for (size_t i = 0; i < nd; ++i) {                           // :656-680
+        std::vector<double> edges(axes_[i].n_bins + 1);
+        for (unsigned k = 0; k <= axes_[i].n_bins; ++k) edges[k] = axes_[i].bin_edge(k);
+        w.key_string("XTENSION", "IMAGE");
+        image_axes(-64, std::vector<size_t>(1, edges.size()));
+        w.key_int("PCOUNT", 0);
+        w.key_int("GCOUNT", 1);
+        w.key_string("EXTNAME", "EDGES" + std::to_string(i));
+        w.end_header();
+        w.data<double, uint64_t>(edges);
+    }
 }
 
 } // namespace clsimhip

@@ -43,6 +43,11 @@ public:
     void bin_content_double(double *out, size_t n, bool squared);
     double bin_volume(const size_t idxs[3]) const;
     void statistics(double out[8]);
+    // WriteFITSFile (StepToTableConverter.cxx:595-686): normalised bin content as the primary image, the header keywords
+    // (n_photons, n_group, n_phase and the caller's), squared weights as "ERRORS", one "EDGESi" extension per axis
+    struct HeaderEntry { std::string key; bool is_int; long long i; double d; };
+    void write_fits_file(const std::string &path, const std::vector<HeaderEntry> &header);
+    double spectral_bias_factor() const { return spectral_bias_factor_; }
     void get_rng_state(uint64_t *x, size_t count);
     long get_table(const std::string &name, double *out, size_t cap) const;
 
@@ -56,6 +61,7 @@ private:
     bool squared_;
     double reference_area_, step_length_;
     double n_group_ = 0, n_phase_ = 0;
+    double spectral_bias_factor_ = 1.;  // spectralBiasFactor_ (StepToTableConverter.cxx:142-152)
     CompiledTables tables_;
     size_t streams_;
     uint32_t *d_tables_ = nullptr;

@@ -140,6 +140,19 @@ class I3CLSimStepToTableConverterHIP:
         keys = ["NumPhotons", "SumOfPhotonWeights", "n_group", "n_phase", "KernelTimeMs", "NumKernelCalls", "NumBins"]
         return dict(zip(keys, list(out)))
 
+    def WriteFITSFile(self, path, tableHeader=None):
+        """WriteFITSFile(path, tableHeader) (StepToTableConverter.cxx:595-686): ints and floats of the dict become
+        "HIERARCH _i3_<key>" keywords (other value types are skipped, as in the reference)"""
+        items = [(k, v) for k, v in (tableHeader or {}).items() if isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)]
+        n = len(items)
+        keys = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in items])
+        is_int = (C.c_int32 * max(n, 1))(*[1 if isinstance(v, (int, np.integer)) else 0 for _, v in items])
+        ints = (C.c_int64 * max(n, 1))(*[int(v) if isinstance(v, (int, np.integer)) else 0 for _, v in items])
+        dbls = (C.c_double * max(n, 1))(*[float(v) for _, v in items])
+        rc = self._lib.clsimhip_tabulator_write_fits_file(self._h, str(path).encode(), keys, is_int, ints, dbls, n)
+        if rc != _lib.OK:
+            raise I3CLSimStepToPhotonConverter_exception((self._lib.clsimhip_tabulator_last_error(self._h) or b"").decode(), rc)
+
     def GetRNGState(self, count):
         out = np.zeros(count, dtype=np.uint64)
         self._call("clsimhip_tabulator_get_rng_state", out.ctypes.data_as(C.c_void_p), int(count))

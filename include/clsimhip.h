@@ -583,6 +583,13 @@ int clsimhip_tabulator_get_bin_edges(const clsimhip_tabulator *t, int axis, doub
 /* [0] photons enqueued, [1] sum of photon weights (numPhotons*weight), [2] n_group, [3] n_phase of
  * GetMinimumRefractiveIndex (:96-120), [4] kernel time ms, [5] launches, [6] bins, [7] reserved */
 int clsimhip_tabulator_get_statistics(clsimhip_tabulator *t, double out[8]);
+/* WriteFITSFile(path, tableHeader) (:595-686): normalised bin content as the primary image (axis counts reversed, as
+ * cfitsio/PyFITS store it), "HIERARCH _i3_<key>" header keywords -- n_photons (= spectralBiasFactor x sum of photon
+ * weights), n_group, n_phase, then the caller's n_keys entries (is_int[i] ? int_values[i] : double_values[i]) --, the
+ * squared weights as the IMAGE extension "ERRORS", one double IMAGE extension "EDGESi" per axis.  Written without cfitsio;
+ * refuses to overwrite an existing file, like fits_create_diskfile. */
+int clsimhip_tabulator_write_fits_file(clsimhip_tabulator *t, const char *path, const char *const *keys, const int32_t *is_int,
+                                       const int64_t *int_values, const double *double_values, size_t n_keys);
 int clsimhip_tabulator_get_rng_state(clsimhip_tabulator *t, uint64_t *x, size_t count);
 long clsimhip_tabulator_get_table(const clsimhip_tabulator *t, const char *name, double *out, size_t cap);
 

@@ -164,3 +164,82 @@ def test_table_matches_the_oracle(kind, ice, step_length):
     st = tab.GetStatistics()
     assert st["NumPhotons"] == 2 * float(steps["num"].sum()) and st["NumKernelCalls"] == 2
     assert abs(st["SumOfPhotonWeights"] - 2 * float((steps["num"] * steps["weight"].astype(np.float64)).sum())) < 1e-6
+
+
+def read_fits(path):
+    """Minimal FITS reader: list of (header dict, numpy array) per HDU."""
+    raw = open(path, "rb").read()
+    assert len(raw) % 2880 == 0
+    pos, hdus = 0, []
+    while pos < len(raw):
+        header, order = {}, []
+        while True:
+            block = raw[pos:pos + 2880]; pos += 2880
+            done = False
+            for k in range(36):
+                card = block[80 * k:80 * k + 80].decode("ascii")
+                if card.startswith("END"):
+                    done = True
+                    break
+                if card.startswith("HIERARCH"):
+                    key, _, val = card[9:].partition("=")
+                elif card[8:10] == "= ":
+                    key, val = card[:8], card[10:]
+                else:
+                    continue
+                key, val = key.strip(), val.split("/")[0].strip()
+                if val.startswith("'"):
+                    header[key] = val.strip("'").strip()
+                elif val in ("T", "F"):
+                    header[key] = (val == "T")
+                else:
+                    header[key] = float(val) if any(c in val for c in ".E") else int(val)
+                order.append(key)
+            if done:
+                break
+        shape = [header["NAXIS%d" % (i + 1)] for i in range(header["NAXIS"])]
+        count = int(np.prod(shape)) if shape else 0
+        size = abs(header["BITPIX"]) // 8 * count
+        dtype = {-32: ">f4", -64: ">f8"}[header["BITPIX"]]
+        data = np.frombuffer(raw[pos:pos + size], dtype=dtype).reshape(shape[::-1]) if count else np.zeros(0)
+        pos += (size + 2879) // 2880 * 2880
+        header["_order"] = order
+        hdus.append((header, data))
+    return hdus
+
+
+@pytest.mark.gpu
+def test_fits_file_has_the_structure_the_reference_writes(tmp_path):
+    """WriteFITSFile (StepToTableConverter.cxx:595-686): primary image = normalised bin content with reversed axis counts,
+    HIERARCH _i3_ keywords, ERRORS and EDGESi extensions -- read back with a FITS parser written from the standard."""
+    cfg = common.config("mie")
+    o, p = axes_pair("spherical")
+    x, a = common.streams(256)
+    tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
+                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=1.0)
+    steps = S.cascade_steps(256, seed=4, vertex=(0.0, 0.0, 0.0), photons_per_step=20, pad_to=256)
+    tab.EnqueueSteps(steps, (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0))
+    tab.Finish()
+    path = tmp_path / "table.fits"
+    tab.WriteFITSFile(path, {"zenith": 0.0, "energy": 1.0, "type": 11, "level": 1, "comment": "skipped: not a number", "n_photons": -1.0})
+    hdus = read_fits(path)
+    names = [h.get("EXTNAME", "PRIMARY") for h, _ in hdus]
+    assert names == ["PRIMARY", "ERRORS", "EDGES0", "EDGES1", "EDGES2", "EDGES3"]
+    h0, img = hdus[0]
+    assert h0["SIMPLE"] is True and h0["BITPIX"] == -32 and h0["NAXIS"] == 4 and h0["EXTEND"] is True
+    assert [h0["NAXIS%d" % (i + 1)] for i in range(4)] == list(tab.shape)[::-1]
+    assert np.array_equal(img.astype(np.float32), tab.GetBinContent(normalized=True))
+    st = tab.GetStatistics()
+    assert h0["_i3_n_group"] == pytest.approx(st["n_group"]) and h0["_i3_n_phase"] == pytest.approx(st["n_phase"])
+    assert h0["_i3_type"] == 11 and h0["_i3_level"] == 1 and h0["_i3_energy"] == 1.0 and "_i3_comment" not in h0
+    # n_photons is the converter's: spectral bias factor (bare 300-600 nm Cherenkov photons per acceptance-weighted photon,
+    # ~ 1/0.1 for the IceCube DOM) x sum of photon weights
+    factor = h0["_i3_n_photons"] / st["SumOfPhotonWeights"]
+    assert 5.0 < factor < 30.0
+    h1, err = hdus[1]
+    assert h1["XTENSION"] == "IMAGE" and np.array_equal(err.astype(np.float32), tab.GetBinContent(squared=True, normalized=True))
+    for i in range(4):
+        he, edges = hdus[2 + i]
+        assert he["BITPIX"] == -64 and np.array_equal(edges.astype(np.float64), tab.GetBinEdges(i))
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Could not create"):
+        tab.WriteFITSFile(path)                       # fits_create_diskfile does not overwrite
