@@ -302,7 +302,8 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
 // TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
 // four-dimensional table maker keeps its register allocation).  4 waves per SIMD: 86-110 VGPRs, nothing spilled, since
 // the sampling constants are scalar loads from the parameter block
-template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
+// FAST: prop_device.hip.h (the standard configuration with every proof in hand; propagation only)
+template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
 __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
     // the only kernel argument sits at offset 0 of the kernarg segment
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             c_created += __popcll(__ballot(do_create && need && !waiting && (photons_left > 0)));
 #endif
             if (do_create && need && !waiting && (photons_left > 0)) {
-                create_photon<MED, TILT, FLASHER, TAB != 0>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER, TAB != 0, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
-            distance = propagate_through_layers<MED, TILT, ANISO>(fresh_params(P0), ph, rx, ra);
+            distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             if (!TAB && !(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
                 parked = true;
@@ -513,7 +514,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
                 if (parked) {
                     distance = __builtin_bit_cast(float, pending[threadIdx.x]);
-                    hit = find_collision(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
                     parked = false;
                     advance = true;
                 }
@@ -590,11 +591,11 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     float4 *ring = reinterpret_cast<float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
                     ring[ph.num_scatters % hn] = make_float4(ph.px, ph.py, ph.pz, ph.abs_lens_left);
                 }
-                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
-                const float cos_s = scattering_cos(P, rx, ra);
+                if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
+                const float cos_s = scattering_cos<FAST>(P, rx, ra);
                 const float sin_s = dm::sqrt_near_(1.0f - sqr(cos_s));       // |cos_s| <= 1: 0 or >= 2^-24
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
-                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, (P->div_ok & kFastMatrices) != 0u);
+                if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
                 ++ph.num_scatters;
             }
         }
@@ -765,7 +766,7 @@ hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipS
     return hipGetLastError();
 }
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -790,10 +791,10 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
             int cus = 0, per_cu = 0;
             hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (e == hipSuccess && lds_bytes > 64 * 1024)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER, TAB>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_kernel<MED, TILT, ANISO, FLASHER, TAB, FAST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e == hipSuccess)
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER, TAB>, kBlock, lds_bytes);
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_kernel<MED, TILT, ANISO, FLASHER, TAB, FAST>, kBlock, lds_bytes);
             if (e != hipSuccess) return e;
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 1;
@@ -840,7 +841,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     }
     hipError_t err = launch_scan_steps(P, stream);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB, FAST>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     err = hipGetLastError();
     if (err != hipSuccess || TAB) return err;
     return launch_assemble_hits(P, FLASHER, dev, stream);
@@ -852,8 +853,10 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
+    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
+    const bool fast = v.fast && P.history_n == 0 && !(no_fast && no_fast[0] == '1');
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, 0>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 0, true>(P, stream) : launch_variant<a, b, c, d, 0, false>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
