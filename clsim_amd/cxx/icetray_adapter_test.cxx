@@ -19,7 +19,9 @@
 #include <sstream>
 
 #include <clsim/I3CLSimSimpleGeometryUserConfigurable.h>
+#include <icetray/I3Units.h>
 #include "I3CLSimStepToPhotonConverterHIP.h"
+#include "I3CLSimLightSourceToStepConverterHIP.h"
 
 namespace {
 
@@ -48,7 +50,7 @@ private:
 // python/MakeIceCubeMediumProperties.py:49-256 in C++: the objects that loader creates, from the numbers of `d`
 I3CLSimMediumPropertiesPtr MediumFromDescription(const clsimhip_medium_desc &d)
 {
-    I3CLSimMediumPropertiesPtr m(new I3CLSimMediumProperties(0.9216, static_cast<uint32_t>(d.num_layers), d.layers_z_start, d.layers_height, -870., 1948.07));
+    I3CLSimMediumPropertiesPtr m(new I3CLSimMediumProperties(0.9216 * I3Units::g / I3Units::cm3, static_cast<uint32_t>(d.num_layers), d.layers_z_start, d.layers_height, -870., 1948.07));
     I3CLSimFunctionConstPtr phase, group;
     if (d.phase_index_kind == CLSIMHIP_REFINDEX_ICECUBE) {
         phase.reset(new I3CLSimFunctionRefIndexIceCube("phase", d.n[0], d.n[1], d.n[2], d.n[3], d.n[4], d.g[0], d.g[1], d.g[2], d.g[3], d.g[4]));
@@ -352,12 +354,111 @@ int Run(const char *ice_dir, const char *geometry_file, const char *steps_file, 
     return 0;
 }
 
+// ---- the producer side: I3CLSimLightSourceToStepConverterHIP through the reference's interface ----
+I3Particle MakeParticle(I3Particle::ParticleType type, double energy_gev, double length_m)
+{
+    I3Particle p;
+    p.SetType(type);
+    p.SetEnergy(energy_gev * I3Units::GeV);
+    p.SetPos(I3Position(1. * I3Units::m, -2. * I3Units::m, 3. * I3Units::m));
+    p.SetDir(I3Direction(0., 0., -1.));
+    p.SetTime(5. * I3Units::ns);
+    p.SetLength(length_m * I3Units::m);
+    return p;
+}
+
+// no GPU: configuration, messages, an empty barrier (one granule of no-op steps)
+int LightSourceCheck(const char *ice_dir)
+{
+    clsimhip_medium *ppc = nullptr;
+    REQUIRE(clsimhip_medium_create_from_ppc(ice_dir, 1948.07, 1, &ppc) == CLSIMHIP_OK);
+    clsimhip_medium_desc d;
+    REQUIRE(clsimhip_medium_describe(ppc, &d) == CLSIMHIP_OK);
+    Inputs in;
+    if (MakeSpectra(ppc, in) != 0) return 1;
+    I3CLSimLightSourceToStepConverterHIP conv(0);
+    I3CLSimLightSourceToStepConverter &iface = conv;                 // everything below goes through the reference's interface
+    REQUIRE(!iface.IsInitialized());
+    REQUIRE(Fatal([&] { iface.EnqueueBarrier(); }, "is not initialized!"));
+    REQUIRE(Fatal([&] { iface.SetMaxBunchSize(0); }, "MaxBunchSize of 0 is invalid!"));
+    REQUIRE(Fatal([&] { iface.SetBunchSizeGranularity(0); }, "BunchSizeGranularity of 0 is invalid!"));
+    REQUIRE(Fatal([&] { iface.Initialize(); }, "WlenBias not set!"));
+    iface.SetWlenBias(in.bias);
+    REQUIRE(Fatal([&] { iface.Initialize(); }, "MediumProperties not set!"));
+    iface.SetMediumProperties(MediumFromDescription(d));
+    iface.SetRandomService(I3RandomServicePtr(new TestRandomService(1)));
+    iface.SetBunchSizeGranularity(64);
+    iface.SetMaxBunchSize(100);
+    REQUIRE(Fatal([&] { iface.Initialize(); }, "not a multiple"));
+    iface.SetMaxBunchSize(256);
+    iface.Initialize();
+    REQUIRE(iface.IsInitialized());
+    REQUIRE(Fatal([&] { iface.SetMaxBunchSize(512); }, "already initialized!"));
+    const double yield = conv.GetMeanPhotonsPerMeter(0);
+    REQUIRE(yield > 2000. && yield < 3000.);
+    {
+        I3CLSimFlasherPulse pulse;
+        REQUIRE(Fatal([&] { iface.EnqueueLightSource(I3CLSimLightSource(pulse), 1); }, "only works on particles"));
+    }
+    bool reset = true;
+    REQUIRE(!iface.GetConversionResultWithBarrierInfo(reset, 1e6 * I3Units::ns) && !reset);       // nothing enqueued: timeout, null
+    iface.EnqueueBarrier();
+    REQUIRE(iface.BarrierActive());
+    REQUIRE(Fatal([&] { iface.EnqueueBarrier(); }, "A barrier is already enqueued!"));
+    REQUIRE(Fatal([&] { iface.EnqueueLightSource(I3CLSimLightSource(MakeParticle(I3Particle::EMinus, 1., NAN)), 2); }, "A barrier is enqueued!"));
+    const I3CLSimStepSeriesConstPtr steps = iface.GetConversionResultWithBarrierInfo(reset);
+    REQUIRE(steps && reset && steps->size() == 64 && !iface.BarrierActive());
+    for (const I3CLSimStep &s : *steps) REQUIRE(s.GetNumPhotons() == 0 && s.GetWeight() == 0.f && s.GetBeta() == 1.f);
+    clsimhip_medium_destroy(ppc);
+    std::printf("light source adapter ok: interface signatures, messages, barrier, %.1f photons per metre\n", yield);
+    return 0;
+}
+
+// GPU: three particles and a barrier; every bunch is appended to `steps_file`, one line per bunch on stdout
+int LightSourceRun(const char *ice_dir, const char *steps_file)
+{
+    clsimhip_medium *ppc = nullptr;
+    REQUIRE(clsimhip_medium_create_from_ppc(ice_dir, 1948.07, 1, &ppc) == CLSIMHIP_OK);
+    clsimhip_medium_desc d;
+    REQUIRE(clsimhip_medium_describe(ppc, &d) == CLSIMHIP_OK);
+    Inputs in;
+    if (MakeSpectra(ppc, in) != 0) return 1;
+    I3CLSimLightSourceToStepConverterHIP conv(0);
+    conv.SetSeed(5);
+    conv.SetWlenBias(in.bias);
+    conv.SetMediumProperties(MediumFromDescription(d));
+    conv.SetBunchSizeGranularity(256);
+    conv.SetMaxBunchSize(2048);
+    conv.Initialize();
+    conv.EnqueueLightSource(I3CLSimLightSource(MakeParticle(I3Particle::EMinus, 30., NAN)), 11);
+    conv.EnqueueLightSource(I3CLSimLightSource(MakeParticle(I3Particle::MuMinus, 100., 120.)), 12);
+    conv.EnqueueLightSource(I3CLSimLightSource(MakeParticle(I3Particle::Hadrons, 50., NAN)), 13);
+    conv.EnqueueBarrier();
+    std::ofstream f(steps_file, std::ios::binary);
+    for (;;) {
+        bool reset = false;
+        std::vector<uint32_t> finished;
+        const I3CLSimStepSeriesConstPtr steps = conv.GetConversionResultWithBarrierInfoAndMarkers(reset, finished, 60e9 * I3Units::ns);
+        REQUIRE(steps);
+        f.write(reinterpret_cast<const char *>(steps->data()), static_cast<std::streamsize>(steps->size() * sizeof(I3CLSimStep)));
+        std::printf("bunch %zu finished", steps->size());
+        for (uint32_t id : finished) std::printf(" %u", id);
+        std::printf(" reset %d\n", reset ? 1 : 0);
+        if (reset) break;
+    }
+    REQUIRE(!conv.BarrierActive() && !conv.MoreStepsAvailable());
+    clsimhip_medium_destroy(ppc);
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
 {
     try {
         if (argc >= 3 && std::strcmp(argv[1], "check") == 0) return Check(argv[2], argc > 3 ? argv[3] : nullptr);
+        if (argc >= 3 && std::strcmp(argv[1], "lightsource_check") == 0) return LightSourceCheck(argv[2]);
+        if (argc >= 4 && std::strcmp(argv[1], "lightsource_run") == 0) return LightSourceRun(argv[2], argv[3]);
         if (argc >= 7 && std::strcmp(argv[1], "run") == 0) return Run(argv[2], argv[3], argv[4], argv[5], static_cast<unsigned>(std::atoi(argv[6])));
     } catch (const std::exception &e) {
         std::printf("FAILED: uncaught %s\n", e.what());

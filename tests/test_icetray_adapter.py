@@ -39,6 +39,58 @@ def test_glue_carries_every_medium_parameter(tmp_path, ice):
     assert "icetray adapter ok" in out
 
 
+def test_light_source_adapter_through_the_reference_interface(tmp_path):
+    """I3CLSimLightSourceToStepConverterHIP (clsim_amd/cxx/): the reference's producer-side interface
+    (public/clsim/I3CLSimLightSourceToStepConverter.h:61-198) on the feeder; no GPU: setters, messages, barrier"""
+    out = subprocess.check_output([build(tmp_path), "lightsource_check", os.path.join(common.ICE, "spice_mie")], text=True)
+    assert "light source adapter ok" in out
+
+
+@pytest.mark.gpu
+def test_light_source_adapter_yields_the_steps_of_the_python_feeder(tmp_path):
+    """particles through the C++ interface (EnqueueLightSource(I3CLSimLightSource, id) ... GetConversionResultWithBarrierInfo)
+    = the same particles through the ctypes feeder with the same seed: bunches, markers and steps bit for bit"""
+    import threading
+    from clsim_amd import converter as CV, step_store as SS
+    from clsim_amd.synthetic import STEP_DTYPE
+    steps_file = str(tmp_path / "steps.bin")
+    out = subprocess.check_output([build(tmp_path), "lightsource_run", os.path.join(common.ICE, "spice_mie"), steps_file], text=True)
+    lines = [l.split() for l in out.splitlines() if l.startswith("bunch")]
+    cxx_steps = np.fromfile(steps_file, dtype=STEP_DTYPE)
+    cfg = common.config("mie")
+    ppc = CV.I3CLSimLightSourceToStepConverterPPC()
+    ppc.SetWlenBias(CV.GetIceCubeDOMAcceptance()); ppc.SetMediumProperties(cfg["med_p"]); ppc.SetRandomSeed(5); ppc.Initialize()
+    parts = np.zeros(3, dtype=CV.PARTICLE_DTYPE)
+    parts["type"] = [CV.ParticleType.EMinus, CV.ParticleType.MuMinus, CV.ParticleType.Hadrons]
+    parts["energy"] = [30.0, 100.0, 50.0]
+    parts["length"] = [np.nan, 120.0, np.nan]
+    parts["x"], parts["y"], parts["z"], parts["time"], parts["dz"] = 1.0, -2.0, 3.0, 5.0, -1.0
+    parts["identifier"] = [11, 12, 13]
+    f = SS.I3CLSimLightSourceToStepConverterAsync()
+    f.SetMaxBunchSize(2048); f.SetBunchSizeGranularity(256); f.SetLightSourceParameterization(ppc, seed=5, device=0); f.Initialize()
+    got = []
+
+    def drain():
+        while True:
+            r = f.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=60000)
+            assert r is not None
+            got.append(r)
+            if r[2]:
+                return
+    t = threading.Thread(target=drain)
+    t.start()
+    for p in parts:
+        f.EnqueueLightSource(p)
+    f.EnqueueBarrier()
+    t.join(120)
+    assert len(got) == len(lines)
+    for (steps, finished, reset), line in zip(got, lines):
+        i = line.index("finished"); j = line.index("reset")
+        assert int(line[1]) == len(steps) and [int(v) for v in line[i + 1:j]] == finished and int(line[j + 1]) == int(reset)
+    assert np.concatenate([s for s, _, _ in got]).tobytes() == cxx_steps.tobytes()
+    assert int(cxx_steps["num"].sum()) > 100000
+
+
 def _test_random_service(seed, count):
     """TestRandomService::Integer(0xffffffff) of icetray_adapter_test.cxx: splitmix64, high word % imax"""
     out = np.empty(count, dtype=np.uint64)
