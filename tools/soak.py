@@ -8,10 +8,14 @@ from clsim_amd import converter as CV, synthetic as S
 from tests import common
 
 cfg = common.config("lea")
-n = 16384
+# usage: soak.py [bunches] [pool]   -- "pool": bunches large enough for the pooled kernel, no photon histories
+POOL = len(sys.argv) > 2 and sys.argv[2] == "pool"
+n = 786432 if POOL else 16384
+HIST = 0 if POOL else 3
 bias = CV.GetIceCubeDOMAcceptance()
 conv = CV.initializeHIP(0, CV.I3CLSimSimpleGeometry.from_dict(cfg["geom"]), cfg["med_p"], bias, [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])],
-                        pancakeFactor=5.0, photonHistoryEntries=3, enableDoubleBuffering=True, approximateNumberOfWorkItems=n, seed=7)
+                        pancakeFactor=5.0, photonHistoryEntries=HIST, enableDoubleBuffering=True, approximateNumberOfWorkItems=n, seed=7)
+assert conv.KernelForBunch(n) == ("pool" if POOL else "classic")
 bunches = [S.cascade_steps(n, seed=s) for s in range(4)]
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 lock = threading.Lock(); nxt = [0]
@@ -26,10 +30,13 @@ t0 = time.time(); rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
 for t in threads: t.start()
 seen, hits = set(), 0
 for k in range(total):
-    ident, ph, hist = conv.GetConversionResult(with_histories=True)
+    if HIST:
+        ident, ph, hist = conv.GetConversionResult(with_histories=True)
+        assert len(hist) == len(ph) and all(len(h) == min(int(s), 3) for h, s in zip(hist, ph["numScatters"]))
+    else:
+        ident, ph = conv.GetConversionResult()
     assert ident not in seen and 0 <= ident < total
     seen.add(ident); hits += len(ph)
-    assert len(hist) == len(ph) and all(len(h) == min(int(s), 3) for h, s in zip(hist, ph["numScatters"]))
     if k == 50: rss50 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
 for t in threads: t.join()
 st = conv.GetStatistics()
