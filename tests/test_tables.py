@@ -218,8 +218,10 @@ def test_string_proximity_map_is_a_lower_bound():
 
 
 def test_dom_proximity_map_is_a_lower_bound():
-    """Second level of the search filter (prop_device.hip.h: dom_free_flight_bound): a cell names its nearest DOM and stores
-    a bound for all others; min(exact distance to the named DOM's sphere, stored bound) must never exceed the true 3D
+    """DOM proximity map (second / third level of the search filter, prop_device.hip.h: dom_search_needed): a cell names its
+    nearest DOM and stores a bound for all others.  The kernel skips a search only when the step is shorter than the stored
+    bound AND the segment stays farther from the named DOM than its radius; both conditions together imply that the step is
+    shorter than min(distance to the named DOM's sphere, stored bound).  That minimum must therefore never exceed the true 3D
     distance from the point to the surface of the nearest DOM sphere -- and should be close to it."""
     for name in ("mie", "c1"):
         cfg = common.config(name)
