@@ -40,7 +40,7 @@ constexpr int kQueueHeadStride = 32;     // words between sub-queue heads (128 B
 constexpr int kQueueWords = 512;         // per launch
 
 struct WorkRecord {
-    DevStep step;
+    DevStep step;           // as photon creation needs it: theta, phi, weight hold the step's direction (scan_steps_kernel)
     uint64_t x;
     uint32_t a;
     uint32_t done;

@@ -418,6 +418,14 @@ DM Vec3 step_direction(const DevStep *step_ptr)
     return d;
 }
 
+// the direction scan_steps_kernel left in a work record's step (in the places of theta, phi and weight)
+DM Vec3 work_direction(const DevStep *work_step)
+{
+    Vec3 d;
+    d.x = work_step->theta; d.y = work_step->phi; d.z = work_step->weight;
+    return d;
+}
+
 // propagation_kernel.c.cl:132-184 + :587.  The step record is re-read from HBM/L2 here
 // (48 B every ~30 loop iterations) instead of living in registers.  Consumes the RNG draws
 // of a photon's birth in the reference's order: position, wavelength, azimuth, absorption budget.

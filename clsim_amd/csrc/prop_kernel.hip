@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     // c.cl:458-461; slice 0 reads the state left by the previous bunch
                     rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ra = rec->a;
-                    step_dir = step_direction(&rec->step);
+                    step_dir = work_direction(&rec->step);
                     waiting = false;
                 }
             }
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
             const KP P = fresh_params(P0);
             const float travelled = P->fixed_abs - ph.abs_lens_left;
-            const float weight = run ? P->work[sidx].step.weight : 0.0f;
+            const float weight = run ? P->steps[sidx].weight : 0.0f;          // (the work record carries the direction there)
             uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
             const bool left_table = save_path_wave<TAB == 2>(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
                                                              ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra);
@@ -636,6 +636,12 @@ __global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, u
             // (MediumPropertiesSource.cxx:392-432) and every length of that photon becomes 0/0
             const bool no_spectrum = (num_generators > 1u) && ((r.step.source_type_and_pad & 0xffu) >= num_generators);
             if ((!finite || no_spectrum) && r.step.num_photons != 0u) { r.step.num_photons = 0u; atomicAdd(meta + 2, 1u); }
+        }
+        {   // The work record's step is the view photon creation needs: the direction of the step (c.cl:482-489), two
+            // sincos per step here instead of per photon, takes the place of theta, phi and of the weight, which only a hit
+            // record needs -- and that reads the caller's step array (make_hit_record, save_path_wave)
+            const Vec3 d = step_direction(&r.step);
+            r.step.theta = d.x; r.step.phi = d.y; r.step.weight = d.z;
         }
         work[i] = r;
         const uint32_t v = r.step.num_photons;

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     if (make) {
                         const WorkRecord *rec = work + e_sidx;
                         const uint32_t e_ra = rec->a;
-                        const Vec3 step_dir = step_direction(&rec->step);
+                        const Vec3 step_dir = work_direction(&rec->step);
                         Photon born;
                         born.layer = 0;
                         create_photon<MED, TILT, FLASHER, false, FAST>(P, &rec->step, step_dir, e_rx, e_ra, born);
