@@ -504,7 +504,12 @@ class I3CLSimLightSourceToStepConverterPPC:
         self._lib = _lib.load()
 
     def SetUseCascadeExtension(self, v):
+        """may be called after Initialize(), as resources/tests/testCascadeExtension.py does (the library object is rebuilt)"""
         self._cfg.use_cascade_extension = int(bool(v))
+        if self._h is not None:
+            self._lib.clsimhip_ppc_destroy(self._h)
+            self._h = None
+            self.Initialize()
 
     def SetWlenBias(self, wlenBias):
         self._bias = wlenBias

@@ -270,3 +270,25 @@ def test_flasher_front_end():
     mean = 5.0e9 * c405
     z = (req["num_photons_with_bias"].astype(np.float64) - mean) / math.sqrt(mean)
     assert abs(z.mean()) < 0.1 and abs(z.std() - 1.0) < 0.06
+
+
+@pytest.mark.gpu
+def test_cascade_extension_can_be_disabled_like_the_reference_test():
+    """resources/tests/testCascadeExtension.py: a 1 GeV electron at the origin along +z -- with the cascade extension (default)
+    every step lies at z > 0, without it every step is at the origin."""
+    cfg = common.config("mie")
+    converter = CV.I3CLSimLightSourceToStepConverterPPC()
+    converter.SetWlenBias(CV.GetIceCubeDOMAcceptance())
+    converter.SetMediumProperties(cfg["med_p"])
+    converter.SetRandomSeed(0)
+    converter.Initialize()
+    p = np.zeros(1, dtype=CV.PARTICLE_DTYPE)
+    p["type"], p["energy"], p["dz"], p["length"], p["identifier"] = PT.EMinus, 1.0, 1.0, np.nan, 1
+    steps = CV.GenerateSteps(converter.EnqueueLightSources(p), seed=1)
+    steps = steps[steps["num"] > 0]
+    assert len(steps) > 50 and np.all(steps["z"] > 0), "Steps are spread along the cascade by default"
+    converter.SetUseCascadeExtension(False)
+    p["identifier"] = 2
+    steps = CV.GenerateSteps(converter.EnqueueLightSources(p), seed=2)
+    steps = steps[steps["num"] > 0]
+    assert len(steps) > 50 and np.all(steps["z"] == 0), "Steps are all at the origin"
