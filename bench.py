@@ -389,6 +389,9 @@ def main():
             state["pending"] = None
 
     def barrier():
+        # the library's communicator and torch's are two RCCL communicators on one device: torch's barrier starts only
+        # once everything queued on this device (the last gather's transfers included) has finished
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
