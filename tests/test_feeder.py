@@ -124,3 +124,23 @@ def test_particles_through_the_front_end_and_the_gpu_step_producer():
     for s, _, last in got:
         real = s["num"][s["num"] > 0] if last else s["num"]
         assert np.all(np.diff(real.astype(np.int64)) >= 0)
+
+
+def test_destroying_a_feeder_with_work_in_flight_does_not_hang():
+    """the worker is blocked on the full output queue and light sources wait in the input queue: destruction closes both
+    queues and joins the thread (no caller is inside a call at that moment, as for any object that is being destroyed)"""
+    rng = np.random.Generator(np.random.PCG64(3))
+    f = SS.I3CLSimLightSourceToStepConverterAsync(maxQueueItems=2)
+    f.SetMaxBunchSize(64); f.SetBunchSizeGranularity(1); f.Initialize()
+    for i in range(3):
+        f.EnqueueSteps(i, random_steps(rng, 1000, i))           # 15 bunches each: the output queue (2 places) is full at once
+    assert f.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=20000) is not None
+    finished = threading.Event()
+
+    def destroy():
+        h, f._h = f._h, None
+        f._lib.clsimhip_feeder_destroy(h)
+        finished.set()
+    t = threading.Thread(target=destroy, daemon=True)
+    t.start()
+    assert finished.wait(20), "clsimhip_feeder_destroy did not return"
