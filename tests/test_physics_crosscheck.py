@@ -1,0 +1,155 @@
+"""An end-to-end check of the ORACLE that does not go through its code: an independent Monte Carlo of the same physics,
+written here from the model's description in numpy double precision (vectorised over photons, no code or expression
+order shared with oracle/ or the reference kernel), against the oracle on configuration C1 -- homogeneous ice, one string
+of 60 DOMs, cascade steps at the origin.
+
+The reference pins no propKernel output, so the oracle's sub-functions are pinned piecewise
+(tests/test_golden_reference.py) and the product is pinned on the oracle bit for bit; what neither shows is that the
+pieces are put together to the right physics.  This test does, statistically: detected fraction, hits per DOM, arrival
+times and scatter counts of the two simulations agree within their Poisson errors.  It corresponds to the reference's
+own statistical validation against PPC (resources/scripts/compareToPPC*, eyeballed plots).
+
+Model (clsim documentation / I3CLSimStep semantics): photons are born uniformly along the step, wavelength from the
+Cherenkov spectrum (1/lambda^2)(1 - 1/n^2) times the DOM acceptance, direction on the Cherenkov cone cos = 1/(beta n)
+around the step; free paths to the next scattering are exponential with the scattering length, the total path to
+absorption exponential with the absorption length; the scattering angle is drawn from 45 % simplified-Liu
+(cos = 2 u^((1-g)/(1+g)) - 1) and 55 % Henyey-Greenstein with mean cosine g = 0.9; a photon is detected by the first DOM
+sphere its path enters; arrival time = path / group velocity."""
+import math
+
+import numpy as np
+
+from clsim_amd import synthetic as S
+from oracle import builders as B
+from oracle import capi
+from tests import common
+
+ABS_LEN, SCA_LEN, G, LIU = 100.0, 25.0, 0.9, 0.45
+N = (1.55749, -1.57988, 3.99993, -4.68271, 2.09354)              # phase index polynomial in lambda / um (inputs of the model)
+GC = (1.227106, -0.954648, 1.42568, -0.711832, 0.0)              # group index correction polynomial
+C = 0.299792458                                                   # m / ns
+
+
+def phase_index(w):
+    x = w / 1e-6
+    return N[0] + x * (N[1] + x * (N[2] + x * (N[3] + x * N[4])))
+
+
+def group_velocity(w):
+    x = w / 1e-6
+    return C / (phase_index(w) * (GC[0] + x * (GC[1] + x * (GC[2] + x * (GC[3] + x * GC[4])))))
+
+
+def rotate(d, cos_t, phi):
+    """unit vectors d rotated by polar angle acos(cos_t) and azimuth phi about themselves"""
+    sin_t = np.sqrt(np.maximum(0.0, 1.0 - cos_t * cos_t))
+    # an orthonormal frame around d
+    a = np.where(np.abs(d[:, 2:3]) < 0.9, np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
+    e1 = np.cross(d, a); e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.cross(d, e1)
+    out = d * cos_t[:, None] + (e1 * np.cos(phi)[:, None] + e2 * np.sin(phi)[:, None]) * sin_t[:, None]
+    return out / np.linalg.norm(out, axis=1, keepdims=True)
+
+
+def independent_monte_carlo(steps, geom, rng, acceptance):
+    """-> (dom index, arrival time, number of scatters) of the detected photons"""
+    n_ph = steps["num"].astype(np.int64)
+    idx = np.repeat(np.arange(len(steps)), n_ph)
+    n = len(idx)
+    st, sp = steps["theta"][idx].astype(np.float64), steps["phi"][idx].astype(np.float64)
+    sdir = np.stack([np.sin(st) * np.cos(sp), np.sin(st) * np.sin(sp), np.cos(st)], axis=1)
+    along = rng.random(n) * steps["length"][idx]
+    pos = np.stack([steps["x"][idx], steps["y"][idx], steps["z"][idx]], axis=1).astype(np.float64) + sdir * along[:, None]
+    time = steps["t"][idx].astype(np.float64) + along / (C * steps["beta"][idx])
+    # wavelength: inverse CDF of the piecewise-linear density on a fine grid
+    grid = np.linspace(acceptance["start"], acceptance["start"] + acceptance["step"] * (len(acceptance["values"]) - 1), 42001)
+    knots = acceptance["start"] + acceptance["step"] * np.arange(len(acceptance["values"]))
+    dens_knots = acceptance["values"] * (1.0 / knots ** 2) * (1.0 - 1.0 / phase_index(knots) ** 2)
+    dens = np.interp(grid, knots, dens_knots)
+    cdf = np.concatenate([[0.0], np.cumsum(0.5 * (dens[1:] + dens[:-1]))]); cdf /= cdf[-1]
+    wlen = np.interp(rng.random(n), cdf, grid)
+    d = rotate(sdir, 1.0 / (steps["beta"][idx] * phase_index(wlen)), 2 * math.pi * rng.random(n))
+    vg = group_velocity(wlen)
+    left = -np.log(1.0 - rng.random(n)) * ABS_LEN                  # path left before absorption
+    scat = np.zeros(n, dtype=np.int64)
+    doms = np.stack([geom["x"], geom["y"], geom["z"]], axis=1)
+    radius = geom["om_radius"]
+    ax, ay = doms[0, 0], doms[0, 1]                                # one string
+    alive = np.arange(n)
+    hit_dom, hit_time, hit_scat = [], [], []
+    beta_liu = (1.0 - G) / (1.0 + G)
+    while len(alive):
+        p, dd = pos[alive], d[alive]
+        seg = np.minimum(-np.log(1.0 - rng.random(len(alive))) * SCA_LEN, left[alive])
+        # candidates: the segment's closest approach to the string axis in xy
+        wx, wy = ax - p[:, 0], ay - p[:, 1]
+        dxy2 = dd[:, 0] ** 2 + dd[:, 1] ** 2
+        t = np.clip((wx * dd[:, 0] + wy * dd[:, 1]) / np.maximum(dxy2, 1e-300), 0.0, seg)
+        near = (wx - t * dd[:, 0]) ** 2 + (wy - t * dd[:, 1]) ** 2 <= radius ** 2
+        first = np.full(len(alive), np.inf)
+        which = np.full(len(alive), -1)
+        for k in np.nonzero(near)[0]:
+            w = doms - p[k]
+            b = w @ dd[k]
+            disc = b * b - np.einsum("ij,ij->i", w, w) + radius ** 2
+            ok = disc >= 0
+            s_in = np.where(ok, b - np.sqrt(np.maximum(disc, 0.0)), np.inf)
+            s_in = np.where(s_in >= 0, s_in, np.inf)                # photons that start inside a sphere are not detected by it
+            j = int(np.argmin(s_in))
+            if s_in[j] < seg[k]:
+                first[k], which[k] = s_in[j], j
+        got = which >= 0
+        if got.any():
+            a = alive[got]
+            hit_dom.append(which[got]); hit_time.append(time[a] + first[got] / vg[a]); hit_scat.append(scat[a])
+        keep = ~got
+        a = alive[keep]
+        pos[a] += dd[keep] * seg[keep][:, None]
+        time[a] += seg[keep] / vg[a]
+        left[a] -= seg[keep]
+        survive = left[a] > 1e-9
+        a = a[survive]
+        u = rng.random(len(a))
+        r2 = rng.random(len(a))
+        s = 2.0 * r2 - 1.0
+        hg = (1.0 + G * G - ((1.0 - G * G) / (1.0 + G * s)) ** 2) / (2.0 * G)
+        liu = 2.0 * r2 ** beta_liu - 1.0
+        cos_t = np.clip(np.where(u < LIU, liu, hg), -1.0, 1.0)
+        d[a] = rotate(d[a], cos_t, 2 * math.pi * rng.random(len(a)))
+        scat[a] += 1
+        alive = a
+    return np.concatenate(hit_dom), np.concatenate(hit_time), np.concatenate(hit_scat)
+
+
+def test_oracle_agrees_with_an_independent_monte_carlo(oracle_lib):
+    cfg = common.config("c1")
+    geom = cfg["geom"]
+    n_steps = 16384                                                # x 200 photons = 3.3e6 per simulation, ~2200 detected
+    steps = S.cascade_steps(n_steps, seed=77, vertex=(0.0, 0.0, 0.0))
+    T = common.oracle_tables(cfg, pancake=1.0)                     # spheres, as in the model above
+    a = B.mwc_multipliers(n_steps)
+    photons, count, _, _ = capi.propagate(T, steps, B.seed_streams(a, 4242), a, threads=8)
+    assert count == len(photons) > 1800
+    rng = np.random.Generator(np.random.PCG64(99))
+    dom_m, time_m, scat_m = independent_monte_carlo(steps, geom, rng, B.icecube_dom_acceptance())
+    # detected fraction: two Poisson counts from the same number of photons
+    no, nm = len(photons), len(dom_m)
+    assert abs(no - nm) < 4.5 * math.sqrt(no + nm), (no, nm)
+    # hits per DOM (the oracle reports DOM indices on the single string)
+    co = np.bincount(photons["omID"].astype(np.int64), minlength=60)[:60]
+    cm = np.bincount(dom_m, minlength=60)[:60]
+    m = (co + cm) >= 20
+    chi2 = float(np.sum((co[m] - cm[m]) ** 2 / (co[m] + cm[m])))
+    ndf = int(m.sum())
+    assert ndf >= 6 and chi2 < ndf + 4.5 * math.sqrt(2 * ndf), (chi2, ndf)
+    # arrival times and scatter counts: means within their standard errors, medians close
+    to = (photons["t"] - photons["st"]).astype(np.float64)
+    for name, x, y in (("time", to, time_m), ("scatters", photons["numScatters"].astype(np.float64), scat_m.astype(np.float64))):
+        err = math.sqrt(x.var() / len(x) + y.var() / len(y))
+        assert abs(x.mean() - y.mean()) < 4.5 * err, (name, x.mean(), y.mean(), err)
+    assert abs(np.median(to) - np.median(time_m)) < 0.08 * np.median(time_m)
+    # direct light: photons that were never scattered arrive at (distance to the DOM) / v_group
+    direct_o = to[photons["numScatters"] == 0]
+    direct_m = time_m[scat_m == 0]
+    assert len(direct_o) > 100 and abs(len(direct_o) - len(direct_m)) < 4.5 * math.sqrt(len(direct_o) + len(direct_m))
+    assert abs(direct_o.mean() - direct_m.mean()) < 4.5 * math.sqrt(direct_o.var() / len(direct_o) + direct_m.var() / len(direct_m))
