@@ -153,3 +153,132 @@ def test_oracle_agrees_with_an_independent_monte_carlo(oracle_lib):
     direct_m = time_m[scat_m == 0]
     assert len(direct_o) > 100 and abs(len(direct_o) - len(direct_m)) < 4.5 * math.sqrt(len(direct_o) + len(direct_m))
     assert abs(direct_o.mean() - direct_m.mean()) < 4.5 * math.sqrt(direct_o.var() / len(direct_o) + direct_m.var() / len(direct_m))
+
+
+def layered_monte_carlo(steps, geom, rng, acceptance, z_start, height, abs_len, sca_len, wl_grid):
+    """The same model in depth-layered ice: abs_len / sca_len[layer, wavelength bin] are the layers' lengths (inputs: the
+    ice model's formulas are pinned separately).  The path to the next scattering is found by accumulating optical depth
+    layer by layer -- sum of (path in layer) / (scattering length of the layer) reaches -ln u -- and the absorption budget,
+    counted in absorption lengths, is used up the same way.  Written for this test (a vectorised march from boundary to
+    boundary), not after the reference's loop."""
+    n_layers = abs_len.shape[0]
+    n_ph = steps["num"].astype(np.int64)
+    idx = np.repeat(np.arange(len(steps)), n_ph)
+    n = len(idx)
+    st, sp = steps["theta"][idx].astype(np.float64), steps["phi"][idx].astype(np.float64)
+    sdir = np.stack([np.sin(st) * np.cos(sp), np.sin(st) * np.sin(sp), np.cos(st)], axis=1)
+    along = rng.random(n) * steps["length"][idx]
+    pos = np.stack([steps["x"][idx], steps["y"][idx], steps["z"][idx]], axis=1).astype(np.float64) + sdir * along[:, None]
+    time = steps["t"][idx].astype(np.float64) + along / (C * steps["beta"][idx])
+    grid = np.linspace(acceptance["start"], acceptance["start"] + acceptance["step"] * (len(acceptance["values"]) - 1), 42001)
+    knots = acceptance["start"] + acceptance["step"] * np.arange(len(acceptance["values"]))
+    dens = np.interp(grid, knots, acceptance["values"] * (1.0 / knots ** 2) * (1.0 - 1.0 / phase_index(knots) ** 2))
+    cdf = np.concatenate([[0.0], np.cumsum(0.5 * (dens[1:] + dens[:-1]))]); cdf /= cdf[-1]
+    wlen = np.interp(rng.random(n), cdf, grid)
+    d = rotate(sdir, 1.0 / (steps["beta"][idx] * phase_index(wlen)), 2 * math.pi * rng.random(n))
+    vg = group_velocity(wlen)
+    wbin = np.clip(np.rint((wlen - wl_grid[0]) / (wl_grid[1] - wl_grid[0])).astype(np.int64), 0, len(wl_grid) - 1)
+    budget = -np.log(1.0 - rng.random(n))                         # absorption lengths left
+    scat = np.zeros(n, dtype=np.int64)
+    doms = np.stack([geom["x"], geom["y"], geom["z"]], axis=1)
+    radius = geom["om_radius"]
+    ax, ay = doms[0, 0], doms[0, 1]
+    alive = np.arange(n)
+    hit_dom, hit_time, hit_scat = [], [], []
+    beta_liu = (1.0 - G) / (1.0 + G)
+    while len(alive):
+        m = len(alive)
+        z, dz = pos[alive, 2].copy(), d[alive, 2]
+        tau_s = -np.log(1.0 - rng.random(m))                       # scattering lengths to the next scatter
+        tau_a = budget[alive].copy()
+        seg = np.zeros(m)
+        absorbed = np.zeros(m, dtype=bool)
+        todo = np.arange(m)
+        while len(todo):
+            zz, dzz = z[todo], dz[todo]
+            layer = np.clip(np.floor((zz - z_start) / height).astype(np.int64), 0, n_layers - 1)
+            # a point exactly on a boundary belongs to the layer it is heading into
+            on_edge = np.isclose(zz, z_start + layer * height, atol=1e-9) & (dzz < 0) & (layer > 0)
+            layer = np.where(on_edge, layer - 1, layer)
+            ls, la = sca_len[layer, wbin[alive[todo]]], abs_len[layer, wbin[alive[todo]]]
+            edge = np.where(dzz > 0, z_start + (layer + 1) * height, z_start + layer * height)
+            outside = ((dzz > 0) & (layer == n_layers - 1)) | ((dzz < 0) & (layer == 0)) | (np.abs(dzz) < 1e-12)
+            to_edge = np.where(outside, np.inf, (edge - zz) / np.where(np.abs(dzz) < 1e-12, 1.0, dzz))
+            to_scat, to_abs = tau_s[todo] * ls, tau_a[todo] * la
+            step = np.minimum(np.minimum(to_edge, to_scat), to_abs)
+            seg[todo] += step
+            tau_s[todo] -= step / ls
+            tau_a[todo] -= step / la
+            z[todo] = np.where(step == to_edge, edge, zz + dzz * step)
+            ends_abs = (step == to_abs) & (to_abs <= to_scat)
+            absorbed[todo[ends_abs]] = True
+            todo = todo[step == to_edge]
+        budget[alive] = np.where(absorbed, 0.0, np.maximum(tau_a, 0.0))
+        p, dd = pos[alive], d[alive]
+        wx, wy = ax - p[:, 0], ay - p[:, 1]
+        dxy2 = dd[:, 0] ** 2 + dd[:, 1] ** 2
+        t = np.clip((wx * dd[:, 0] + wy * dd[:, 1]) / np.maximum(dxy2, 1e-300), 0.0, seg)
+        near = (wx - t * dd[:, 0]) ** 2 + (wy - t * dd[:, 1]) ** 2 <= radius ** 2
+        first = np.full(m, np.inf)
+        which = np.full(m, -1)
+        for k in np.nonzero(near)[0]:
+            w = doms - p[k]
+            b = w @ dd[k]
+            disc = b * b - np.einsum("ij,ij->i", w, w) + radius ** 2
+            s_in = np.where(disc >= 0, b - np.sqrt(np.maximum(disc, 0.0)), np.inf)
+            s_in = np.where(s_in >= 0, s_in, np.inf)
+            j = int(np.argmin(s_in))
+            if s_in[j] < seg[k]:
+                first[k], which[k] = s_in[j], j
+        got = which >= 0
+        if got.any():
+            a = alive[got]
+            hit_dom.append(which[got]); hit_time.append(time[a] + first[got] / vg[a]); hit_scat.append(scat[a])
+        keep = ~got & ~absorbed
+        a = alive[keep]
+        pos[a] += dd[keep] * seg[keep][:, None]
+        time[a] += seg[keep] / vg[a]
+        u, r2 = rng.random(len(a)), rng.random(len(a))
+        s = 2.0 * r2 - 1.0
+        hg = (1.0 + G * G - ((1.0 - G * G) / (1.0 + G * s)) ** 2) / (2.0 * G)
+        liu = 2.0 * r2 ** beta_liu - 1.0
+        d[a] = rotate(d[a], np.clip(np.where(u < LIU, liu, hg), -1.0, 1.0), 2 * math.pi * rng.random(len(a)))
+        scat[a] += 1
+        alive = a
+    return np.concatenate(hit_dom), np.concatenate(hit_time), np.concatenate(hit_scat)
+
+
+def test_layered_ice_assembly_agrees_with_an_independent_monte_carlo(oracle_lib):
+    """SPICE-Mie (171 layers of 10 m, no tilt), one string, cascade steps spread over the whole depth range within 25 m of
+    the string: the number of detected photons per DOM follows the dust layers.  The layers' absorption and scattering
+    lengths are taken from the oracle's (separately pinned) medium functions; how they are put together along a photon's
+    path -- the layer walk, which is the heart of the hot loop -- is computed independently."""
+    import os
+    geom = S.single_string_geometry()
+    med = B.load_ppc_ice(os.path.join(common.ICE, "spice_mie"), use_tilt_if_available=False)
+    cfg = dict(name="mie_no_tilt", geom=geom, med_o=med, med_p=None, flasher=False)
+    T = common.oracle_tables(cfg, pancake=1.0)
+    n_steps = 8192
+    steps = S.cascade_steps(n_steps, seed=31, radius=25.0, half_height=480.0)
+    steps["x"] += np.float32(geom["x"][0]); steps["y"] += np.float32(geom["y"][0])
+    a = B.mwc_multipliers(n_steps)
+    photons, count, _, _ = capi.propagate(T, steps, B.seed_streams(a, 515), a, threads=8)
+    assert count == len(photons) > 2000
+    wl_grid = np.linspace(260e-9, 680e-9, 841)
+    abs_len = np.stack([capi.eval_medium(T, 0, wl_grid, layer=l) for l in range(med["num_layers"])]).astype(np.float64)
+    sca_len = np.stack([capi.eval_medium(T, 1, wl_grid, layer=l) for l in range(med["num_layers"])]).astype(np.float64)
+    rng = np.random.Generator(np.random.PCG64(2718))
+    dom_m, time_m, scat_m = layered_monte_carlo(steps, geom, rng, B.icecube_dom_acceptance(), med["layers_z_start"], med["layers_height"],
+                                                abs_len, sca_len, wl_grid)
+    no, nm = len(photons), len(dom_m)
+    assert abs(no - nm) < 4.5 * math.sqrt(no + nm), (no, nm)
+    co = np.bincount(photons["omID"].astype(np.int64), minlength=60)[:60]
+    cm = np.bincount(dom_m, minlength=60)[:60]
+    assert co.max() > 4 * max(co.min(), 1)                       # the depth structure of the ice is there to be seen
+    msk = (co + cm) >= 20
+    chi2, ndf = float(np.sum((co[msk] - cm[msk]) ** 2 / (co[msk] + cm[msk]))), int(msk.sum())
+    assert ndf >= 30 and chi2 < ndf + 4.5 * math.sqrt(2 * ndf), (chi2, ndf)
+    to = (photons["t"] - photons["st"]).astype(np.float64)
+    for name, x, y in (("time", to, time_m), ("scatters", photons["numScatters"].astype(np.float64), scat_m.astype(np.float64))):
+        err = math.sqrt(x.var() / len(x) + y.var() / len(y))
+        assert abs(x.mean() - y.mean()) < 4.5 * err, (name, x.mean(), y.mean(), err)
