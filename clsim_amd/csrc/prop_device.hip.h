@@ -47,6 +47,10 @@ DM KP fresh_params(KP p)
 
 extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
 
+// Lane mask of a predicate.  (HIP's __ballot takes an int: the bool goes through v_cndmask 0/1 and a compare back into a
+// mask, two vector instructions per vote that the mask the predicate already lives in does not need.)
+DM uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct Rec4 { float a, b, c, d; };
 
 DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
@@ -360,7 +364,7 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
     d.z = oz * cosa + sina * sinb * sinth;
     const bool along_z = !(sinth > 0.0f);
-    if (__ballot(along_z) != 0ull) {
+    if (ballot(along_z) != 0ull) {
         const float sgn = (oz > 0.0f) ? 1.0f : ((oz < 0.0f) ? -1.0f : oz);
         d.x = along_z ? sina * cosb : d.x;
         d.y = along_z ? sina * sinb : d.y;

@@ -379,16 +379,16 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             default: __builtin_amdgcn_s_setprio(3); break;
         }
         bool need = alive && !parked && (ph.abs_lens_left < kEpsilon);
-        const uint64_t m_need = __ballot(need);
-        const uint64_t m_ready = __ballot(alive && !need);
+        const uint64_t m_need = ballot(need);
+        const uint64_t m_ready = ballot(alive && !need);
         if ((m_need | m_ready) == 0ull) break;
 #ifdef CLSIMHIP_CENSUS
         ++c_trips;
         if (t_dry == 0 && used_up > 0) t_dry = wall_clock64();
-        c_need += __popcll(__ballot(need && !waiting));
-        c_wait += __popcll(__ballot(need && waiting));
-        c_parked += __popcll(__ballot(parked));
-        c_dead += __popcll(__ballot(!alive));
+        c_need += __popcll(ballot(need && !waiting));
+        c_wait += __popcll(ballot(need && waiting));
+        c_parked += __popcll(ballot(parked));
+        c_dead += __popcll(ballot(!alive));
 #endif
 
         // ---- new units / new photons, deferred until enough lanes wait for them ----
@@ -397,10 +397,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         // not wait for that: a wave with few running lanes would sit on finished units while their successors
         // elsewhere wait, which spreads (every waiting lane is one running lane less).  Finished units are published,
         // and predecessors polled for, at the latest every fourth trip.
-        const uint64_t m_poll = __ballot(need && waiting);
+        const uint64_t m_poll = ballot(need && waiting);
         const bool do_create = (m_ready == 0ull) || ((int)__popcll(m_need & ~m_poll) >= fresh_params(P0)->k_new);
         const bool finished = need && !waiting && (photons_left == 0) && (sidx != kNoStep);
-        const uint64_t m_finished = __ballot(finished);
+        const uint64_t m_finished = ballot(finished);
         // (not the table maker: its waves have fp64 atomics in flight, which a poll would have to wait for first)
         if (do_create || (!TAB && ((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
             const KP P = fresh_params(P0);
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
             const bool want_unit = do_create && need && (photons_left == 0) && !waiting;
-            const uint64_t m_want = __ballot(want_unit);
+            const uint64_t m_want = ballot(want_unit);
             if (m_want != 0ull) {
                 // next units from the wave's sub-queue: one atomic per wave
                 const uint32_t n_sub = (n_steps + (uint32_t)kSubQueues - 1u - sub_queue) / (uint32_t)kSubQueues;   // its steps
@@ -473,14 +473,14 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
 #ifdef CLSIMHIP_CENSUS
             if (do_create) ++c_phases;
-            c_created += __popcll(__ballot(do_create && need && !waiting && (photons_left > 0)));
+            c_created += __popcll(ballot(do_create && need && !waiting && (photons_left > 0)));
 #endif
             if (do_create && need && !waiting && (photons_left > 0)) {
                 create_photon<MED, TILT, FLASHER, TAB != 0, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
-            if ((m_ready == 0ull) && (__ballot(alive && !need) == 0ull)) {
+            if ((m_ready == 0ull) && (ballot(alive && !need) == 0ull)) {
 #ifdef CLSIMHIP_DEBUG_COUNTERS
                 if (lane == 0) atomicAdd(P->queue + 3, 1u);
 #endif
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         // for all of them at once: the search costs the wave the same whether 1 or 12 lanes need it.
         const bool run = alive && !need && !parked;
 #ifdef CLSIMHIP_CENSUS
-        c_run += __popcll(__ballot(run));
+        c_run += __popcll(ballot(run));
 #endif
         float distance = 0.0f;
         bool hit = false;
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         }
         bool advance = run && !parked;
         if (!TAB) {
-            const uint64_t m_parked = __ballot(parked);
-            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
+            const uint64_t m_parked = ballot(parked);
+            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
                 if (parked) {
                     distance = __builtin_bit_cast(float, pending[threadIdx.x]);
                     hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
-        const uint64_t hit_mask = __ballot(hit);
+        const uint64_t hit_mask = ballot(hit);
         if (hit_mask != 0ull) {
             const KP P = fresh_params(P0);
             const uint32_t total = (uint32_t)__popcll(hit_mask);

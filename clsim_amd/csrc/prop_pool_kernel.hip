@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     }
     const uint32_t R = (uint32_t)P0->pool_ready;
     const uint32_t U = 64u + R;
-    uint32_t *wave_lds = lds_words + P0->table_words + (threadIdx.x >> 6) * pool_wave_words(R);
+    // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes, and everything derived from it --
+    // the sub-queue, hence every unit count below and the loop's exit -- would be treated as lane-varying)
+    const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *wave_lds = lds_words + P0->table_words + wave_in_group * pool_wave_words(R);
     uint32_t *stage = wave_lds;
     uint32_t *parked_len = wave_lds + kStageRecords * kStubWords;
     uint32_t *ready = wave_lds + kPoolFixedWords;
@@ -82,14 +85,15 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         if (rounds == 0u) rounds = 1u;
     }
     // wave-uniform bookkeeping of the U unit slots: each is in a lane, in `ready`, in `pending`, empty or gone
-    uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + (threadIdx.x >> 6)) % (uint32_t)kSubQueues;
+    uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group) % (uint32_t)kSubQueues;
     uint32_t used_up = 0;                       // sub-queues found used up in a row
     uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_gone = 0;     // n_wait: pending units that wait for a predecessor
 
     // per lane: the photon it carries and the unit that photon belongs to
-    bool has = false;          // carries a photon
-    bool spent = false;        // that photon has been absorbed or detected
-    bool parked = false;       // has a step length and waits for the wave's next DOM search
+    // what the lane holds: one register compared against constants (three bools would live in scalar lane masks, and every
+    // update under a lane-varying condition would be scalar mask arithmetic -- the scalar unit is the scarcer one here)
+    constexpr uint32_t kVacant = 0u, kSpent = 1u, kLive = 2u, kParked = 3u;     // kParked: has a step length, waits for the wave's next DOM search
+    uint32_t st = kVacant;
     uint32_t sidx = kNoStep, ra = 0, photons_left = 0, uflags = 0;
     uint64_t rx = 0;
     Photon ph;
@@ -101,6 +105,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     if (lane == 0) atomicMin(fresh_params(P0)->census + 8, wall_clock64());
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
 #endif
+    // who holds what, as lane masks; taken at the end of a trip for the next one (and for the loop's exit, a plain backward branch)
+    uint64_t m_spent = 0ull, m_vacant = ~0ull, m_live = 0ull;
     for (uint32_t trip = 0;; ++trip) {
         if ((trip & ((1u << kPrioShift) - 1u)) == 0u) {            // the priority changes every 2^kPrioShift trips
             switch (((trip >> kPrioShift) + wave_slot) & 3u) {
@@ -116,10 +122,6 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #ifdef CLSIMHIP_EXP_VALU
         { uint32_t dummy = lane; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_VALU) "\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(dummy)); if (dummy == 0xdeadbeefu) ++n_gone; }
 #endif
-        const uint64_t m_spent = __ballot(has && spent);
-        const uint64_t m_vacant = __ballot(!has);
-        const uint64_t m_live = __ballot(has && !spent);
-        if ((m_live == 0ull) && (m_spent == 0ull) && (n_gone == U)) break;       // every unit slot has been retired
 #ifdef CLSIMHIP_CENSUS
         ++c_trips;
         c_vacant += __popcll(m_vacant | m_spent);
@@ -134,10 +136,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             ++c_services;
 #endif
             if (m_spent != 0ull) {
-                const bool mine = has && spent;
+                const bool mine = (st == kSpent);
                 const bool finished = mine && (photons_left == 0u);
                 const bool next = mine && (photons_left != 0u);
-                const uint64_t m_finished = __ballot(finished), m_next = __ballot(next);
+                const uint64_t m_finished = ballot(finished), m_next = ballot(next);
                 if (m_finished != 0ull) {
                     // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
                     // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     e[0] = sidx; e[1] = (uint32_t)rx; e[2] = (uint32_t)(rx >> 32); e[3] = photons_left; e[4] = uflags;
                 }
                 n_pend += (uint32_t)__popcll(m_next);
-                if (mine) { has = false; spent = false; }
+                if (mine) st = kVacant;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                             flags = s_new | (last ? kFlagLast : 0u) | kFlagWaiting;
                         }
                     }
-                    const uint64_t m_got = __ballot(got);
+                    const uint64_t m_got = ballot(got);
                     if (got) {
                         uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_got & lanes_below));
                         e[0] = i_new; e[1] = 0u; e[2] = 0u; e[3] = left; e[4] = flags;
@@ -250,9 +252,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                             waiting = false;
                         }
                     }
-                    still_waiting += (uint32_t)__popcll(__ballot(waiting));
+                    still_waiting += (uint32_t)__popcll(ballot(waiting));
                     const bool can = have && !waiting;
-                    const uint64_t m_can = __ballot(can);
+                    const uint64_t m_can = ballot(can);
                     const uint32_t slot = created + (uint32_t)__popcll(m_can & lanes_below);
                     const bool make = can && (slot < (R - n_ready));
                     if (make) {
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         q[15] = e_sidx; q[16] = (uint32_t)e_rx; q[17] = (uint32_t)(e_rx >> 32); q[18] = e_ra; q[19] = e_left; q[20] = e_flags;
                     }
                     const bool keep = have && !make;
-                    const uint64_t m_keep = __ballot(keep);
+                    const uint64_t m_keep = ballot(keep);
                     // (every lane has read its entry above; the compacted entries land at or before the ones read)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         e[0] = e_sidx; e[1] = (uint32_t)e_rx; e[2] = (uint32_t)(e_rx >> 32); e[3] = e_left; e[4] = e_flags;
                     }
                     kept += (uint32_t)__popcll(m_keep);
-                    created += (uint32_t)__popcll(__ballot(make));
+                    created += (uint32_t)__popcll(ballot(make));
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -300,8 +302,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 
             // ready photons for the lanes without one, oldest first
             if (n_ready != 0u) {
-                const bool want = !has;
-                const uint64_t m_want = __ballot(want);
+                const bool want = (st == kVacant);
+                const uint64_t m_want = ballot(want);
                 const uint32_t rank = (uint32_t)__popcll(m_want & lanes_below);
                 if (want && (rank < n_ready)) {
                     uint32_t pos = ready_head + rank;
@@ -316,8 +318,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     ph.num_scatters = 0;
                     ph.total_path = 0.0f;
                     sidx = q[15]; rx = (uint64_t)q[16] | ((uint64_t)q[17] << 32); ra = q[18]; photons_left = q[19]; uflags = q[20];
-                    has = true;
-                    spent = false;
+                    st = kLive;
                 }
                 uint32_t taken = (uint32_t)__popcll(m_want);
                 if (taken > n_ready) taken = n_ready;
@@ -329,14 +330,14 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             // nothing runnable in this wave: every unit it holds waits for another wave's slice
-            if (__ballot(has) == 0ull) __builtin_amdgcn_s_sleep(16);
+            if (ballot(st != kVacant) == 0ull) __builtin_amdgcn_s_sleep(16);
         }
 
         // ---- one reference loop iteration for the lanes that hold a live photon ----
-        const bool run = has && !spent && !parked;
+        const bool run = (st == kLive);
 #ifdef CLSIMHIP_CENSUS
-        c_run += __popcll(__ballot(run));
-        c_parked += __popcll(__ballot(parked));
+        c_run += __popcll(ballot(run));
+        c_parked += __popcll(ballot(st == kParked));
         if (n_ready == 0u) ++c_empty_ring;
 #endif
         float distance = 0.0f;
@@ -348,27 +349,27 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
             if (!(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
-                parked = true;
+                st = kParked;
                 parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
             }
         }
-        bool advance = run && !parked;
+        bool advance = (st == kLive);
         {
-            const uint64_t m_parked = __ballot(parked);
-            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (__ballot(advance) == 0ull))) {
+            const uint64_t m_parked = ballot(st == kParked);
+            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
 #endif
-                if (parked) {
+                if (st == kParked) {
                     distance = __builtin_bit_cast(float, parked_len[lane]);
                     hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
-                    parked = false;
+                    st = kLive;
                     advance = true;
                 }
             }
         }
         // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
-        const uint64_t hit_mask = __ballot(hit);
+        const uint64_t hit_mask = ballot(hit);
         if (hit_mask != 0ull) {
             const KP P = fresh_params(P0);
             const uint32_t total = (uint32_t)__popcll(hit_mask);
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             ph.total_path += distance;
             if (ph.abs_lens_left < kEpsilon) {
                 --photons_left;                                                 // absorbed or detected
-                spent = true;
+                st = kSpent;
             } else {
                 const KP P = fresh_params(P0);
                 if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
@@ -423,6 +424,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 ++ph.num_scatters;
             }
         }
+        m_spent = ballot(st == kSpent);
+        m_vacant = ballot(st == kVacant);
+        m_live = ballot(st >= kLive);
+        if ((m_live == 0ull) && (m_spent == 0ull) && (n_gone == U)) break;       // every unit slot has been retired
     }
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0) {
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_services); atomicAdd(d + 3, c_creations);
         atomicAdd(d + 4, c_created); atomicAdd(d + 5, c_vacant); atomicAdd(d + 6, c_polls); atomicAdd(d + 7, c_parked);
         atomicAdd(d + 9, c_searches); atomicAdd(d + 10, c_chunks); atomicAdd(d + 11, c_empty_ring);
-        const uint32_t w = blockIdx.x * (uint32_t)kPoolWavesPerBlock + (threadIdx.x >> 6);
+        const uint32_t w = blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group;
         d[16 + 3 * w] = wall_clock64();
         d[16 + 3 * w + 1] = 0;
         d[16 + 3 * w + 2] = c_trips;
