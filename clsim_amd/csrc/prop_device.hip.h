@@ -643,7 +643,7 @@ DM bool dom_search_needed(KP P, const Photon &ph, float len)
     const int ix = clampi((int)((ph.px - P->dprox_x0) * inv), 0, P->dprox_nx - 1);
     const int iy = clampi((int)((ph.py - P->dprox_y0) * inv), 0, ny - 1);
     const int iz = clampi((int)((ph.pz - P->dprox_z0) * inv), 0, nz - 1);
-    const uint32_t w = P->dom_prox[((size_t)ix * (size_t)ny + (size_t)iy) * (size_t)nz + (size_t)iz];      // z runs fastest
+    const uint32_t w = P->dom_prox[((uint32_t)ix * (uint32_t)ny + (uint32_t)iy) * (uint32_t)nz + (uint32_t)iz];      // z runs fastest; at most 2^24 cells
     const float others = (float)((w >> 16) & 0xffu) * 0.25f;
     if (!(len < others)) return true;
     const uint32_t id = w & 0xffffu;

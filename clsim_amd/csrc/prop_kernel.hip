@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         rounds = (max_photons + slice_photons - 1u) / slice_photons;
         if (rounds == 0u) rounds = 1u;
     }
-    uint32_t sub_queue = (blockIdx.x * (uint32_t)kWavesPerBlock + (threadIdx.x >> 6)) % (uint32_t)kSubQueues;     // wave-uniform
+    uint32_t sub_queue = (blockIdx.x * (uint32_t)kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % (uint32_t)kSubQueues;     // wave-uniform, and known to be
     uint32_t used_up = 0;                                                                                          // in a row
     uint32_t sidx = kNoStep;
     uint64_t rx = 0;
@@ -371,17 +371,18 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     if (lane == 0 && !TAB) atomicMin(fresh_params(P0)->census + 8, t_start);
     unsigned long long c_trips = 0, t_dry = 0, c_run = 0, c_need = 0, c_wait = 0, c_parked = 0, c_dead = 0, c_phases = 0, c_created = 0;
 #endif
+    // which lanes need a photon and which hold one, taken at the end of a trip for the next one (and for the loop's exit, a
+    // plain backward branch)
+    bool need_next = true;
+    uint64_t m_need = ~0ull, m_ready = 0ull;
     for (uint32_t trip = 0;; ++trip) {
-        if (!TAB) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
+        if (!TAB && ((trip & ((1u << kPrioShift) - 1u)) == 0u)) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
-        bool need = alive && !parked && (ph.abs_lens_left < kEpsilon);
-        const uint64_t m_need = ballot(need);
-        const uint64_t m_ready = ballot(alive && !need);
-        if ((m_need | m_ready) == 0ull) break;
+        bool need = need_next;
 #ifdef CLSIMHIP_CENSUS
         ++c_trips;
         if (t_dry == 0 && used_up > 0) t_dry = wall_clock64();
@@ -599,6 +600,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 ++ph.num_scatters;
             }
         }
+        need_next = alive && !parked && (ph.abs_lens_left < kEpsilon);
+        m_need = ballot(need_next);
+        m_ready = ballot(alive && !need_next);
+        if ((m_need | m_ready) == 0ull) break;
     }
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0 && !TAB) {

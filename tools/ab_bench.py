@@ -18,6 +18,7 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--workloads", default="c2")
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--bunch", type=int, default=0, help="steps per pass (default: the workload's own)")
 ap.add_argument("--out", default="gpurun_out/ab_bench.jsonl")
 args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,8 @@ with open(os.path.join(root, args.out), "a") as log:
                 env = dict(os.environ, CLSIMHIP_LIB=os.path.abspath(lib))
                 cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--warmup", "2",
                        "--no-cpu-baseline", "--no-host-path"]
+                if args.bunch:
+                    cmd += ["--bunch", str(args.bunch)]
                 p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
                 line = [l for l in p.stdout.splitlines() if l.startswith("{")]
                 if p.returncode != 0 or not line:
