@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // wave-uniform bookkeeping of the U unit slots: each is in a lane, in `ready`, in `pending`, empty or gone
     uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group) % (uint32_t)kSubQueues;
     uint32_t used_up = 0;                       // sub-queues found used up in a row
-    uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_gone = 0;     // n_wait: pending units that wait for a predecessor
+    uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_left = U;     // n_wait: pending units that wait for a predecessor; n_left: unit slots not yet retired
 
     // per lane: the photon it carries and the unit that photon belongs to
     // what the lane holds: one register compared against constants (three bools would live in scalar lane masks, and every
@@ -117,10 +117,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             }
         }
 #ifdef CLSIMHIP_EXP_SALU        // experiment: marginal cost of scalar / vector instructions (tools/exp_issue_cost.sh)
-        { uint32_t dummy = trip; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_SALU) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : : "scc"); if (dummy == 0xdeadbeefu) ++n_gone; }
+        { uint32_t dummy = trip; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_SALU) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : : "scc"); if (dummy == 0xdeadbeefu) --n_left; }
 #endif
 #ifdef CLSIMHIP_EXP_VALU
-        { uint32_t dummy = lane; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_VALU) "\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(dummy)); if (dummy == 0xdeadbeefu) ++n_gone; }
+        { uint32_t dummy = lane; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_VALU) "\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(dummy)); if (dummy == 0xdeadbeefu) --n_left; }
 #endif
 #ifdef CLSIMHIP_CENSUS
         ++c_trips;
@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 
         // ---- service: retire the units of spent photons, create photons when the ring has room, hand out ready photons ----
         const uint32_t n_free = (uint32_t)__popcll(m_spent | m_vacant);
-        if ((n_free != 0u) && ((n_free >= (uint32_t)fresh_params(P0)->k_pop) || (m_live == 0ull))) {
+        // (1 <= k_pop <= 64, so this also covers "no lane holds a live photon": then all 64 are free)
+        if (n_free >= (uint32_t)fresh_params(P0)->k_pop) {
             const KP P = fresh_params(P0);
             WorkRecord *work = P->work;
 #ifdef CLSIMHIP_CENSUS
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 
-            if (used_up >= (uint32_t)kSubQueues) { n_gone += n_empty; n_empty = 0u; }          // the queues are dry: empty slots retire
+            if (used_up >= (uint32_t)kSubQueues) { n_left -= n_empty; n_empty = 0u; }          // the queues are dry: empty slots retire
 
             // photon creation: when a batch fits the ring, or when lanes would otherwise go without a photon.  A wave
             // whose pending units all wait for predecessors elsewhere looks again every fourth trip.
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     n_pend += n_got;
                     n_empty -= n_got;
                 }
-                if (used_up >= (uint32_t)kSubQueues) { n_gone += n_empty; n_empty = 0u; }      // no work is left anywhere
+                if (used_up >= (uint32_t)kSubQueues) { n_left -= n_empty; n_empty = 0u; }      // no work is left anywhere
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -355,8 +356,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         }
         bool advance = (st == kLive);
         {
-            const uint64_t m_parked = ballot(st == kParked);
-            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
+            // the DOM search runs when k_search lanes are parked, or for any parked lane when nothing else can advance
+            const uint32_t n_parked = (uint32_t)__popcll(ballot(st == kParked));
+            const uint32_t enough = (ballot(advance) == 0ull) ? 1u : (uint32_t)fresh_params(P0)->k_search;
+            if (n_parked >= enough) {
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
 #endif
@@ -366,42 +369,42 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     st = kLive;
                     advance = true;
                 }
-            }
-        }
-        // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
-        const uint64_t hit_mask = ballot(hit);
-        if (hit_mask != 0ull) {
-            const KP P = fresh_params(P0);
-            const uint32_t total = (uint32_t)__popcll(hit_mask);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P->hit_count, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
-            const uint32_t max_hits = P->max_hits;
-            uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
-            for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
-                if (hit && rank >= chunk && rank < chunk + kStageRecords) {
-                    uint32_t *st = stage + (rank - chunk) * kStubWords;
-                    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
-                    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
-                    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
-                    st[11] = ph.num_scatters; st[12] = sidx;
-                    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
-                    st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
+                // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+                const uint64_t hit_mask = ballot(hit);
+                if (hit_mask != 0ull) {
+                    const KP P = fresh_params(P0);
+                    const uint32_t total = (uint32_t)__popcll(hit_mask);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P->hit_count, total);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
+                    const uint32_t max_hits = P->max_hits;
+                    uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
+                    for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
+                        if (hit && rank >= chunk && rank < chunk + kStageRecords) {
+                            uint32_t *st = stage + (rank - chunk) * kStubWords;
+                            st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
+                            st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
+                            st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
+                            st[11] = ph.num_scatters; st[12] = sidx;
+                            st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
+                            st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const uint32_t first = base + chunk;
+                        const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
+                        // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
+                        const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
+                        const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
+                        uint32_t *dst = out_words + (size_t)first * 20u;
+                        // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
+                        for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t first = base + chunk;
-                const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
-                // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
-                const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
-                const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
-                uint32_t *dst = out_words + (size_t)first * 20u;
-                // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
-                for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         }
         if (advance) {
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         m_spent = ballot(st == kSpent);
         m_vacant = ballot(st == kVacant);
         m_live = ballot(st >= kLive);
-        if ((m_live == 0ull) && (m_spent == 0ull) && (n_gone == U)) break;       // every unit slot has been retired
+        if ((m_live | m_spent | (uint64_t)n_left) == 0ull) break;                // every unit slot has been retired (one test: the loop is scalar-issue bound)
     }
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0) {
@@ -511,6 +514,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // most trips whatever the filter (flasher steps: 5 parked lanes 1.30e9, 3: 1.24, 1: 1.20)
         if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 5 : 3);
         if (P.k_pop <= 0) P.k_pop = 4;
+        if (P.k_pop > 64) P.k_pop = 64;
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon
         // (ring of 34: threshold 20 2.76e9 photons/s, 26: 2.81, 30: 2.84, 33: 2.85)
         if (P.k_new <= 0 || P.k_new > R) P.k_new = (R > 8) ? R - 1 : R;
