@@ -511,9 +511,10 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
         // lanes parked per DOM search: with the two-level proximity filter about 1 % of the lanes need one per trip (cascade
         // steps: 3 parked lanes 2.55e9 photons/s, 1: 2.49, 5: 2.53, 8: 2.27 at 1M steps); photons born at a DOM need one on
-        // most trips whatever the filter (flasher steps: 5 parked lanes 1.30e9, 3: 1.24, 1: 1.20)
-        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 5 : 3);
-        if (P.k_pop <= 0) P.k_pop = 4;
+        // most trips whatever the filter (flasher steps: 3 parked lanes 1.50e9, 5: 1.58, 7: 1.615, 9: 1.625, 12: 1.616, 16: 1.57)
+        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 8 : 3);
+        // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
+        if (P.k_pop <= 0) P.k_pop = FLASHER ? 8 : 4;
         if (P.k_pop > 64) P.k_pop = 64;
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon
         // (ring of 34: threshold 20 2.76e9 photons/s, 26: 2.81, 30: 2.84, 33: 2.85)
