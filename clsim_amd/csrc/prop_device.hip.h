@@ -107,6 +107,16 @@ template <bool FAST>
 DM float rcp_t(float x, bool fast) { return FAST ? dm::rcp_(x) : rcp_sel(x, fast); }
 DM float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
 DM int clampi(int v, int lo, int hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }
+// The same for bounds known to be ordered, as one median instruction (the compiler forms it only for constant bounds, and
+// canonicalises a float before max/min).  A NaN comes out as the lower bound either way.
+DM float clampf_ordered(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+// clampi(v, 0, hi) for a wave-uniform hi >= 0 (a table dimension minus one, in a scalar register)
+DM int clamp_index(int v, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
+}
 
 struct Vec3 { float x, y, z; };
 
@@ -195,7 +205,7 @@ DM float hg_cos(KP P, float u)
 {
     const float s = 2.0f * u - 1.0f;
     const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
-    return clampf(div_by_t<FAST>(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, FAST || (P->div_ok & 16u) != 0), -1.0f, 1.0f);
+    return clampf_ordered(div_by_t<FAST>(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, FAST || (P->div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
 template <bool FAST = false>
@@ -204,7 +214,7 @@ DM float liu_cos(KP P, float u)
     const float beta = P->liu_beta;
     // beta <= 0.09 (mean cosine >= 0.835, wave-uniform): beta |log u| <= 2 for u >= 2^-32, the single-word logarithm form
     const float p = (FAST || beta <= 0.09f) ? dm::powr_unit_(u, beta) : dm::powr_(u, beta);
-    return clampf(2.0f * p - 1.0f, -1.0f, 1.0f);
+    return clampf_ordered(2.0f * p - 1.0f, -1.0f, 1.0f);
 }
 // Mixed.cxx:115-157, single random number form
 template <bool FAST = false>
@@ -257,7 +267,7 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     const float z_rescaled = div_by_t<FAST>(pz - P->tilt_first_z, P->tilt_dz, P->rcp_tilt_dz, (P->div_ok & 1u) != 0);
     const int nz = P->tilt_nz, nd = P->tilt_nd;
     const uint32_t off_dist = P->off_tilt_dist;
-    const int k = clampi((int)__builtin_floorf(z_rescaled), 0, nz - 2);
+    const int k = clamp_index((int)__builtin_floorf(z_rescaled), nz - 2);           // nz >= 2 (tables.cpp)
     const float fraction_z_above = z_rescaled - (float)k;
     const float fraction_z_below = 1.0f - fraction_z_above;
     const float nr = P->tilt_lnx * px + P->tilt_lny * py;
@@ -475,7 +485,7 @@ DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
     ph.d = b.d;
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
-    if (!TILT) ph.layer = clampi((int)div_by_t<FAST>(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, P->num_layers - 1);
+    if (!TILT) ph.layer = clamp_index((int)div_by_t<FAST>(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), P->num_layers - 1);
     ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
     ph.abs_lens_left = b.abs_lens_initial;
     ph.ice = ice_factors<MED>(P, b.wlen);
@@ -494,7 +504,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     int current_layer;
     if (TILT) {
         effective_z = ph.pz - tilt_z_shift<FAST>(P, ph.px, ph.py, ph.pz);
-        current_layer = clampi((int)div_by_t<FAST>(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), 0, num_layers - 1);
+        current_layer = clamp_index((int)div_by_t<FAST>(effective_z - bottom, thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), num_layers - 1);
     } else {
         effective_z = ph.pz - P->tilt_const;
         current_layer = ph.layer;
@@ -622,9 +632,9 @@ DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_x
 DM float free_flight_bound(KP P, float x, float y)
 {
     const int n = P->prox_n;
-    const int ix = clampi((int)((x - P->prox_x0) * P->prox_inv_cell), 0, n - 1);
-    const int iy = clampi((int)((y - P->prox_y0) * P->prox_inv_cell), 0, n - 1);
-    return (float)P->prox_map[iy * n + ix] * 0.25f;
+    const int ix = clamp_index((int)((x - P->prox_x0) * P->prox_inv_cell), n - 1);
+    const int iy = clamp_index((int)((y - P->prox_y0) * P->prox_inv_cell), n - 1);
+    return (float)P->prox_map[(uint32_t)iy * (uint32_t)n + (uint32_t)ix] * 0.25f;
 }
 
 // Second and third level of the search filter (kparams.h: DOM proximity map), for a lane whose step of length `len` reaches a
@@ -640,9 +650,9 @@ DM bool dom_search_needed(KP P, const Photon &ph, float len)
 {
     const float inv = P->dprox_inv_cell;
     const int ny = P->dprox_ny, nz = P->dprox_nz;
-    const int ix = clampi((int)((ph.px - P->dprox_x0) * inv), 0, P->dprox_nx - 1);
-    const int iy = clampi((int)((ph.py - P->dprox_y0) * inv), 0, ny - 1);
-    const int iz = clampi((int)((ph.pz - P->dprox_z0) * inv), 0, nz - 1);
+    const int ix = clamp_index((int)((ph.px - P->dprox_x0) * inv), P->dprox_nx - 1);
+    const int iy = clamp_index((int)((ph.py - P->dprox_y0) * inv), ny - 1);
+    const int iz = clamp_index((int)((ph.pz - P->dprox_z0) * inv), nz - 1);
     const uint32_t w = P->dom_prox[((uint32_t)ix * (uint32_t)ny + (uint32_t)iy) * (uint32_t)nz + (uint32_t)iz];      // z runs fastest; at most 2^24 cells
     const float others = (float)((w >> 16) & 0xffu) * 0.25f;
     if (!(len < others)) return true;
@@ -650,7 +660,7 @@ DM bool dom_search_needed(KP P, const Photon &ph, float len)
     if (id == 0xffffu) return false;
     const float4 c = P->dom_centres[id];
     const float wx = c.x - ph.px, wy = c.y - ph.py, wz = c.z - ph.pz;
-    const float along = clampf((wx * ph.d.x + wy * ph.d.y) + wz * ph.d.z, 0.0f, len);
+    const float along = clampf_ordered((wx * ph.d.x + wy * ph.d.y) + wz * ph.d.z, 0.0f, len);      // len > 0
     const float qx = wx - along * ph.d.x, qy = wy - along * ph.d.y, qz = wz - along * ph.d.z;
     const float reach = P->dprox_radius + 0.01f;
     return !((qx * qx + qy * qy) + qz * qz > reach * reach);

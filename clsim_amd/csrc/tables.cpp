@@ -251,6 +251,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     if (m.has_tilt) {
         // ScalarFieldIceTiltZShift.cxx:62-100 (constructor) and :145-213
         const size_t nd = m.tilt_distances.size(), nz = m.tilt_z.size();
+        // (interpolation between neighbours in both dimensions, :170-205: a table with a single row or column has none; the
+        // kernel's index clamps rely on nz - 2 >= 0)
+        if (nd < 2 || nz < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "the ice tilt table needs at least two distances and two z coordinates");
         double mean_spacing = 0.;
         for (size_t i = 0; i + 1 < nz; ++i) {
             const double sp = m.tilt_z[i + 1] - m.tilt_z[i];
