@@ -18,7 +18,7 @@ constexpr uint32_t kQueueSlots = 256;
 // The pooled kernel keeps 64 + R units per wave in flight (about 0.6M on the chip): it wins on bunches that hold more
 // steps than that by a margin (1M steps: +9 %, 4M: +8 %) and loses on smaller ones (0.5M: -17 %), where the classic
 // kernel's smaller grids apply.  Chosen per launch; results do not depend on the choice.
-constexpr size_t kPooledKernelMinSteps = 655360;   // 0.52M steps: classic 2.28e9 photons/s, pooled 1.96; 0.66M: 2.36 / 2.55; 0.79M: 2.46 / 2.75
+constexpr size_t kPooledKernelMinSteps = 614400;   // 0.52M steps: classic 2.54e9 photons/s, pooled 2.29; 0.59M: 2.63 / 2.59; 0.66M: pooled 3.01
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
