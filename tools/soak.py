@@ -37,7 +37,7 @@ for k in range(total):
         ident, ph = conv.GetConversionResult()
     assert ident not in seen and 0 <= ident < total
     seen.add(ident); hits += len(ph)
-    if k == 50: rss50 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    if k == min(50, total // 2): rss50 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss      # after the warm-up half (or 50 bunches)
 for t in threads: t.join()
 st = conv.GetStatistics()
 rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
