@@ -204,7 +204,9 @@ template <bool FAST = false>
 DM float hg_cos(KP P, float u)
 {
     const float s = 2.0f * u - 1.0f;
-    const float ii = P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
+    // FAST: 1 - g^2 >= 2^-40 and 1 - g >= 2^-50 were checked at Compile() (tables.cpp), so the numerator and every divisor
+    // 1 + g s, |s| <= 1, are inside div_near_'s range
+    const float ii = FAST ? dm::div_near_(P->hg_one_minus_g2, 1.0f + P->hg_g * s) : P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
     return clampf_ordered(div_by_t<FAST>(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, FAST || (P->div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
@@ -370,11 +372,21 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     const float t = 1.0f - d.z * d.z;
     const float sinth = dm::sqrt_near_((t > 0.0f) ? t : 0.0f);     // 0 or >= 2^-24: |d.z| <= 1 is a float
     const float ox = d.x, oy = d.y, oz = d.z;
-    d.x = ox * cosa - ((oy * cosb + oz * ox * sinb) * sina) / sinth;
-    d.y = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
+    // two numerators (at most 2 in magnitude) over one divisor in [2^-12, 1]: the exact divide of detmath.hip.h on a shared
+    // reciprocal.  A numerator that is zero (sina = 0: a scattering cosine rounded to +-1), signed zero or below 2^-40 is
+    // outside its range: such a lane -- one wave trip in 1e5 -- takes the IEEE divide in the block below.
+    const float num_x = (oy * cosb + oz * ox * sinb) * sina, num_y = (ox * cosb - oz * oy * sinb) * sina;
+    const float recip_sinth = dm::rcp_(sinth);             // (sinth = 0: infinite, and what follows from it is discarded below)
+    d.x = ox * cosa - dm::div_near_with_(num_x, sinth, recip_sinth);
+    d.y = oy * cosa + dm::div_near_with_(num_y, sinth, recip_sinth);
     d.z = oz * cosa + sina * sinb * sinth;
     const bool along_z = !(sinth > 0.0f);
-    if (ballot(along_z) != 0ull) {
+    const bool ieee = !(dm::div_near_ok_(num_x) && dm::div_near_ok_(num_y));
+    if (ballot(along_z || ieee) != 0ull) {
+        if (ieee) {
+            d.x = ox * cosa - num_x / sinth;
+            d.y = oy * cosa + num_y / sinth;
+        }
         const float sgn = (oz > 0.0f) ? 1.0f : ((oz < 0.0f) ? -1.0f : oz);
         d.x = along_z ? sina * cosb : d.x;
         d.y = along_z ? sina * sinb : d.y;
@@ -519,8 +531,20 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     float sca_len, abs_len;
     layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, fast);
     const float recip_thickness = P->recip_thickness;
-    float ais = (dz * sca_step_left - ((boundary - effective_z) / sca_len)) * recip_thickness;
-    float aia = (dz * ph.abs_lens_left - ((boundary - effective_z) / abs_len)) * recip_thickness;
+    // Two divides of one numerator by lengths that Compile() has bounded to (2^-50, 2^50) (`fast`): the 8-instruction exact
+    // divide when every lane's height above the boundary is inside its range (a photon ON a boundary, or within 1e-12 m of
+    // one at z = 0, sends its wave through the IEEE sequence instead; positions stay below 2^55 m with those lengths)
+    const float to_boundary = boundary - effective_z;
+    float over_sca, over_abs;
+    if (fast && (ballot(!dm::div_near_ok_(to_boundary)) == 0ull)) {
+        over_sca = dm::div_near_(to_boundary, sca_len);
+        over_abs = dm::div_near_(to_boundary, abs_len);
+    } else {
+        over_sca = to_boundary / sca_len;
+        over_abs = to_boundary / abs_len;
+    }
+    float ais = (dz * sca_step_left - over_sca) * recip_thickness;
+    float aia = (dz * ph.abs_lens_left - over_abs) * recip_thickness;
     int j = current_layer;
     {
         // c.cl:643-668 has one loop for photons going down and one for photons going up; a wave holds both kinds, so the
@@ -553,9 +577,10 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         distance = to_absorption;
         ph.abs_lens_left = 0.0f;
     } else {
-        ph.abs_lens_left = (to_absorption - distance) / abs_len;
+        const float left = to_absorption - distance;       // >= +0, below 2^55
+        ph.abs_lens_left = (fast && (ballot(!dm::div_near_ok_(left)) == 0ull)) ? dm::div_near_(left, abs_len) : left / abs_len;
     }
-    if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;
+    if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;       // (the exact divide with its range test gains nothing here: measured)
     return distance;
 }
 

@@ -717,6 +717,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
     case 13: r = dm::rsqrt_near_(x); break;
     case 14: r = dm::powr_unit_(x, y); break;
     case 15: r = dm::cbrt_(x); break;
+    case 16: r = dm::div_near_(x, y); break;
     default: break;
     }
     out[i] = r;
@@ -724,12 +725,54 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 
 // Exhaustive proof runs for the range-restricted operations of detmath.hip.h: every significand (2^23) x every binary
 // exponent in [exp_lo, exp_hi], both signs for the reciprocal, against the IEEE operation.  what: 11 rcp_, 12 sqrt_near_,
-// 13 rsqrt_near_.
+// 13 rsqrt_near_; 16 div_near_ (two-argument: see the kernel).
 // result[0] = mismatches, result[1..] = bit patterns of the first few mismatching arguments.
 __global__ void check_math_kernel(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;        // significand bits
     if (m >= (1u << 23)) return;
+    if (what == 16) {
+        // div_near_: every divisor significand x the divisor exponents [exp_lo, exp_hi] x both divisor signs x 40 numerators:
+        // 32 pseudo-random ones over the whole admissible range and both signs, and 8 built from the divisor (exact and
+        // nearly exact quotients, all-ones and power-of-two significands), where a wrong last bit would show first
+        for (int e = exp_lo; e <= exp_hi; ++e) {
+            const uint32_t bbits = ((uint32_t)(e + 127) << 23) | m;
+            for (int j = 0; j < 40; ++j) {
+                uint32_t h = (m * 2654435761u) ^ ((uint32_t)(e + 1000) * 40503u) ^ ((uint32_t)j * 2246822519u);
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+                uint32_t abits;
+                if (j < 32) {
+                    const uint32_t ae = 127u - 40u + (h >> 23) % 101u;                     // exponents -40 ... 60
+                    abits = (h & 0x807fffffu) | (ae << 23);
+                } else {
+                    const uint32_t ae = 127u - 40u + (h >> 9) % 101u;
+                    const uint32_t k = (h & 7u) + 1u;
+                    const float bb = dm::u2f((127u << 23) | m);                            // the divisor's significand in [1, 2)
+                    float t;
+                    switch (j - 32) {
+                        case 0: t = bb * (float)k; break;                                   // exact small quotients (when the product is exact)
+                        case 1: t = dm::u2f(dm::f2u(bb * (float)k) + 1u); break;            // ... and their neighbours
+                        case 2: t = dm::u2f(dm::f2u(bb * (float)k) - 1u); break;
+                        case 3: t = dm::u2f((127u << 23) | 0x7fffffu); break;               // all ones
+                        case 4: t = 1.0f; break;                                           // a power of two: the quotient is RN(1/b) scaled
+                        case 5: t = dm::u2f((127u << 23) | (0x7fffffu & ~m)); break;        // complement of the divisor's bits
+                        case 6: t = bb * bb; break;                                        // quotient close to the divisor itself
+                        default: t = dm::u2f((127u << 23) | ((m + k) & 0x7fffffu)); break;  // quotient within a few ulp of one
+                    }
+                    abits = (dm::f2u(t) & 0x007fffffu) | (ae << 23) | (h & 0x80000000u);
+                }
+                for (int sign = 0; sign < 2; ++sign) {
+                    const float b = dm::u2f(bbits | ((uint32_t)sign << 31)), a = dm::u2f(abits);
+                    const float want = a / b, got = dm::div_near_(a, b);
+                    if (dm::f2u(want) != dm::f2u(got)) {
+                        const uint32_t k2 = atomicAdd(result, 1u);
+                        if (k2 + 2u < result_cap && (k2 & 1u) == 0u) { result[k2 + 1u] = dm::f2u(a); result[k2 + 2u] = dm::f2u(b); }
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int e = exp_lo; e <= exp_hi; ++e) {
         const uint32_t bits = ((uint32_t)(e + 127) << 23) | m;
         for (int sign = 0; sign < ((what == 11) ? 2 : 1); ++sign) {

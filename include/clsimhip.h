@@ -311,11 +311,15 @@ long clsimhip_get_table(const clsimhip_converter *c, const char *name, double *o
 /* current RNG state words (after the bunches run so far) */
 int clsimhip_get_rng_state(clsimhip_converter *c, uint64_t *x_out, size_t count);
 /* evaluates the device math library on the GPU: what = 0 log,1 exp,2 sin,3 cos,4 powr(x,y),
- * 5 acos,6 atan2(x,y),7 rsqrt,8 sqrt,9 x/y,10 acos (single precision),11 rcp_,12 sqrt_near_,13 rsqrt_near_ */
+ * 5 acos,6 atan2(x,y),7 rsqrt,8 sqrt,9 x/y,10 acos (single precision),11 rcp_,12 sqrt_near_,13 rsqrt_near_,
+ * 14 powr_unit_(x,y),15 cbrt_,16 div_near_(x,y) */
 int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out);
 /* exhaustive device-side check of the range-restricted operations of the kernel's math library (what = 11 reciprocal,
  * 12 square root, 13 reciprocal square root) against the IEEE divide / sqrt: all 2^23 significands x every binary
- * exponent in [exp_lo, exp_hi].  result[0] = number of mismatches, result[1..cap) = bit patterns of the first ones. */
+ * exponent in [exp_lo, exp_hi].  result[0] = number of mismatches, result[1..cap) = bit patterns of the first ones.
+ * what = 16: the range-restricted divide, all 2^23 divisor significands x the divisor exponents [exp_lo, exp_hi] x both
+ * divisor signs x 40 numerators each (random and adversarial, exponents -40 ... 60); result[1..] = (numerator, divisor)
+ * pairs of the first mismatches. */
 int clsimhip_check_math_exhaustive(int device_ordinal, int what, int exp_lo, int exp_hi, uint32_t *result, size_t result_cap);
 
 const char *clsimhip_version(void);

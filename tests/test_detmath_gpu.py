@@ -89,6 +89,28 @@ def check_exhaustive(what, exp_lo, exp_hi, cap=64):
     return int(res[0]), res[1:1 + min(int(res[0]), cap - 1)].view(np.float32)
 
 
+def test_range_restricted_divide_equals_the_ieee_divide():
+    """dm::div_near_ (detmath.hip.h; Markstein's scheme on the exact reciprocal) against the IEEE divide on the device: all
+    2^23 divisor significands x divisor exponents -50 ... 50 (every fifth and both ends) x both divisor signs x 40
+    numerators each over exponents -40 ... 60 and both signs -- 32 pseudo-random, 8 built from the divisor (exact and
+    nearly exact quotients, all-ones, powers of two)."""
+    total = 0
+    for e in sorted(set(list(range(-50, 51, 5)) + [-49, -1, 0, 1, 49])):
+        bad, res = check_exhaustive(16, e, e)
+        assert bad == 0, "divisor exponent %d: %d mismatches, first (numerator, divisor) %s" % (e, bad, [float.hex(float(v)) for v in res[:4]])
+        total += (1 << 23) * 80
+    assert total > 1.5e10
+
+
+def test_range_restricted_divide_through_the_evaluation_entry_point():
+    """dm::div_near_ on ordinary operands (numerators of magnitude >= 2^-40, divisors in [2^-50, 2^50]) equals x / y."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    y = np.exp(rng.uniform(np.log(2.0 ** -50), np.log(2.0 ** 50), 1 << 16)).astype(np.float32)
+    x = (rng.standard_normal(1 << 16) * np.exp(rng.uniform(-20, 20, 1 << 16))).astype(np.float32)
+    x = np.where(np.abs(x) < 2.0 ** -40, np.float32(1.0), x)
+    assert np.array_equal(device_eval(16, x, y).view(np.uint32), (x / y).view(np.uint32))
+
+
 @pytest.mark.parametrize("what,exp_lo,exp_hi", [(11, -100, 100), (12, -96, 100), (13, -96, 100)])
 def test_range_restricted_operations_equal_the_ieee_ones_on_every_input(what, exp_lo, exp_hi):
     """dm::rcp_ / dm::sqrt_near_ / dm::rsqrt_near_ (detmath.hip.h) against the IEEE divide and sqrt
