@@ -72,13 +72,20 @@ DM float div_near_with_(float a, float b, float y)      // y = rcp_(b): shared b
 DM float div_near_(float a, float b) { return div_near_with_(a, b, rcp_(b)); }
 DM float sqrt_near_(float x)
 {
+    // s is within an ulp of the root; the residuals of its two neighbours say which of the three is nearest: x - s_dn s <= 0
+    // means s is too large (take s_dn), x - s_up s > 0 that it is too small (take s_up).  The two answers are taken from the
+    // residuals' bit patterns -- positive and non-zero <=> positive as an integer -- and added to s_dn's pattern: two
+    // v_med3_i32 and a three-operand add where the compare / select pairs went through VCC with wait states between them.
+    // (x = 0: s = 0, the saturating subtraction keeps s_dn at 0, both residuals are +0 and the result is 0.)
     const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = u2f(f2u(s) - 1u), s_up = u2f(f2u(s) + 1u);
-    const float r_dn = fma_(-s_dn, s, x);            // x - s_dn * s <= 0: s is too large, take s_dn
-    const float r_up = fma_(-s_up, s, x);            // x - s_up * s > 0: s is too small, take s_up
-    float r = (r_dn <= 0.0f) ? s_dn : s;
-    r = (r_up > 0.0f) ? s_up : r;
-    return r;
+    const uint32_t dn = __builtin_elementwise_sub_sat(f2u(s), 1u);
+    const float s_dn = u2f(dn), s_up = u2f(f2u(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x);
+    const float r_up = fma_(-s_up, s, x);
+    uint32_t m_dn, m_up;                                             // 1 if the residual is > 0, else 0
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(m_dn) : "v"(r_dn));         // (asm: the compiler turns the clamp back into compare + carry)
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(m_up) : "v"(r_up));
+    return u2f(dn + m_dn + m_up);
 }
 DM float rsqrt_near_(float x) { return rcp_(sqrt_near_(x)); }
 
