@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
 #endif
 }
 
+#ifndef CLSIMHIP_TAB_UNIT      // (prop_tab_kernel.hip compiles this file for the TABULATE instantiations only)
 // meta[1] = largest numPhotons of the bunch (sizes the slices of the unit queue)
 __global__ void __launch_bounds__(256) scan_steps_kernel(const DevStep *steps, uint32_t n, uint32_t *meta, WorkRecord *work,
                                                          const uint64_t *rng_x, const uint32_t *rng_a, uint32_t num_generators)
@@ -820,6 +821,11 @@ hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipS
     return hipGetLastError();
 }
 
+#else
+hipError_t launch_scan_steps(const KParams &P, hipStream_t stream);
+hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream);
+#endif
+
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
@@ -901,6 +907,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     return launch_assemble_hits(P, FLASHER, dev, stream);
 }
 
+#ifndef CLSIMHIP_TAB_UNIT
 hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
 {
     if (P.n_steps == 0) return hipSuccess;
@@ -923,6 +930,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     return hipErrorInvalidValue;
 }
 
+#else
 // TABULATE variants: FLASHER is always compiled in (the source type is looked at per step)
 hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
 {
@@ -942,6 +950,8 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
     return hipErrorInvalidValue;
 }
 
+#endif
+#ifndef CLSIMHIP_TAB_UNIT
 size_t prop_kernel_lds_bytes(uint32_t table_words) { return (size_t)(table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock) * 4; }
 int prop_kernel_block_size() { return kBlock; }
 // upper bound of the lanes of one launch (persistent grid: at most 2048 resident threads per CU)
@@ -967,4 +977,5 @@ hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t
     return hipGetLastError();
 }
 
+#endif
 } // namespace clsimhip

@@ -1,0 +1,6 @@
+// The TABULATE instantiations of prop_kernel (the table maker, prop_kernel.hip: TAB = 1, 2) as a translation unit of their
+// own: they are compiled with the compiler's default code generation -- the table maker's limit is its fp64 atomics, and it
+// loses 3 % under the settings that the propagation instantiations gain 8-12 % from (Makefile: KERNEL_CODEGEN) -- and in
+// parallel with them.
+#define CLSIMHIP_TAB_UNIT 1
+#include "prop_kernel.hip"
