@@ -299,7 +299,7 @@ def main():
     import torch.distributed as dist
     from clsim_amd import converter as CV
     from clsim_amd import synthetic as S
-    from clsim_amd.distributed import HitGatherer
+    from clsim_amd.distributed import HitGatherer, gather_hits as dist_gather_hits
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -356,7 +356,33 @@ def main():
     if use_gather:
         # detected photons of all ranks on rank 0 through the C ABI (RCCL called from the library; torch.distributed
         # only distributes the unique id): counts all-gather, then one point-to-point transfer per peer
-        gatherer = HitGatherer.from_process_group(local_rank) if world > 1 else HitGatherer(local_rank, 0, 1, HitGatherer.unique_id())
+        gather_note = None
+        try:
+            HitGatherer.unique_id()                     # loads RCCL: a local call, before anything collective
+        except Exception as exc:
+            gather_note = "%s: %s" % (type(exc).__name__, str(exc)[:120])
+        if world > 1:
+            ok = torch.tensor([0 if gather_note else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                gather_note = gather_note or "RCCL could not be loaded on another rank"
+        if gather_note is None:
+            try:
+                gatherer = HitGatherer.from_process_group(local_rank) if world > 1 else HitGatherer(local_rank, 0, 1, HitGatherer.unique_id())
+            except Exception as exc:                    # (communicator refused ...)
+                gatherer, gather_note = None, "%s: %s" % (type(exc).__name__, str(exc)[:120])
+        if world > 1:
+            # every rank takes the same path: if the library's communicator failed anywhere, all fall back to the
+            # same gather through torch.distributed (clsim_amd/distributed.py: gather_hits), and the line says so
+            ok = torch.tensor([1 if gatherer is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if gatherer is not None:
+                    gatherer.close()
+                gatherer = None
+                gather_note = gather_note or "the communicator failed on another rank"
+        elif gatherer is None:
+            raise RuntimeError(gather_note)
         gathered = torch.empty(((capacity if rank == 0 else 1), 80), dtype=torch.uint8, device=dev)
         comm_stream = torch.cuda.Stream(device=dev)
     kernel_done = [torch.cuda.Event() for _ in range(n_buffers)]
@@ -365,8 +391,16 @@ def main():
 
     def do_gather(b):
         comm_stream.wait_event(kernel_done[b])
-        counts = gatherer.gather(d_photons[b].data_ptr(), d_count[b].data_ptr(), capacity, 0, gathered.data_ptr(), gathered.shape[0],
-                                 comm_stream.cuda_stream)
+        if gatherer is not None:
+            counts = gatherer.gather(d_photons[b].data_ptr(), d_count[b].data_ptr(), capacity, 0, gathered.data_ptr(), gathered.shape[0],
+                                     comm_stream.cuda_stream)
+        else:                                           # fallback: torch.distributed (synchronous on the comm stream)
+            with torch.cuda.stream(comm_stream):
+                raw = int(d_count[b].item())
+                _, c = dist_gather_hits(d_photons[b], raw, dst=0, out=(gathered if rank == 0 else None))
+                counts = c.numpy().astype(np.uint64)
+                if raw > capacity:
+                    counts[rank] = raw
         gather_done[b].record(comm_stream)
         state["hits"] += int(np.minimum(counts, capacity).sum())
         state["overflow"] += int((counts > capacity).sum())
@@ -458,7 +492,9 @@ def main():
                        "kind": {"c2": "cascade steps", "c3": "cascade steps", "c5": "flasher steps (405 nm point source at a DOM)"}[args.workload],
                        "ice_layers": 171, "doms": 5160,
                        "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
-                       "hit_gather": "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if use_gather else "none",
+                       "hit_gather": ("none" if not use_gather else
+                                      "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if gatherer is not None else
+                                      "FALLBACK torch.distributed gather_hits (%s)" % gather_note),
                        "hits_last_pass_rank0": hits_last, "hit_counter_last_pass_rank0": counted_last,
                        "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
                        "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0)},
