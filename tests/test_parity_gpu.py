@@ -111,6 +111,49 @@ def _run_custom(med_o, med_p, geom, gens_o, gens_p, steps, pancake=5.0, max_item
     assert np.array_equal(conv.GetRNGState(n), x_o)
 
 
+def test_range_restricted_divides_fall_back_to_the_ieee_sequence():
+    """The exact divide of the layer walk and of the rotation (detmath.hip.h: div_near_) serves numerators of magnitude
+    >= 2^-40 only; a wave that holds anything else takes the IEEE branch.  Two kinds of steps force those branches:
+    photons born EXACTLY on a layer boundary and heading down (height above the boundary = +0), and steps of a particle
+    below the Cherenkov threshold (cos = min(1, 1/(beta n)) = 1, so the cone's sine and both numerators of the rotation
+    are zero).  Output and RNG states must equal the oracle's, which divides the IEEE way throughout."""
+    import os
+    from clsim_amd import converter as CV
+    from oracle import builders as B
+    ice = os.path.join(common.ICE, "spice_mie")
+    med_o = B.load_ppc_ice(ice, use_tilt_if_available=False)
+    med_p = CV.MakeIceCubeMediumProperties(iceDataDirectory=ice, useTiltIfAvailable=False)
+    geom = S.ic86_geometry()
+    steps = common.steps_for(common.config("mie"), 3072, seed=77)
+    bottom, height = np.float32(med_o["layers_z_start"]), np.float32(med_o["layers_height"])
+    k = np.arange(1024) % 120 + 25
+    on_boundary = (k.astype(np.float32) * height) + bottom                      # mediumLayerBoundary, c.cl:78-81, in float
+    steps["z"][:1024] = on_boundary
+    steps["length"][:1024] = 0.0                                                # photons are born at the step's start
+    steps["theta"][:1024] = np.float32(np.pi)                                   # heading down
+    # the layer the kernel finds for such a point must be the one whose lower boundary it sits on, at least for many of them
+    layer = ((on_boundary - bottom) / height).astype(np.int32)
+    assert np.count_nonzero((layer.astype(np.float32) * height) + bottom == on_boundary) > 500
+    steps["beta"][1024:2048] = 0.5
+    x, a = common.streams(len(steps))
+    geo = B.build_geometry(geom["string_ids"], geom["dom_ids"], geom["x"], geom["y"], geom["z"], geom["subdetectors"], geom["om_radius"])
+    bias_o = B.icecube_dom_acceptance()
+    T = capi.make_tables(med_o, geo, [B.cherenkov_wlen_generator(bias_o, med_o)], bias_o, pancake=5.0)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    ph_o = capi.replace_indices_with_ids(ph_o, T.geo)
+    bias_p = CV.GetIceCubeDOMAcceptance()
+    conv = CV.initializeHIP(0, CV.I3CLSimSimpleGeometry.from_dict(geom), med_p, bias_p, [CV.makeCherenkovWavelengthGenerator(bias_p, med_p)],
+                            pancakeFactor=5.0, approximateNumberOfWorkItems=len(steps), streams=(x, a))
+    conv.EnqueueSteps(steps, 5)
+    _, ph_p = conv.GetConversionResult()
+    assert cnt_o > 100 and len(ph_p) == cnt_o
+    assert common.sort_photons(ph_o).tobytes() == common.sort_photons(ph_p).tobytes()
+    assert np.array_equal(conv.GetRNGState(len(steps)), x_o)
+    for part in (slice(0, 1024), slice(1024, 2048)):                            # both kinds of steps did produce detected photons
+        ids = set(steps["id"][part].tolist())
+        assert any(int(i) in ids for i in ph_p["id"])
+
+
 @pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1",
                                   "table_float", "table_with_tilt_and_aniso", "no_dispersion_no_bias"])
 def test_other_kernel_variants(kind):
