@@ -797,4 +797,21 @@ DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
     return born.abs_lens_initial;
 }
 
+// `count` staged 64-byte stubs of a wave into the photon buffer: one atomic on the hit counter, then every stub as one
+// contiguous run of 16 dwords into its 80-byte slot, by all 64 lanes.  The counter keeps counting past max_hits; only the
+// first max_hits arrivals are stored (c.cl:329-334).
+DM void flush_hit_stubs(KP P, const uint32_t *stage, uint32_t count, uint32_t lane)
+{
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(P->hit_count, count);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t max_hits = P->max_hits;
+    const uint32_t room = (base < max_hits) ? (max_hits - base) : 0u;
+    const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(P->out) + (size_t)base * 20u;
+    for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 } // namespace clsimhip

@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     }
     uint32_t sub_queue = (blockIdx.x * (uint32_t)kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % (uint32_t)kSubQueues;     // wave-uniform, and known to be
     uint32_t used_up = 0;                                                                                          // in a row
+    uint32_t n_staged = 0;     // hit stubs waiting in the wave's staging area
     uint32_t sidx = kNoStep;
     uint64_t rx = 0;
     uint32_t ra = 0;
@@ -534,9 +535,37 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
             }
         }
-        // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+        // ---- hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+        // Without photon histories the stubs collect in the wave's staging area across trips and leave kStageRecords at a
+        // time (prop_pool_kernel.hip: one atomic on the chip-wide hit counter per eight hits).  A photon history is copied
+        // next to its hit and needs the hit's final index at once: that mode keeps the flush per trip.
         const uint64_t hit_mask = ballot(hit);
-        if (hit_mask != 0ull) {
+        if ((hit_mask != 0ull) && (fresh_params(P0)->history_n == 0)) {
+            const uint32_t total = (uint32_t)__popcll(hit_mask);
+            const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
+            for (uint32_t done = 0; done < total;) {
+                const uint32_t space = (uint32_t)kStageRecords - n_staged;
+                const uint32_t take = (total - done < space) ? (total - done) : space;
+                if (hit && rank >= done && rank < done + take) {
+                    uint32_t *st = stage + (n_staged + rank - done) * kStubWords;
+                    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
+                    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
+                    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
+                    st[11] = ph.num_scatters; st[12] = sidx;
+                    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
+                    st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
+                }
+                n_staged += take;
+                done += take;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (n_staged == (uint32_t)kStageRecords) {
+                    flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
+                    n_staged = 0u;
+                }
+            }
+        } else if (hit_mask != 0ull) {
             const KP P = fresh_params(P0);
             const uint32_t total = (uint32_t)__popcll(hit_mask);
             uint32_t base = 0;
@@ -605,6 +634,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         m_ready = ballot(alive && !need_next);
         if ((m_need | m_ready) == 0ull) break;
     }
+    if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0 && !TAB) {
         unsigned long long *d = fresh_params(P0)->census;

@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // wave-uniform bookkeeping of the U unit slots: each is in a lane, in `ready`, in `pending`, empty or gone
     uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group) % (uint32_t)kSubQueues;
     uint32_t used_up = 0;                       // sub-queues found used up in a row
+    uint32_t n_staged = 0;                      // hit stubs waiting in the staging area
     uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_left = U;     // n_wait: pending units that wait for a predecessor; n_left: unit slots not yet retired
 
     // per lane: the photon it carries and the unit that photon belongs to
@@ -369,20 +370,20 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     st = kLive;
                     advance = true;
                 }
-                // ---- wave-aggregated hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+                // ---- hit write-out (c.cl:329-385, collision c.cl:557-578) ----
+                // Stubs collect in the wave's staging area ACROSS trips and leave for the photon buffer kStageRecords at
+                // a time (and at the end of the kernel): one atomic on the hit counter per eight hits.  That counter is one
+                // address for the whole chip and sustains about 1e8 additions per second (like the queue heads, section 5):
+                // a cascade next to a string (the reference's benchmark: 4 % of the photons detected) asked for that many.
                 const uint64_t hit_mask = ballot(hit);
                 if (hit_mask != 0ull) {
-                    const KP P = fresh_params(P0);
                     const uint32_t total = (uint32_t)__popcll(hit_mask);
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P->hit_count, total);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
-                    const uint32_t max_hits = P->max_hits;
-                    uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
-                    for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
-                        if (hit && rank >= chunk && rank < chunk + kStageRecords) {
-                            uint32_t *st = stage + (rank - chunk) * kStubWords;
+                    for (uint32_t done = 0; done < total;) {
+                        const uint32_t space = (uint32_t)kStageRecords - n_staged;
+                        const uint32_t take = (total - done < space) ? (total - done) : space;
+                        if (hit && rank >= done && rank < done + take) {
+                            uint32_t *st = stage + (n_staged + rank - done) * kStubWords;
                             st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
                             st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
                             st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
@@ -390,19 +391,15 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                             st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
                             st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
                         }
+                        n_staged += take;
+                        done += take;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const uint32_t first = base + chunk;
-                        const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
-                        // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
-                        const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
-                        const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
-                        uint32_t *dst = out_words + (size_t)first * 20u;
-                        // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
-                        for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        if (n_staged == (uint32_t)kStageRecords) {
+                            flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
+                            n_staged = 0u;
+                        }
                     }
                 }
             }
@@ -432,6 +429,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         m_live = ballot(st >= kLive);
         if ((m_live | m_spent | (uint64_t)n_left) == 0ull) break;                // every unit slot has been retired (one test: the loop is scalar-issue bound)
     }
+    if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0) {
         unsigned long long *d = fresh_params(P0)->census;
