@@ -155,12 +155,13 @@ def test_oracle_agrees_with_an_independent_monte_carlo(oracle_lib):
     assert abs(direct_o.mean() - direct_m.mean()) < 4.5 * math.sqrt(direct_o.var() / len(direct_o) + direct_m.var() / len(direct_m))
 
 
-def layered_monte_carlo(steps, geom, rng, acceptance, z_start, height, abs_len, sca_len, wl_grid):
+def layered_monte_carlo(steps, geom, rng, acceptance, z_start, height, abs_len, sca_len, wl_grid, layer_shift=None):
     """The same model in depth-layered ice: abs_len / sca_len[layer, wavelength bin] are the layers' lengths (inputs: the
     ice model's formulas are pinned separately).  The path to the next scattering is found by accumulating optical depth
     layer by layer -- sum of (path in layer) / (scattering length of the layer) reaches -ln u -- and the absorption budget,
     counted in absorption lengths, is used up the same way.  Written for this test (a vectorised march from boundary to
-    boundary), not after the reference's loop."""
+    boundary), not after the reference's loop.  `layer_shift(pos)`: how far the ice layers lie above their nominal depth at a
+    point (ice tilt); the layers are taken as flat at the height they have at the scattering vertex the path starts from."""
     n_layers = abs_len.shape[0]
     n_ph = steps["num"].astype(np.int64)
     idx = np.repeat(np.arange(len(steps)), n_ph)
@@ -189,6 +190,8 @@ def layered_monte_carlo(steps, geom, rng, acceptance, z_start, height, abs_len, 
     while len(alive):
         m = len(alive)
         z, dz = pos[alive, 2].copy(), d[alive, 2]
+        if layer_shift is not None:
+            z -= layer_shift(pos[alive])                             # depth in the layers' own frame
         tau_s = -np.log(1.0 - rng.random(m))                       # scattering lengths to the next scatter
         tau_a = budget[alive].copy()
         seg = np.zeros(m)
@@ -282,3 +285,67 @@ def test_layered_ice_assembly_agrees_with_an_independent_monte_carlo(oracle_lib)
     for name, x, y in (("time", to, time_m), ("scatters", photons["numScatters"].astype(np.float64), scat_m.astype(np.float64))):
         err = math.sqrt(x.var() / len(x) + y.var() / len(y))
         assert abs(x.mean() - y.mean()) < 4.5 * err, (name, x.mean(), y.mean(), err)
+
+
+def test_ice_tilt_agrees_with_an_independent_monte_carlo(oracle_lib):
+    """SPICE-Mie with its tilt table made six times steeper, one string 440 m along the tilt direction, where the layers
+    then lie about 50 m off their nominal depth: the dust layers move by three DOM spacings along the string (the real
+    table moves them by half a spacing there -- too little to tell from hit counts).  The independent code interpolates
+    the table itself (bilinearly in the distance along the tilt direction and in depth) and looks the layers up at the
+    shifted depth; the table's numbers are inputs (pinned against the reference's loader elsewhere), its use -- the
+    direction of the gradient and the sign of the shift included -- is what is compared."""
+    import os
+    med = B.load_ppc_ice(os.path.join(common.ICE, "spice_mie"))
+    med["tilt"] = dict(med["tilt"], zcorr=6.0 * np.asarray(med["tilt"]["zcorr"], dtype=np.float64))
+    tilt = med["tilt"]
+    dist, zc, corr, az = (np.asarray(tilt[k], dtype=np.float64) for k in ("distances", "zcoords", "zcorr", "azimuth"))
+    along_gradient = 440.0
+    sx, sy = along_gradient * math.cos(float(az)), along_gradient * math.sin(float(az))
+    geom = S.single_string_geometry()
+    geom["x"] = np.full(60, sx); geom["y"] = np.full(60, sy)
+    cfg = dict(name="mie_tilt_one_string", geom=geom, med_o=med, med_p=None, flasher=False)
+    T = common.oracle_tables(cfg, pancake=1.0)
+    n_steps = 8192
+    steps = S.cascade_steps(n_steps, seed=41, radius=25.0, half_height=330.0)
+    steps["z"] += np.float32(120.0)                                                    # z = -210 ... 450: the table's flat part, dust layer included
+    steps["x"] += np.float32(sx); steps["y"] += np.float32(sy)
+    a = B.mwc_multipliers(n_steps)
+    photons, count, _, _ = capi.propagate(T, steps, B.seed_streams(a, 616), a, threads=8)
+    assert count == len(photons) > 2000
+
+    def layer_shift(p):
+        nr = math.cos(float(az)) * p[:, 0] + math.sin(float(az)) * p[:, 1]
+        j = np.clip(np.searchsorted(dist, nr, side="right"), 1, len(dist) - 1)          # dist[j-1] <= nr < dist[j]
+        w = (nr - dist[j - 1]) / (dist[j] - dist[j - 1])
+        lo = np.empty(len(p)); hi = np.empty(len(p))
+        for k in range(1, len(dist)):                                                   # depth profile at the two neighbouring distances
+            m = j == k
+            if m.any():
+                lo[m] = np.interp(p[m, 2], zc, corr[k - 1]); hi[m] = np.interp(p[m, 2], zc, corr[k])
+        return lo + w * (hi - lo)
+
+    shift_at_string = layer_shift(np.array([[sx, sy, 0.0]]))[0]
+    assert 35.0 < abs(shift_at_string) < 70.0                                           # a shift worth measuring
+    wl_grid = np.linspace(260e-9, 680e-9, 841)
+    abs_len = np.stack([capi.eval_medium(T, 0, wl_grid, layer=l) for l in range(med["num_layers"])]).astype(np.float64)
+    sca_len = np.stack([capi.eval_medium(T, 1, wl_grid, layer=l) for l in range(med["num_layers"])]).astype(np.float64)
+    rng = np.random.Generator(np.random.PCG64(31415))
+    args = (steps, geom, rng, B.icecube_dom_acceptance(), med["layers_z_start"], med["layers_height"], abs_len, sca_len, wl_grid)
+    dom_m, time_m, scat_m = layered_monte_carlo(*args, layer_shift=layer_shift)
+    no, nm = len(photons), len(dom_m)
+    assert abs(no - nm) < 4.5 * math.sqrt(no + nm), (no, nm)
+    co = np.bincount(photons["omID"].astype(np.int64), minlength=60)[:60]
+    cm = np.bincount(dom_m, minlength=60)[:60]
+    msk = (co + cm) >= 20
+    chi2, ndf = float(np.sum((co[msk] - cm[msk]) ** 2 / (co[msk] + cm[msk]))), int(msk.sum())
+    assert ndf >= 30 and chi2 < ndf + 4.5 * math.sqrt(2 * ndf), (chi2, ndf)
+    # ... and the comparison can tell: without the shift the same code misplaces the main dust layer, which the steep
+    # table moves by three DOMs (the string's DOMs between z = -250 and +80 m see it)
+    rng = np.random.Generator(np.random.PCG64(31415))
+    args = (steps, geom, rng) + args[3:]
+    dom_flat, _, _ = layered_monte_carlo(*args, layer_shift=None)
+    cf = np.bincount(dom_flat, minlength=60)[:60]
+    window = slice(25, 45)
+    local = float(np.sum((co[window] - cm[window]) ** 2 / np.maximum(co[window] + cm[window], 1)))
+    local_flat = float(np.sum((co[window] - cf[window]) ** 2 / np.maximum(co[window] + cf[window], 1)))
+    assert local < 20 + 4.5 * math.sqrt(40) and local_flat > local + 20.0, (local, local_flat)
