@@ -800,7 +800,7 @@ DM float make_hit_record(KP P, const HitStub &h, uint32_t *rec)
 // `count` staged 64-byte stubs of a wave into the photon buffer: one atomic on the hit counter, then every stub as one
 // contiguous run of 16 dwords into its 80-byte slot, by all 64 lanes.  The counter keeps counting past max_hits; only the
 // first max_hits arrivals are stored (c.cl:329-334).
-DM void flush_hit_stubs(KP P, const uint32_t *stage, uint32_t count, uint32_t lane)
+DM uint32_t flush_hit_stubs(KP P, const uint32_t *stage, uint32_t count, uint32_t lane)      // returns the first stub's index
 {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(P->hit_count, count);
@@ -812,6 +812,7 @@ DM void flush_hit_stubs(KP P, const uint32_t *stage, uint32_t count, uint32_t la
     for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    return base;
 }
 
 } // namespace clsimhip

@@ -536,18 +536,21 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
         }
         // ---- hit write-out (c.cl:329-385, collision c.cl:557-578) ----
-        // Without photon histories the stubs collect in the wave's staging area across trips and leave kStageRecords at a
-        // time (prop_pool_kernel.hip: one atomic on the chip-wide hit counter per eight hits).  A photon history is copied
-        // next to its hit and needs the hit's final index at once: that mode keeps the flush per trip.
+        // The stubs collect in the wave's staging area across trips and leave kStageRecords at a time (and at the end of the
+        // kernel): one atomic on the chip-wide hit counter per eight hits (prop_pool_kernel.hip).  A photon history is
+        // copied next to its hit and needs the hit's final index at once: with histories every chunk leaves right away.
         const uint64_t hit_mask = ballot(hit);
-        if ((hit_mask != 0ull) && (fresh_params(P0)->history_n == 0)) {
+        if (hit_mask != 0ull) {
             const uint32_t total = (uint32_t)__popcll(hit_mask);
             const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
+            const uint32_t hn = (uint32_t)fresh_params(P0)->history_n;
             for (uint32_t done = 0; done < total;) {
                 const uint32_t space = (uint32_t)kStageRecords - n_staged;
                 const uint32_t take = (total - done < space) ? (total - done) : space;
-                if (hit && rank >= done && rank < done + take) {
-                    uint32_t *st = stage + (n_staged + rank - done) * kStubWords;
+                const bool mine = hit && rank >= done && rank < done + take;
+                const uint32_t slot = n_staged + rank - done;
+                if (mine) {
+                    uint32_t *st = stage + slot * kStubWords;
                     st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
                     st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
                     st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
@@ -560,49 +563,16 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (n_staged == (uint32_t)kStageRecords) {
-                    flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
+                if ((n_staged == (uint32_t)kStageRecords) || (hn != 0u)) {
+                    const KP P = fresh_params(P0);
+                    const uint32_t base = flush_hit_stubs(P, stage, n_staged, lane);
                     n_staged = 0u;
+                    if ((hn != 0u) && mine && (base + slot < P->max_hits)) {    // c.cl:387-392 (the staging area was empty before this chunk)
+                        const float4 *ring = reinterpret_cast<const float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
+                        float4 *dst = reinterpret_cast<float4 *>(P->hist_out) + (size_t)(base + slot) * hn;
+                        for (uint32_t k = 0; k < hn; ++k) dst[k] = ring[k];
+                    }
                 }
-            }
-        } else if (hit_mask != 0ull) {
-            const KP P = fresh_params(P0);
-            const uint32_t total = (uint32_t)__popcll(hit_mask);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P->hit_count, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
-            const uint32_t max_hits = P->max_hits;
-            uint32_t *out_words = reinterpret_cast<uint32_t *>(P->out);
-            for (uint32_t chunk = 0; chunk < total; chunk += kStageRecords) {
-                if (hit && rank >= chunk && rank < chunk + kStageRecords) {
-                    uint32_t *st = stage + (rank - chunk) * kStubWords;
-                    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
-                    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(distance);
-                    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
-                    st[11] = ph.num_scatters; st[12] = sidx;
-                    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
-                    st[15] = (hit_string & 0xffffu) | (hit_dom << 16);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t first = base + chunk;
-                const uint32_t count = (total - chunk < (uint32_t)kStageRecords) ? (total - chunk) : (uint32_t)kStageRecords;
-                // the counter keeps counting past max_hits; only the first max_hits arrivals are stored
-                const uint32_t room = (first < max_hits) ? (max_hits - first) : 0u;
-                const uint32_t words = ((count < room) ? count : room) * (uint32_t)kStubWords;
-                uint32_t *dst = out_words + (size_t)first * 20u;
-                // 64-byte stubs into 80-byte slots: each stub is one contiguous run of 16 dwords
-                for (uint32_t w = lane; w < words; w += 64u) dst[(w >> 4) * 20u + (w & 15u)] = stage[w];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            const uint32_t hn = (uint32_t)P->history_n;
-            if ((hn != 0u) && hit && (base + rank < max_hits)) {                // c.cl:387-392
-                const float4 *ring = reinterpret_cast<const float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * hn;
-                float4 *dst = reinterpret_cast<float4 *>(P->hist_out) + (size_t)(base + rank) * hn;
-                for (uint32_t k = 0; k < hn; ++k) dst[k] = ring[k];
             }
         }
         if (advance) {
