@@ -131,7 +131,7 @@ public:
         I3CLSimStepSeriesPtr out(new I3CLSimStepSeries());
         out->resize(n);
         static_assert(sizeof(I3CLSimStep) == sizeof(clsimhip_step), "I3CLSimStep is the 48-byte record of the C ABI");
-        if (n) std::memcpy(&(*out)[0], steps, n * sizeof(clsimhip_step));
+        if (n) std::memcpy(static_cast<void *>(&(*out)[0]), steps, n * sizeof(clsimhip_step));
         finished.assign(fin, fin + nfin);
         barrierWasReset = reset != 0;
         check(clsimhip_feeder_release_result(feeder_, steps));

@@ -104,7 +104,9 @@ public:
         if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
     }
 #endif
-    ~I3CLSimStepToPhotonConverterHIP() override { clsimhip_destroy(handle_); }
+    // the reference interface declares no virtual destructor (I3CLSimStepToPhotonConverter.h:88 has it commented out):
+    // converters live in shared_ptrs made from the concrete type, as I3CLSimStepToPhotonConverterOpenCLPtr does
+    virtual ~I3CLSimStepToPhotonConverterHIP() { clsimhip_destroy(handle_); }
     I3CLSimStepToPhotonConverterHIP(const I3CLSimStepToPhotonConverterHIP &) = delete;
     I3CLSimStepToPhotonConverterHIP &operator=(const I3CLSimStepToPhotonConverterHIP &) = delete;
 

@@ -7,7 +7,7 @@
 #include <icetray/I3PointerTypedefs.h>
 class I3CLSimSimpleGeometry {
 public:
-    virtual ~I3CLSimSimpleGeometry() {}
+    // no virtual destructor in the reference (I3CLSimSimpleGeometry.h:44-63): geometries live in shared_ptrs of the concrete type
     virtual std::size_t size() const = 0;
     virtual double GetOMRadius() const = 0;
     virtual const std::vector<int32_t> &GetStringIDVector() const = 0;

@@ -33,7 +33,7 @@ public:
         I3CLSimPhotonSeriesPtr photons;
         I3CLSimPhotonHistorySeriesPtr photonHistories;
     };
-    virtual ~I3CLSimStepToPhotonConverter() {}
+    // no virtual destructor: the reference has it commented out (I3CLSimStepToPhotonConverter.h:88)
     virtual void SetWlenGenerators(const std::vector<I3CLSimRandomValueConstPtr> &wlenGenerators) = 0;
     virtual void SetWlenBias(I3CLSimFunctionConstPtr wlenBias) = 0;
     virtual void SetMediumProperties(I3CLSimMediumPropertiesConstPtr mediumProperties) = 0;

@@ -8,4 +8,5 @@ struct I3Vector : public std::vector<T>, public I3FrameObject {
     explicit I3Vector(typename std::vector<T>::size_type s) : std::vector<T>(s) {}
     I3Vector(typename std::vector<T>::size_type s, const T &v) : std::vector<T>(s, v) {}
     template <typename It> I3Vector(It first, It last) : std::vector<T>(first, last) {}
+    template <class Archive> void serialize(Archive &ar, unsigned version);
 };

@@ -3,22 +3,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
-struct I3Position {
-    I3Position(double x = 0, double y = 0, double z = 0) : x_(x), y_(y), z_(z) {}
-    double GetX() const { return x_; }
-    double GetY() const { return y_; }
-    double GetZ() const { return z_; }
-private:
-    double x_, y_, z_;
-};
-struct I3Direction {
-    I3Direction(double x = 0, double y = 0, double z = 1) : x_(x), y_(y), z_(z) {}
-    double GetX() const { return x_; }
-    double GetY() const { return y_; }
-    double GetZ() const { return z_; }
-private:
-    double x_, y_, z_;
-};
+#include <dataclasses/I3Position.h>
+#include <dataclasses/I3Direction.h>
 class I3Particle {
 public:
     enum ParticleType { unknown = 0, Gamma = 22, EPlus = -11, EMinus = 11, MuPlus = -13, MuMinus = 13, TauPlus = -15, TauMinus = 15, Pi0 = 111,

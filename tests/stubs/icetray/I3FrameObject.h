@@ -1,6 +1,7 @@
 // stand-in (tests/stubs/README.md)
 #pragma once
 #include <icetray/I3PointerTypedefs.h>
+#include <icetray/serialization.h>
 class I3FrameObject {
 public:
     virtual ~I3FrameObject() {}
