@@ -5,13 +5,21 @@ One "step" = one pass of the hot path (the HIP propagation kernel behind the C
 ABI) over one bunch of synthetic I3CLSimSteps that is already resident in HBM.
 N=1 workload = BASELINE.json configs[1]: 1M cascade-like steps x 200 photons,
 SPICE-Mie layered ice with tilt, synthetic 86-string detector, DOM oversize 5.
-N>1: one process per GPU, every rank propagates its own bunch of the same size
-(weak scaling: steps are independent units, no data-path collective) and the
-detected photons are gathered on rank 0 inside the timed region (config C4)
+N>1: one process per GPU; a pass is the rank's whole shard of the configuration
+BASELINE.json names -- C4 = configs[3]: 100M steps / 8 = 12 500 000 steps per
+GPU, run as 3 bunches of 4 166 912 (a converter holds at most 6 139 850 RNG
+streams, OpenCL.cxx:250; the last bunch padded with no-op steps), weak scaling:
+the per-GPU shard is the same at N = 2, 4, 8; `--workload c5`: 10^9 photons / N,
+strong scaling.  Steps are independent units, no data-path collective; the
+detected photons of every bunch are gathered on rank 0 inside the timed region
 through the C ABI's RCCL gather (clsimhip_gather_hits: counts all-gather + one
-point-to-point transfer per peer); the gather of pass k runs on its own stream
-while the kernel of pass k+1 runs (two photon buffers).  torch.distributed only
-carries the RCCL unique id, the barriers and the max-over-ranks time.
+point-to-point transfer per peer), between two launches on the launch stream
+(`--gather-overlap`: on a second stream while the next kernel runs -- measured
+slower, the persistent propagation grid leaves a concurrent kernel only slivers
+of the chip).  torch.distributed only
+carries the RCCL unique id, the barriers and the max-over-ranks time.  If the C
+ABI's communicator cannot be used the torch.distributed twin runs instead, the
+line says so and the exit code is 3.
 
 Prints ONE JSON line on rank 0.  At N=1 the line also carries `host_path`: the
 reference's own calling pattern (a producer thread calls EnqueueSteps, the
@@ -57,6 +65,14 @@ def parse():
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the host_path object (profile passes: counters then cover the timed launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather-overlap", action="store_true",
+                    help="N>1: gather the photons of launch k on a second stream while launch k+1 runs (two photon buffers). Default: "
+                         "the gather runs between two launches on the launch stream -- the propagation kernel is a persistent grid "
+                         "that fills every CU, a copy or RCCL kernel beside it gets slivers of the chip and slows it down (DESIGN.md 7)")
+    ap.add_argument("--shard-steps", type=int, default=0,
+                    help="I3CLSimSteps per GPU and pass, cut into equal bunches of at most 6 139 850 (the converter's stream limit, "
+                         "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
+                         "c2 -> C4 = 100M steps / 8 = 12 500 000 per GPU (weak scaling), c5 -> 10^9 photons / N (strong scaling)")
     return ap.parse_args()
 
 
@@ -315,7 +331,22 @@ def main():
         return tabulator_bench(args, torch, local_rank)
     if args.workload == "benchmark":
         return benchmark_workload(args, torch, local_rank)
-    n = (args.bunch // 512) * 512
+    # ---- the rank's share of one pass: `shard` real steps in `n_bunches` equal bunches of n steps (a multiple of 512; the
+    # last bunch is padded with no-op steps like the reference pads a bunch before a barrier, Async.cxx:240-257) ----
+    STREAM_LIMIT = 6139850                              # 32-bit safeprime multipliers available (OpenCL.cxx:250)
+    scaling = "weak"
+    shard = args.shard_steps
+    if shard <= 0 and world > 1 and args.workload == "c2":
+        shard = 100000000 // 8                          # C4 = BASELINE configs[3]: 100M steps over 8 GPUs
+    if shard <= 0 and world > 1 and args.workload == "c5":
+        shard = -(-(10 ** 9 // args.photons_per_step) // world)     # C5 = BASELINE configs[4]: 10^9 photons over the GPUs
+        scaling = "strong"
+    if shard > 0:
+        n_bunches = -(-shard // ((STREAM_LIMIT // 512) * 512))
+        n = -(-(-(-shard // n_bunches)) // 512) * 512
+    else:
+        n_bunches, n = 1, (args.bunch // 512) * 512
+        shard = n
     # ---- configuration (same sequence as I3CLSimModuleHelper::initializeOpenCL) ----
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", args.ice))
     bias = CV.GetIceCubeDOMAcceptance()
@@ -326,13 +357,16 @@ def main():
         gens.append(CV.I3CLSimRandomValueConstant(405e-9))          # delta-peak spectrum (ModuleHelper.cxx:81-88)
     conv = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=args.host_path,
                             approximateNumberOfWorkItems=n, seed=12345 + rank)
-    if args.workload == "c5":
-        k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))   # a DOM near the detector centre
-        steps_np = S.flasher_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step,
+    def make_bunch(b):
+        real = min(n, shard - b * n)                    # the last bunch of a shard carries the padding
+        seed = 1000 + rank + 7919 * b
+        if args.workload == "c5":
+            k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))   # a DOM near the detector centre
+            return S.flasher_steps(real, seed=seed, photons_per_step=args.photons_per_step, pad_to=n,
                                    position=(float(g86["x"][k]), float(g86["y"][k]), float(g86["z"][k])))
-    else:
-        steps_np = S.cascade_steps(n, seed=1000 + rank, photons_per_step=args.photons_per_step)
-    photons_per_pass = int(steps_np["num"].sum())
+        return S.cascade_steps(real, seed=seed, photons_per_step=args.photons_per_step, pad_to=n)
+    steps_np = make_bunch(0)
+    assert len(steps_np) == n
 
     if args.host_path:
         hp = host_path_run(CV, args, steps_np, conv, max(args.steps, 1))
@@ -342,12 +376,19 @@ def main():
                           "config": {"workload": WORKLOAD_NAMES[args.workload], "steps_per_bunch": n}}))
         return
 
-    d_steps = torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)
+    d_steps = [torch.from_numpy(steps_np.view(np.uint8).reshape(n, 48)).to(dev)]
+    photons_per_pass = int(steps_np["num"].sum())
+    for b in range(1, n_bunches):
+        more = make_bunch(b)
+        photons_per_pass += int(more["num"].sum())
+        d_steps.append(torch.from_numpy(more.view(np.uint8).reshape(n, 48)).to(dev))
+        del more
     capacity = (4 if args.workload == "c2" else 48) * 1024 * 1024
     # two photon buffers: with several GPUs the gather of pass k (its own stream) runs while the kernel of pass k+1 does
     # (CLSIMHIP_BENCH_GATHER=1 runs the gather path in a world of one rank: the multi-GPU code path on a single GPU)
     use_gather = (world > 1) or (os.environ.get("CLSIMHIP_BENCH_GATHER") == "1")
-    n_buffers = 2 if use_gather else 1
+    overlap = use_gather and args.gather_overlap
+    n_buffers = 2 if overlap else 1
     d_photons = [torch.empty((capacity, 80), dtype=torch.uint8, device=dev) for _ in range(n_buffers)]
     d_count = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(n_buffers)]
     compute = torch.cuda.current_stream()
@@ -383,8 +424,13 @@ def main():
                 gather_note = gather_note or "the communicator failed on another rank"
         elif gatherer is None:
             raise RuntimeError(gather_note)
-        gathered = torch.empty(((capacity if rank == 0 else 1), 80), dtype=torch.uint8, device=dev)
-        comm_stream = torch.cuda.Stream(device=dev)
+        # room on the root for every rank's photons of one bunch: a rank stores at most `capacity` records, and fills a
+        # few per cent of that (C2: 0.2 hits per step) -- sized for four times the expected number, at least one
+        # rank's capacity; clsimhip_gather_hits reports on every rank if it ever were too small
+        expected = {"c2": 0.2, "c3": 0.2, "c5": 7.0}[args.workload] * n
+        gathered_rows = int(min(world * capacity, max(capacity, 4 * world * expected)))
+        gathered = torch.empty(((gathered_rows if rank == 0 else 1), 80), dtype=torch.uint8, device=dev)
+        comm_stream = torch.cuda.Stream(device=dev) if overlap else compute
     kernel_done = [torch.cuda.Event() for _ in range(n_buffers)]
     gather_done = [torch.cuda.Event() for _ in range(n_buffers)]
     state = {"pending": None, "hits": 0, "pass": 0, "overflow": 0}
@@ -405,17 +451,24 @@ def main():
         state["hits"] += int(np.minimum(counts, capacity).sum())
         state["overflow"] += int((counts > capacity).sum())
 
-    def one_pass():
+    def one_launch(bunch):
         b = state["pass"] % n_buffers
         state["pass"] += 1
         if use_gather:
             compute.wait_event(gather_done[b])          # buffer b is free once its previous gather has left it
-        conv.PropagateDevice(d_steps.data_ptr(), n, d_photons[b].data_ptr(), capacity, d_count[b].data_ptr(), stream=stream)
+        conv.PropagateDevice(d_steps[bunch].data_ptr(), n, d_photons[b].data_ptr(), capacity, d_count[b].data_ptr(), stream=stream)
         if use_gather:
             kernel_done[b].record(compute)
-            if state["pending"] is not None:
-                do_gather(state["pending"])             # the previous pass's photons travel while this kernel runs
-            state["pending"] = b
+            if not overlap:
+                do_gather(b)                            # in stream order, before the next launch
+            else:
+                if state["pending"] is not None:
+                    do_gather(state["pending"])         # the previous launch's photons travel while this kernel runs
+                state["pending"] = b
+
+    def one_pass():                                     # the rank's whole shard: one launch per bunch
+        for bunch in range(n_bunches):
+            one_launch(bunch)
 
     def flush():
         if use_gather and state["pending"] is not None:
@@ -451,6 +504,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if args.workload == "c2" and shard == 100000000 // 8:
+        workload_name = "C4 = BASELINE configs[3]: 100M steps / 8 GPUs = 12 500 000 steps per GPU%s, hits gathered on rank 0" % (
+            "" if world == 8 else " (this run: %d GPU%s, the same per-GPU shard)" % (world, "" if world == 1 else "s"))
+    elif args.workload == "c5" and world > 1:
+        workload_name = "C5 = BASELINE configs[4] (flasher half): 10^9 photons / %d GPUs, hits gathered on rank 0" % world
+    else:
+        workload_name = WORKLOAD_NAMES[args.workload]
     if rank == 0:
         value = photons_per_pass * args.steps * world / elapsed
         avg_ms = kernel_ms / max(launches, 1)
@@ -464,7 +524,7 @@ def main():
         valu = None
         traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and args.photons_per_step == 200:
+        if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and n_bunches == 1 and args.photons_per_step == 200:
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this same command
             # (FETCH_SIZE, WRITE_SIZE; see the file for how they were taken).  The file names the kernel and the git
             # revision it was profiled at: numbers of another kernel are not quoted.
@@ -484,16 +544,16 @@ def main():
         out = {
             "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d steps x %d photons per GPU, %s + tilt, 86 strings, oversize 5" %
-                                   (WORKLOAD_NAMES[args.workload] if world == 1 or args.workload != "c2" else "C4 = BASELINE configs[3] (per-GPU shard of C2 size)",
-                                    n, args.photons_per_step, args.ice),
+            "config": {"workload": "%s: %d steps x %d photons per GPU and pass in %d bunch%s of %d, %s + tilt, 86 strings, oversize 5" %
+                                   (workload_name, shard, args.photons_per_step, n_bunches, "" if n_bunches == 1 else "es", n, args.ice),
                        "kind": {"c2": "cascade steps", "c3": "cascade steps", "c5": "flasher steps (405 nm point source at a DOM)"}[args.workload],
                        "ice_layers": 171, "doms": 5160,
-                       "steps_per_gpu": n, "photons_per_step": args.photons_per_step,
+                       "steps_per_gpu": shard, "bunches_per_pass": n_bunches, "steps_per_bunch": n, "photons_per_step": args.photons_per_step,
+                       "photons_per_pass_all_gpus": photons_per_pass * world,
                        "hit_gather": ("none" if not use_gather else
-                                      "clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), overlapped with the next kernel" if gatherer is not None else
+                                      ("clsimhip_gather_hits (RCCL: counts all-gather + p2p to rank 0), " + ("overlapped with the next kernel" if overlap else "between two launches")) if gatherer is not None else
                                       "FALLBACK torch.distributed gather_hits (%s)" % gather_note),
                        "hits_last_pass_rank0": hits_last, "hit_counter_last_pass_rank0": counted_last,
                        "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
@@ -503,7 +563,7 @@ def main():
                          "kernel": kernel_name, "avg_kernel_ms": avg_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
-                                 (photons_per_pass / (avg_ms * 1e-3))},
+                                 (photons_per_pass / n_bunches / (avg_ms * 1e-3))},
         }
         if world == 1 and not args.no_host_path:
             # the reference's "actual" metric, outside the timed region of `value`: a second converter with two buffer sets
@@ -516,11 +576,17 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
         emit(json.dumps(out))
+    fell_back = use_gather and gatherer is None
     if gatherer is not None:
         gatherer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if fell_back:
+        # the line above measured the torch.distributed twin of the gather, not the C ABI's: say so to whoever reads the
+        # exit code as well
+        sys.stderr.write("bench.py: the C ABI's RCCL gather could not be used (%s); the fallback was measured\n" % gather_note)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -84,8 +84,13 @@ void hip_ok(hipError_t e, const char *what)
 struct Comm {
     int device = 0, rank = 0, world = 1;
     ncclComm_t comm = nullptr;
-    uint32_t *d_counts = nullptr;       // world counts, device
-    uint32_t *h_counts = nullptr;       // pinned
+    // what a rank announces: {hit counter, 0, room in its gather buffer (low, high word)}; the root's room decides, on
+    // every rank alike, how much travels
+    static constexpr size_t kWords = 4;
+    uint32_t *d_mine = nullptr;         // kWords, device
+    uint32_t *d_all = nullptr;          // world x kWords, device
+    uint32_t *h_mine = nullptr;         // kWords, pinned
+    uint32_t *h_all = nullptr;          // world x kWords, pinned
     hipEvent_t counted = nullptr;
 };
 
@@ -110,8 +115,11 @@ Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNI
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     nccl_check(rccl().CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
-    hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_counts), sizeof(uint32_t) * static_cast<size_t>(world)), "hipMalloc");
-    hip_ok(hipHostMalloc(reinterpret_cast<void **>(&c->h_counts), sizeof(uint32_t) * static_cast<size_t>(world), hipHostMallocDefault), "hipHostMalloc");
+    const size_t words = Comm::kWords * static_cast<size_t>(world);
+    hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_mine), sizeof(uint32_t) * Comm::kWords), "hipMalloc");
+    hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_all), sizeof(uint32_t) * words), "hipMalloc");
+    hip_ok(hipHostMalloc(reinterpret_cast<void **>(&c->h_mine), sizeof(uint32_t) * Comm::kWords, hipHostMallocDefault), "hipHostMalloc");
+    hip_ok(hipHostMalloc(reinterpret_cast<void **>(&c->h_all), sizeof(uint32_t) * words, hipHostMallocDefault), "hipHostMalloc");
     hip_ok(hipEventCreateWithFlags(&c->counted, hipEventDisableTiming), "hipEventCreate");
     return c.release();
 }
@@ -123,8 +131,10 @@ void comm_destroy(Comm *c)
     if (hipGetDevice(&previous) != hipSuccess) previous = -1;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
-    (void)hipFree(c->d_counts);
-    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    (void)hipFree(c->d_mine);
+    (void)hipFree(c->d_all);
+    if (c->h_mine) (void)hipHostFree(c->h_mine);
+    if (c->h_all) (void)hipHostFree(c->h_all);
     if (c->counted) (void)hipEventDestroy(c->counted);
     if (previous >= 0) (void)hipSetDevice(previous);
     delete c;
@@ -132,50 +142,78 @@ void comm_destroy(Comm *c)
 
 // Blocks the calling thread only until the hit counts are known (the kernel that produced them must have finished
 // anyway); the payload transfers are left running on `stream`.
+//
+// Every decision about what travels is taken from all-gathered numbers that every rank holds -- the ranks' hit counters
+// and the room in the ROOT's gather buffer -- so the sends and receives always pair up.  A gather buffer that is too
+// small is not an error one rank may throw on its own (its peers would post sends that nobody receives, and an RCCL send
+// kernel spins on the GPU until it is matched): the root receives the prefix that fits, rank by rank, and then EVERY
+// rank reports CLSIMHIP_ERR_ARGUMENT.  The same goes for unequal photon buffer capacities: a rank announces what it
+// stored, not its counter.
 void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, size_t capacity, int root, void *d_gathered,
                       size_t gathered_capacity, uint64_t *counts_out, hipStream_t stream)
 {
     if (!c) throw Error(CLSIMHIP_ERR_ARGUMENT, "communicator is (null)");
     if (!d_photons || !d_hit_count) throw Error(CLSIMHIP_ERR_ARGUMENT, "device pointers are (null)");
     if (root < 0 || root >= c->world) throw Error(CLSIMHIP_ERR_ARGUMENT, "root rank out of range");
-    if (c->rank == root && !d_gathered) throw Error(CLSIMHIP_ERR_ARGUMENT, "the root needs a gather buffer");
+    // a root without a buffer announces room for nothing: the collective below still pairs up and every rank gets the error
+    if (c->rank == root && !d_gathered) gathered_capacity = 0;
     DeviceGuard on_device(c->device);
     const Rccl &R = rccl();
-    nccl_check(R.AllGather(d_hit_count, c->d_counts, 1, ncclUint32, c->comm, stream), "ncclAllGather (hit counts)");
-    hip_ok(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t) * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, stream), "download hit counts");
+    const size_t W = Comm::kWords;
+    c->h_mine[0] = 0;
+    c->h_mine[1] = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffu));
+    c->h_mine[2] = static_cast<uint32_t>(static_cast<uint64_t>(gathered_capacity) & 0xffffffffu);
+    c->h_mine[3] = static_cast<uint32_t>(static_cast<uint64_t>(gathered_capacity) >> 32);
+    hip_ok(hipMemcpyAsync(c->d_mine, c->h_mine, sizeof(uint32_t) * W, hipMemcpyHostToDevice, stream), "upload gather header");
+    hip_ok(hipMemcpyAsync(c->d_mine, d_hit_count, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream), "copy hit counter");
+    nccl_check(R.AllGather(c->d_mine, c->d_all, W, ncclUint32, c->comm, stream), "ncclAllGather (hit counts)");
+    hip_ok(hipMemcpyAsync(c->h_all, c->d_all, sizeof(uint32_t) * W * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, stream), "download hit counts");
     hip_ok(hipEventRecord(c->counted, stream), "event");
     hip_ok(hipEventSynchronize(c->counted), "hit counts");
     // The kernel's counter keeps counting past the capacity of the photon buffer (propagation_kernel.c.cl:329-334);
-    // a rank sends what it stored.  Every rank clamps every count the same way (equal capacities per rank).
-    std::vector<size_t> stored(static_cast<size_t>(c->world));
-    size_t total = 0;
+    // a rank sends what it stored, and no more than still fits on the root.
+    const uint64_t room = static_cast<uint64_t>(c->h_all[W * root + 2]) | (static_cast<uint64_t>(c->h_all[W * root + 3]) << 32);
+    std::vector<size_t> travels(static_cast<size_t>(c->world));
+    uint64_t total = 0, accepted = 0;
     for (int r = 0; r < c->world; ++r) {
-        stored[r] = std::min<size_t>(c->h_counts[r], capacity);
-        if (counts_out) counts_out[r] = c->h_counts[r];
-        total += stored[r];
+        const uint64_t stored = std::min<uint64_t>(c->h_all[W * r], c->h_all[W * r + 1]);
+        if (counts_out) counts_out[r] = c->h_all[W * r];
+        travels[r] = static_cast<size_t>(std::min<uint64_t>(stored, room - accepted));
+        accepted += travels[r];
+        total += stored;
     }
-    if (c->rank == root && total > gathered_capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "gather buffer too small for the detected photons of all ranks");
     constexpr size_t kRecord = sizeof(clsimhip_photon);
     if (c->world > 1) {
         nccl_check(R.GroupStart(), "ncclGroupStart");
+        ncclResult_t failed = ncclSuccess;
+        const char *where = "";
         if (c->rank == root) {
             size_t offset = 0;
-            for (int r = 0; r < c->world; ++r) {
-                if (r != root && stored[r] != 0)
-                    nccl_check(R.Recv(static_cast<uint8_t *>(d_gathered) + offset * kRecord, stored[r] * kRecord, ncclUint8, r, c->comm, stream), "ncclRecv");
-                offset += stored[r];
+            for (int r = 0; r < c->world && failed == ncclSuccess; ++r) {
+                if (r != root && travels[r] != 0) {
+                    failed = R.Recv(static_cast<uint8_t *>(d_gathered) + offset * kRecord, travels[r] * kRecord, ncclUint8, r, c->comm, stream);
+                    where = "ncclRecv";
+                }
+                offset += travels[r];
             }
-        } else if (stored[c->rank] != 0) {
-            nccl_check(R.Send(d_photons, stored[c->rank] * kRecord, ncclUint8, root, c->comm, stream), "ncclSend");
+        } else if (travels[c->rank] != 0) {
+            failed = R.Send(d_photons, travels[c->rank] * kRecord, ncclUint8, root, c->comm, stream);
+            where = "ncclSend";
         }
-        nccl_check(R.GroupEnd(), "ncclGroupEnd");
+        const ncclResult_t closed = R.GroupEnd();          // a group that was opened is always closed
+        nccl_check(failed, where);
+        nccl_check(closed, "ncclGroupEnd");
     }
-    if (c->rank == root && stored[root] != 0) {
+    if (c->rank == root && travels[root] != 0) {
         size_t offset = 0;
-        for (int r = 0; r < root; ++r) offset += stored[r];
-        hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(d_gathered) + offset * kRecord, d_photons, stored[root] * kRecord, hipMemcpyDeviceToDevice, stream),
+        for (int r = 0; r < root; ++r) offset += travels[r];
+        hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(d_gathered) + offset * kRecord, d_photons, travels[root] * kRecord, hipMemcpyDeviceToDevice, stream),
                "copy the root's own photons");
     }
+    if (total > room)
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "gather buffer too small for the detected photons of all ranks: " + std::to_string(total) +
+                                               " stored, room for " + std::to_string(room) + " on the root (it received the first " +
+                                               std::to_string(accepted) + ", rank by rank)");
 }
 
 } // namespace clsimhip

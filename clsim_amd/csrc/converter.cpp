@@ -78,10 +78,10 @@ void Converter::release_device()
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
         sl = Slot();
     }
-    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_);
+    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_);
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
     (void)hipFree(d_queue_); (void)hipFree(d_work_); (void)hipFree(d_hist_ring_);
-    d_tables_ = nullptr; d_dom_tx_ = d_dom_ty_ = nullptr; d_dom_tz_ = nullptr; d_len_table_ = nullptr; d_prox_map_ = nullptr; d_dom_prox_ = nullptr; d_dom_centres_ = nullptr;
+    d_tables_ = nullptr; d_dom_tx_ = d_dom_ty_ = nullptr; d_dom_tz_ = nullptr; d_len_table_ = nullptr; d_prox_map_ = nullptr; d_dom_prox_ = nullptr; d_dom_centres_ = nullptr; d_dom_named_ = nullptr;
     d_rng_x_ = nullptr; d_rng_a_ = nullptr; d_queue_ = nullptr; d_work_ = nullptr; d_hist_ring_ = nullptr;
     last_queue_ = nullptr;
 #ifdef CLSIMHIP_CENSUS
@@ -281,6 +281,7 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size(), "string proximity map");
     upload(reinterpret_cast<void **>(&d_dom_prox_), tables_.dom_prox.data(), tables_.dom_prox.size() * 4, "DOM proximity map");
     upload(reinterpret_cast<void **>(&d_dom_centres_), tables_.dom_centres.data(), tables_.dom_centres.size() * 4, "DOM centres");
+    upload(reinterpret_cast<void **>(&d_dom_named_), tables_.dom_named.data(), tables_.dom_named.size() * 4, "named-DOM records");
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
     upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
@@ -363,6 +364,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.prox_map = d_prox_map_;
     P.dom_prox = d_dom_prox_;
     P.dom_centres = reinterpret_cast<const float4 *>(d_dom_centres_);
+    P.dom_named = reinterpret_cast<const uint4 *>(d_dom_named_);
     P.hist_ring = d_hist_ring_;
     P.hist_out = nullptr;               // set per slot by submit(); the device path has no history output
     P.dom_tx = d_dom_tx_;
@@ -644,6 +646,11 @@ long Converter::get_table(const std::string &name, double *out, size_t cap) cons
     if (name == "dom_proximity_map") {                  // 16 MB of bytes: converted on request, not kept as doubles
         const size_t n = tables_.dom_prox.size();
         if (out) for (size_t i = 0; i < std::min(n, cap); ++i) out[i] = tables_.dom_prox[i];
+        return static_cast<long>(n);
+    }
+    if (name == "dom_named") {
+        const size_t n = tables_.dom_named.size();
+        if (out) for (size_t i = 0; i < std::min(n, cap); ++i) out[i] = tables_.dom_named[i];
         return static_cast<long>(n);
     }
     if (name == "dom_centres") {

@@ -52,6 +52,7 @@ struct CompiledTables {
     std::vector<uint8_t> prox_map;      // KParams::prox_map
     std::vector<uint32_t> dom_prox;     // KParams::dom_prox
     std::vector<float> dom_centres;     // KParams::dom_centres (4 floats per DOM)
+    std::vector<uint32_t> dom_named;    // KParams::dom_named (4 words per DOM)
     GeoTables geo;
     std::map<std::string, std::vector<double>> named;
 };
@@ -220,6 +221,7 @@ private:
     float *d_len_table_ = nullptr;
     uint8_t *d_prox_map_ = nullptr;
     uint32_t *d_dom_prox_ = nullptr;
+    uint32_t *d_dom_named_ = nullptr;
     float *d_dom_centres_ = nullptr;
     float *d_hist_ring_ = nullptr;           // per resident lane: the last history_entries_ scatter points
     float *d_dom_tz_ = nullptr;

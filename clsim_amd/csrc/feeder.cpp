@@ -44,8 +44,17 @@ std::string Feeder::worker_error() const
     return error_;
 }
 
+// A feeder whose worker thread has died (a device error in the step producer, say) accepts nothing more: the caller gets
+// the worker's message instead of an item that would be dropped, or of a put() that waits on a queue nobody drains.
+void Feeder::check_worker() const
+{
+    const std::string e = worker_error();
+    if (!e.empty()) throw Error(CLSIMHIP_ERR_DEVICE, "feeder thread: " + e);
+}
+
 void Feeder::enqueue_light_source(const clsimhip_particle &particle)
 {
+    check_worker();
     if (!ppc_) throw Error(CLSIMHIP_ERR_STATE, "this feeder was created without a particle parameterisation");
     if (barrier_enqueued_) throw Error(CLSIMHIP_ERR_STATE, "A barrier is enqueued! You must receive all steps before enqueuing a new particle.");   // :476-477
     Item it;
@@ -53,24 +62,29 @@ void Feeder::enqueue_light_source(const clsimhip_particle &particle)
     it.particle = particle;
     it.identifier = particle.identifier;
     in_->put(std::move(it));
+    check_worker();                                         // (the worker may have died while this call waited for room)
 }
 
 void Feeder::enqueue_steps(uint32_t identifier, const clsimhip_step *steps, size_t n)
 {
+    check_worker();
     if (barrier_enqueued_) throw Error(CLSIMHIP_ERR_STATE, "A barrier is enqueued! You must receive all steps before enqueuing a new particle.");
     Item it;
     it.identifier = identifier;
     it.steps.assign(steps, steps + n);
     in_->put(std::move(it));
+    check_worker();
 }
 
 void Feeder::enqueue_barrier()
 {
+    check_worker();
     bool expected = false;
     if (!barrier_enqueued_.compare_exchange_strong(expected, true)) throw Error(CLSIMHIP_ERR_STATE, "A barrier is already enqueued!");   // :497-498
     Item it;
     it.barrier = true;
     in_->put(std::move(it));
+    if (!worker_error().empty()) { barrier_enqueued_ = false; check_worker(); }
 }
 
 bool Feeder::get_result(double timeout_ms, Result &out)
@@ -147,7 +161,8 @@ void Feeder::worker()
                 std::vector<clsimhip_step> steps(padded);
                 if (padded) {
                     // one random stream set per light source: results do not depend on what else is in the queue
-                    const uint64_t seed = seed_ ^ (0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(it.identifier) + 1ull));
+                    // (and an identifier that comes back gets streams of its own: OccurrenceCounter, lightsource.h)
+                    const uint64_t seed = seed_ ^ (0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(it.identifier) + 1ull)) ^ occurrences_.mix(it.identifier);
                     if (clsimhip_generate_steps(device_, requests.data(), requests.size(), seed, 1, steps.data(), steps.size(), &padded) != CLSIMHIP_OK)
                         throw Error(CLSIMHIP_ERR_DEVICE, clsimhip_last_error(nullptr));
                 }
@@ -157,14 +172,15 @@ void Feeder::worker()
             }
             markers_.push_back(it.identifier);              // :388: eligible for finalisation after the next bunch
         }
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> lk(error_mutex_);
-        error_ = e.what();
-        out_->close();
     } catch (const std::exception &e) {
-        std::lock_guard<std::mutex> lk(error_mutex_);
-        error_ = e.what();
+        {
+            std::lock_guard<std::mutex> lk(error_mutex_);
+            error_ = e.what();
+            if (error_.empty()) error_ = "unknown error";
+        }
+        // both ends: a consumer waiting for steps and a producer waiting for room wake up and find the error
         out_->close();
+        in_->close();
     }
 }
 

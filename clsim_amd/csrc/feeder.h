@@ -30,6 +30,7 @@ public:
     // false on timeout (timeout_ms < 0: wait for ever)
     bool get_result(double timeout_ms, Result &out);
     std::string worker_error() const;
+    void check_worker() const;
 
 private:
     struct Item {
@@ -50,6 +51,7 @@ private:
     std::unique_ptr<BoundedQueue<Result>> out_;
     StepStore store_{0};
     std::deque<uint32_t> markers_;
+    OccurrenceCounter occurrences_;     // worker thread only
     std::atomic<bool> barrier_enqueued_{false};
     std::thread thread_;
     mutable std::mutex error_mutex_;

@@ -101,6 +101,10 @@ struct KParams {
     // at a DOM (flashers) spend their lives within metres of it.  <= 64 MB in HBM, the words in use L2 / MALL resident.
     const uint32_t *dom_prox;
     const float4 *dom_centres;          // x, y, z of every DOM as dom_position() reconstructs it, w = 0
+    // Where the reference's search would meet that DOM (prop_device.hip.h: find_collision_named): x = string index | DOM number
+    // in the string << 16; y = cell column | cell row << 12 | subdetector << 24 of the string in its subdetector's grid;
+    // z = first | last << 16 of the z layers of the string's layering that hold this DOM; w = 0
+    const uint4 *dom_named;
     int32_t dprox_nx, dprox_ny, dprox_nz;
     float dprox_x0, dprox_y0, dprox_z0, dprox_inv_cell;
     float dprox_radius;                 // OM radius + safety

@@ -172,8 +172,9 @@ void PPCConverter::enqueue(const clsimhip_particle &particle, std::vector<clsimh
     const double E = particle.energy;
     const double logE = std::max(0., std::log(E));
     if (!(E >= 0.) || !std::isfinite(E)) throw Error(CLSIMHIP_ERR_ARGUMENT, "particle energy must be finite and non-negative");
-    // one random stream per light source: results do not depend on the order particles are enqueued in
-    Rng rng{config_.seed ^ (0xD1B54A32D192ED03ull * (static_cast<uint64_t>(particle.identifier) + 1ull))};
+    // one random stream per light source: results do not depend on the order particles of different identifiers are
+    // enqueued in, and an identifier that comes back gets fresh fluctuations (OccurrenceCounter)
+    Rng rng{config_.seed ^ (0xD1B54A32D192ED03ull * (static_cast<uint64_t>(particle.identifier) + 1ull)) ^ occurrences_.mix(particle.identifier)};
 
     clsimhip_step_request r{};
     r.x = static_cast<float>(particle.x); r.y = static_cast<float>(particle.y); r.z = static_cast<float>(particle.z);
@@ -264,12 +265,13 @@ double flasher_correction_factor(const FunctionData *spectrum, double peak_wavel
 // I3CLSimLightSourceToStepConverterFlasher::EnqueueLightSource (Flasher.cxx:214-265): pulses without photons are skipped
 void flasher_enqueue(double correction, uint64_t seed, const clsimhip_flasher_pulse *pulses, size_t n, std::vector<clsimhip_flasher_request> &out)
 {
+    OccurrenceCounter occurrences;          // stateless entry point: the caller owns the seed and varies it from call to call
     for (size_t i = 0; i < n; ++i) {
         const clsimhip_flasher_pulse &p = pulses[i];
         if (!(p.num_photons_no_bias > 0.)) continue;
         const double with_bias = p.num_photons_no_bias * correction;
         if (!(with_bias > 0.)) continue;
-        Rng rng{seed ^ (0xD1B54A32D192ED03ull * (static_cast<uint64_t>(p.identifier) + 1ull))};
+        Rng rng{seed ^ (0xD1B54A32D192ED03ull * (static_cast<uint64_t>(p.identifier) + 1ull)) ^ occurrences.mix(p.identifier)};
         const uint64_t photons = draw_photons(rng, with_bias, 1e6);             // :237-253
         if (photons == 0) continue;
         clsimhip_flasher_request r{};

@@ -671,7 +671,10 @@ DM float free_flight_bound(KP P, float x, float y)
 // search would find nothing and is skipped; closer, the lane goes to the full search, which decides.  Conservative in one
 // direction only, so no bit of the result depends on it.  Photons born at a DOM (flashers) spend their lives within metres
 // of it: nearly all of their steps pass this sphere by.
-DM bool dom_search_needed(KP P, const Photon &ph, float len)
+// Returns 0: no search (it would find nothing); 1: the full search; 2 + id: only DOM `id` is in reach and the segment comes
+// close to it -- the search may then be confined to what the full search would do for that one DOM (find_collision_named).
+constexpr uint32_t kSearchNone = 0u, kSearchFull = 1u, kSearchNamed = 2u;
+DM uint32_t dom_search_needed(KP P, const Photon &ph, float len)
 {
     const float inv = P->dprox_inv_cell;
     const int ny = P->dprox_ny, nz = P->dprox_nz;
@@ -680,15 +683,104 @@ DM bool dom_search_needed(KP P, const Photon &ph, float len)
     const int iz = clamp_index((int)((ph.pz - P->dprox_z0) * inv), nz - 1);
     const uint32_t w = P->dom_prox[((uint32_t)ix * (uint32_t)ny + (uint32_t)iy) * (uint32_t)nz + (uint32_t)iz];      // z runs fastest; at most 2^24 cells
     const float others = (float)((w >> 16) & 0xffu) * 0.25f;
-    if (!(len < others)) return true;
+    if (!(len < others)) return kSearchFull;
     const uint32_t id = w & 0xffffu;
-    if (id == 0xffffu) return false;
+    if (id == 0xffffu) return kSearchNone;
     const float4 c = P->dom_centres[id];
     const float wx = c.x - ph.px, wy = c.y - ph.py, wz = c.z - ph.pz;
     const float along = clampf_ordered((wx * ph.d.x + wy * ph.d.y) + wz * ph.d.z, 0.0f, len);      // len > 0
     const float qx = wx - along * ph.d.x, qy = wy - along * ph.d.y, qz = wz - along * ph.d.z;
     const float reach = P->dprox_radius + 0.01f;
-    return !((qx * qx + qy * qy) + qz * qz > reach * reach);
+    return ((qx * qx + qy * qy) + qz * qz > reach * reach) ? kSearchNone : (kSearchNamed + id);
+}
+
+// The search for a lane that dom_search_needed() sent here with a name: every DOM but `id` is farther from the photon than
+// the step is long, so the reference's search (find_collision below: sparse_collision_kernel.c.cl:462-547 -> :305-460 ->
+// :194-303 -> :27-192) can report nothing but a hit on that DOM -- and reports it only if its own pruning leads it there:
+//   (1) the string's cell lies in the range of cells the segment's end points span in the string's subdetector (c.cl:478-540),
+//   (2) the string passes the tests of checkForCollision_OnString (:45-75): infinite line within GEO_STRING_MAX_RADIUS of the
+//       axis, photon not already above / below the string and moving away,
+//   (3) one of the z layers between the end points' layers names the DOM (:96-118); a DOM may lie in several layers and is
+//       then tested several times, which changes nothing after the first (smin1 < step_len is strict),
+//   (4) the sphere test itself (:133-190).
+// These are evaluated here for the one string and the one DOM, with the arithmetic of the full search, and nothing else is:
+// the result is the full search's for every input (tests/test_named_search_gpu.py runs both on whole production bunches).
+// A hit on no other DOM can precede it, so the step length the ranges are computed from is the one passed in.
+template <bool FAST = false>
+DM bool find_collision_named(KP P, const Photon &ph, float &step_len, uint32_t id, const uint4 named, uint32_t &hit_string, uint32_t &hit_dom)
+{
+    const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
+    if (dir_len_xy_sqr <= 0.0f) return false;
+    const uint32_t s = named.x & 0xffffu, dom = named.x >> 16;
+    const int cell_x = (int)(named.y & 0xfffu), cell_y = (int)((named.y >> 12) & 0xfffu);
+    const uint32_t sd = named.y >> 24;
+    {   // (1)
+        const uint32_t off_subdet = P->off_subdet;
+        const Rec4 g0 = lds_rec4(off_subdet + 12u * sd);
+        const Rec4 g1 = lds_rec4(off_subdet + 12u * sd + 4u);
+        const Rec4 g2 = lds_rec4(off_subdet + 12u * sd + 8u);
+        const int nx = (int)__builtin_bit_cast(uint32_t, g0.a), ny = (int)__builtin_bit_cast(uint32_t, g0.b);
+        const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
+        const uint32_t proven = FAST ? 3u : __builtin_bit_cast(uint32_t, g1.d);       // (lanes may be in different subdetectors here)
+        const bool okx = (proven & 1u) != 0, oky = (proven & 2u) != 0;
+        int low_x, low_y, high_x, high_y;
+        if (FAST) {
+            low_x = (int)div_by_t<true>(ph.px - sx, wx, g2.a, true);
+            low_y = (int)div_by_t<true>(ph.py - sy, wy, g2.b, true);
+            high_x = (int)div_by_t<true>(ph.px + ph.d.x * step_len - sx, wx, g2.a, true);
+            high_y = (int)div_by_t<true>(ph.py + ph.d.y * step_len - sy, wy, g2.b, true);
+        } else {
+            // the proof bits are per subdetector and the lanes here may be in different ones: select per lane
+            const float ax = ph.px - sx, ay = ph.py - sy, bx = ph.px + ph.d.x * step_len - sx, by = ph.py + ph.d.y * step_len - sy;
+            low_x = (int)(okx ? div_by_t<true>(ax, wx, g2.a, true) : ax / wx);
+            low_y = (int)(oky ? div_by_t<true>(ay, wy, g2.b, true) : ay / wy);
+            high_x = (int)(okx ? div_by_t<true>(bx, wx, g2.a, true) : bx / wx);
+            high_y = (int)(oky ? div_by_t<true>(by, wy, g2.b, true) : by / wy);
+        }
+        if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
+        if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
+        low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);
+        high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
+        if ((cell_x < low_x) || (cell_x > high_x) || (cell_y < low_y) || (cell_y > high_y)) return false;
+    }
+    // (2)
+    const uint32_t off_strings = P->off_strings;
+    const Rec4 str = lds_rec4(off_strings + 8u * s);          // x, y, maxZ+R, minZ-R
+    {
+        const float smin = sqr((ph.px - str.a) * ph.d.y - (ph.py - str.b) * ph.d.x) / dir_len_xy_sqr;
+        if (smin > P->string_max_radius_sq) return false;
+    }
+    if ((ph.d.z > 0.0f) && (ph.pz > str.c)) return false;
+    if ((ph.d.z < 0.0f) && (ph.pz < str.d)) return false;
+    {   // (3)
+        const uint32_t set = ldsu(off_strings + 8u * s + 4) & 0xffu;
+        const Rec4 lay = lds_rec4(P->off_sets + 4u * set);        // nlayers (bits), start z, height
+        const float start_z = lay.b, height = lay.c;
+        const int nl = (int)__builtin_bit_cast(uint32_t, lay.a);
+        int low = (int)((ph.pz - start_z) / height);
+        int high = (int)((ph.pz + ph.d.z * step_len - start_z) / height);
+        if (high < low) { const int tmp = low; low = high; high = tmp; }
+        low = clampi(low, 0, nl - 1);
+        high = clampi(high, 0, nl - 1);
+        const int first = (int)(named.z & 0xffffu), last = (int)(named.z >> 16);
+        if ((high < first) || (low > last)) return false;
+    }
+    // (4) the DOM's position: dom_centres holds what dom_position() reconstructs, made with the same operations
+    const float4 c = P->dom_centres[id];
+    const float dx = c.x - ph.px, dy = c.y - ph.py, dzz = c.z - ph.pz;
+    const float dr2 = (dx * dx + dy * dy) + dzz * dzz;
+    const float urdot = (dx * ph.d.x + dy * ph.d.y) + dzz * ph.d.z;
+    float discr = sqr(urdot) - dr2 + P->om_radius_sq;
+    if (discr < 0.0f) return false;
+    discr = P->has_pancake ? (dm::sqrt_(discr) / P->pancake) : dm::sqrt_(discr);
+    if (urdot + discr < 0.0f) return false;
+    const float smin1 = urdot - discr;
+    if (smin1 < 0.0f) return false;
+    if (!(smin1 < step_len)) return false;
+    step_len = smin1;
+    hit_string = s;
+    hit_dom = dom;
+    return true;
 }
 
 // collision c.cl:194-303 + :462-547

@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     uint32_t photons_left = 0;
     uint32_t slice = 0;
     bool parked = false;       // has a step length and waits for the wave's next DOM search
+    uint32_t search_kind = kSearchFull;     // of a parked lane: the full search, or kSearchNamed + the only DOM in reach
     uint32_t *pending = lds_words + P0->table_words + kWavesPerBlock * kStageRecords * kStubWords;     // per lane: that step length
     bool waiting = false;      // holds a unit whose previous slice has not been published yet
     bool last_slice = false;   // the unit ends its step
@@ -505,9 +506,13 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
-            if (!TAB && !(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
-                parked = true;
-                pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance);
+            if (!TAB && !(distance < free_flight)) {
+                const uint32_t kind = dom_search_needed(fresh_params(P0), ph, distance);
+                if (kind != kSearchNone) {
+                    parked = true;
+                    search_kind = kind;
+                    pending[threadIdx.x] = __builtin_bit_cast(uint32_t, distance);
+                }
             }
         }
         bool advance = run && !parked;
@@ -516,7 +521,16 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
                 if (parked) {
                     distance = __builtin_bit_cast(float, pending[threadIdx.x]);
-                    hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    // (as in prop_pool_kernel.hip: the confined search in the flasher instantiations, for all parked lanes or none)
+                    bool full = FLASHER ? (ballot(search_kind == kSearchFull) != 0ull) : true;
+                    if (!full) {
+                        // only one DOM is in reach: what the reference's search does for that DOM, and nothing else
+                        const uint32_t id = search_kind - kSearchNamed;
+                        const uint4 named = fresh_params(P0)->dom_named[id];
+                        if (named.x != 0xffffffffu) hit = find_collision_named<FAST>(fresh_params(P0), ph, distance, id, named, hit_string, hit_dom);
+                        else full = true;
+                    }
+                    if (full) hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
                     parked = false;
                     advance = true;
                 }

@@ -40,6 +40,9 @@ namespace clsimhip {
 #define CLSIMHIP_POOL_BLOCK 768                 // 12 waves per workgroup, 2 workgroups per CU
 #define CLSIMHIP_POOL_WAVES 6                   // waves per SIMD the register allocation aims at (<= 80 VGPRs)
 #endif
+#ifndef CLSIMHIP_NAMED_POLICY
+#define CLSIMHIP_NAMED_POLICY 4                 // which parked lanes take the search confined to one DOM (see the search block)
+#endif
 constexpr int kPoolBlock = CLSIMHIP_POOL_BLOCK;
 constexpr int kPoolWavesPerBlock = kPoolBlock / 64;
 constexpr int kPoolMinWaves = CLSIMHIP_POOL_WAVES;
@@ -47,6 +50,8 @@ constexpr uint32_t kReadyWords = 21;            // odd strides: consecutive entr
 constexpr uint32_t kPendWords = 5;
 constexpr uint32_t kPoolFixedWords = kStageRecords * kStubWords + 64;      // hit stub staging + parked step lengths
 constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // unit flags above the slice number
+constexpr int kPoolMinReady = 4;                // smallest ready ring the kernel runs with
+constexpr int kPoolWorthwhileReady = 8;         // smallest ring with which it is chosen over the classic kernel
 
 __host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R) { return kPoolFixedWords + kReadyWords * R + kPendWords * (64u + R); }
 
@@ -93,7 +98,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // per lane: the photon it carries and the unit that photon belongs to
     // what the lane holds: one register compared against constants (three bools would live in scalar lane masks, and every
     // update under a lane-varying condition would be scalar mask arithmetic -- the scalar unit is the scarcer one here)
-    constexpr uint32_t kVacant = 0u, kSpent = 1u, kLive = 2u, kParked = 3u;     // kParked: has a step length, waits for the wave's next DOM search
+    // kParked: has a step length, waits for the wave's next DOM search; kParked + 1 + id: the same, and only DOM `id` is in reach
+    constexpr uint32_t kVacant = 0u, kSpent = 1u, kLive = 2u, kParked = 3u;
     uint32_t st = kVacant;
     uint32_t sidx = kNoStep, ra = 0, photons_left = 0, uflags = 0;
     uint64_t rx = 0;
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         const bool run = (st == kLive);
 #ifdef CLSIMHIP_CENSUS
         c_run += __popcll(ballot(run));
-        c_parked += __popcll(ballot(st == kParked));
+        c_parked += __popcll(ballot(st >= kParked));
         if (n_ready == 0u) ++c_empty_ring;
 #endif
         float distance = 0.0f;
@@ -350,23 +356,52 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
-            if (!(distance < free_flight) && dom_search_needed(fresh_params(P0), ph, distance)) {
-                st = kParked;
-                parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
+            if (!(distance < free_flight)) {
+                const uint32_t need = dom_search_needed(fresh_params(P0), ph, distance);
+                if (need != kSearchNone) {
+                    st = kParked + need - kSearchFull;                   // kParked, or kParked + 1 + id
+                    parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
+                }
             }
         }
         bool advance = (st == kLive);
         {
             // the DOM search runs when k_search lanes are parked, or for any parked lane when nothing else can advance
-            const uint32_t n_parked = (uint32_t)__popcll(ballot(st == kParked));
+            const uint32_t n_parked = (uint32_t)__popcll(ballot(st >= kParked));
             const uint32_t enough = (ballot(advance) == 0ull) ? 1u : (uint32_t)fresh_params(P0)->k_search;
             if (n_parked >= enough) {
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
 #endif
-                if (st == kParked) {
+                if (st >= kParked) {
                     distance = __builtin_bit_cast(float, parked_len[lane]);
-                    hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
+                    // Lanes with only one DOM in reach take the search confined to it (find_collision_named: what the
+                    // reference's search does for that DOM, and nothing else) -- in the flasher instantiations, and when
+                    // every parked lane of the wave is of that kind: a wave that has to run the full search for one lane runs
+                    // it for all of them, which costs nothing more and gives the same answer.  Measured (tools/ab_bench.py,
+                    // profiles/r03/named_search_policies.txt; 1e9 photons/s for C2 / C3 / benchmark.py / C5): 0 never
+                    // 3.546 / 3.053 / 2.889 / 1.915; 1 per lane, both searches in one trip 3.504 / 3.017 / 2.816 / 2.038;
+                    // 2 all parked lanes or none 3.505 / 3.024 / 2.848 / 2.045; 4 = 2 in the flasher instantiations only
+                    // 3.553 / 3.050 / 2.886 / 2.042.  Cascade photons that reach a string mostly arrive with steps longer than
+                    // the distance to the second-nearest DOM, so their waves run the full search anyway and only pay for the
+                    // second code path; photons born at a DOM live within metres of it.
+                    bool full = (st == kParked);
+#if CLSIMHIP_NAMED_POLICY == 0
+                    full = true;
+#elif CLSIMHIP_NAMED_POLICY == 2
+                    full = (ballot(full) != 0ull);
+#elif CLSIMHIP_NAMED_POLICY == 3
+                    if (!FLASHER) full = true;
+#elif CLSIMHIP_NAMED_POLICY == 4
+                    full = FLASHER ? (ballot(full) != 0ull) : true;
+#endif
+                    if (!full) {
+                        const uint32_t id = st - (kParked + 1u);
+                        const uint4 named = fresh_params(P0)->dom_named[id];
+                        if (named.x != 0xffffffffu) hit = find_collision_named<FAST>(fresh_params(P0), ph, distance, id, named, hit_string, hit_dom);
+                        else full = true;
+                    }
+                    if (full) hit = find_collision<FAST>(fresh_params(P0), ph, distance, hit_string, hit_dom);
                     st = kLive;
                     advance = true;
                 }
@@ -465,7 +500,11 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
         if (R <= 0 || R > fit) R = fit;
         if (R > 64) R = 64;
-        if (R < 4) return hipErrorInvalidValue;            // the caller falls back to the classic kernel for such an image
+        // a ring the user asked for (CLSIMHIP_POOL_R) below the smallest one the kernel runs with is raised to it; an image
+        // that leaves no room even for that never gets here: pool_kernel_fits() (below, the same arithmetic with the
+        // larger threshold from which the pooled kernel pays) sends its bunches to the classic kernel
+        if (R < kPoolMinReady) R = kPoolMinReady;
+        if (R > fit) return hipErrorInvalidValue;
         P.pool_ready = R;
     }
     const size_t lds_bytes = (size_t)(P.table_words + kPoolWavesPerBlock * pool_wave_words((uint32_t)R)) * 4;
@@ -558,7 +597,8 @@ bool pool_kernel_fits(uint32_t table_words)
     const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)table_words;
     const int per_wave = budget_words / kPoolWavesPerBlock;
     const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
-    return fit >= 8;
+    static_assert(kPoolWorthwhileReady >= kPoolMinReady, "an image the pooled kernel is chosen for must be one it can run");
+    return fit >= kPoolWorthwhileReady;
 }
 
 } // namespace clsimhip

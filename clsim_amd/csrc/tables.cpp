@@ -585,6 +585,42 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
                 }
             }
         }
+        // Where the reference's search meets each DOM (find_collision_named): its string's cell in the subdetector's grid and
+        // the z layers of the string's layering that name it.  A DOM whose string is not in exactly one cell, or whose layers
+        // are not one contiguous run, is marked 0xffffffff and always takes the full search.
+        C.dom_named.assign(4 * n_doms, 0u);
+        {
+            // CLSIMHIP_NO_NAMED_SEARCH=1: every DOM takes the full search (tests compare the two on whole bunches)
+            const char *env = std::getenv("CLSIMHIP_NO_NAMED_SEARCH");
+            const bool no_named = env && env[0] == '1';
+            std::vector<uint32_t> cell_of(static_cast<size_t>(G.num_strings), 0xffffffffu);
+            std::vector<int> seen(static_cast<size_t>(G.num_strings), 0);
+            for (size_t k = 0; k < G.cells.size(); ++k) {
+                const GeoTables::Cells &c = G.cells[k];
+                for (int cy = 0; cy < c.ny; ++cy)
+                    for (int cx = 0; cx < c.nx; ++cx) {
+                        const uint16_t str = c.index[static_cast<size_t>(cy) * c.nx + cx];
+                        if (str == 0xFFFFu || str >= G.num_strings) continue;
+                        ++seen[str];
+                        cell_of[str] = (cx < 4096 && cy < 4096 && k < 256) ? (static_cast<uint32_t>(cx) | (static_cast<uint32_t>(cy) << 12) | (static_cast<uint32_t>(k) << 24)) : 0xffffffffu;
+                    }
+            }
+            for (int str = 0; str < G.num_strings; ++str) {
+                const size_t first = G.dom_start[str], last = (str + 1 < G.num_strings) ? G.dom_start[str + 1] : n_doms;
+                const unsigned set = G.str_set[str];
+                const unsigned nl = G.set_nlayers[set];
+                for (size_t i = first; i < last; ++i) {
+                    const uint32_t dom = static_cast<uint32_t>(i - first);
+                    int lmin = -1, lmax = -1, count = 0;
+                    for (unsigned l = 0; l < nl; ++l)
+                        if (G.layer_to_om[static_cast<size_t>(set) * G.max_layers + l] == dom) { if (lmin < 0) lmin = static_cast<int>(l); lmax = static_cast<int>(l); ++count; }
+                    const bool ok = !no_named && (seen[str] == 1) && (cell_of[str] != 0xffffffffu) && (count > 0) && (lmax - lmin + 1 == count) && (str < 0x10000) && (dom < 0x10000);
+                    C.dom_named[4 * i] = ok ? (static_cast<uint32_t>(str) | (dom << 16)) : 0xffffffffu;
+                    C.dom_named[4 * i + 1] = ok ? cell_of[str] : 0u;
+                    C.dom_named[4 * i + 2] = ok ? (static_cast<uint32_t>(lmin) | (static_cast<uint32_t>(lmax) << 16)) : 0u;
+                }
+            }
+        }
         C.dom_prox.resize(cells);
         // a cell without a named DOM keeps the bound of its nearest one (255 = nothing within range) in the same place
         for (size_t c = 0; c < cells; ++c)

@@ -293,7 +293,10 @@ void clsimhip_comm_destroy(clsimhip_comm *comm);
  * photons, then rank 1's ...; counts_out[world_size] (host, every rank, may be NULL) receives the ranks' hit counters
  * (a rank transfers min(counter, capacity) records).  Ordered after the work already queued on `hip_stream`; returns
  * once the counts are known -- the transfers (ncclAllGather of the counts, then one ncclSend/ncclRecv per peer in one
- * group: every peer uses its own xGMI link to the root) may still be running on `hip_stream`. */
+ * group: every peer uses its own xGMI link to the root) may still be running on `hip_stream`.
+ * A gather buffer that is too small for all ranks' photons: every rank learns the root's gathered_capacity with the counts,
+ * the root receives the records that fit (rank 0's first), sends and receives still pair up, and EVERY rank returns
+ * CLSIMHIP_ERR_ARGUMENT (counts_out is filled). */
 int clsimhip_gather_hits(clsimhip_comm *comm, const void *d_photons, const void *d_hit_count, size_t capacity, int root,
                          void *d_gathered, size_t gathered_capacity, uint64_t *counts_out, void *hip_stream);
 

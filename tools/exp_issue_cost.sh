@@ -9,3 +9,6 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().split(chr(10))[-1])
 print('flags=[$flags]', '%.4g photons/s'%d['value'], '%.2f ms'%d['roofline']['avg_kernel_ms'])"
 done
+# leave the default library behind: the Makefile does not track EXTRA, so the last variant would otherwise stay in place
+rm -f clsim_amd/csrc/prop_pool_kernel.o
+make -s -C clsim_amd/csrc
