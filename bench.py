@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--bunch", type=int, default=1 << 20, help="I3CLSimSteps per pass and GPU")
     ap.add_argument("--photons-per-step", type=int, default=200)
     ap.add_argument("--ice", default="spice_mie", choices=["spice_mie", "spice_lea"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab", "tab5", "benchmark"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "tab", "tab5", "benchmark", "benchmark-host"],
                     help="BASELINE.json configs: c2 (default, the headline) 1M cascade steps SPICE-Mie; c3 10M steps "
                          "SPICE-Lea; c5 flasher: 405 nm point source at a DOM, 400 photons per step, SPICE-Lea; tab: the "
                          "table-maker half of configs[4] (point cascade, default spherical axes, SPICE-Mie) -- prints its own line")
@@ -281,6 +281,121 @@ def benchmark_workload(args, torch, device):
                      "launches": int(launches), "algorithmic_bytes_per_launch": alg_bytes}}))
 
 
+def benchmark_host_workload(args, torch, device):
+    """The reference's benchmark as its host code runs it (resources/scripts/benchmark.py:284-340; I3CLSimModule): 40 TeV
+    electrons at the origin -> I3CLSimLightSourceToStepConverterAsync (the feeder: PPC front end + GPU step producer + step
+    store, clsimhip_feeder_*) -> HOST step bunches -> EnqueueSteps -> GetConversionResult with double buffering.  Three threads
+    like the module's: one feeds particles, one moves step bunches from the feeder to the propagator, the caller collects
+    photons.  Reports the reference's two figures (benchmark.py:326-340: device time per photon, wall time per photon with
+    the device utilisation), the feeder's own rate (the same events with nothing downstream) and which stage limits the chain."""
+    import threading
+    from clsim_amd import converter as CV
+    from clsim_amd import step_store as SS
+    from clsim_amd import synthetic as S
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_lea"))
+    bias = CV.GetIceCubeDOMAcceptance(efficiency=0.95)
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, medium)]
+    geom = CV.I3CLSimSimpleGeometry.from_dict(S.ic86_geometry())
+    bunch = (args.bunch // 512) * 512                    # steps per bunch handed to the propagator (default 1 048 576)
+    events = max(1, args.events_per_pass) * max(1, args.steps)
+
+    def make_feeder(seed):
+        ppc = CV.I3CLSimLightSourceToStepConverterPPC()
+        ppc.SetWlenBias(bias); ppc.SetMediumProperties(medium); ppc.SetRandomSeed(seed); ppc.Initialize()
+        f = SS.I3CLSimLightSourceToStepConverterAsync()
+        f.SetMaxBunchSize(bunch); f.SetBunchSizeGranularity(512); f.SetLightSourceParameterization(ppc, seed=seed, device=device); f.Initialize()
+        return f, ppc
+
+    def particles(first, n):
+        ev = np.zeros(n, dtype=CV.PARTICLE_DTYPE)
+        ev["type"], ev["energy"], ev["dz"], ev["length"] = CV.ParticleType.EMinus, 40.0e3, -1.0, np.nan
+        ev["identifier"] = np.arange(first, first + n, dtype=np.uint32)
+        return ev
+
+    def feed(feeder, ev):
+        for i in range(len(ev)):
+            feeder.EnqueueLightSource(ev[i])
+        feeder.EnqueueBarrier()
+
+    # ---- the feeder alone: particles -> host step bunches, nothing downstream ----
+    feeder, ppc = make_feeder(12345)
+    ev = particles(0, events)
+    t0 = time.perf_counter()
+    th = threading.Thread(target=feed, args=(feeder, ev))
+    th.start()
+    steps_alone = photons_alone = 0
+    while True:
+        r = feeder.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=600000)
+        assert r is not None
+        steps_alone += len(r[0])
+        photons_alone += int(r[0]["num"].sum())
+        if r[2]:
+            break
+    th.join()
+    feeder_seconds = time.perf_counter() - t0
+    del feeder
+
+    # ---- the whole chain ----
+    conv = CV.initializeHIP(device, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=True,
+                            approximateNumberOfWorkItems=bunch, seed=12345)
+    warm = S.cascade_steps(bunch, seed=1, photons_per_step=200)
+    conv.EnqueueSteps(warm, 0)
+    conv.GetConversionResult()
+    feeder, ppc = make_feeder(12345)
+    before = conv.GetStatistics()
+    state = {"bunches": 0, "steps": 0, "photons": 0}
+
+    def forward():
+        while True:
+            r = feeder.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=600000)
+            assert r is not None
+            steps, _, last = r
+            if len(steps):
+                state["bunches"] += 1
+                state["steps"] += len(steps)
+                state["photons"] += int(steps["num"].sum())
+                conv.EnqueueSteps(steps, state["bunches"])
+            if last:
+                return
+    t0 = time.perf_counter()
+    th_feed = threading.Thread(target=feed, args=(feeder, particles(0, events)))
+    th_fwd = threading.Thread(target=forward)
+    th_feed.start(); th_fwd.start()
+    hits = got = 0
+    while th_fwd.is_alive() or got < state["bunches"]:
+        if got < state["bunches"]:
+            _, ph = conv.GetConversionResult()
+            hits += len(ph)
+            got += 1
+        else:
+            time.sleep(0.0005)
+    th_feed.join(); th_fwd.join()
+    elapsed = time.perf_counter() - t0
+    st = conv.GetStatistics()
+    device_ns = st["TotalDeviceTime"] - before["TotalDeviceTime"]
+    photons = state["photons"]
+    assert photons == photons_alone and state["steps"] == steps_alone
+    value = photons / elapsed
+    feeder_rate = photons_alone / feeder_seconds
+    device_rate = photons / (device_ns * 1e-9)
+    stages = {"feeder (particles -> host step bunches)": feeder_rate, "propagator device time": device_rate}
+    emit(json.dumps({
+        "metric": "propagated photons/sec through the reference's host flow (light sources -> feeder -> EnqueueSteps -> GetConversionResult)",
+        "value": value, "unit": "photons/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "reference benchmark.py through host buffers: %d x 40 TeV e- at the origin pointing down, spice_lea + tilt, "
+                               "86 strings, oversize 5, step bunches of %d, double buffering" % (events, bunch),
+                   "events": events, "steps": state["steps"], "bunches": state["bunches"], "photons": photons, "hits": hits,
+                   "shower_parameters": "restated from the published parameterisation (parity unpinned)"},
+        "reference_figures": {"AverageDeviceTimePerPhoton_ns": device_ns / photons, "AverageHostTimePerPhoton_ns": 1e9 * elapsed / photons,
+                              "DeviceUtilization": device_ns * 1e-9 / elapsed,
+                              "definition": "resources/scripts/benchmark.py:326-340"},
+        "feeder": {"photons_per_s": feeder_rate, "steps_per_s": steps_alone / feeder_seconds, "seconds": feeder_seconds,
+                   "note": "the same events with nothing downstream: PPC front end, GPU step producer, download, step store, bunching"},
+        "limiting_stage": min(stages, key=stages.get), "stage_rates_photons_per_s": stages}))
+
+
 WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
@@ -331,6 +446,8 @@ def main():
         return tabulator_bench(args, torch, local_rank)
     if args.workload == "benchmark":
         return benchmark_workload(args, torch, local_rank)
+    if args.workload == "benchmark-host":
+        return benchmark_host_workload(args, torch, local_rank)
     # ---- the rank's share of one pass: `shard` real steps in `n_bunches` equal bunches of n steps (a multiple of 512; the
     # last bunch is padded with no-op steps like the reference pads a bunch before a barrier, Async.cxx:240-257) ----
     STREAM_LIMIT = 6139850                              # 32-bit safeprime multipliers available (OpenCL.cxx:250)

@@ -11,6 +11,8 @@
 #include <fstream>
 
 namespace clsimhip {
+[[maybe_unused]] constexpr size_t kCensusBytes = 4u << 20;      // analysis build: counters + per-wave records + per-wave region counters
+
 
 static_assert(sizeof(clsimhip_step) == sizeof(DevStep), "step layouts");
 static_assert(sizeof(clsimhip_photon) == sizeof(DevPhoton), "photon layouts");
@@ -354,9 +356,9 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.pool_ready = pool_ready_;
     P.chip_share = concurrent_launches_;
 #ifdef CLSIMHIP_CENSUS
-    if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), 1 << 20), "census");
+    if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), kCensusBytes), "census");
     P.census = d_census_;
-    hip_check(hipMemsetAsync(P.census, 0, 1 << 20, stream), "reset census");
+    hip_check(hipMemsetAsync(P.census, 0, kCensusBytes, stream), "reset census");
     hip_check(hipMemsetAsync(P.census + 8, 0xff, 8, stream), "reset census");
 #endif
     P.work = d_work_ + rng_offset;       // work records live with the stream slots: launches on disjoint slots may overlap
@@ -671,7 +673,7 @@ void Converter::debug_counters(uint32_t out[4])
     DeviceGuard on_device(device_);
     hip_check(hipDeviceSynchronize(), "sync");
 #ifdef CLSIMHIP_CENSUS
-    hip_check(hipMemcpy(out, d_census_, 1 << 20, hipMemcpyDeviceToHost), "download census");     // the caller passes 1 MiB
+    hip_check(hipMemcpy(out, d_census_, kCensusBytes, hipMemcpyDeviceToHost), "download census");     // the caller passes kCensusBytes (4 MiB)
 #else
     if (last_queue_) hip_check(hipMemcpy(out, last_queue_, 16, hipMemcpyDeviceToHost), "download counters");
 #endif

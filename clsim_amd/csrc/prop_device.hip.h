@@ -53,6 +53,24 @@ DM uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 struct Rec4 { float a, b, c, d; };
 
+// Analysis build (make EXTRA=-DCLSIMHIP_CENSUS, tools/exp_pool_census.py): one visit of a divergent region and the lanes that
+// are active in it, per wave, in the census buffer behind the per-wave records (word 32768 + 32 x wave + 2 x region).
+enum CensusRegion { kCensusCrossing = 0, kCensusFilter = 1, kCensusLiu = 2, kCensusHG = 3, kCensusSearchFull = 4, kCensusSearchNamed = 5,
+                    kCensusCreation = 6, kCensusService = 7, kCensusScatter = 8, kCensusWalk = 9, kCensusRegions = 16 };
+#ifdef CLSIMHIP_CENSUS
+#define CENSUS_REGION(P, region)                                                                                                 \
+    do {                                                                                                                          \
+        const uint64_t census_m = __builtin_amdgcn_ballot_w64(true);                                                              \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(census_m)) {                                                         \
+            unsigned long long *census_d = (P)->census + 32768u + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32u + 2u * (uint32_t)(region); \
+            census_d[0] += 1ull;                                                                                                  \
+            census_d[1] += (unsigned long long)__builtin_popcountll(census_m);                                                    \
+        }                                                                                                                         \
+    } while (0)
+#else
+#define CENSUS_REGION(P, region) ((void)0)
+#endif
+
 DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
 DM uint32_t ldsu(uint32_t i) { return lds_words[i]; }
 DM Rec4 lds_rec4(uint32_t i) { return *reinterpret_cast<const Rec4 *>(&lds_words[i]); }   // i % 4 == 0
@@ -229,7 +247,12 @@ DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
         if (kind == 1) return liu_cos(P, rr);
     }
     const uint32_t ok = FAST ? 0xffu : P->div_ok;
-    if (rr < P->mix_frac) return liu_cos<FAST>(P, div_by_t<FAST>(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
+    CENSUS_REGION(P, kCensusScatter);
+    if (rr < P->mix_frac) {
+        CENSUS_REGION(P, kCensusLiu);
+        return liu_cos<FAST>(P, div_by_t<FAST>(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
+    }
+    CENSUS_REGION(P, kCensusHG);
     return hg_cos<FAST>(P, div_by_t<FAST>(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
 }
 
@@ -488,6 +511,7 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
 template <int MED, bool TILT, bool FLASHER, bool TAB, bool FAST = false>
 DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra, Photon &ph)
 {
+    CENSUS_REGION(P, kCensusCreation);
     ph.rx_start = rx;
     // TABULATE: the first sub-step is drawn between the photon's creation and its (fixed) absorption budget,
     // which draws nothing (c.cl:559-563, 582-588)
@@ -512,6 +536,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const uint32_t off_layers = P->off_layers;
     const float *len_table = (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr;
     const bool fast = FAST || (P->div_ok & kFastLengths) != 0u;
+    CENSUS_REGION(P, kCensusWalk);
     float effective_z;
     int current_layer;
     if (TILT) {
@@ -556,6 +581,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         const int last = down ? 0 : (num_layers - 1);
         const float signed_thickness = sgn * thickness;
         while ((j != last) && (sgn * ais > 0.0f) && (sgn * aia > 0.0f)) {
+            CENSUS_REGION(P, kCensusCrossing);
             j += step;
             boundary += signed_thickness;
             layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, j, sca_len, abs_len, fast);
@@ -676,6 +702,7 @@ DM float free_flight_bound(KP P, float x, float y)
 constexpr uint32_t kSearchNone = 0u, kSearchFull = 1u, kSearchNamed = 2u;
 DM uint32_t dom_search_needed(KP P, const Photon &ph, float len)
 {
+    CENSUS_REGION(P, kCensusFilter);
     const float inv = P->dprox_inv_cell;
     const int ny = P->dprox_ny, nz = P->dprox_nz;
     const int ix = clamp_index((int)((ph.px - P->dprox_x0) * inv), P->dprox_nx - 1);
@@ -709,6 +736,7 @@ DM uint32_t dom_search_needed(KP P, const Photon &ph, float len)
 template <bool FAST = false>
 DM bool find_collision_named(KP P, const Photon &ph, float &step_len, uint32_t id, const uint4 named, uint32_t &hit_string, uint32_t &hit_dom)
 {
+    CENSUS_REGION(P, kCensusSearchNamed);
     const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
     if (dir_len_xy_sqr <= 0.0f) return false;
     const uint32_t s = named.x & 0xffffu, dom = named.x >> 16;
@@ -787,6 +815,7 @@ DM bool find_collision_named(KP P, const Photon &ph, float &step_len, uint32_t i
 template <bool FAST = false>
 DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_string, uint32_t &hit_dom)
 {
+    CENSUS_REGION(P, kCensusSearchFull);
     const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
     if (dir_len_xy_sqr <= 0.0f) return false;
     Detector D;

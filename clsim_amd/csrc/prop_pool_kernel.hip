@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             WorkRecord *work = P->work;
 #ifdef CLSIMHIP_CENSUS
             ++c_services;
+            if (st != kLive) CENSUS_REGION(P, kCensusService);
 #endif
             if (m_spent != 0ull) {
                 const bool mine = (st == kSpent);

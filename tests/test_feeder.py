@@ -112,7 +112,11 @@ def test_particles_through_the_front_end_and_the_gpu_step_producer():
     consumer.join(120)
     assert not consumer.is_alive()
     allsteps = np.concatenate([s for s, _, _ in got])
-    req = ppc.EnqueueLightSources(parts)
+    # (a front end of its own with the same seed: on `ppc` these identifiers would now be seen for the second time and get
+    # fresh fluctuations, lightsource.h: OccurrenceCounter)
+    ppc2 = CV.I3CLSimLightSourceToStepConverterPPC()
+    ppc2.SetWlenBias(CV.GetIceCubeDOMAcceptance()); ppc2.SetMediumProperties(cfg["med_p"]); ppc2.SetRandomSeed(11); ppc2.Initialize()
+    req = ppc2.EnqueueLightSources(parts)
     expected_photons = int((req["num_steps"] * req["photons_per_step"] + req["num_photons_in_last_step"]).sum())
     assert int(allsteps["num"].sum()) == expected_photons
     for ident in (11, 12, 13, 14, 15):

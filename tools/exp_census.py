@@ -33,13 +33,13 @@ for spec in sys.argv[1:]:
         conv.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ms, _ = conv.KernelTimeMs(reset=True)
-    buf = np.zeros(1 << 17, dtype=np.uint64)
+    buf = np.zeros(1 << 19, dtype=np.uint64)
     lib = _lib.load(); lib.clsimhip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.clsimhip_debug_counters(conv._h, buf.ctypes.data_as(C.c_void_p))
     trips, run, need, wait, parked, dead, phases, created = (float(v) for v in buf[:8])
     lanes = 64.0 * trips
     t0 = int(buf[8])
-    rec = buf[16:16 + 3 * ((len(buf) - 16) // 3)].reshape(-1, 3).astype(np.int64)
+    rec = buf[16:16 + 3 * 10917].reshape(-1, 3).astype(np.int64)      # (region counters follow from word 32768)
     rec = rec[rec[:, 0] > 0]
     end = (rec[:, 0] - t0) / 100e3                      # ms at 100 MHz
     dry = np.where(rec[:, 1] > 0, (rec[:, 1] - t0) / 100e3, np.nan)

@@ -41,13 +41,13 @@ for spec in sys.argv[1:]:
         conv.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ms, _ = conv.KernelTimeMs(reset=True)
-    buf = np.zeros(1 << 17, dtype=np.uint64)
+    buf = np.zeros(1 << 19, dtype=np.uint64)
     lib = _lib.load(); lib.clsimhip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.clsimhip_debug_counters(conv._h, buf.ctypes.data_as(C.c_void_p))
     trips, run, services, creations, created, vacant, polls, parked = (float(v) for v in buf[:8])
     searches, chunks, empty_ring = (float(v) for v in buf[9:12])
     t0 = int(buf[8])
-    rec = buf[16:16 + 3 * ((len(buf) - 16) // 3)].reshape(-1, 3).astype(np.int64)
+    rec = buf[16:16 + 3 * 8192].reshape(-1, 3).astype(np.int64)
     rec = rec[rec[:, 0] > 0]
     end = (rec[:, 0] - t0) / 100e3
     q = lambda a, p: float(np.percentile(a, p))
@@ -58,4 +58,12 @@ for spec in sys.argv[1:]:
           % (spec, ms, len(rec), (run + parked) / photons, trips * 64.0 / photons, 100 * run / lanes, 100 * parked / lanes, 100 * vacant / lanes, services / trips, creations / trips,
              created / max(creations, 1), chunks / max(creations, 1), searches / trips, 100 * empty_ring / trips, polls / trips,
              q(end, 1), q(end, 50), q(end, 99), end.max(), q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
+    # divergent regions (prop_device.hip.h: CENSUS_REGION): visits per wave trip and active lanes per visit
+    names = ["layer crossing body", "search filter levels 2-3", "Liu branch", "HG branch", "full DOM search", "named DOM search", "photon creation",
+             "service (free lanes)", "scattering (all)", "layer walk (all)"]
+    reg = buf[32768:32768 + 32 * 8192].reshape(-1, 16, 2).astype(np.float64).sum(axis=0)
+    print("   region                      visits/trip   lanes/visit   lane-visits/trip")
+    for k, nm in enumerate(names):
+        v, l = reg[k]
+        print("   %-26s %12.4f %13.2f %18.3f" % (nm, v / trips, l / max(v, 1.0), l / trips), flush=True)
     del conv
