@@ -187,6 +187,7 @@ def host_path_run(CV, args, steps_np, conv, bunches):
     """The reference's own calling pattern (benchmark.py:300-360): a producer thread enqueues bunches, the consumer takes
     results; wall clock from the first enqueue to the last result -- host buffers, PCIe transfers, index->ID conversion."""
     import threading
+    from clsim_amd.synthetic import PHOTON_DTYPE
     conv.EnqueueSteps(steps_np, 0)          # warm-up bunch
     conv.GetConversionResult()
     before = conv.GetStatistics()
@@ -194,8 +195,9 @@ def host_path_run(CV, args, steps_np, conv, bunches):
     producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(bunches)])
     producer.start()
     hits = 0
+    recycled = np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=PHOTON_DTYPE)        # the consumer's photon buffer, reused per bunch
     for _ in range(bunches):
-        _, ph = conv.GetConversionResult()
+        _, ph = conv.GetConversionResult(out=recycled)
         hits += len(ph)
     producer.join()
     elapsed = time.perf_counter() - t0
@@ -362,9 +364,10 @@ def benchmark_host_workload(args, torch, device):
     th_fwd = threading.Thread(target=forward)
     th_feed.start(); th_fwd.start()
     hits = got = 0
+    recycled = np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=S.PHOTON_DTYPE)      # the consumer's photon buffer, reused per bunch
     while th_fwd.is_alive() or got < state["bunches"]:
         if got < state["bunches"]:
-            _, ph = conv.GetConversionResult()
+            _, ph = conv.GetConversionResult(out=recycled)
             hits += len(ph)
             got += 1
         else:

@@ -313,16 +313,22 @@ class I3CLSimStepToPhotonConverterHIP:
         steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
         self._call("clsimhip_enqueue_steps", steps.ctypes.data_as(C.c_void_p), len(steps), int(identifier))
 
-    def GetConversionResult(self, with_histories=False):
+    def GetConversionResult(self, with_histories=False, out=None):
         """ConversionResult_t (I3CLSimStepToPhotonConverter.h:70-90): (identifier, photons), plus with
         with_histories=True the photonHistories as a list of [k_i, 4] arrays (k_i = min(numScatters_i,
-        PhotonHistoryEntries); None when no histories are recorded)."""
+        PhotonHistoryEntries); None when no histories are recorded).  The photons are copied out of the library's buffer
+        (like the C++ adapter copies them into the I3CLSimPhotonSeries it hands to the caller): into `out`, a PHOTON_DTYPE
+        array the caller recycles, when it is given and large enough -- a view of it is returned."""
         ident, ptr, n = C.c_uint32(), C.c_void_p(), C.c_size_t()
         self._call("clsimhip_get_conversion_result", C.byref(ident), C.byref(ptr), C.byref(n))
         histories = None
         if n.value:
             buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
-            photons = np.frombuffer(buf, dtype=PHOTON_DTYPE).copy()
+            if out is not None and len(out) >= n.value:
+                C.memmove(out.ctypes.data, ptr.value, n.value * 80)
+                photons = out[:n.value]
+            else:
+                photons = np.frombuffer(buf, dtype=PHOTON_DTYPE).copy()
             if with_histories:
                 hp, entries = C.POINTER(C.c_float)(), C.c_uint32()
                 self._call("clsimhip_get_result_histories", ptr, C.byref(hp), C.byref(entries))

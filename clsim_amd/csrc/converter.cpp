@@ -80,10 +80,18 @@ void Converter::release_device()
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
         sl = Slot();
     }
-    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_);
+    (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_); (void)hipFree(d_id_strings_); (void)hipFree(d_id_doms_); (void)hipFree(d_id_dom_start_);
+    for (clsimhip_photon *b : free_result_buffers_) (void)hipHostFree(b);
+    free_result_buffers_.clear(); result_buffers_made_ = 0;
+    // results nobody released, and results nobody fetched: their page-locked buffers go with the converter
+    handed_out_.clear();
+    if (out_queue_) {
+        Result r;
+        while (out_queue_->get_for(r, 0)) {}
+    }
     (void)hipFree(d_rng_x_); (void)hipFree(d_rng_a_);
     (void)hipFree(d_queue_); (void)hipFree(d_work_); (void)hipFree(d_hist_ring_);
-    d_tables_ = nullptr; d_dom_tx_ = d_dom_ty_ = nullptr; d_dom_tz_ = nullptr; d_len_table_ = nullptr; d_prox_map_ = nullptr; d_dom_prox_ = nullptr; d_dom_centres_ = nullptr; d_dom_named_ = nullptr;
+    d_tables_ = nullptr; d_dom_tx_ = d_dom_ty_ = nullptr; d_dom_tz_ = nullptr; d_len_table_ = nullptr; d_prox_map_ = nullptr; d_dom_prox_ = nullptr; d_dom_centres_ = nullptr; d_dom_named_ = nullptr; d_id_strings_ = nullptr; d_id_doms_ = nullptr; d_id_dom_start_ = nullptr;
     d_rng_x_ = nullptr; d_rng_a_ = nullptr; d_queue_ = nullptr; d_work_ = nullptr; d_hist_ring_ = nullptr;
     last_queue_ = nullptr;
 #ifdef CLSIMHIP_CENSUS
@@ -287,6 +295,24 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
     upload(reinterpret_cast<void **>(&d_dom_ty_), G.dom_ty.data(), G.dom_ty.size() * 2, "dom_ty");
     upload(reinterpret_cast<void **>(&d_dom_tz_), G.dom_tz.data(), G.dom_tz.size() * 4, "dom_tz");
+    {   // index -> ID tables for assemble_hits_kernel; an ID that does not fit the record's short / ushort keeps the
+        // conversion on the host, which reports it when a photon carries it (OpenCL.cxx:1577-1586)
+        std::vector<int16_t> sid(G.string_index_to_id.size());
+        std::vector<uint32_t> start(G.string_index_to_id.size());
+        std::vector<uint16_t> did;
+        bool fits = true;
+        for (size_t k = 0; k < G.string_index_to_id.size(); ++k) {
+            fits = fits && G.string_index_to_id[k] >= -32768 && G.string_index_to_id[k] <= 32767;
+            sid[k] = static_cast<int16_t>(G.string_index_to_id[k]);
+            start[k] = static_cast<uint32_t>(did.size());
+            for (uint32_t v : G.dom_index_to_id[k]) { fits = fits && v <= 65535u; did.push_back(static_cast<uint16_t>(v)); }
+        }
+        if (fits && !sid.empty()) {
+            upload(reinterpret_cast<void **>(&d_id_strings_), sid.data(), sid.size() * 2, "string IDs");
+            upload(reinterpret_cast<void **>(&d_id_doms_), did.data(), did.size() * 2, "OM IDs");
+            upload(reinterpret_cast<void **>(&d_id_dom_start_), start.data(), start.size() * 4, "OM ID offsets");
+        }
+    }
     if (history_entries_) {
         const size_t bytes = prop_kernel_max_lanes() * history_entries_ * 16;
         hip_check(hipMalloc(reinterpret_cast<void **>(&d_hist_ring_), bytes), "history ring");
@@ -405,6 +431,7 @@ void Converter::submit(Slot &s, const Job &job)
     hip_check(hipMemsetAsync(s.d_hit_count, 0, 4, stream_), "reset hit counter");
     KParams P = launch_params(s.d_steps, n, 0, s.d_photons, max_output_photons_, s.d_hit_count, stream_);
     P.hist_out = s.d_hist_out;
+    P.id_strings = d_id_strings_; P.id_doms = d_id_doms_; P.id_dom_start = d_id_dom_start_;
     hip_check(hipEventRecord(s.start, stream_), "event");
     hip_check(launch(P, stream_), "propagation kernel launch");
     hip_check(hipEventRecord(s.stop, stream_), "event");
@@ -427,12 +454,24 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
         std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);
         hits = max_output_photons_;
     }
-    std::unique_ptr<std::vector<clsimhip_photon>> photons(new std::vector<clsimhip_photon>(hits));
+    // The download lands in the slot's page-locked buffer, which then IS the result: the slot takes a fresh buffer from the
+    // pool.  (Round 2 zero-filled a vector per result, copied the download into it and converted indices one by one on
+    // this thread: 0.4 s per bunch of 8.4 M photons in the reference's benchmark, the device idle 80 % of the time.)
+    Result r;
+    r.count = hits;
+    std::unique_ptr<std::vector<clsimhip_photon>> photons;
+    clsimhip_photon *where = s.h_photons;
     if (hits) {
         hip_check(hipMemcpyAsync(s.h_photons, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
         hip_check(hipStreamSynchronize(copy_stream_), "download photons");
-        std::memcpy(photons->data(), s.h_photons, static_cast<size_t>(hits) * sizeof(clsimhip_photon));
-        replace_indices(photons->data(), hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
+        if (clsimhip_photon *fresh = take_result_buffer()) {
+            r.pinned.reset(s.h_photons);
+            s.h_photons = fresh;
+        } else {
+            photons.reset(new std::vector<clsimhip_photon>(s.h_photons, s.h_photons + hits));
+            where = photons->data();
+        }
+        if (!d_id_strings_) replace_indices(where, hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
     }
     std::unique_ptr<std::vector<float>> histories;
     if (hits && history_entries_) {
@@ -442,7 +481,7 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
         hip_check(hipStreamSynchronize(copy_stream_), "download photon histories");
         histories.reset(new std::vector<float>(static_cast<size_t>(hits) * N * 4, 0.f));
         for (size_t i = 0; i < hits; ++i) {
-            const uint32_t num_scatters = (*photons)[i].num_scatters;
+            const uint32_t num_scatters = where[i].num_scatters;
             if (num_scatters == 0) continue;
             const size_t recorded = std::min<size_t>(num_scatters, N);
             size_t cur = (num_scatters <= N) ? 0 : (num_scatters % N);
@@ -466,7 +505,6 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
     }
     first = false;
     last_done = now;
-    Result r;
     r.id = s.id;
     r.photons = std::move(photons);
     r.histories = std::move(histories);
@@ -537,9 +575,9 @@ void Converter::get_result(uint32_t *identifier, const clsimhip_photon **photons
         throw Error(CLSIMHIP_ERR_STATE, "converter is shutting down");
     }
     *identifier = r.id;
-    *n = r.photons->size();
+    *n = r.count;
     static const clsimhip_photon empty_sentinel{};
-    const clsimhip_photon *key = r.photons->empty() ? nullptr : r.photons->data();
+    const clsimhip_photon *key = r.count ? r.data() : nullptr;
     *photons = key ? key : &empty_sentinel;
     if (key) {
         std::lock_guard<std::mutex> lk(results_mutex_);
@@ -564,8 +602,42 @@ void Converter::result_histories(const clsimhip_photon *photons, const float **h
 
 void Converter::release_result(const clsimhip_photon *photons)
 {
-    std::lock_guard<std::mutex> lk(results_mutex_);
-    handed_out_.erase(photons);
+    clsimhip_photon *back = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(results_mutex_);
+        auto it = handed_out_.find(photons);
+        if (it == handed_out_.end()) return;
+        back = it->second.pinned.release();
+        handed_out_.erase(it);
+    }
+    if (back) {
+        std::lock_guard<std::mutex> lk(result_pool_mutex_);
+        free_result_buffers_.push_back(back);
+    }
+}
+
+void Converter::Result::HostFree::operator()(clsimhip_photon *p) const { if (p) (void)hipHostFree(p); }
+
+clsimhip_photon *Converter::take_result_buffer()
+{
+    {
+        std::lock_guard<std::mutex> lk(result_pool_mutex_);
+        if (!free_result_buffers_.empty()) {
+            clsimhip_photon *b = free_result_buffers_.back();
+            free_result_buffers_.pop_back();
+            return b;
+        }
+        if (result_buffers_made_ >= kResultBuffers) return nullptr;
+        ++result_buffers_made_;
+    }
+    clsimhip_photon *b = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&b), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(result_pool_mutex_);
+        result_buffers_made_ = kResultBuffers;      // the host will not pin more: results are copied out from now on
+        return nullptr;
+    }
+    return b;
 }
 
 size_t Converter::queue_size() const { need_init(); return in_queue_->size(); }

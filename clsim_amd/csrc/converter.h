@@ -185,10 +185,17 @@ public:
 
 private:
     struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
+    // The photons of a result live in a page-locked buffer of the converter's pool (the download lands there and the
+    // caller reads them there until ReleaseResult: no host copy in between), or -- when the pool is exhausted because the
+    // caller holds more results than it has buffers -- in a vector of their own.
     struct Result {
-        uint32_t id;
+        uint32_t id = 0;
+        struct HostFree { void operator()(clsimhip_photon *p) const; };
+        std::unique_ptr<clsimhip_photon, HostFree> pinned;  // pool buffer (returned to the pool by release_result; freed with a result nobody fetched)
+        size_t count = 0;
         std::unique_ptr<std::vector<clsimhip_photon>> photons;
         std::unique_ptr<std::vector<float>> histories;     // [photons][history_entries_][4], forward order
+        const clsimhip_photon *data() const { return pinned ? pinned.get() : (photons ? photons->data() : nullptr); }
     };
 
     void guard() const { if (initialized_) throw Error(CLSIMHIP_ERR_STATE, "I3CLSimStepToPhotonConverterHIP already initialized!"); }
@@ -244,6 +251,16 @@ private:
     };
     Slot slots_[2];
     int num_slots_ = 1;
+    // page-locked result buffers not in use (each max_output_photons_ records); at most kResultBuffers exist besides the slots' own
+    static constexpr int kResultBuffers = 4;
+    std::vector<clsimhip_photon *> free_result_buffers_;
+    int result_buffers_made_ = 0;
+    std::mutex result_pool_mutex_;
+    clsimhip_photon *take_result_buffer();              // nullptr when the pool is exhausted
+    // index -> ID tables on the device (host path: converted by assemble_hits_kernel); null when an ID does not fit the record
+    int16_t *d_id_strings_ = nullptr;
+    uint16_t *d_id_doms_ = nullptr;
+    uint32_t *d_id_dom_start_ = nullptr;
     void submit(Slot &s, const Job &job);
     void finish(Slot &s, std::chrono::steady_clock::time_point &last_done, bool &first);
     WorkRecord *d_work_ = nullptr;           // per step: work record (kparams.h), rebuilt by every launch

@@ -102,9 +102,16 @@ struct KParams {
     const uint32_t *dom_prox;
     const float4 *dom_centres;          // x, y, z of every DOM as dom_position() reconstructs it, w = 0
     // Where the reference's search would meet that DOM (prop_device.hip.h: find_collision_named): x = string index | DOM number
-    // in the string << 16; y = cell column | cell row << 12 | subdetector << 24 of the string in its subdetector's grid;
-    // z = first | last << 16 of the z layers of the string's layering that hold this DOM; w = 0
+    // in the string << 16; y = first cell column | first cell row << 12 | subdetector << 24 and w = last column | last row << 12 of
+    // the rectangle of cells the string lies in (its bounding square may overlap several, GeometrySource.cxx:135-271);
+    // z = first | last << 16 of the z layers of the string's layering that hold this DOM
     const uint4 *dom_named;
+    // Host path only (null on the device path, whose records keep the kernel's indices): string index -> string ID and
+    // (string index, DOM index) -> OM ID, applied to the hit records by assemble_hits_kernel (the reference converts on the
+    // host, one photon after the other, OpenCL.cxx:1565-1619)
+    const int16_t *id_strings;
+    const uint16_t *id_doms;
+    const uint32_t *id_dom_start;
     int32_t dprox_nx, dprox_ny, dprox_nz;
     float dprox_x0, dprox_y0, dprox_z0, dprox_inv_cell;
     float dprox_radius;                 // OM radius + safety

@@ -83,7 +83,22 @@ bool is_tau(int32_t t) { return t == CLSIMHIP_PARTICLE_TAUMINUS || t == CLSIMHIP
 
 } // namespace
 
-// I3SimConstants::ShowerParameters(type, E, density): see the header comment (PARITY UNPINNED).  E in GeV, density in g/cm3.
+// I3SimConstants::ShowerParameters(type, E, density) (sim-services; NOT in the reference tree: PARITY UNPINNED).  E in GeV,
+// density in g/cm3.  Where the numbers come from, and what could and could not be checked here:
+//   * form: longitudinal profile dE/dt ~ t^(a-1) exp(-t/b') with a = alpha + beta ln E and b = X0 / b0 [m]; hadronic
+//     cascades scale their light by F = 1 - (E/E0)^(-m) (1 - f0) with a relative width rms0 (ln E)^(-gamma).  This is the
+//     parameterisation of L. Raedel & C. Wiebusch, Astropart. Phys. 44 (2013) 102 (electromagnetic cascades: gamma
+//     distribution fit of the longitudinal profile, one (alpha, beta, b0) triple for e-, e+ and gamma) and of L. Raedel's
+//     RWTH Aachen thesis (2012) behind it for the hadronic species (pi+-, K0L, p, n, pbar: (alpha, beta, b0) and
+//     (E0, m, f0, rms0, gamma)), as IceCube's sim-services (I3SimConstants.cxx) and PPC (pro.cu) carry it;
+//   * UNVERIFIED: none of the 9 + 48 constants below could be compared with those publications or with I3SimConstants.cxx
+//     in this environment (no network; no file of the reference tree holds them; the reference only CALLS the function,
+//     I3CLSimLightSourceToStepConverterPPC.cxx:286, 349).  They are written down from the builder's recollection of that
+//     source file.  Table and equation numbers are deliberately not quoted: they could not be checked either;
+//   * what IS checked: the functional form (tests/test_lightsource.py: closed forms, 1/density scaling of b, clamping of
+//     ln E at 0, no extension below 1 GeV, the electromagnetic fraction's mean and width), and that nothing but the number
+//     of photons and steps of the benchmark workload depends on these values -- the propagator's parity does not.
+// A maintainer adopting the producer side should diff this switch against I3SimConstants::ShowerParameters first.
 ShowerParameters shower_parameters(int32_t type, double E, double density)
 {
     ShowerParameters p;

@@ -481,7 +481,16 @@ DM Vec3 work_direction(const DevStep *work_step)
 template <bool FLASHER>
 DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra)
 {
+#ifdef CLSIMHIP_EXP_NT          // experiment: work records read around the L2 (they are used once per photon and flush the DOM proximity map's lines)
+    DevStep st;
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(step_ptr);
+        uint4 v[3] = {__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2)};
+        __builtin_memcpy(&st, v, sizeof st);
+    }
+#else
     const DevStep st = *step_ptr;
+#endif
     Birth b;
     const float shift = st.length * rng_co(rx, ra);
     const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);
@@ -724,7 +733,8 @@ DM uint32_t dom_search_needed(KP P, const Photon &ph, float len)
 // The search for a lane that dom_search_needed() sent here with a name: every DOM but `id` is farther from the photon than
 // the step is long, so the reference's search (find_collision below: sparse_collision_kernel.c.cl:462-547 -> :305-460 ->
 // :194-303 -> :27-192) can report nothing but a hit on that DOM -- and reports it only if its own pruning leads it there:
-//   (1) the string's cell lies in the range of cells the segment's end points span in the string's subdetector (c.cl:478-540),
+//   (1) one of the string's cells lies in the range of cells the segment's end points span in the string's subdetector
+//       (c.cl:478-540),
 //   (2) the string passes the tests of checkForCollision_OnString (:45-75): infinite line within GEO_STRING_MAX_RADIUS of the
 //       axis, photon not already above / below the string and moving away,
 //   (3) one of the z layers between the end points' layers names the DOM (:96-118); a DOM may lie in several layers and is
@@ -740,7 +750,8 @@ DM bool find_collision_named(KP P, const Photon &ph, float &step_len, uint32_t i
     const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
     if (dir_len_xy_sqr <= 0.0f) return false;
     const uint32_t s = named.x & 0xffffu, dom = named.x >> 16;
-    const int cell_x = (int)(named.y & 0xfffu), cell_y = (int)((named.y >> 12) & 0xfffu);
+    const int cell_x0 = (int)(named.y & 0xfffu), cell_y0 = (int)((named.y >> 12) & 0xfffu);
+    const int cell_x1 = (int)(named.w & 0xfffu), cell_y1 = (int)((named.w >> 12) & 0xfffu);
     const uint32_t sd = named.y >> 24;
     {   // (1)
         const uint32_t off_subdet = P->off_subdet;
@@ -769,7 +780,9 @@ DM bool find_collision_named(KP P, const Photon &ph, float &step_len, uint32_t i
         if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
         low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);
         high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
-        if ((cell_x < low_x) || (cell_x > high_x) || (cell_y < low_y) || (cell_y > high_y)) return false;
+        // the string is met in any of its cells (and then possibly several times: the repeats find the same DOM at the same
+        // distance, which is not closer than itself)
+        if ((cell_x1 < low_x) || (cell_x0 > high_x) || (cell_y1 < low_y) || (cell_y0 > high_y)) return false;
     }
     // (2)
     const uint32_t off_strings = P->off_strings;

@@ -697,6 +697,10 @@ __global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue
         for (int w = 0; w < kStubWords; ++w) hw[w] = slot[w];
         uint32_t rec[20];
         const float abs_lens_initial = make_hit_record<FLASHER>(P, h, rec);
+        if (P->id_strings) {                 // index -> ID (OpenCL.cxx:1565-1600), same for every record: wave-uniform branch
+            const uint32_t s_index = rec[11] & 0xffffu, d_index = rec[11] >> 16;
+            rec[11] = (uint32_t)(uint16_t)P->id_strings[s_index] | ((uint32_t)P->id_doms[P->id_dom_start[s_index] + d_index] << 16);
+        }
 #pragma unroll
         for (int w = 0; w < 20; ++w) slot[w] = rec[w];
         // c.cl:836: the ring holds the absorption lengths LEFT at each scatter; the reference stores initial - left

@@ -476,7 +476,9 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         }
         // largest xy offset of a DOM (as the kernel reconstructs it from the int16 templates) from its string's axis
         for (int s = 0; s < G.num_strings; ++s) {
-            const size_t first = G.dom_start[s], last = (s + 1 < G.num_strings) ? G.dom_start[s + 1] : G.dom_tx.size();
+            // (strings with the same DOM offsets share one template: dom_start is not a running sum; a string's DOMs are
+            // the entries dom_start[s] ... + its number of DOMs)
+            const size_t first = G.dom_start[s], last = first + G.dom_index_to_id[static_cast<size_t>(s)].size();
             for (size_t i = first; i < last; ++i) {
                 const double dx = double(G.dom_tx[i]) * G.dom_mul_x + G.dom_meanx[s] - G.str_x[s];
                 const double dy = double(G.dom_ty[i]) * G.dom_mul_y + G.dom_meany[s] - G.str_y[s];
@@ -518,19 +520,23 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         // "search anyway".  Cubic cells; at most 256 per axis (64 MB); border cells reach to infinity.
         int n_max = 256;
         if (const char *e = std::getenv("CLSIMHIP_DOM_PROX_N")) n_max = std::max(4, std::min(512, std::atoi(e)));
-        const size_t n_doms = G.dom_tx.size();
+        // DOM numbers of the maps: strings in index order, each with its DOMs in order (NOT the template index: strings with
+        // equal DOM offsets share a template, GeometrySource.cxx:449-495)
+        std::vector<size_t> first_dom(static_cast<size_t>(G.num_strings) + 1, 0);
+        for (int s = 0; s < G.num_strings; ++s) first_dom[s + 1] = first_dom[s] + G.dom_index_to_id[static_cast<size_t>(s)].size();
+        const size_t n_doms = first_dom[static_cast<size_t>(G.num_strings)];
         if (n_doms >= 0xffffu) throw Error(CLSIMHIP_ERR_CONFIG, "more than 65534 DOMs");     // (GEO_MAX_DOM_INDEX is a ushort in the reference too)
         std::vector<double> dx(n_doms), dy(n_doms), dz(n_doms);
         C.dom_centres.assign(4 * n_doms, 0.f);
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int s = 0; s < G.num_strings; ++s) {
-            const size_t first = G.dom_start[s], last = (s + 1 < G.num_strings) ? G.dom_start[s + 1] : n_doms;
-            for (size_t i = first; i < last; ++i) {
+            for (size_t i = first_dom[s]; i < first_dom[s + 1]; ++i) {
                 // the position the kernel reconstructs (dom_position), same float operations
-                const float fx = static_cast<float>(G.dom_tx[i]) * G.dom_mul_x + G.dom_meanx[s];
-                const float fy = static_cast<float>(G.dom_ty[i]) * G.dom_mul_y + G.dom_meany[s];
-                C.dom_centres[4 * i] = fx; C.dom_centres[4 * i + 1] = fy; C.dom_centres[4 * i + 2] = G.dom_tz[i];
-                dx[i] = fx; dy[i] = fy; dz[i] = G.dom_tz[i];
+                const size_t t = G.dom_start[s] + (i - first_dom[s]);           // entry of the string's template
+                const float fx = static_cast<float>(G.dom_tx[t]) * G.dom_mul_x + G.dom_meanx[s];
+                const float fy = static_cast<float>(G.dom_ty[t]) * G.dom_mul_y + G.dom_meany[s];
+                C.dom_centres[4 * i] = fx; C.dom_centres[4 * i + 1] = fy; C.dom_centres[4 * i + 2] = G.dom_tz[t];
+                dx[i] = fx; dy[i] = fy; dz[i] = G.dom_tz[t];
                 const double p[3] = {dx[i], dy[i], dz[i]};
                 for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
             }
@@ -586,27 +592,39 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             }
         }
         // Where the reference's search meets each DOM (find_collision_named): its string's cell in the subdetector's grid and
-        // the z layers of the string's layering that name it.  A DOM whose string is not in exactly one cell, or whose layers
-        // are not one contiguous run, is marked 0xffffffff and always takes the full search.
+        // the z layers of the string's layering that name it.  A DOM whose string's cells are not one full rectangle of one
+        // subdetector's grid, or whose layers are not one contiguous run, is marked 0xffffffff and always takes the full search.
         C.dom_named.assign(4 * n_doms, 0u);
         {
             // CLSIMHIP_NO_NAMED_SEARCH=1: every DOM takes the full search (tests compare the two on whole bunches)
             const char *env = std::getenv("CLSIMHIP_NO_NAMED_SEARCH");
             const bool no_named = env && env[0] == '1';
-            std::vector<uint32_t> cell_of(static_cast<size_t>(G.num_strings), 0xffffffffu);
-            std::vector<int> seen(static_cast<size_t>(G.num_strings), 0);
+            // a string lies in every cell its bounding square overlaps (GeometrySource.cxx:135-271): a rectangle of cells
+            struct Rect { int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1, count = 0, sd = -1; bool bad = false; };
+            std::vector<Rect> rect(static_cast<size_t>(G.num_strings));
             for (size_t k = 0; k < G.cells.size(); ++k) {
                 const GeoTables::Cells &c = G.cells[k];
                 for (int cy = 0; cy < c.ny; ++cy)
                     for (int cx = 0; cx < c.nx; ++cx) {
                         const uint16_t str = c.index[static_cast<size_t>(cy) * c.nx + cx];
                         if (str == 0xFFFFu || str >= G.num_strings) continue;
-                        ++seen[str];
-                        cell_of[str] = (cx < 4096 && cy < 4096 && k < 256) ? (static_cast<uint32_t>(cx) | (static_cast<uint32_t>(cy) << 12) | (static_cast<uint32_t>(k) << 24)) : 0xffffffffu;
+                        Rect &r = rect[str];
+                        if (r.sd >= 0 && r.sd != static_cast<int>(k)) r.bad = true;       // (a string belongs to one subdetector)
+                        r.sd = static_cast<int>(k);
+                        r.x0 = std::min(r.x0, cx); r.x1 = std::max(r.x1, cx); r.y0 = std::min(r.y0, cy); r.y1 = std::max(r.y1, cy);
+                        ++r.count;
                     }
             }
+            std::vector<uint32_t> cell_lo(static_cast<size_t>(G.num_strings), 0xffffffffu), cell_hi(static_cast<size_t>(G.num_strings), 0u);
             for (int str = 0; str < G.num_strings; ++str) {
-                const size_t first = G.dom_start[str], last = (str + 1 < G.num_strings) ? G.dom_start[str + 1] : n_doms;
+                const Rect &r = rect[str];
+                const bool whole = !r.bad && r.count > 0 && r.count == (r.x1 - r.x0 + 1) * (r.y1 - r.y0 + 1) && r.x1 < 4096 && r.y1 < 4096 && r.sd < 256;
+                if (!whole) continue;
+                cell_lo[str] = static_cast<uint32_t>(r.x0) | (static_cast<uint32_t>(r.y0) << 12) | (static_cast<uint32_t>(r.sd) << 24);
+                cell_hi[str] = static_cast<uint32_t>(r.x1) | (static_cast<uint32_t>(r.y1) << 12);
+            }
+            for (int str = 0; str < G.num_strings; ++str) {
+                const size_t first = first_dom[str], last = first_dom[str + 1];
                 const unsigned set = G.str_set[str];
                 const unsigned nl = G.set_nlayers[set];
                 for (size_t i = first; i < last; ++i) {
@@ -614,10 +632,11 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
                     int lmin = -1, lmax = -1, count = 0;
                     for (unsigned l = 0; l < nl; ++l)
                         if (G.layer_to_om[static_cast<size_t>(set) * G.max_layers + l] == dom) { if (lmin < 0) lmin = static_cast<int>(l); lmax = static_cast<int>(l); ++count; }
-                    const bool ok = !no_named && (seen[str] == 1) && (cell_of[str] != 0xffffffffu) && (count > 0) && (lmax - lmin + 1 == count) && (str < 0x10000) && (dom < 0x10000);
+                    const bool ok = !no_named && (cell_lo[str] != 0xffffffffu) && (count > 0) && (lmax - lmin + 1 == count) && (str < 0x10000) && (dom < 0x10000);
                     C.dom_named[4 * i] = ok ? (static_cast<uint32_t>(str) | (dom << 16)) : 0xffffffffu;
-                    C.dom_named[4 * i + 1] = ok ? cell_of[str] : 0u;
+                    C.dom_named[4 * i + 1] = ok ? cell_lo[str] : 0u;
                     C.dom_named[4 * i + 2] = ok ? (static_cast<uint32_t>(lmin) | (static_cast<uint32_t>(lmax) << 16)) : 0u;
+                    C.dom_named[4 * i + 3] = ok ? cell_hi[str] : 0u;
                 }
             }
         }

@@ -32,7 +32,11 @@ def streams(n, seed=12345):
 
 def config(name):
     """name: 'c1' homogeneous/single string, 'mie' SPICE-Mie/IC86, 'lea' SPICE-Lea/IC86,
-    'flasher' SPICE-Lea/IC86 + 405 nm generator."""
+    'flasher' SPICE-Lea/IC86 + 405 nm generator; '<name>_regular': the same with a detector whose DOMs sit exactly on
+    their string axes -- the strings then share two DOM position templates (GeometrySource.cxx:449-495)."""
+    if name.endswith("_regular"):
+        cfg = config(name[:-len("_regular")])
+        return dict(cfg, name=name, geom=S.ic86_geometry(jitter=0.0))
     if name == "c1":
         geom = S.single_string_geometry()
         med_o = B.homogeneous_medium()
@@ -46,7 +50,7 @@ def config(name):
         d = os.path.join(ICE, "spice_mie" if name == "mie" else "spice_lea")
         med_o = B.load_ppc_ice(d)
         med_p = CV.MakeIceCubeMediumProperties(iceDataDirectory=d)
-    return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=(name == "flasher"))
+    return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=name.startswith("flasher"))
 
 
 def oracle_tables(cfg, pancake=5.0):

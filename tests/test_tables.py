@@ -222,8 +222,9 @@ def test_dom_proximity_map_is_a_lower_bound():
     nearest DOM and stores a bound for all others.  The kernel skips a search only when the step is shorter than the stored
     bound AND the segment stays farther from the named DOM than its radius; both conditions together imply that the step is
     shorter than min(distance to the named DOM's sphere, stored bound).  That minimum must therefore never exceed the true 3D
-    distance from the point to the surface of the nearest DOM sphere -- and should be close to it."""
-    for name in ("mie", "c1"):
+    distance from the point to the surface of the nearest DOM sphere -- and should be close to it.  ("mie_regular": the
+    strings share DOM position templates; round 2 numbered the maps' DOMs by template entry and lost all but 120 of them.)"""
+    for name in ("mie", "c1", "mie_regular"):
         cfg = common.config(name)
         conv = common.product_converter(cfg, 512, initialize=False)
         conv.Compile()
@@ -277,3 +278,73 @@ def test_a_detector_beyond_the_lds_budget_of_seven_workgroups_compiles():
     T = common.oracle_tables(cfg)
     assert int(conv.GetTable("NUM_STRINGS")[0]) == 576
     assert np.array_equal(conv.GetTable("geoStringPosX").astype(np.float32), np.asarray(T.geo["str_x"], dtype=np.float32))
+
+
+def _check_named_records(cfg):
+    """dom_named (kparams.h) against an independent reading of the oracle's geometry tables: for every DOM the string and
+    DOM number, the rectangle of cells of the string's subdetector that name the string, the z layers that name the DOM"""
+    T = common.oracle_tables(cfg)
+    geo = T.geo
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    named = conv.GetTable("dom_named").astype(np.uint64).reshape(-1, 4)
+    centres = conv.GetTable("dom_centres").reshape(-1, 4)
+    assert len(named) == len(centres)
+    ns = geo["num_strings"]
+    # DOM records follow the strings in index order, dom_start.. (one record per DOM of every string)
+    counts = [len(ids) for ids in geo["dom_index_to_id"]]
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    assert starts[-1] == len(named)
+    nameable = 0
+    straddling = 0
+    for s in range(ns):
+        cells_of = []
+        for k, c in enumerate(geo["cells"]):
+            idx = np.asarray(c["index"]).reshape(c["ny"], c["nx"])
+            ys, xs = np.nonzero(idx == s)
+            cells_of += [(k, int(x), int(y)) for x, y in zip(xs, ys)]
+        sds = {k for k, _, _ in cells_of}
+        xs = [x for _, x, _ in cells_of]; ys = [y for _, _, y in cells_of]
+        whole = len(sds) == 1 and len(cells_of) == (max(xs) - min(xs) + 1) * (max(ys) - min(ys) + 1)
+        straddling += len(cells_of) > 1
+        st = int(geo["str_set"][s])
+        table = np.asarray(geo["layer_to_om"])[st * geo["max_layers"]: st * geo["max_layers"] + int(geo["set_nlayers"][st])]
+        for d in range(counts[s]):
+            rec = named[starts[s] + d]
+            layers = np.nonzero(table == d)[0]
+            ok = whole and len(layers) > 0 and layers[-1] - layers[0] + 1 == len(layers)
+            if not ok:
+                assert rec[0] == 0xffffffff
+                continue
+            nameable += 1
+            assert rec[0] == (s | (d << 16))
+            assert rec[1] == (min(xs) | (min(ys) << 12) | (next(iter(sds)) << 24)) and rec[3] == (max(xs) | (max(ys) << 12))
+            assert rec[2] == (int(layers[0]) | (int(layers[-1]) << 16))
+            # and the centre is the position the search reconstructs for (string, DOM)
+            i = int(geo["dom_start"][s]) + d
+            x = np.float32(np.float32(geo["dom_tx"][i]) * np.float32(geo["dom_mul_x"]) + np.float32(geo["dom_meanx"][s]))
+            assert np.float32(centres[starts[s] + d][0]) == x and np.float32(centres[starts[s] + d][2]) == np.float32(geo["dom_tz"][i])
+    return nameable, len(named), straddling
+
+
+def test_named_dom_records():
+    nameable, total, _ = _check_named_records(common.config("mie"))
+    assert nameable == total == 5160
+
+
+def test_named_dom_records_when_strings_straddle_cell_borders():
+    """strings whose bounding square overlaps several cells of the grid (a string belongs to every cell it touches,
+    GeometrySource.cxx:135-271): the record holds the rectangle"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    g = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in common.config("mie")["geom"].items()}
+    # lean the strings: DOM positions drift by up to +-12 m in x and y along a string, so the bounding squares grow
+    for sid in np.unique(g["string_ids"]):
+        m = g["string_ids"] == sid
+        z = g["z"][m]
+        t = (z - z.min()) / max(z.max() - z.min(), 1.0) - 0.5
+        g["x"][m] += 24.0 * rng.uniform(-1, 1) * t
+        g["y"][m] += 24.0 * rng.uniform(-1, 1) * t
+    cfg = dict(common.config("mie"), geom=g)
+    nameable, total, straddling = _check_named_records(cfg)
+    assert straddling > 0, "the test geometry should have strings in several cells"
+    assert nameable > 0.9 * total
