@@ -69,6 +69,9 @@ def parse():
                     help="N>1: gather the photons of launch k on a second stream while launch k+1 runs (two photon buffers). Default: "
                          "the gather runs between two launches on the launch stream -- the propagation kernel is a persistent grid "
                          "that fills every CU, a copy or RCCL kernel beside it gets slivers of the chip and slows it down (DESIGN.md 7)")
+    ap.add_argument("--consume-in-place", action="store_true",
+                    help="benchmark-host: the consumer reads the photons in the library's result buffer and releases it (a C/C++ "
+                         "consumer working on the records where they are) instead of copying them out first")
     ap.add_argument("--shard-steps", type=int, default=0,
                     help="I3CLSimSteps per GPU and pass, cut into equal bunches of at most 6 139 850 (the converter's stream limit, "
                          "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
@@ -367,8 +370,13 @@ def benchmark_host_workload(args, torch, device):
     recycled = np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=S.PHOTON_DTYPE)      # the consumer's photon buffer, reused per bunch
     while th_fwd.is_alive() or got < state["bunches"]:
         if got < state["bunches"]:
-            _, ph = conv.GetConversionResult(out=recycled)
-            hits += len(ph)
+            if args.consume_in_place:
+                _, ph, release = conv.GetConversionResultInPlace()
+                hits += len(ph)
+                release()
+            else:
+                _, ph = conv.GetConversionResult(out=recycled)
+                hits += len(ph)
             got += 1
         else:
             time.sleep(0.0005)
@@ -390,6 +398,8 @@ def benchmark_host_workload(args, torch, device):
         "config": {"workload": "reference benchmark.py through host buffers: %d x 40 TeV e- at the origin pointing down, spice_lea + tilt, "
                                "86 strings, oversize 5, step bunches of %d, double buffering" % (events, bunch),
                    "events": events, "steps": state["steps"], "bunches": state["bunches"], "photons": photons, "hits": hits,
+                   "consumer": "reads the records in the library's result buffer, then releases it" if args.consume_in_place else
+                               "copies every result (80 B per detected photon) into a buffer of its own, like the C++ adapter fills an I3CLSimPhotonSeries",
                    "shower_parameters": "restated from the published parameterisation (parity unpinned)"},
         "reference_figures": {"AverageDeviceTimePerPhoton_ns": device_ns / photons, "AverageHostTimePerPhoton_ns": 1e9 * elapsed / photons,
                               "DeviceUtilization": device_ns * 1e-9 / elapsed,

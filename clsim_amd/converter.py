@@ -342,6 +342,19 @@ class I3CLSimStepToPhotonConverterHIP:
                 histories = []
         return (ident.value, photons, histories) if with_histories else (ident.value, photons)
 
+    def GetConversionResultInPlace(self):
+        """(identifier, photons, release): `photons` is a read-only view of the library's page-locked result buffer -- what
+        a C or C++ consumer that works on the records where they are gets from clsimhip_get_conversion_result -- valid until
+        `release()` is called (clsimhip_release_result), which the caller must do"""
+        ident, ptr, n = C.c_uint32(), C.c_void_p(), C.c_size_t()
+        self._call("clsimhip_get_conversion_result", C.byref(ident), C.byref(ptr), C.byref(n))
+        if not n.value:
+            return ident.value, np.zeros(0, dtype=PHOTON_DTYPE), (lambda: None)
+        buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
+        view = np.frombuffer(buf, dtype=PHOTON_DTYPE)
+        view.flags.writeable = False
+        return ident.value, view, (lambda: self._call("clsimhip_release_result", ptr))
+
     def _size(self, name):
         v = C.c_size_t()
         self._call(name, C.byref(v))

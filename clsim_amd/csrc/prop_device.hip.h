@@ -481,16 +481,7 @@ DM Vec3 work_direction(const DevStep *work_step)
 template <bool FLASHER>
 DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint64_t &rx, uint32_t ra)
 {
-#ifdef CLSIMHIP_EXP_NT          // experiment: work records read around the L2 (they are used once per photon and flush the DOM proximity map's lines)
-    DevStep st;
-    {
-        const uint4 *q = reinterpret_cast<const uint4 *>(step_ptr);
-        uint4 v[3] = {__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2)};
-        __builtin_memcpy(&st, v, sizeof st);
-    }
-#else
     const DevStep st = *step_ptr;
-#endif
     Birth b;
     const float shift = st.length * rng_co(rx, ra);
     const float inv_speed = 1.0f / (kSpeedOfLight * st.beta);

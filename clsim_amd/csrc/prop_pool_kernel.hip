@@ -268,15 +268,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     const bool make = can && (slot < (R - n_ready));
                     if (make) {
                         const WorkRecord *rec = work + e_sidx;
-#ifdef CLSIMHIP_EXP_NT
-                        const uint32_t e_ra = __builtin_nontemporal_load(&rec->a);
-                        Vec3 step_dir;
-                        step_dir.x = __builtin_nontemporal_load(&rec->step.theta); step_dir.y = __builtin_nontemporal_load(&rec->step.phi);
-                        step_dir.z = __builtin_nontemporal_load(&rec->step.weight);
-#else
                         const uint32_t e_ra = rec->a;
                         const Vec3 step_dir = work_direction(&rec->step);
-#endif
                         Photon born;
                         born.layer = 0;
                         create_photon<MED, TILT, FLASHER, false, FAST>(P, &rec->step, step_dir, e_rx, e_ra, born);

@@ -1,0 +1,31 @@
+"""profiles/latest_traffic.json -- the file bench.py quotes `roofline.traffic` and `roofline.valu` from -- must describe the
+kernels that ship: its git_revision has to be an ancestor of (or equal to) HEAD, and no kernel source may have changed since.
+(Where there is no git history -- the GPU box gets a snapshot without .git -- the test has nothing to check and is skipped.)"""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_FILES = ["clsim_amd/csrc/prop_kernel.hip", "clsim_amd/csrc/prop_pool_kernel.hip", "clsim_amd/csrc/prop_tab_kernel.hip",
+                "clsim_amd/csrc/prop_device.hip.h", "clsim_amd/csrc/detmath.hip.h", "clsim_amd/csrc/kparams.h", "clsim_amd/csrc/Makefile"]
+
+
+def git(*args):
+    return subprocess.run(["git", "-C", ROOT] + list(args), capture_output=True, text=True)
+
+
+def test_traffic_profile_was_taken_at_the_shipped_kernels():
+    if not os.path.isdir(os.path.join(ROOT, ".git")) or git("rev-parse", "HEAD").returncode != 0:
+        pytest.skip("no git history here")
+    with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+        prof = json.load(f)
+    rev = prof["git_revision"]
+    assert git("cat-file", "-e", rev + "^{commit}").returncode == 0, "profiles/latest_traffic.json names an unknown revision: " + rev
+    assert git("merge-base", "--is-ancestor", rev, "HEAD").returncode == 0, rev + " is not an ancestor of HEAD"
+    changed = git("diff", "--name-only", rev, "HEAD", "--", *KERNEL_FILES).stdout.split()
+    # uncommitted edits count as well
+    changed += git("diff", "--name-only", "HEAD", "--", *KERNEL_FILES).stdout.split()
+    assert not changed, "kernel sources changed since the profile of %s was taken: %s -- rerun tools/profile_round.sh + tools/make_latest_traffic.py" % (rev, sorted(set(changed)))
+    assert "prop_pool_kernel<1, true, false, false, true>" in prof["kernel"]
