@@ -348,18 +348,23 @@ def benchmark_host_workload(args, torch, device):
     conv.GetConversionResult()
     feeder, ppc = make_feeder(12345)
     before = conv.GetStatistics()
-    state = {"bunches": 0, "steps": 0, "photons": 0}
+    state = {"bunches": 0, "steps": 0, "photons": 0, "wait_feeder": 0.0, "wait_enqueue": 0.0, "wait_result": 0.0}
 
     def forward():
         while True:
+            t_a = time.perf_counter()
             r = feeder.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=600000)
+            t_b = time.perf_counter()
+            state["wait_feeder"] += t_b - t_a           # the propagator's input queue is not being filled meanwhile
             assert r is not None
             steps, _, last = r
             if len(steps):
                 state["bunches"] += 1
                 state["steps"] += len(steps)
                 state["photons"] += int(steps["num"].sum())
+                t_c = time.perf_counter()
                 conv.EnqueueSteps(steps, state["bunches"])
+                state["wait_enqueue"] += time.perf_counter() - t_c     # (blocks while the input queue is full: the propagator is busy)
             if last:
                 return
     t0 = time.perf_counter()
@@ -370,6 +375,7 @@ def benchmark_host_workload(args, torch, device):
     recycled = np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=S.PHOTON_DTYPE)      # the consumer's photon buffer, reused per bunch
     while th_fwd.is_alive() or got < state["bunches"]:
         if got < state["bunches"]:
+            t_r = time.perf_counter()
             if args.consume_in_place:
                 _, ph, release = conv.GetConversionResultInPlace()
                 hits += len(ph)
@@ -377,6 +383,7 @@ def benchmark_host_workload(args, torch, device):
             else:
                 _, ph = conv.GetConversionResult(out=recycled)
                 hits += len(ph)
+            state["wait_result"] += time.perf_counter() - t_r
             got += 1
         else:
             time.sleep(0.0005)
@@ -406,6 +413,10 @@ def benchmark_host_workload(args, torch, device):
                               "definition": "resources/scripts/benchmark.py:326-340"},
         "feeder": {"photons_per_s": feeder_rate, "steps_per_s": steps_alone / feeder_seconds, "seconds": feeder_seconds,
                    "note": "the same events with nothing downstream: PPC front end, GPU step producer, download, step store, bunching"},
+        "threads": {"forwarding thread: seconds waiting for the feeder": state["wait_feeder"],
+                    "forwarding thread: seconds inside EnqueueSteps (copy + waiting for room in the input queue)": state["wait_enqueue"],
+                    "consumer: seconds inside GetConversionResult (waiting + taking the photons)": state["wait_result"],
+                    "wall clock": elapsed},
         "limiting_stage": min(stages, key=stages.get), "stage_rates_photons_per_s": stages}))
 
 

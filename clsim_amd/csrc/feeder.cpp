@@ -20,6 +20,84 @@ extern "C" const char *clsimhip_last_error(const clsimhip_converter *c);
 
 namespace clsimhip {
 
+namespace {
+void hip_must(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+} // namespace
+
+StepProducer::~StepProducer()
+{
+    if (!stream_ && !d_steps_ && !h_steps_) return;
+    int previous = -1;
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+    (void)hipSetDevice(device_);
+    if (stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
+    (void)hipFree(d_steps_); (void)hipFree(d_req_); (void)hipFree(d_first_);
+    if (h_steps_) (void)hipHostFree(h_steps_);
+    if (h_req_) (void)hipHostFree(h_req_);
+    if (h_first_) (void)hipHostFree(h_first_);
+    if (previous >= 0) (void)hipSetDevice(previous);
+}
+
+const clsimhip_step *StepProducer::generate(const std::vector<clsimhip_step_request> &requests, uint64_t seed, size_t granularity, size_t &real, size_t &padded)
+{
+    // the plan of clsimhip_generate_steps (c_api.cpp: plan_steps), with its checks
+    const size_t n = requests.size();
+    if (granularity == 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "granularity must not be 0");
+    std::vector<uint64_t> first(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const clsimhip_step_request &q = requests[i];
+        if (q.kind > CLSIMHIP_STEPS_MUON) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown step request kind");
+        if (q.photons_per_step == 0 && q.num_steps > 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "photonsPerStep may not be <= 0!");
+        if (q.kind == CLSIMHIP_STEPS_CASCADE && !(q.pa > 0.f)) throw Error(CLSIMHIP_ERR_ARGUMENT, "cascade shape parameter must be positive");
+        first[i + 1] = first[i] + q.num_steps + (q.num_photons_in_last_step > 0 ? 1 : 0);
+    }
+    real = static_cast<size_t>(first[n]);
+    padded = ((real + granularity - 1) / granularity) * granularity;
+    if (padded == 0) return nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
+    if (device_ < 0 || device_ >= count) throw Error(CLSIMHIP_ERR_DEVICE, "device ordinal out of range");
+    DeviceGuard on_device(device_);
+    if (!stream_) {
+        int least = 0, greatest = 0;
+        hip_must(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priorities");
+        hip_must(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "step producer stream");
+    }
+    if (padded > cap_steps_) {
+        const size_t cap = padded + padded / 4;
+        (void)hipFree(d_steps_); d_steps_ = nullptr;
+        if (h_steps_) { (void)hipHostFree(h_steps_); h_steps_ = nullptr; }
+        cap_steps_ = 0;
+        hip_must(hipMalloc(&d_steps_, cap * sizeof(clsimhip_step)), "step buffer");
+        hip_must(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), cap * sizeof(clsimhip_step), hipHostMallocDefault), "pinned step buffer");
+        cap_steps_ = cap;
+    }
+    if (n + 1 > cap_req_) {
+        const size_t cap = 2 * (n + 1);
+        (void)hipFree(d_req_); (void)hipFree(d_first_); d_req_ = d_first_ = nullptr;
+        if (h_req_) { (void)hipHostFree(h_req_); h_req_ = nullptr; }
+        if (h_first_) { (void)hipHostFree(h_first_); h_first_ = nullptr; }
+        cap_req_ = 0;
+        hip_must(hipMalloc(&d_req_, cap * sizeof(clsimhip_step_request)), "request buffer");
+        hip_must(hipMalloc(&d_first_, cap * sizeof(uint64_t)), "offset buffer");
+        hip_must(hipHostMalloc(&h_req_, cap * sizeof(clsimhip_step_request), hipHostMallocDefault), "pinned request buffer");
+        hip_must(hipHostMalloc(&h_first_, cap * sizeof(uint64_t), hipHostMallocDefault), "pinned offset buffer");
+        cap_req_ = cap;
+    }
+    if (n) std::memcpy(h_req_, requests.data(), n * sizeof(clsimhip_step_request));
+    std::memcpy(h_first_, first.data(), (n + 1) * sizeof(uint64_t));
+    if (n) hip_must(hipMemcpyAsync(d_req_, h_req_, n * sizeof(clsimhip_step_request), hipMemcpyHostToDevice, stream_), "upload requests");
+    hip_must(hipMemcpyAsync(d_first_, h_first_, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_), "upload offsets");
+    hip_must(launch_generate_steps(static_cast<const clsimhip_step_request *>(d_req_), static_cast<const uint64_t *>(d_first_),
+                                   static_cast<uint32_t>(n ? n : 1), real, padded, seed, d_steps_, stream_), "step generation kernel launch");
+    hip_must(hipMemcpyAsync(h_steps_, d_steps_, padded * sizeof(clsimhip_step), hipMemcpyDeviceToHost, stream_), "download steps");
+    hip_must(hipStreamSynchronize(stream_), "step generation");
+    return h_steps_;
+}
+
 Feeder::Feeder(const PPCConverter *ppc, int device, uint64_t seed, size_t max_bunch_size, size_t granularity, size_t queue_depth)
     : ppc_(ppc), device_(device), seed_(seed), max_bunch_(max_bunch_size), granularity_(granularity)
 {
@@ -155,18 +233,13 @@ void Feeder::worker()
             if (it.has_particle) {
                 std::vector<clsimhip_step_request> requests;
                 ppc_->enqueue(it.particle, requests);
+                // one random stream set per light source: results do not depend on what else is in the queue
+                // (and an identifier that comes back gets streams of its own: OccurrenceCounter, lightsource.h)
+                const uint64_t seed = seed_ ^ (0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(it.identifier) + 1ull)) ^ occurrences_.mix(it.identifier);
+                if (!producer_) producer_.reset(new StepProducer(device_));
                 size_t real = 0, padded = 0;
-                if (clsimhip_count_generated_steps(requests.data(), requests.size(), 1, &real, &padded) != CLSIMHIP_OK)
-                    throw Error(CLSIMHIP_ERR_STATE, clsimhip_last_error(nullptr));
-                std::vector<clsimhip_step> steps(padded);
-                if (padded) {
-                    // one random stream set per light source: results do not depend on what else is in the queue
-                    // (and an identifier that comes back gets streams of its own: OccurrenceCounter, lightsource.h)
-                    const uint64_t seed = seed_ ^ (0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(it.identifier) + 1ull)) ^ occurrences_.mix(it.identifier);
-                    if (clsimhip_generate_steps(device_, requests.data(), requests.size(), seed, 1, steps.data(), steps.size(), &padded) != CLSIMHIP_OK)
-                        throw Error(CLSIMHIP_ERR_DEVICE, clsimhip_last_error(nullptr));
-                }
-                insert_and_flush(steps.data(), real);
+                const clsimhip_step *steps = producer_->generate(requests, seed, 1, real, padded);
+                if (real) insert_and_flush(steps, real);
             } else {
                 insert_and_flush(it.steps.data(), it.steps.size());
             }

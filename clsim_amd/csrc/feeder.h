@@ -12,6 +12,28 @@
 
 namespace clsimhip {
 
+// The feeder's GPU step producer: one HIP stream of its own (non-blocking, highest priority: a propagator on the same GPU
+// runs persistent grids, and a launch that has to share the chip with one gets slivers of it), device and page-locked host
+// buffers that only grow.  (The stateless clsimhip_generate_steps allocates and frees device memory per call; hipFree
+// waits for the whole device, i.e. for the propagation kernel that happens to be running.)
+class StepProducer {
+public:
+    explicit StepProducer(int device) : device_(device) {}
+    ~StepProducer();
+    StepProducer(const StepProducer &) = delete;
+    StepProducer &operator=(const StepProducer &) = delete;
+    // the steps of `requests` (padded to `granularity`); the pointer stays valid until the next call
+    const clsimhip_step *generate(const std::vector<clsimhip_step_request> &requests, uint64_t seed, size_t granularity, size_t &real, size_t &padded);
+
+private:
+    int device_;
+    hipStream_t stream_ = nullptr;
+    void *d_steps_ = nullptr, *d_req_ = nullptr, *d_first_ = nullptr;
+    clsimhip_step *h_steps_ = nullptr;
+    void *h_req_ = nullptr, *h_first_ = nullptr;
+    size_t cap_steps_ = 0, cap_req_ = 0;
+};
+
 class Feeder {
 public:
     struct Result {                         // the tuple the reference puts on queueFromGeant4_ (:222, :268)
@@ -52,6 +74,7 @@ private:
     StepStore store_{0};
     std::deque<uint32_t> markers_;
     OccurrenceCounter occurrences_;     // worker thread only
+    std::unique_ptr<StepProducer> producer_;    // worker thread only
     std::atomic<bool> barrier_enqueued_{false};
     std::thread thread_;
     mutable std::mutex error_mutex_;

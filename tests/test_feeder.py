@@ -148,3 +148,38 @@ def test_destroying_a_feeder_with_work_in_flight_does_not_hang():
     t = threading.Thread(target=destroy, daemon=True)
     t.start()
     assert finished.wait(20), "clsimhip_feeder_destroy did not return"
+
+
+def test_a_dead_worker_wakes_producers_and_refuses_further_input():
+    """the worker thread dies of a device error (here: a device ordinal that does not exist, so the GPU step producer
+    fails on its first light source): a consumer waiting for steps gets the error, a producer blocked on the full input
+    queue wakes up with it, later EnqueueLightSource / EnqueueBarrier calls are refused instead of being dropped silently"""
+    cfg = common.config("mie")
+    ppc = CV.I3CLSimLightSourceToStepConverterPPC()
+    ppc.SetWlenBias(CV.GetIceCubeDOMAcceptance()); ppc.SetMediumProperties(cfg["med_p"]); ppc.SetRandomSeed(3); ppc.Initialize()
+    f = SS.I3CLSimLightSourceToStepConverterAsync(maxQueueItems=1)
+    f.SetMaxBunchSize(512); f.SetBunchSizeGranularity(64); f.SetLightSourceParameterization(ppc, seed=3, device=4242); f.Initialize()
+    parts = np.zeros(6, dtype=CV.PARTICLE_DTYPE)
+    parts["type"], parts["energy"], parts["dz"], parts["length"] = CV.ParticleType.EMinus, 5.0, -1.0, np.nan
+    parts["identifier"] = np.arange(6)
+    outcome = []
+
+    def produce():
+        try:
+            for p in parts:
+                f.EnqueueLightSource(p)
+            outcome.append("accepted everything")
+        except I3CLSimStepToPhotonConverter_exception as e:
+            outcome.append(str(e))
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    t.join(30)
+    assert not t.is_alive(), "a producer hangs on the input queue of a feeder whose worker is dead"
+    assert outcome and "feeder thread" in outcome[0], outcome
+    with pytest.raises(I3CLSimStepToPhotonConverter_exception, match="feeder thread"):
+        f.GetConversionResultWithBarrierInfoAndMarkers(timeout_ms=5000)
+    with pytest.raises(I3CLSimStepToPhotonConverter_exception, match="feeder thread"):
+        f.EnqueueLightSource(parts[0])
+    with pytest.raises(I3CLSimStepToPhotonConverter_exception, match="feeder thread"):
+        f.EnqueueBarrier()
+    assert not f.BarrierActive()

@@ -46,7 +46,10 @@ def test_pooled_hit_multiset_bit_exact(pooled, name, n_steps):
 
 
 @pytest.mark.parametrize("ring,k_pop,k_new,slices,k_search", [(4, 1, 1, 1, 1), (8, 64, 8, 3, 5), (34, 4, 30, 16, 5), (17, 2, 64, 7, 64),
-                                                               (64, 16, 1, 64, 2), (33, 7, 12, 16, 13)])
+                                                               (64, 16, 1, 64, 2), (33, 7, 12, 16, 13),
+                                                               # a ring below the smallest the kernel runs with (4) is raised to it:
+                                                               # round 2 failed the launch and with it the converter
+                                                               (1, 4, 1, 16, 3), (3, 2, 3, 5, 2)])
 def test_pooled_ragged_bunch_under_every_schedule(pooled, ring, k_pop, k_new, slices, k_search):
     """Pool sizes and thresholds must not change results: a bunch whose steps hold 0 ... 1500 photons (empty steps,
     single photons, steps much longer than a slice), two bunches in a row."""
