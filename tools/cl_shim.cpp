@@ -44,6 +44,8 @@ float cl_convert_float_i(int) CL("_Z13convert_floati");
 float cl_convert_float_i(int v) { return (float)v; }
 float cl_convert_float_s(short) CL("_Z13convert_floats");
 float cl_convert_float_s(short v) { return (float)v; }
+float cl_convert_float_t(unsigned short) CL("_Z13convert_floatt");
+float cl_convert_float_t(unsigned short v) { return (float)v; }
 short cl_convert_short_t(unsigned short) CL("_Z13convert_shortt");
 short cl_convert_short_t(unsigned short v) { return (short)v; }
 unsigned short cl_convert_ushort_t(unsigned short) CL("_Z14convert_ushortt");
@@ -70,8 +72,18 @@ float cl_sqrt(float) CL("_Z4sqrtf");
 float cl_sqrt(float x) { return om_sqrt(x); }
 float cl_rsqrt(float) CL("_Z5rsqrtf");
 float cl_rsqrt(float x) { return om_rsqrt(x); }
+// acos: this repository's definition differs by call site: the hit record's angles (sphDirFromCar) take
+// the arccosine through binary64, the table maker's azimuth (getCoordinates) a single-precision polynomial.  A program has
+// one or the other call site alive: saveHit is never called under TABULATE, getCoordinates exists only there.
+#ifndef VERBATIM_TABULATE
+#define VERBATIM_TABULATE 0
+#endif
 float cl_acos(float) CL("_Z4acosf");
+#if VERBATIM_TABULATE
+float cl_acos(float x) { return om_acos_f(x); }
+#else
 float cl_acos(float x) { return om_acos(x); }
+#endif
 float cl_atan2(float, float) CL("_Z5atan2ff");
 float cl_atan2(float y, float x) { return om_atan2(y, x); }
 float cl_fabs(float) CL("_Z4fabsf");
@@ -111,19 +123,69 @@ int cl_mini(int a, int b) { return (b < a) ? b : a; }
 float cl_dot4(float4, float4) CL("_Z3dotDv4_fS_");
 float cl_dot4(float4 a, float4 b) { return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]; }
 
-// ---- the kernel (STOP_PHOTONS_ON_DETECTION, no TABULATE, no SAVE_PHOTON_HISTORY: propagation_kernel.c.cl:406-430) ----
+// ---- builtins only the table maker's variant uses ----
+int cl_convert_int_sat_rtn_f(float) CL("_Z19convert_int_sat_rtnf");
+int cl_convert_int_sat_rtn_f(float v)
+{
+    const float f = std::floor(v);
+    if (!(f >= -2147483648.0f)) return (f != f) ? 0 : INT32_MIN;       // NaN converts to 0 (6.2.3.3)
+    if (f >= 2147483648.0f) return INT32_MAX;
+    return (int)f;
+}
+int cl_clampi(int, int, int) CL("_Z5clampiii");
+int cl_clampi(int x, int lo, int hi) { const int t = (x > lo) ? x : lo; return (t < hi) ? t : hi; }
+float cl_cbrt(float) CL("_Z4cbrtf");
+float cl_cbrt(float x) { return om_cbrt(x); }
+float cl_pow(float, float) CL("_Z3powff");
+float cl_pow(float x, float y) { return om_pow_frac(x, y); }
+float4 cl_cross(float4, float4) CL("_Z5crossDv4_fS_");
+float4 cl_cross(float4 a, float4 b)
+{
+    float4 r = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0], 0.0f};
+    return r;
+}
+
+// ---- the kernel (STOP_PHOTONS_ON_DETECTION, no TABULATE; with or without SAVE_PHOTON_HISTORY: propagation_kernel.c.cl:406-430) ----
+#ifndef VERBATIM_HISTORY
+#define VERBATIM_HISTORY 0
+#endif
+#ifndef VERBATIM_TABULATE
+#define VERBATIM_TABULATE 0
+#endif
+#if VERBATIM_TABULATE
+// -DTABULATE (propagation_kernel.c.cl:406-430): steps, reference particle, table entries, entry counters, RNG
+extern "C" void propKernel(void *inputSteps, void *referenceParticle, void *outputTableEntries, unsigned *numOutputEntries, uint64_t *MWC_RNG_x,
+                           unsigned *MWC_RNG_a);
+extern "C" void verbatim_tabulate(void *steps, void *reference, void *entries, unsigned *num_entries, uint64_t *rng_x, unsigned *rng_a, unsigned n_steps)
+{
+    for (unsigned i = 0; i < n_steps; ++i) {
+        g_global_id = i;
+        propKernel(steps, reference, entries, num_entries, rng_x, rng_a);
+    }
+}
+#elif VERBATIM_HISTORY
+extern "C" void propKernel(unsigned *hitIndex, unsigned maxHitIndex, unsigned short *geoLayerToOMNumIndexPerStringSet, void *inputSteps,
+                           void *outputPhotons, float4 *photonHistory, uint64_t *MWC_RNG_x, unsigned *MWC_RNG_a);
+#else
 extern "C" void propKernel(unsigned *hitIndex, unsigned maxHitIndex, unsigned short *geoLayerToOMNumIndexPerStringSet, void *inputSteps,
                            void *outputPhotons, uint64_t *MWC_RNG_x, unsigned *MWC_RNG_a);
+#endif
 
+#if !VERBATIM_TABULATE
 // serial NDRange: one work item after the other (the kernel's __local array is a static of the object)
 extern "C" unsigned verbatim_run(void *photons, unsigned capacity, unsigned short *layer_to_om, void *steps, uint64_t *rng_x, unsigned *rng_a,
-                                 void *unused, unsigned n_steps)
+                                 void *histories, unsigned n_steps)
 {
-    (void)unused;
+    (void)histories;
     unsigned hit_index = 0;
     for (unsigned i = 0; i < n_steps; ++i) {
         g_global_id = i;
+#if VERBATIM_HISTORY
+        propKernel(&hit_index, capacity, layer_to_om, steps, photons, static_cast<float4 *>(histories), rng_x, rng_a);
+#else
         propKernel(&hit_index, capacity, layer_to_om, steps, photons, rng_x, rng_a);
+#endif
     }
     return hit_index;
 }
+#endif

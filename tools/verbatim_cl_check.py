@@ -24,7 +24,7 @@ conditions, the layer walk, the collision search, saveHit).  What it cannot pin:
 this repository's on both sides.  `--write-fixtures` stores the verbatim kernel's hit records under tests/golden/ (data:
 inputs are regenerated from seeds, outputs are stored); tests/test_verbatim_cl.py compares oracle and HIP path with them.
 
-usage: tools/verbatim_cl_check.py [--configs c1,mie,lea,flasher] [--steps 4096] [--write-fixtures]
+usage: tools/verbatim_cl_check.py [--configs c1,mie,lea,flasher,photonics_mie,mie_history,mie_fixed_abs,lea_no_pancake] [--steps 4096] [--write-fixtures]
 """
 import argparse
 import ctypes as C
@@ -56,7 +56,7 @@ def fl(v):
 # ---------------------------------------------------------------------------------------------------------------------------
 # the generated section
 # ---------------------------------------------------------------------------------------------------------------------------
-def emit_preamble(pancake, stop_detected=True):
+def emit_preamble(pancake, stop_detected=True, fixed_abs=None, history_n=0):
     """I3CLSimHelperMath.cxx:16-46 (single precision) + OpenCL.cxx:390-442 (mode #defines)"""
     s = ("#pragma OPENCL EXTENSION cl_khr_global_int32_base_atomics : enable\n"
          "#pragma OPENCL EXTENSION cl_khr_byte_addressable_store : enable\n"
@@ -64,6 +64,10 @@ def emit_preamble(pancake, stop_detected=True):
          "#define convert_floating_t convert_float\n#define ZERO 0.f\n#define ONE 1.f\n\n")
     if stop_detected:
         s += "#define STOP_PHOTONS_ON_DETECTION\n"
+    if history_n:
+        s += "#define SAVE_PHOTON_HISTORY\n#define NUM_PHOTONS_IN_HISTORY %d\n" % history_n
+    if fixed_abs is not None:
+        s += "#define PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS %s\n" % fl(fixed_abs)
     if pancake != 1.0:
         s += "#define PANCAKE_FACTOR %s\n" % fl(pancake)
     return s
@@ -135,6 +139,38 @@ def emit_function_from_table(name, tab):
     return s
 
 
+def emit_function_from_table_16bit(name, tab_start, tab_step, values):
+    """function/I3CLSimFunctionFromTable.cxx:183-207, 262-277: values stored as 16-bit fractions of their range"""
+    from oracle import builders as B
+    lo, hi, q = B.quantize_table(values)
+    n = len(q)
+    d = name + "_data"
+    s = "#define %s_SMALLEST_ENTRY %s \n#define %s_LARGEST_ENTRY %s \n" % (d, hexf(lo), d, hexf(hi))
+    s += "__constant unsigned short %s[%d] = {%s};\n" % (d, n, ", ".join("%d" % int(v) for v in q))
+    h = name + "_getInterpolationBinAndFraction"
+    s += "inline void %s(float wavelength, int *bin, float *fraction);\n" % h
+    s += "inline void %s(float wavelength, int *bin, float *fraction)\n{\n    float fbin;\n" % h
+    s += "    *fraction = modf((wavelength - %s)/%s, &fbin);\n    int ibin=(int)fbin;\n" % (fl(tab_start), fl(tab_step))
+    s += "    if ((ibin<0) || ((ibin==0) && (*fraction<0))) {\n        ibin=0;\n        *fraction=0.f;\n"
+    s += "    } else if (ibin>=%d-1) {\n        ibin=%d-2;\n        *fraction=1.f;\n    }\n    *bin = ibin;\n}\n" % (n, n)
+    s += "inline float %s(float wavelength);\ninline float %s(float wavelength)\n{\n    int bin; float fraction;\n" % (name, name)
+    s += "    %s(wavelength, &bin, &fraction);\n" % h
+    s += ("    return mix(convert_float(%s[bin])  *((%s_LARGEST_ENTRY-%s_SMALLEST_ENTRY)/65535.f) + %s_SMALLEST_ENTRY,\n"
+          "               convert_float(%s[bin+1])*((%s_LARGEST_ENTRY-%s_SMALLEST_ENTRY)/65535.f) + %s_SMALLEST_ENTRY,\n"
+          "               fraction);\n}\n" % (d, d, d, d, d, d, d, d))
+    return s
+
+
+def emit_layer_switch(name, n_layers):
+    """MediumPropertiesSource.cxx:91-125: one function per layer behind a switch (identical function objects would share
+    one; the tables of different layers differ)"""
+    s = "inline float %s(unsigned int layer, float wavelength);\ninline float %s(unsigned int layer, float wavelength)\n{\n    switch(layer)\n    {\n" % (name, name)
+    for i in range(n_layers):
+        s += "        case %d: return %s_func%d(wavelength);\n" % (i, name, i)
+    s += "        default: return 0.;\n    }\n}\n\n"
+    return s
+
+
 def emit_refindex(name, n, g, mode):
     """function/I3CLSimFunctionRefIndexIceCube.cxx:128-180"""
     from oracle import builders as B
@@ -168,9 +204,14 @@ def emit_medium(m):
     s += "#define MEDIUM_LAYER_BOTTOM_POS %s\n#define MEDIUM_LAYER_THICKNESS  %s\n\n" % (fl(m["layers_z_start"]), fl(m["layers_height"]))
     # phase refractive index: one RefIndexIceCube object for all layers (the dispersion function the reference also emits
     # is not called by the kernel when a group-index override exists: left out)
-    assert "phase_table" not in m and "group_table" not in m, "tabulated refractive indices: not emitted by this tool"
-    s += emit_refindex("getPhaseRefIndex_func0", m["n"], m["g"], "phase") + emit_single_layer_wrapper("getPhaseRefIndex")
-    s += emit_refindex("getGroupRefIndex_func0", m["n"], m["g"], "group") + emit_single_layer_wrapper("getGroupRefIndex")
+    if "phase_table" in m:
+        s += emit_function_from_table("getPhaseRefIndex_func0", m["phase_table"]) + emit_single_layer_wrapper("getPhaseRefIndex")
+    else:
+        s += emit_refindex("getPhaseRefIndex_func0", m["n"], m["g"], "phase") + emit_single_layer_wrapper("getPhaseRefIndex")
+    if "group_table" in m:
+        s += emit_function_from_table("getGroupRefIndex_func0", m["group_table"]) + emit_single_layer_wrapper("getGroupRefIndex")
+    else:
+        s += emit_refindex("getGroupRefIndex_func0", m["n"], m["g"], "group") + emit_single_layer_wrapper("getGroupRefIndex")
     s += "#ifdef FUNCTION_getGroupRefIndex_DOES_NOT_DEPEND_ON_LAYER\n#define FUNCTION_getGroupVelocity_DOES_NOT_DEPEND_ON_LAYER\n#endif\n"
     s += "inline float getGroupVelocity(unsigned int layer, float wavelength);\n"
     s += "inline float getGroupVelocity(unsigned int layer, float wavelength)\n{\n    const float c_light = %s;\n" % fl(B.C_LIGHT)
@@ -213,6 +254,13 @@ def emit_medium(m):
                 for i, w in enumerate(which):
                     s += "        case %d: return %s_func%d(wavelength);\n" % (i, name, w)
                 s += "        default: return 0.;\n    }\n}\n\n"
+    elif m["len_mode"] == "table":
+        tb = m["table"]
+        assert tb["store16"]
+        for name, key in (("getScatteringLength", "sca"), ("getAbsorptionLength", "abs")):
+            for i in range(m["num_layers"]):
+                s += emit_function_from_table_16bit("%s_func%d" % (name, i), tb["start"], tb["step"], tb[key][i])
+            s += emit_layer_switch(name, m["num_layers"])
     else:
         raise NotImplementedError(m["len_mode"])
     # scattering angle (random_value/I3CLSimRandomValueMixed.cxx:115-157, SimplifiedLiu.cxx:64-88, HenyeyGreenstein.cxx:69-92)
@@ -344,12 +392,68 @@ def emit_geometry(geo):
     return s
 
 
-def emit_program(medium, geo, generators, bias, pancake):
+def emit_polynomial(name, coefficients):
+    """function/I3CLSimFunctionPolynomial.cxx:104-156, no range limits (two or more coefficients)"""
+    assert len(coefficients) >= 2
+    body = "".join("%s + x*(" % fl(c) for c in coefficients[:-1]) + fl(coefficients[-1]) + ")" * (len(coefficients) - 1)
+    return "inline float %s(float x);\ninline float %s(float x)\n{\nreturn %s;\n}\n" % (name, name, body)
+
+
+def emit_binning_code(tb):
+    """tabulator/Axes.cxx:68-117 (GenerateBinningCode for spherical axes), Axis.cxx:45-60, 110-113, 151-171"""
+    assert tb["kind"] == "spherical"
+    s = ""
+    if tb["full_azimuth"]:
+        s += "#define HAS_FULL_AZIMUTH_EXTENSION\n"
+    with open(os.path.join(KERNELS, "spherical_coordinates.c.cl")) as f:
+        s += f.read() + "\n"
+    s += "inline bool isOutOfBounds(const coordinate_t coords)\n{\n    return (coords.s3 > %s)|| (coords.s0 > %s);\n}\n\n" % (
+        hexf(tb["max3"]), hexf(tb["max0"]))
+    terms = []
+    for i, ax in enumerate(tb["axes"]):
+        var = "coords.s%d" % i
+        power = ax["power"] if ax["kind"] == "power" else 1
+        inv = {1: var, 2: "sqrt(%s)" % var, 3: "cbrt(%s)" % var}.get(power, "pow(%s, %s)" % (var, fl(1.0 / power)))
+        terms.append("%d*(clamp(convert_int_sat_rtn(%s*%s - %s), -1, %d)+1)" % (tb["strides"][i], hexf(tb["scale"][i]), inv, hexf(tb["offset"][i]), ax["n_bins"]))
+    s += "inline uint getBinIndex(coordinate_t coords)\n{\n    return " + "\n         + ".join(terms) + ";\n}\n\n"
+    return s
+
+
+def emit_tabulate_program(medium, generators, bias, tb):
+    """tabulator/I3CLSimStepToTableConverter.cxx:178-207: the table maker's program (no geometry: SAVE_ALL_PHOTONS)"""
+    from oracle import builders as B
+
+    def kernel(name):
+        with open(os.path.join(KERNELS, name)) as f:
+            return f.read()
+    s = emit_preamble(1.0, stop_detected=False)
+    s += "#define SAVE_ALL_PHOTONS\n#define SAVE_ALL_PHOTONS_PRESCALE 1\n#define PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS 42\n#define TABULATE\n"
+    if len(tb["axes"]) > 4:
+        s += "#define TABULATE_IMPACT_ANGLE\n"
+    s += "#define TABLE_ENTRIES_PER_STREAM %d\n#define VOLUME_MODE_STEP %s\n" % (tb["entries_per_stream"], hexf(tb["volume_step"]))
+    s += "__constant floating_t min_invGroupVel = %s;\n__constant floating_t tan_thetaC = %s;\n" % (hexf(tb["min_inv_groupvel"]), hexf(tb["tan_thetac"]))
+    s += kernel("mwcrng_kernel.cl")
+    s += emit_wavelength_generators(generators)
+    s += emit_function_from_table("getWavelengthBias", bias) + "\n"
+    s += emit_medium(medium)
+    s += emit_polynomial("getAngularAcceptance", tb["angular"])
+    # saveHit() (c.cl:307-404, compiled but never called under TABULATE) calls geometryGetDomPosition, which only the geometry
+    # source defines -- and the table maker's program has none (StepToTableConverter.cxx:196-206): at this revision the
+    # reference's own table-maker program does not compile either.  An empty definition stands in for it here.
+    s += ("inline void geometryGetDomPosition(unsigned short stringNum, unsigned short domNum, floating_t *domPosX, floating_t *domPosY, "
+          "floating_t *domPosZ) { *domPosX = 0.f; *domPosY = 0.f; *domPosZ = 0.f; }\n")
+    s += kernel("propagation_kernel.h.cl")
+    s += emit_binning_code(tb)
+    s += kernel("propagation_kernel.c.cl")
+    return s
+
+
+def emit_program(medium, geo, generators, bias, pancake, fixed_abs=None, history_n=0):
     """OpenCL.cxx:659-667: preamble, RNG, wavelength generators, bias, medium, geometry, kernels"""
     def kernel(name):
         with open(os.path.join(KERNELS, name)) as f:
             return f.read()
-    s = emit_preamble(pancake)
+    s = emit_preamble(pancake, fixed_abs=fixed_abs, history_n=history_n)
     s += kernel("mwcrng_kernel.cl")
     s += emit_wavelength_generators(generators)
     s += emit_function_from_table("getWavelengthBias", bias) + "\n"
@@ -363,7 +467,7 @@ def emit_program(medium, geo, generators, bias, pancake):
 # ---------------------------------------------------------------------------------------------------------------------------
 # build and run
 # ---------------------------------------------------------------------------------------------------------------------------
-def build(program_text, workdir, no_flasher):
+def build(program_text, workdir, no_flasher, history, tabulate=False):
     cl = os.path.join(workdir, "program.cl")
     with open(cl, "w") as f:
         f.write(program_text)
@@ -375,28 +479,127 @@ def build(program_text, workdir, no_flasher):
     subprocess.check_call(cmd)
     so = os.path.join(workdir, "libverbatim.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-I" + os.path.join(ROOT, "oracle"),
-                           "-o", so, os.path.join(ROOT, "tools", "cl_shim.cpp"), obj])
+                           "-DVERBATIM_HISTORY=%d" % (1 if history else 0), "-DVERBATIM_TABULATE=%d" % (1 if tabulate else 0), "-o", so, os.path.join(ROOT, "tools", "cl_shim.cpp"), obj])
     return so
 
 
-def run_verbatim(so, geo, steps, x, a, capacity):
+def run_verbatim(so, geo, steps, x, a, capacity, history_n=0):
     lib = C.CDLL(so)
     lib.verbatim_run.restype = C.c_uint32
     lib.verbatim_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     n = len(steps)
     out = np.zeros((capacity, 80), dtype=np.uint8)
+    hist = np.zeros((capacity, max(history_n, 1), 4), dtype=np.float32)
     xs = np.ascontiguousarray(x, dtype=np.uint64).copy()
     a32 = np.ascontiguousarray(a, dtype=np.uint32).copy()
     lto = np.ascontiguousarray(geo["layer_to_om"], dtype=np.uint16)
     st = np.ascontiguousarray(steps)
-    cnt = lib.verbatim_run(out.ctypes.data, capacity, lto.ctypes.data, st.ctypes.data, xs.ctypes.data, a32.ctypes.data, None, n)
-    return out[:min(cnt, capacity)], int(cnt), xs
+    cnt = lib.verbatim_run(out.ctypes.data, capacity, lto.ctypes.data, st.ctypes.data, xs.ctypes.data, a32.ctypes.data, hist.ctypes.data, n)
+    k = min(cnt, capacity)
+    return out[:k], int(cnt), xs, hist[:k]
 
 
-def check_config(name, n_steps, write_fixtures):
+def used_history_entries(photons, rings):
+    """the ring entries that hold scatter points, in forward order (OpenCL.cxx:940-989), the rest zeroed"""
+    n = rings.shape[1]
+    out = np.zeros_like(rings)
+    for i, ns in enumerate(photons["numScatters"]):
+        ns = int(ns)
+        recorded = min(ns, n)
+        cur = 0 if ns <= n else ns % n
+        for j in range(recorded):
+            out[i, j] = rings[i, cur]
+            cur = (cur + 1) % n
+    return out
+
+
+# name -> (configuration of tests/common.py, converter options): the static kernel files' #ifdef branches in use
+CASES = {
+    "c1": ("c1", {}), "mie": ("mie", {}), "lea": ("lea", {}), "flasher": ("flasher", {}),
+    "photonics_mie": ("photonics_mie", {}),                         # per-layer tables in 16 bits, tabulated refractive indices, HG only
+    "mie_history": ("mie", dict(history=4)),                        # SAVE_PHOTON_HISTORY
+    "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)),                  # PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
+    "lea_no_pancake": ("lea", dict(pancake=1.0)),                   # no PANCAKE_FACTOR
+    # the table maker's kernel (-DTABULATE, spherical_coordinates.c.cl): 4 axes; azimuth to 360 degrees; impact-angle axis;
+    # too little entry space
+    "tabulate": ("mie", {}), "tabulate360": ("mie", {}), "tabulate5": ("mie", {}), "tabulate_overflow": ("mie", {}),
+}
+
+
+def check_tabulate(case, write_fixtures):
+    """the TABULATE variant (propagation_kernel.c.cl:228-303, 755-785 + spherical_coordinates.c.cl) against oracle_tabulate:
+    table entries (bin index, weight) of every stream in order, entry counts, photons left and RNG states"""
+    from clsim_amd import synthetic as S
+    from oracle import builders as B, capi
+    from tests import common
+    cfg = common.config("mie")
+    angular = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
+    if case == "tabulate5":
+        axes = [B.power_axis(0, 580, 40, 2), B.linear_axis(0, 180, 8), B.linear_axis(-1, 1, 20), B.power_axis(0, 7e3, 21, 2), B.linear_axis(-1, 1, 10)]
+    elif case == "tabulate360":
+        axes = [B.power_axis(0, 300, 30, 2), B.linear_axis(0, 360, 24), B.linear_axis(-1, 1, 20), B.power_axis(0, 3e3, 30, 2)]
+    else:
+        axes = [B.power_axis(0, 580, 40, 2), B.linear_axis(0, 180, 8), B.linear_axis(-1, 1, 20), B.power_axis(0, 7e3, 21, 2)]
+    eps = 6000 if case == "tabulate_overflow" else 40000              # too few entries: streams stop early and rewind (c.cl:770-776)
+    tb = B.tabulator_config("spherical", axes, cfg["med_o"], angular, entries_per_stream=eps)
+    bias = B.icecube_dom_acceptance()
+    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=1.0, tabulator=tb)
+    n = 64
+    steps = S.cascade_steps(n, seed=5, vertex=(3.0, -2.0, 10.0), photons_per_step=12, pad_to=n)
+    x, a = common.streams(n)
+    ref = B.reference_particle((1.0, 0.5, -2.0), 3.0, (0.3, -0.2, 0.9327379053))
+    ent_o, num_o, left_o, x_o = capi.tabulate(T, steps, x, a, ref, threads=8)
+    text = emit_tabulate_program(cfg["med_o"], gens, bias, tb)
+    with tempfile.TemporaryDirectory() as d:
+        so = build(text, d, no_flasher=True, history=False, tabulate=True)
+        lib = C.CDLL(so)
+        lib.verbatim_tabulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        st = np.ascontiguousarray(steps).copy()
+        ent_v = np.zeros((n, eps), dtype=capi.ENTRY_DTYPE)
+        num_v = np.zeros(n, dtype=np.uint32)
+        xs = np.ascontiguousarray(x, dtype=np.uint64).copy()
+        a32 = np.ascontiguousarray(a, dtype=np.uint32).copy()
+        refv = np.ascontiguousarray(ref, dtype=np.float32)
+        lib.verbatim_tabulate(st.ctypes.data, refv.ctypes.data, ent_v.ctypes.data, num_v.ctypes.data, xs.ctypes.data, a32.ctypes.data, n)
+    # the kernel leaves the photons it could not finish in inputSteps[i].numPhotons (c.cl:773); a finished step keeps its count
+    left_v = np.where(num_v >= eps - 0, st["num"], 0).astype(np.uint32)
+    left_v = np.where(st["num"] != steps["num"], st["num"], 0).astype(np.uint32)
+    same_num = np.array_equal(num_v, num_o)
+    same_left = np.array_equal(left_v, left_o)
+    same_rng = np.array_equal(xs, x_o)
+    same_entries = same_num and all(ent_v[i, :num_v[i]].tobytes() == ent_o[i, :num_o[i]].tobytes() for i in range(n))
+    print("%-18s %4d streams %8d entries: entry counts %s | entries (bin, weight) %s | photons left (%d) %s | RNG states %s"
+          % (case, n, int(num_v.sum()), "IDENTICAL" if same_num else "DIFFER", "IDENTICAL" if same_entries else "DIFFER", int(left_v.sum()),
+             "IDENTICAL" if same_left else "DIFFER", "IDENTICAL" if same_rng else "DIFFER"), flush=True)
+    ok = same_num and same_entries and same_left and same_rng
+    if write_fixtures and ok:
+        out = os.path.join(ROOT, "tests", "golden", "verbatim_cl_%s.npz" % case)
+        # the entry stream itself is 10 MB: stored are its SHA-256 (stream after stream, entries in order), the table it
+        # adds up to in binary64 (the order-independent sum) and the per-stream bookkeeping
+        import hashlib
+        flat = np.concatenate([ent_v[i, :num_v[i]] for i in range(n)])
+        bins = np.zeros(tb["n_bins"], dtype=np.float64)
+        np.add.at(bins, flat["index"], flat["weight"].astype(np.float64))
+        nz = np.nonzero(bins)[0]
+        if len(nz) > 60000:             # (the five-dimensional table: the hash of the entry stream says it all; keep the fixture small)
+            nz = nz[:0]
+        np.savez_compressed(out, num=num_v, left=left_v, rng_x=xs, entries_sha256=np.frombuffer(hashlib.sha256(flat.tobytes()).digest(), dtype=np.uint8),
+                            bins_nonzero=nz.astype(np.uint32), bins_sum=bins[nz], n_bins=np.int64(tb["n_bins"]), entries_per_stream=np.int64(eps))
+        print("   wrote", os.path.relpath(out, ROOT))
+    return ok
+
+
+def check_config(case, n_steps, write_fixtures):
+    if case.startswith("tabulate"):
+        return check_tabulate(case, write_fixtures)
     from clsim_amd.synthetic import PHOTON_DTYPE
     from oracle import builders as B, capi
     from tests import common
+    name, opt = CASES[case]
+    pancake, fixed_abs, history = opt.get("pancake", 5.0), opt.get("fixed_abs"), opt.get("history", 0)
     cfg = common.config(name)
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
@@ -406,29 +609,43 @@ def check_config(name, n_steps, write_fixtures):
         gens.append(dict(kind="const", value=common.FLASHER_WLEN))
     steps = common.steps_for(cfg, n_steps, seed=3)
     x, a = common.streams(len(steps))
-    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=5.0)
-    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
-    text = emit_program(cfg["med_o"], geo, gens, bias, 5.0)
+    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, fixed_abs_lengths=fixed_abs, history_entries=history)
+    if history:
+        ph_o, cnt_o, x_o, _, hist_o = capi.propagate(T, steps, x, a, history=True)
+    else:
+        ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
+    text = emit_program(cfg["med_o"], geo, gens, bias, pancake, fixed_abs=fixed_abs, history_n=history)
     with tempfile.TemporaryDirectory() as d:
-        so = build(text, d, no_flasher=not cfg["flasher"])
-        rec, cnt_v, x_v = run_verbatim(so, geo, steps, x, a, max(4 * cnt_o, 1024))
+        so = build(text, d, no_flasher=not cfg["flasher"], history=bool(history))
+        rec, cnt_v, x_v, hist_v = run_verbatim(so, geo, steps, x, a, max(4 * cnt_o, 1024), history)
     ph_v = np.frombuffer(rec.tobytes(), dtype=PHOTON_DTYPE)
     same_count = cnt_v == cnt_o
     same_rng = np.array_equal(x_v, x_o)
     same_hits = same_count and common.sort_photons(ph_v).tobytes() == common.sort_photons(ph_o).tobytes()
-    print("%-8s %6d steps %9d photons: verbatim kernel %6d hits, oracle %6d hits | hit records %s | final RNG states %s"
-          % (name, len(steps), int(steps["num"].sum()), cnt_v, cnt_o, "IDENTICAL" if same_hits else "DIFFER", "IDENTICAL" if same_rng else "DIFFER"), flush=True)
+    extra = ""
+    if history:
+        # both sides run serially, step after step: the records come out in the same order, each with its history ring
+        # (ring entries a photon never wrote are uninitialised private memory in the reference, c.cl:452-455: compared are the
+        # entries ConvertPhotonHistories reads, OpenCL.cxx:940-989)
+        same_hist = same_count and ph_v.tobytes() == ph_o.tobytes() and \
+            np.array_equal(used_history_entries(ph_v, hist_v).view(np.uint32), used_history_entries(ph_o, hist_o).view(np.uint32))
+        extra = " | photon histories %s" % ("IDENTICAL" if same_hist else "DIFFER")
+        same_hits = same_hits and same_hist
+    print("%-14s %6d steps %9d photons: verbatim kernel %6d hits, oracle %6d hits | hit records %s | final RNG states %s%s"
+          % (case, len(steps), int(steps["num"].sum()), cnt_v, cnt_o, "IDENTICAL" if same_hits else "DIFFER", "IDENTICAL" if same_rng else "DIFFER", extra), flush=True)
     if write_fixtures and same_hits and same_rng:
-        out = os.path.join(ROOT, "tests", "golden", "verbatim_cl_%s.npz" % name)
-        np.savez_compressed(out, n_steps=np.int64(n_steps), seed=np.int64(3), hits=common.sort_photons(ph_v).view(np.uint8).reshape(-1, 80),
-                            rng_x=x_v)
+        out = os.path.join(ROOT, "tests", "golden", "verbatim_cl_%s.npz" % case)
+        data = dict(n_steps=np.int64(n_steps), seed=np.int64(3), hits=common.sort_photons(ph_v).view(np.uint8).reshape(-1, 80), rng_x=x_v)
+        if history:
+            data.update(unsorted_hits=ph_v.view(np.uint8).reshape(-1, 80), histories=used_history_entries(ph_v, hist_v))
+        np.savez_compressed(out, **data)
         print("   wrote", os.path.relpath(out, ROOT))
     return same_hits and same_rng
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="c1,mie,lea,flasher")
+    ap.add_argument("--configs", default=",".join(CASES))
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--write-fixtures", action="store_true")
     args = ap.parse_args()
@@ -436,7 +653,7 @@ def main():
         raise SystemExit("the reference tree is not on this machine: this check runs in the build container only")
     ok = True
     for name in args.configs.split(","):
-        ok = check_config(name, 1000 if name == "c1" else args.steps, args.write_fixtures) and ok
+        ok = check_config(name, 1000 if name == "c1" else (2048 if name in ("mie_history", "photonics_mie") else args.steps), args.write_fixtures) and ok
     raise SystemExit(0 if ok else 1)
 
 
