@@ -151,9 +151,15 @@ def test_hip_table_maker_equals_the_verbatim_kernel(case):
     cfg, axes, tb, steps, x, a, ref, f = tab_setup(case)
     p_axes = TB.SphericalAxes([(TB.PowerAxis if ax["kind"] == "power" else TB.LinearAxis)(*((ax["min"], ax["max"], ax["n_bins"]) +
                               ((ax["power"],) if ax["kind"] == "power" else ()))) for ax in axes])
+    # the table maker takes bunches and stream sets in multiples of 256: the 64 steps of the fixture, then steps without
+    # photons (they draw nothing); a stream set's first 64 streams are the set of 64
+    x256, a256 = common.streams(256)
+    assert np.array_equal(x256[:64], x) and np.array_equal(a256[:64], a)
+    padded = S.cascade_steps(64, seed=5, vertex=(3.0, -2.0, 10.0), photons_per_step=12, pad_to=256)
+    assert np.array_equal(padded[:64], steps) and not padded["num"][64:].any()
     tab = TB.I3CLSimStepToTableConverterHIP(0, p_axes, False, cfg["med_p"], np.pi * 0.16510 ** 2, CV.GetIceCubeDOMAcceptance(),
-                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a))
-    tab.EnqueueSteps(steps, tuple(float(v) for v in (ref[0], ref[1], ref[2], ref[3], ref[4], ref[5], ref[6])))
+                                            TB.I3CLSimFunctionPolynomial(ANGULAR), (x256, a256))
+    tab.EnqueueSteps(padded, tuple(float(v) for v in (ref[0], ref[1], ref[2], ref[3], ref[4], ref[5], ref[6])))
     tab.Finish()
     sums = tab.GetBinSums().ravel()
     expect = np.zeros(int(f["n_bins"]), dtype=np.float64)
