@@ -76,6 +76,9 @@ def parse():
                     help="I3CLSimSteps per GPU and pass, cut into equal bunches of at most 6 139 850 (the converter's stream limit, "
                          "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
                          "c2 -> C4 = 100M steps / 8 = 12 500 000 per GPU (weak scaling), c5 -> 10^9 photons / N (strong scaling)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N>1 (or CLSIMHIP_BENCH_GATHER=1): after the timed region, one more launch whose gathered photons on rank 0 "
+                         "are compared with every rank's own buffer (record counts and a 64-bit sum); config.gather_verified")
     return ap.parse_args()
 
 
@@ -461,10 +464,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the propagator has no CPU path")
+    # CLSIMHIP_BENCH_REHEARSAL=1: a FUNCTIONAL rehearsal of the --gpus N path on a box with one GPU -- every rank uses
+    # device 0, torch.distributed runs over gloo (control messages on the CPU) and CLSIMHIP_RCCL_LIBRARY is expected to
+    # name tests/libfake_rccl.so in its process mode (FAKE_RCCL_DIR).  The line is flagged; its rate measures nothing.
+    rehearsal = os.environ.get("CLSIMHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if rehearsal else dev     # where the control tensors of torch.distributed live
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload in ("tab", "tab5"):
         return tabulator_bench(args, torch, local_rank)
@@ -544,7 +557,7 @@ def main():
         except Exception as exc:
             gather_note = "%s: %s" % (type(exc).__name__, str(exc)[:120])
         if world > 1:
-            ok = torch.tensor([0 if gather_note else 1], dtype=torch.int32, device=dev)
+            ok = torch.tensor([0 if gather_note else 1], dtype=torch.int32, device=ctl)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 gather_note = gather_note or "RCCL could not be loaded on another rank"
@@ -556,7 +569,7 @@ def main():
         if world > 1:
             # every rank takes the same path: if the library's communicator failed anywhere, all fall back to the
             # same gather through torch.distributed (clsim_amd/distributed.py: gather_hits), and the line says so
-            ok = torch.tensor([1 if gatherer is not None else 0], dtype=torch.int32, device=dev)
+            ok = torch.tensor([1 if gatherer is not None else 0], dtype=torch.int32, device=ctl)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 if gatherer is not None:
@@ -640,10 +653,37 @@ def main():
     counted_last = int(d_count[(state["pass"] - 1) % n_buffers].cpu().item())
     hits_last = min(counted_last, capacity)             # the counter keeps counting past the buffer; `capacity` records are stored
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    verified = None
+    if args.verify_gather and use_gather:
+        # outside the timed region: one more launch of the last bunch, gathered, and rank 0's buffer compared with what
+        # each rank holds -- a 64-bit sum over every rank's records and the exact record counts
+        hits_timed, state["hits"] = state["hits"], 0
+        one_launch(n_bunches - 1)
+        flush()
+        barrier()
+        b = (state["pass"] - 1) % n_buffers
+        mine = min(int(d_count[b].cpu().item()), capacity)
+        sums = torch.zeros(world, 2, dtype=torch.int64)
+        sums[rank, 0] = mine
+        sums[rank, 1] = int(d_photons[b][:mine].view(torch.int64).sum().item()) if mine else 0
+        if world > 1:
+            box = sums.to(ctl)
+            dist.all_reduce(box, op=dist.ReduceOp.SUM)
+            sums = box.cpu()
+        if rank == 0:
+            verified, at = True, 0
+            for r in range(world):
+                k = int(sums[r, 0])
+                seen = int(gathered[at:at + k].view(torch.int64).sum().item()) if k else 0
+                verified = verified and (seen == int(sums[r, 1]))
+                at += k
+            verified = bool(verified and at == state["hits"])
+        state["hits"] = hits_timed
 
     if args.workload == "c2" and shard == 100000000 // 8:
         workload_name = "C4 = BASELINE configs[3]: 100M steps / 8 GPUs = 12 500 000 steps per GPU%s, hits gathered on rank 0" % (
@@ -698,7 +738,8 @@ def main():
                                       "FALLBACK torch.distributed gather_hits (%s)" % gather_note),
                        "hits_last_pass_rank0": hits_last, "hit_counter_last_pass_rank0": counted_last,
                        "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
-                       "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0)},
+                       "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0),
+                       "gather_verified": verified},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "avg_kernel_ms": avg_ms, "launches": int(launches),
@@ -706,6 +747,10 @@ def main():
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / n_bunches / (avg_ms * 1e-3))},
         }
+        if rehearsal:
+            out["rehearsal"] = ("FUNCTIONAL REHEARSAL, NOT A MEASUREMENT: %d ranks time-share one GPU, torch.distributed over gloo, "
+                                "RCCL library = %s" % (world, os.environ.get("CLSIMHIP_RCCL_LIBRARY", "(default)")))
+            out["value"] = None
         if world == 1 and not args.no_host_path:
             # the reference's "actual" metric, outside the timed region of `value`: a second converter with two buffer sets
             del d_photons, d_count

@@ -1,0 +1,60 @@
+"""bench.py's --gpus N path, executed for real on a box with ONE GPU.
+
+The driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` on a whole node at round
+end; nothing in this repository can start that.  This test starts the very same command with N = 2 and 4 processes that
+time-share the one GPU (CLSIMHIP_BENCH_REHEARSAL=1: every rank on device 0, torch.distributed over gloo) and with
+tests/libfake_rccl.so in its process mode standing in for librccl (the real one refuses two ranks on one device).  What
+it proves: the sharding into bunches per rank, clsimhip_comm_create / clsimhip_gather_hits between PROCESSES, the
+fallback agreement, the max-over-ranks clock and the JSON line -- and, with --verify-gather, that rank 0 holds exactly the
+records the ranks produced.  The rate it prints is not a measurement and the line says so (`value` null).
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "libfake_rccl.so")
+
+
+def _run(world, workload, shard_steps, port):
+    scratch = tempfile.mkdtemp(prefix="fake_rccl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    env = dict(os.environ, CLSIMHIP_BENCH_REHEARSAL="1", CLSIMHIP_RCCL_LIBRARY=FAKE, FAKE_RCCL_DIR=scratch,
+               MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+           "--workload", workload, "--verify-gather"] + (["--shard-steps", str(shard_steps)] if shard_steps else [])
+    try:
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    assert p.returncode == 0, "bench.py --gpus %d failed (%d):\n%s\n%s" % (world, p.returncode, p.stdout[-3000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,workload,shard,port", [(2, "c2", 700000, 29711), (4, "c2", 300000, 29713), (2, "c5", 100000, 29715),
+                                                      (2, "c2", None, 29717)])   # None: the driver's own command, C4's shard of 12.5M steps per rank
+def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port):
+    from tests.test_comm_fake_rccl import build_fake
+    assert build_fake() == FAKE
+    out = _run(world, workload, shard, port)
+    assert out["n_gpus"] == world and out["steps"] == 1
+    assert out["value"] is None and "REHEARSAL" in out["rehearsal"]
+    cfg = out["config"]
+    assert cfg["hit_gather"].startswith("clsimhip_gather_hits"), cfg["hit_gather"]          # not the torch.distributed fallback
+    assert cfg["gather_verified"] is True
+    if shard is None:
+        shard = 12500000
+        assert cfg["bunches_per_pass"] == 3 and "C4 = BASELINE configs[3]" in cfg["workload"]
+    assert cfg["steps_per_gpu"] == shard
+    assert cfg["bunches_per_pass"] * cfg["steps_per_bunch"] >= shard
+    assert cfg["overflowed_buffers"] == 0
+    assert cfg["hits_gathered_per_pass"] > cfg["hits_last_pass_rank0"] > 0                  # more than rank 0's own photons arrived
+    assert cfg["photons_per_pass_all_gpus"] == world * shard * cfg["photons_per_step"]
