@@ -76,7 +76,7 @@ typedef struct {
 
 typedef struct {
     /* ---- compile-time switches of the reference (OpenCL.cxx:390-442) ---- */
-    int32_t stop_detected;      /* STOP_PHOTONS_ON_DETECTION (only 1 is restated) */
+    int32_t stop_detected;      /* STOP_PHOTONS_ON_DETECTION (OpenCL.cxx:395-397); 0: detected photons travel on */
     int32_t has_pancake;        /* PANCAKE_FACTOR defined (pancakeFactor != 1) */
     float pancake;
     /* ---- medium (MediumPropertiesSource.cxx:207-389) ---- */
@@ -635,6 +635,121 @@ static int checkForCollision(const oracle_tables *T, const float pos[4], const f
     return hitRecorded;
 }
 
+/* ---- the same search without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false), OpenCL.cxx:395-397): every DOM the
+ * segment enters is saved on the spot with the distance to it, the step is not shortened, the photon travels on
+ * (sparse_collision_kernel.c.cl:165-186, :580-584; propagation_kernel.c.cl:704-750) ---- */
+typedef struct {
+    float inv_groupvel, totalPath, distAbsLens;
+    uint32_t numScatters;
+    const float *startPos, *startDirw;
+    const oracle_step *step;
+    hit_sink *sink;
+} keep_ctx;
+
+/* `1 << convert_ulong(n%64)` (c.cl:103-104, :252-253): the literal 1 is an int, so OpenCL takes the shift count modulo 32
+ * (6.3.j) and the int result is widened to ulong with its sign: DOMs (strings) n and n+32 share a bit, and bit 31 drags bits
+ * 32..63 along */
+static inline uint64_t opencl_int_bit(unsigned n) { return (uint64_t)(int64_t)(int32_t)(1u << ((n % 64u) & 31u)); }
+
+/* c.cl:27-192, #ifndef STOP_PHOTONS_ON_DETECTION */
+static void checkForCollision_OnString_keep(const oracle_tables *T, unsigned stringNum, float dirLenXYSqr,
+                                            const float pos[4], const float dirw[4], float thisStepLength, const keep_ctx *K)
+{
+    const unsigned stringSet = T->str_set[stringNum];
+    {
+        const float smin = sqr(((pos[0] - T->str_x[stringNum]) * dirw[1]
+                                - (pos[1] - T->str_y[stringNum]) * dirw[0])) / dirLenXYSqr;
+        if (smin > sqr(T->string_max_radius)) return;
+    }
+    {
+        if ((dirw[2] > 0.0f) && (pos[2] > T->str_maxz[stringNum] + T->om_radius)) return;
+        if ((dirw[2] < 0.0f) && (pos[2] < T->str_minz[stringNum] - T->om_radius)) return;
+    }
+    int lowLayerZ = (int)((pos[2] - T->set_startz[stringSet]) / T->set_height[stringSet]);
+    int highLayerZ = (int)((pos[2] + dirw[2] * thisStepLength - T->set_startz[stringSet]) / T->set_height[stringSet]);
+    if (highLayerZ < lowLayerZ) { int tmp = lowLayerZ; lowLayerZ = highLayerZ; highLayerZ = tmp; }
+    lowLayerZ = imin(imax(lowLayerZ, 0), (int)T->set_nlayers[stringSet] - 1);
+    highLayerZ = imin(imax(highLayerZ, 0), (int)T->set_nlayers[stringSet] - 1);
+
+    /* :85-90: `ulong dom_bitmask[(GEO_MAX_DOM_INDEX+63)/64]`, zeroed per call, of which a call touches the one word
+     * [stringNum/64] (:103-104 index with the STRING number).  That word exists for stringNum < 64*((GEO_MAX_DOM_INDEX+63)/64);
+     * beyond (a 65th string of a detector with at most 64 DOMs per string) the reference reads and writes past its array,
+     * which is undefined: the restatement behaves as an array that is long enough, i.e. one zeroed word per call. */
+    uint64_t dom_bitmask = 0;
+    const uint16_t *geoLayerToOMNumIndex = T->layer_to_om + (stringSet * (unsigned)T->max_layers) + lowLayerZ;
+    for (int layer_z = lowLayerZ; layer_z <= highLayerZ; ++layer_z, ++geoLayerToOMNumIndex) {
+        const unsigned domNum = *geoLayerToOMNumIndex;
+        if (domNum == 0xFFFF) continue;
+        if (dom_bitmask & opencl_int_bit(domNum)) continue;         /* a DOM named by several layers is tested once */
+        dom_bitmask |= opencl_int_bit(domNum);
+        float domPosX, domPosY, domPosZ;
+        geometryGetDomPosition(T, stringNum, domNum, &domPosX, &domPosY, &domPosZ);
+        float urdot, discr;
+        {
+            const float dx = domPosX - pos[0], dy = domPosY - pos[1], dz = domPosZ - pos[2], dw = 0.0f;
+            const float dr2 = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+            urdot = ((dx * dirw[0] + dy * dirw[1]) + dz * dirw[2]) + dw * dirw[3];
+            discr = sqr(urdot) - dr2 + T->om_radius * T->om_radius;
+        }
+        if (discr < 0.0f) continue;
+        if (T->has_pancake) discr = om_sqrt(discr) / T->pancake;
+        else discr = om_sqrt(discr);
+        {
+            const float smin2 = urdot + discr;
+            if (smin2 < 0.0f) continue;
+        }
+        const float smin1 = urdot - discr;
+        if (smin1 < 0.0f) continue;
+        if (smin1 < thisStepLength)                                  /* :165-186 */
+            saveHit(T, pos, dirw, smin1, K->inv_groupvel, K->totalPath, K->numScatters, K->distAbsLens, K->startPos,
+                    K->startDirw, K->step, stringNum, domNum, K->sink);
+    }
+}
+
+/* c.cl:194-303, #ifndef STOP_PHOTONS_ON_DETECTION */
+static void checkForCollision_InCell_keep(const oracle_tables *T, int sd, float dirLenXYSqr, const float pos[4],
+                                          const float dirw[4], float thisStepLength, const keep_ctx *K)
+{
+    const float sx = T->cell_sx[sd], sy = T->cell_sy[sd], wx = T->cell_wx[sd], wy = T->cell_wy[sd];
+    const int nx = T->cell_nx[sd], ny = T->cell_ny[sd];
+    int lowCellX = (int)((pos[0] - sx) / wx);
+    int lowCellY = (int)((pos[1] - sy) / wy);
+    int highCellX = (int)((pos[0] + dirw[0] * thisStepLength - sx) / wx);
+    int highCellY = (int)((pos[1] + dirw[1] * thisStepLength - sy) / wy);
+    if (highCellX < lowCellX) { int tmp = lowCellX; lowCellX = highCellX; highCellX = tmp; }
+    if (highCellY < lowCellY) { int tmp = lowCellY; lowCellY = highCellY; highCellY = tmp; }
+    lowCellX = imin(imax(lowCellX, 0), nx - 1);
+    lowCellY = imin(imax(lowCellY, 0), ny - 1);
+    highCellX = imin(imax(highCellX, 0), nx - 1);
+    highCellY = imin(imax(highCellY, 0), ny - 1);
+    /* :245-249: one bit per string, in words of 64, zeroed per subdetector */
+    const int words = (T->num_strings + 63) / 64;
+    uint64_t string_bitmask[words > 0 ? words : 1];
+    for (int i = 0; i < words; ++i) string_bitmask[i] = 0;
+    for (int cell_y = lowCellY; cell_y <= highCellY; ++cell_y) {
+        for (int cell_x = lowCellX; cell_x <= highCellX; ++cell_x) {
+            const unsigned stringNum = T->cell_index[sd][cell_y * nx + cell_x];
+            if (stringNum == 0xFFFF) continue;
+            if (string_bitmask[stringNum / 64] & opencl_int_bit(stringNum)) continue;      /* :252 */
+            string_bitmask[stringNum / 64] |= opencl_int_bit(stringNum);                   /* :253 */
+            checkForCollision_OnString_keep(T, stringNum, dirLenXYSqr, pos, dirw, thisStepLength, K);
+        }
+    }
+}
+
+/* c.cl:462-587, #ifndef STOP_PHOTONS_ON_DETECTION: "this will always return false" */
+static int checkForCollision_keep(const oracle_tables *T, const float pos[4], const float dirw[4], float inv_groupvel,
+                                  float totalPath, uint32_t numScatters, float distAbsLens, const float startPos[4],
+                                  const float startDirw[4], const oracle_step *step, float thisStepLength, hit_sink *sink)
+{
+    const float dirLenXYSqr = sqr(dirw[0]) + sqr(dirw[1]);
+    if (dirLenXYSqr <= 0.0f) return 0;
+    const keep_ctx K = { inv_groupvel, totalPath, distAbsLens, numScatters, startPos, startDirw, step, sink };
+    for (int sd = 0; sd < T->num_subdet; ++sd)
+        checkForCollision_InCell_keep(T, sd, dirLenXYSqr, pos, dirw, thisStepLength, &K);
+    return 0;
+}
+
 /* ---------------- TABULATE ---------------- */
 typedef struct __attribute__((packed)) { uint32_t index; float weight; } oracle_table_entry;   /* h.cl:83-87 */
 typedef struct {
@@ -874,7 +989,10 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             }
             abs_lens_left = abs_lens_left / abs_len_correction_factor;
         }
-        if (!tc) {
+        if (!tc && !T->stop_detected) {                                     /* c.cl:704-750 without STOP_PHOTONS_ON_DETECTION */
+            checkForCollision_keep(T, pos, dirw, inv_groupvel, totalPath, numScatters, abs_lens_initial - abs_lens_left,
+                                   startPos, startDirw, &step, distancePropagated, sink);
+        } else if (!tc) {
             const int collided = checkForCollision(T, pos, dirw, inv_groupvel, totalPath, numScatters,
                                                    abs_lens_initial - abs_lens_left, startPos, startDirw, &step,
                                                    &distancePropagated, sink);

@@ -33,7 +33,18 @@ def streams(n, seed=12345):
 def config(name):
     """name: 'c1' homogeneous/single string, 'mie' SPICE-Mie/IC86, 'lea' SPICE-Lea/IC86,
     'flasher' SPICE-Lea/IC86 + 405 nm generator; '<name>_regular': the same with a detector whose DOMs sit exactly on
-    their string axes -- the strings then share two DOM position templates (GeometrySource.cxx:449-495)."""
+    their string axes -- the strings then share two DOM position templates (GeometrySource.cxx:449-495); '<name>_60': 60 of
+    the 86 strings (52 standard + the 8 dense ones: both subdetectors) -- the largest kind of detector for which the
+    reference's search WITHOUT STOP_PHOTONS_ON_DETECTION stays inside its bit mask (oracle/clsim_oracle.c:
+    checkForCollision_OnString_keep)."""
+    if name.endswith("_60"):
+        cfg = config(name[:-len("_60")])
+        g = cfg["geom"]
+        ids = np.asarray(g["string_ids"])
+        keep = (ids <= 52) | (ids >= 79)
+        geom = {k: (np.asarray(v)[keep] if (hasattr(v, "__len__") and not isinstance(v, str) and len(v) == len(ids)) else v) for k, v in g.items()}
+        assert len(np.unique(geom["string_ids"])) == 60
+        return dict(cfg, name=name, geom=geom)
     if name.endswith("_regular"):
         cfg = config(name[:-len("_regular")])
         return dict(cfg, name=name, geom=S.ic86_geometry(jitter=0.0))
@@ -41,6 +52,12 @@ def config(name):
         geom = S.single_string_geometry()
         med_o = B.homogeneous_medium()
         med_p = CV.MakeHomogeneousMediumProperties()
+    elif name.startswith("clear"):
+        # one layer of ice nobody has seen: scattering length 600 m, absorption length 2 km -- segments that pass dozens of
+        # DOMs and several strings (the search without STOP_PHOTONS_ON_DETECTION: many hits per photon, its bit masks at work)
+        geom = S.ic86_geometry()
+        med_o = B.homogeneous_medium(abs_len=2000.0, sca_len=600.0)
+        med_p = CV.MakeHomogeneousMediumProperties(absLen=2000.0, scaLen=600.0)
     elif name.startswith("photonics"):
         geom = S.ic86_geometry()
         med_o = B.load_photonics_ice(PHOTONICS[name])

@@ -8,7 +8,9 @@ item over seeded step bunches.  They hold outputs only (sorted 80-byte hit recor
 the table maker: entry counts, the SHA-256 of the entry stream and the table it adds up to); the inputs are regenerated here
 from the same seeds.  Cases = the #ifdef branches of the static kernel files in use: plain (C1, SPICE-Mie, SPICE-Lea, flasher),
 per-layer tables in 16 bits with tabulated refractive indices, SAVE_PHOTON_HISTORY, a fixed absorption budget, no pancake
-factor, and -DTABULATE with 4 axes / full azimuth / the impact-angle axis / too little entry space.
+factor, -DTABULATE with 4 axes / full azimuth / the impact-angle axis / too little entry space, and the search without
+STOP_PHOTONS_ON_DETECTION (`*_keep`: SetStopDetectedPhotons(false) -- every DOM on a segment's way is saved and the photon
+travels on; `clear*` = ice with a 600 m scattering length, where the quirks of that branch's bit masks decide 5 % of the hits).
 
 What they pin: the transcription of the static kernel files by oracle/clsim_oracle.c (CPU tests below) and by the HIP kernels
 (GPU tests) -- a guard against one author misreading 1 500 lines of OpenCL C twice in the same way.  They do not pin the
@@ -30,7 +32,10 @@ from tests import common
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # case -> (configuration, converter options)   [tools/verbatim_cl_check.py: CASES]
 CASES = {"c1": ("c1", {}), "mie": ("mie", {}), "lea": ("lea", {}), "flasher": ("flasher", {}), "photonics_mie": ("photonics_mie", {}),
-         "mie_history": ("mie", dict(history=4)), "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)), "lea_no_pancake": ("lea", dict(pancake=1.0))}
+         "mie_history": ("mie", dict(history=4)), "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)), "lea_no_pancake": ("lea", dict(pancake=1.0)),
+         "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
+         "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
+         "clear_keep": ("clear", dict(stop_detected=False)), "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4))}
 TAB_CASES = ["tabulate", "tabulate360", "tabulate5", "tabulate_overflow"]
 ANGULAR = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
 
@@ -51,13 +56,12 @@ def inputs(case):
 @pytest.mark.parametrize("case", list(CASES))
 def test_oracle_equals_the_verbatim_kernel(case):
     cfg, opt, steps, x, a, f = inputs(case)
-    T = common.oracle_tables(cfg, pancake=opt.get("pancake", 5.0)) if not (opt.get("fixed_abs") or opt.get("history")) else None
-    if T is None:
-        g = cfg["geom"]
-        geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
-        bias = B.icecube_dom_acceptance()
-        T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=opt.get("pancake", 5.0),
-                             fixed_abs_lengths=opt.get("fixed_abs"), history_entries=opt.get("history", 0))
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    bias = B.icecube_dom_acceptance()
+    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])] + ([dict(kind="const", value=common.FLASHER_WLEN)] if cfg["flasher"] else [])
+    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=opt.get("pancake", 5.0), stop_detected=opt.get("stop_detected", True),
+                         fixed_abs_lengths=opt.get("fixed_abs"), history_entries=opt.get("history", 0))
     hits = np.frombuffer(f["hits"].tobytes(), dtype=PHOTON_DTYPE)
     if opt.get("history"):
         ph_o, cnt_o, x_o, _, hist_o = capi.propagate(T, steps, x, a, history=True)
@@ -118,6 +122,8 @@ def test_hip_path_equals_the_verbatim_kernel(case):
         conv.SetFixedNumberOfAbsorptionLengths(opt["fixed_abs"])
     if opt.get("history"):
         conv.SetPhotonHistoryEntries(opt["history"])
+    if not opt.get("stop_detected", True):
+        conv.SetStopDetectedPhotons(False)
     conv.SetMaxNumWorkitems(len(steps))
     conv.Compile()
     conv.InitializeWithStreams(x, a)

@@ -38,6 +38,8 @@ unsigned cl_convert_uint_h(unsigned char) CL("_Z12convert_uinth");
 unsigned cl_convert_uint_h(unsigned char v) { return v; }
 unsigned cl_convert_uint_t(unsigned short) CL("_Z12convert_uintt");
 unsigned cl_convert_uint_t(unsigned short v) { return v; }
+unsigned long cl_convert_ulong_i(int) CL("_Z13convert_ulongi");          // the bit masks of the search without STOP_PHOTONS_ON_DETECTION
+unsigned long cl_convert_ulong_i(int v) { return (unsigned long)(long)v; }
 float cl_convert_float_f(float) CL("_Z13convert_floatf");
 float cl_convert_float_f(float v) { return v; }
 float cl_convert_float_i(int) CL("_Z13convert_floati");

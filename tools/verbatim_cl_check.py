@@ -448,12 +448,12 @@ def emit_tabulate_program(medium, generators, bias, tb):
     return s
 
 
-def emit_program(medium, geo, generators, bias, pancake, fixed_abs=None, history_n=0):
+def emit_program(medium, geo, generators, bias, pancake, fixed_abs=None, history_n=0, stop_detected=True):
     """OpenCL.cxx:659-667: preamble, RNG, wavelength generators, bias, medium, geometry, kernels"""
     def kernel(name):
         with open(os.path.join(KERNELS, name)) as f:
             return f.read()
-    s = emit_preamble(pancake, fixed_abs=fixed_abs, history_n=history_n)
+    s = emit_preamble(pancake, stop_detected=stop_detected, fixed_abs=fixed_abs, history_n=history_n)
     s += kernel("mwcrng_kernel.cl")
     s += emit_wavelength_generators(generators)
     s += emit_function_from_table("getWavelengthBias", bias) + "\n"
@@ -520,6 +520,13 @@ CASES = {
     "mie_history": ("mie", dict(history=4)),                        # SAVE_PHOTON_HISTORY
     "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)),                  # PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
     "lea_no_pancake": ("lea", dict(pancake=1.0)),                   # no PANCAKE_FACTOR
+    # without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false)): every DOM on the way is saved, the photon travels on.
+    # 60 strings: the reference's per-string DOM bit mask is indexed with stringNum/64 (sparse_collision_kernel.c.cl:103-104)
+    # and has (GEO_MAX_DOM_INDEX+63)/64 = 1 word here, so a 65th string makes it read and write past its array
+    "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
+    "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
+    "clear_keep": ("clear", dict(stop_detected=False)),             # 86 strings: strings 64-85 index the DOM mask out of bounds (informational)
+    "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4)),
     # the table maker's kernel (-DTABULATE, spherical_coordinates.c.cl): 4 axes; azimuth to 360 degrees; impact-angle axis;
     # too little entry space
     "tabulate": ("mie", {}), "tabulate360": ("mie", {}), "tabulate5": ("mie", {}), "tabulate_overflow": ("mie", {}),
@@ -600,6 +607,7 @@ def check_config(case, n_steps, write_fixtures):
     from tests import common
     name, opt = CASES[case]
     pancake, fixed_abs, history = opt.get("pancake", 5.0), opt.get("fixed_abs"), opt.get("history", 0)
+    stop_detected = opt.get("stop_detected", True)
     cfg = common.config(name)
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
@@ -609,12 +617,12 @@ def check_config(case, n_steps, write_fixtures):
         gens.append(dict(kind="const", value=common.FLASHER_WLEN))
     steps = common.steps_for(cfg, n_steps, seed=3)
     x, a = common.streams(len(steps))
-    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, fixed_abs_lengths=fixed_abs, history_entries=history)
+    T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, stop_detected=stop_detected, fixed_abs_lengths=fixed_abs, history_entries=history)
     if history:
         ph_o, cnt_o, x_o, _, hist_o = capi.propagate(T, steps, x, a, history=True)
     else:
         ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=8)
-    text = emit_program(cfg["med_o"], geo, gens, bias, pancake, fixed_abs=fixed_abs, history_n=history)
+    text = emit_program(cfg["med_o"], geo, gens, bias, pancake, fixed_abs=fixed_abs, history_n=history, stop_detected=stop_detected)
     with tempfile.TemporaryDirectory() as d:
         so = build(text, d, no_flasher=not cfg["flasher"], history=bool(history))
         rec, cnt_v, x_v, hist_v = run_verbatim(so, geo, steps, x, a, max(4 * cnt_o, 1024), history)
