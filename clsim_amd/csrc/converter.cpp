@@ -24,6 +24,7 @@ constexpr size_t kPooledKernelMinSteps = 614400;   // 0.52M steps: classic 2.54e
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
+    if (tables_.variant.keep_detected) return launch_keep_kernel(P, tables_.variant, stream);
     return pooled_for(P.n_steps) ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
 }
 
@@ -169,11 +170,13 @@ void Converter::compile()
     if (!have_medium_) throw Error(CLSIMHIP_ERR_CONFIG, "MediumProperties not set!");
     if (!have_geometry_) throw Error(CLSIMHIP_ERR_CONFIG, "Geometry not set!");
     if (double_precision_) throw Error(CLSIMHIP_ERR_CONFIG, "DoublePrecision is not available in the HIP propagator");
-    // Both modes are unusable in the reference at this revision: without STOP_PHOTONS_ON_DETECTION the collision
-    // code indexes dom_bitmask[stringNum/64] in an array of (GEO_MAX_DOM_INDEX+63)/64 words -- out of bounds from
-    // the 65th string on (sparse_collision_kernel.c.cl:85-103); SAVE_ALL_PHOTONS leaves out the geometry source
-    // (OpenCL.cxx:461-466) that saveHit() needs for geometryGetDomPosition (propagation_kernel.c.cl:339).
-    if (!stop_detected_) throw Error(CLSIMHIP_ERR_CONFIG, "StopDetectedPhotons=false is not available in the HIP propagator");
+    // SAVE_ALL_PHOTONS is unusable in the reference at this revision: it leaves out the geometry source (OpenCL.cxx:461-466)
+    // that saveHit() needs for geometryGetDomPosition (propagation_kernel.c.cl:339).
+    // StopDetectedPhotons=false (no STOP_PHOTONS_ON_DETECTION) runs the classic kernel's instantiations of their own
+    // (prop_keep_kernel.hip).  The reference's collision code indexes dom_bitmask[stringNum/64] in an array of
+    // (GEO_MAX_DOM_INDEX+63)/64 words there -- out of bounds from the 65th string on when no string has more than 64 DOMs
+    // (sparse_collision_kernel.c.cl:85-104), undefined; here (and in the oracle) that word exists, which is also what the
+    // kernel text compiled for x86-64 does (tools/verbatim_cl_check.py clear_keep).
     if (save_all_) throw Error(CLSIMHIP_ERR_CONFIG, "SaveAllPhotons is not available in the HIP propagator");
     if (history_entries_ > 1024) throw Error(CLSIMHIP_ERR_CONFIG, "PhotonHistoryEntries > 1024 is not supported");
     tables_ = compile_tables(medium_, geometry_, generators_, bias_, pancake_);
@@ -182,6 +185,7 @@ void Converter::compile()
         tables_.params.fixed_abs = to_float_literal(fixed_abs_lengths_);
     }
     tables_.params.history_n = static_cast<int32_t>(history_entries_);   // OpenCL.cxx:416-419
+    tables_.variant.keep_detected = !stop_detected_;                     // OpenCL.cxx:395-397
     compiled_ = true;
 }
 
@@ -355,7 +359,7 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_POOL_MIN_STEPS")) pool_min_steps_ = static_cast<size_t>(std::max(0ll, std::atoll(e)));
     // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
     // leaves its pools no LDS
-    if (history_entries_ != 0 || !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()))) use_pool_ = false;
+    if (history_entries_ != 0 || !stop_detected_ || !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()))) use_pool_ = false;
 }
 
 KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)

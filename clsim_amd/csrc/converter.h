@@ -31,6 +31,7 @@ hipError_t launch_generate_flasher_steps(const clsimhip_flasher_config &cfg, con
 hipError_t launch_generate_steps(const clsimhip_step_request *d_requests, const uint64_t *d_first_step, uint32_t n_requests,
                                  uint64_t total_real, uint64_t total_padded, uint64_t seed, void *d_out, hipStream_t stream);
 hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
+hipError_t launch_keep_kernel(const KParams &P, const KVariant &v, hipStream_t stream);     // prop_keep_kernel.hip: without STOP_PHOTONS_ON_DETECTION
 size_t prop_kernel_max_lanes();
 size_t prop_kernel_lds_budget();
 
@@ -213,7 +214,8 @@ private:
     MediumData medium_;
     GeometryInput geometry_;
     bool have_bias_ = false, have_medium_ = false, have_geometry_ = false;
-    bool double_buffering_ = false, double_precision_ = false, stop_detected_ = true, save_all_ = false;
+    bool double_buffering_ = false, double_precision_ = false, stop_detected_ = false, save_all_ = false;     // (OpenCL.cxx:83-87: the class's own defaults;
+                                                                                                          // initializeOpenCL's callers pass stopDetectedPhotons = true)
     double save_all_prescale_ = 0.01, fixed_abs_lengths_ = NAN, pancake_ = 1.0;
     uint32_t history_entries_ = 0;
     size_t workgroup_size_ = 0, max_workitems_ = 0;

@@ -208,6 +208,7 @@ struct KVariant {
     bool aniso;             // anisotropy scaling + pre/post transforms present
     bool flasher;           // more than one wavelength generator (no NO_FLASHER)
     bool tabulate = false;  // TABULATE: record path samples into table bins instead of looking for DOMs
+    bool keep_detected = false;     // no STOP_PHOTONS_ON_DETECTION: every DOM on a segment's way is saved, the photon travels on
     bool fast = false;      // standard configuration, every proof in hand (prop_device.hip.h: FAST): the pooled kernel runs the
                             // instantiation without the wave-uniform tests of those facts
 };

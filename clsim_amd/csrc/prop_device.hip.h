@@ -858,6 +858,128 @@ DM bool find_collision(KP P, const Photon &ph, float &step_len, uint32_t &hit_st
     return hit;
 }
 
+// ---- the search without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false), OpenCL.cxx:395-397): the #else / #ifndef
+// branches of sparse_collision_kernel.c.cl (:85-104, :165-186, :245-253, :580-584).  Every DOM the segment enters is saved on
+// the spot with the distance to it, the step is not shortened and the photon travels on.  The reference keeps a string from
+// being tested twice (it lies in every cell its bounding square overlaps) and a DOM from being tested twice (several z layers
+// name it) with bit masks whose bit is `1 << convert_ulong(n % 64)`: the literal is an int, so OpenCL shifts by n % 32 and
+// widens the result with its sign -- strings (DOMs) n and n + 32 share a bit, and bit 31 drags bits 32..63 along, which makes
+// the upper half of each 64-bit word a copy of bit 31: a word's state is its lower 32 bits.  Restated as such; the string
+// words live in LDS (one per 64 strings and lane), the DOM word of a string call in a register (:86-90 index that array with
+// the STRING number and size it by the DOM number: one word is in use per call, and where stringNum/64 lies beyond it the
+// reference is undefined -- here, as in oracle/clsim_oracle.c, the word is there).
+struct KeepSink {
+    uint32_t step_index;
+    const float4 *ring;                 // SAVE_PHOTON_HISTORY: the lane's ring, copied beside every hit (c.cl:387-392)
+    uint32_t history_n;
+    uint32_t *string_mask;              // LDS: word w of this lane at string_mask[w * mask_stride]
+    uint32_t mask_stride, mask_words;
+};
+
+// c.cl:307-404 from inside the search: one atomic per hit (this is not the fast path), the stub into its slot
+DM void save_hit_now(KP P, const Photon &ph, float smin1, const KeepSink &K, uint32_t s, uint32_t dom)
+{
+    const uint32_t index = atomicAdd(P->hit_count, 1u);                     // keeps counting past the buffer (c.cl:329-334)
+    if (index >= P->max_hits) return;
+    uint32_t *st = reinterpret_cast<uint32_t *>(P->out) + (size_t)index * 20u;
+    st[0] = dm::f2u(ph.px); st[1] = dm::f2u(ph.py); st[2] = dm::f2u(ph.pz); st[3] = dm::f2u(ph.pt);
+    st[4] = dm::f2u(ph.d.x); st[5] = dm::f2u(ph.d.y); st[6] = dm::f2u(ph.d.z); st[7] = dm::f2u(smin1);
+    st[8] = dm::f2u(ph.total_path); st[9] = dm::f2u(ph.abs_lens_left); st[10] = dm::f2u(ph.inv_groupvel);
+    st[11] = ph.num_scatters; st[12] = K.step_index;
+    st[13] = (uint32_t)ph.rx_start; st[14] = (uint32_t)(ph.rx_start >> 32);
+    st[15] = (s & 0xffffu) | (dom << 16);
+    if (K.history_n != 0u) {
+        float4 *dst = reinterpret_cast<float4 *>(P->hist_out) + (size_t)index * K.history_n;
+        for (uint32_t k = 0; k < K.history_n; ++k) dst[k] = K.ring[k];
+    }
+}
+
+// c.cl:27-192 without STOP_PHOTONS_ON_DETECTION
+DM void collide_with_string_keep(KP P, const Detector &D, uint32_t s, float dir_len_xy_sqr, const Photon &ph, float step_len, const KeepSink &K)
+{
+    const Rec4 str = lds_rec4(D.off_strings + 8u * s);      // x, y, maxZ+R, minZ-R
+    {
+        const float smin = sqr((ph.px - str.a) * ph.d.y - (ph.py - str.b) * ph.d.x) / dir_len_xy_sqr;
+        if (smin > D.string_max_radius_sq) return;
+    }
+    if ((ph.d.z > 0.0f) && (ph.pz > str.c)) return;
+    if ((ph.d.z < 0.0f) && (ph.pz < str.d)) return;
+    const uint32_t set = ldsu(D.off_strings + 8u * s + 4) & 0xffu;
+    const Rec4 lay = lds_rec4(D.off_sets + 4u * set);        // nlayers (bits), start z, height
+    const float start_z = lay.b, height = lay.c;
+    const int nl = (int)__builtin_bit_cast(uint32_t, lay.a);
+    int low = (int)((ph.pz - start_z) / height);
+    int high = (int)((ph.pz + ph.d.z * step_len - start_z) / height);
+    if (high < low) { const int tmp = low; low = high; high = tmp; }
+    low = clampi(low, 0, nl - 1);
+    high = clampi(high, 0, nl - 1);
+    const uint32_t base = set * (uint32_t)D.max_layers;
+    uint32_t dom_mask = 0u;                                    // :85-90
+    for (int layer = low; layer <= high; ++layer) {
+        const uint32_t dom = lds_u16(D.off_layer_to_om, base + (uint32_t)layer);
+        if (dom == 0xFFFFu) continue;
+        const uint32_t bit = 1u << (dom & 31u);
+        if ((dom_mask & bit) != 0u) continue;                   // :103
+        dom_mask |= bit;                                        // :104
+        float dom_x, dom_y, dom_z;
+        dom_position(P, s, dom, dom_x, dom_y, dom_z);
+        const float dx = dom_x - ph.px, dy = dom_y - ph.py, dzz = dom_z - ph.pz;
+        const float dr2 = (dx * dx + dy * dy) + dzz * dzz;
+        const float urdot = (dx * ph.d.x + dy * ph.d.y) + dzz * ph.d.z;
+        float discr = sqr(urdot) - dr2 + D.om_radius_sq;
+        if (discr < 0.0f) continue;
+        discr = D.has_pancake ? (dm::sqrt_(discr) / D.pancake) : dm::sqrt_(discr);
+        if (urdot + discr < 0.0f) continue;
+        const float smin1 = urdot - discr;
+        if (smin1 < 0.0f) continue;
+        if (smin1 < step_len) save_hit_now(P, ph, smin1, K, s, dom);          // :165-186
+    }
+}
+
+// c.cl:194-303 + :462-587 without STOP_PHOTONS_ON_DETECTION
+DM void find_collisions_keep(KP P, const Photon &ph, float step_len, const KeepSink &K)
+{
+    const float dir_len_xy_sqr = sqr(ph.d.x) + sqr(ph.d.y);
+    if (dir_len_xy_sqr <= 0.0f) return;
+    Detector D;
+    D.off_strings = P->off_strings; D.off_sets = P->off_sets; D.off_layer_to_om = P->off_layer_to_om;
+    D.max_layers = P->max_layers;
+    D.string_max_radius_sq = P->string_max_radius_sq; D.string_max_radius = P->string_max_radius; D.om_radius_sq = P->om_radius_sq;
+    D.pancake = P->pancake; D.has_pancake = P->has_pancake;
+    const int num_subdet = P->num_subdet;
+    const uint32_t off_subdet = P->off_subdet;
+    for (int sd = 0; sd < num_subdet; ++sd) {
+        const Rec4 g0 = lds_rec4(off_subdet + 12u * (uint32_t)sd);        // nx, ny (bits), width x, width y
+        const Rec4 g1 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 4u);   // start x, start y, cell offset, proof bits
+        const Rec4 g2 = lds_rec4(off_subdet + 12u * (uint32_t)sd + 8u);   // 1/width x, 1/width y
+        const int nx = (int)__builtin_bit_cast(uint32_t, g0.a), ny = (int)__builtin_bit_cast(uint32_t, g0.b);
+        const float wx = g0.c, wy = g0.d, sx = g1.a, sy = g1.b;
+        const uint32_t cells = __builtin_bit_cast(uint32_t, g1.c);
+        const uint32_t proven = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, g1.d));
+        const bool okx = (proven & 1u) != 0, oky = (proven & 2u) != 0;
+        int low_x = (int)div_by_t<false>(ph.px - sx, wx, g2.a, okx);
+        int low_y = (int)div_by_t<false>(ph.py - sy, wy, g2.b, oky);
+        int high_x = (int)div_by_t<false>(ph.px + ph.d.x * step_len - sx, wx, g2.a, okx);
+        int high_y = (int)div_by_t<false>(ph.py + ph.d.y * step_len - sy, wy, g2.b, oky);
+        if (high_x < low_x) { const int tmp = low_x; low_x = high_x; high_x = tmp; }
+        if (high_y < low_y) { const int tmp = low_y; low_y = high_y; high_y = tmp; }
+        low_x = clampi(low_x, 0, nx - 1); low_y = clampi(low_y, 0, ny - 1);
+        high_x = clampi(high_x, 0, nx - 1); high_y = clampi(high_y, 0, ny - 1);
+        for (uint32_t w = 0; w < K.mask_words; ++w) K.string_mask[w * K.mask_stride] = 0u;      // :245-249
+        for (int cy = low_y; cy <= high_y; ++cy)
+            for (int cx = low_x; cx <= high_x; ++cx) {
+                const uint32_t s = lds_u16(cells, (uint32_t)(cy * nx + cx));
+                if (s == 0xFFFFu) continue;
+                uint32_t *word = K.string_mask + (s >> 6) * K.mask_stride;
+                const uint32_t bit = 1u << (s & 31u);
+                const uint32_t seen = *word;
+                if ((seen & bit) != 0u) continue;               // :252
+                *word = seen | bit;                             // :253
+                collide_with_string_keep(P, D, s, dir_len_xy_sqr, ph, step_len, K);
+            }
+    }
+}
+
 // A detected photon leaves the propagation kernel as a 16-word stub written into its 80-byte output
 // slot; assemble_hits_kernel expands it in place into the I3CLSimPhoton record.  Everything saveHit
 // (propagation_kernel.c.cl:307-404) stores is a function of the stub: the birth of the photon is

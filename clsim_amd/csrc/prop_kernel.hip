@@ -301,7 +301,9 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
 
 // TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
 // four-dimensional table maker keeps its register allocation).  4 waves per SIMD: 86-110 VGPRs, nothing spilled, since
-// the sampling constants are scalar loads from the parameter block
+// the sampling constants are scalar loads from the parameter block.
+// 3 = photon propagation without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false)): every DOM on a segment's way is
+// saved and the photon travels on (find_collisions_keep); a translation unit of its own as well (prop_keep_kernel.hip)
 // FAST: prop_device.hip.h (the standard configuration with every proof in hand; propagation only)
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
 __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
@@ -316,7 +318,9 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     }
     uint32_t *stage = lds_words + P0->table_words + (threadIdx.x >> 6) * (kStageRecords * kStubWords);
     // TABULATE: no hits are staged; the first 12 words behind the image hold the reference particle instead
-    if (TAB && threadIdx.x < 12u) lds_words[P0->table_words + threadIdx.x] = __builtin_bit_cast(uint32_t, P0->tab_ref[threadIdx.x]);
+    constexpr bool TABULATE = (TAB == 1) || (TAB == 2);
+    constexpr bool KEEP = (TAB == 3);
+    if (TABULATE && threadIdx.x < 12u) lds_words[P0->table_words + threadIdx.x] = __builtin_bit_cast(uint32_t, P0->tab_ref[threadIdx.x]);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         const bool finished = need && !waiting && (photons_left == 0) && (sidx != kNoStep);
         const uint64_t m_finished = ballot(finished);
         // (not the table maker: its waves have fp64 atomics in flight, which a poll would have to wait for first)
-        if (do_create || (!TAB && ((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
+        if (do_create || (!TABULATE && ((m_finished | m_poll) != 0ull) && ((trip & 3u) == 0u))) {
             const KP P = fresh_params(P0);
             WorkRecord *work = P->work;
             if (m_finished != 0ull) {
@@ -479,7 +483,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             c_created += __popcll(ballot(do_create && need && !waiting && (photons_left > 0)));
 #endif
             if (do_create && need && !waiting && (photons_left > 0)) {
-                create_photon<MED, TILT, FLASHER, TAB != 0, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
+                create_photon<MED, TILT, FLASHER, TABULATE, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
             // nothing runnable in this wave: every lane waits for another wave's slice
@@ -503,10 +507,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
-            const float free_flight = TAB ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
+            const float free_flight = TABULATE ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
-            if (!TAB && !(distance < free_flight)) {
+            if (!TABULATE && !(distance < free_flight)) {
                 const uint32_t kind = dom_search_needed(fresh_params(P0), ph, distance);
                 if (kind != kSearchNone) {
                     parked = true;
@@ -516,10 +520,25 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
         }
         bool advance = run && !parked;
-        if (!TAB) {
+        if (!TABULATE) {
             const uint64_t m_parked = ballot(parked);
             if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
-                if (parked) {
+                if (KEEP && parked) {
+                    // without STOP_PHOTONS_ON_DETECTION (c.cl:704-750): the search saves what it finds, nothing is shortened or absorbed
+                    const KP P = fresh_params(P0);
+                    distance = __builtin_bit_cast(float, pending[threadIdx.x]);
+                    KeepSink K;
+                    K.step_index = sidx;
+                    K.history_n = (uint32_t)P->history_n;
+                    K.ring = reinterpret_cast<const float4 *>(P->hist_ring) + (size_t)(blockIdx.x * kBlock + threadIdx.x) * K.history_n;
+                    K.string_mask = pending + kBlock + threadIdx.x;
+                    K.mask_stride = (uint32_t)kBlock;
+                    K.mask_words = ((uint32_t)P->num_strings + 63u) >> 6;
+                    find_collisions_keep(P, ph, distance, K);
+                    parked = false;
+                    advance = true;
+                }
+                if (!KEEP && parked) {
                     distance = __builtin_bit_cast(float, pending[threadIdx.x]);
                     // (as in prop_pool_kernel.hip: the confined search in the flasher instantiations, for all parked lanes or none)
                     bool full = FLASHER ? (ballot(search_kind == kSearchFull) != 0ull) : true;
@@ -536,7 +555,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
         }
-        if (TAB) {
+        if (TABULATE) {
             // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
             const KP P = fresh_params(P0);
             const float travelled = P->fixed_abs - ph.abs_lens_left;
@@ -848,8 +867,12 @@ template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = fal
 static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
-    const size_t lds_bytes = TAB ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
-                                 : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock) * 4;
+    constexpr bool TABULATE = (TAB == 1) || (TAB == 2);
+    // (without STOP_PHOTONS_ON_DETECTION: one more word per lane and 64 strings, find_collisions_keep's string mask)
+    const size_t lds_bytes = TABULATE ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
+                                      : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock
+                                                 + ((TAB == 3) ? kBlock * (((size_t)P.num_strings + 63u) >> 6) : 0u)) * 4;
+    if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
     // persistent grid: as many workgroups as the chip holds at once (queue-fed), never more than the work.
     // Occupancy, CU count and the function attributes are per (device, variant): one process may drive converters on
     // several GPUs (the reference's usual model, I3CLSimServer.cxx:77-137) and from several threads.
@@ -921,7 +944,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL((prop_kernel<MED, TILT, ANISO, FLASHER, TAB, FAST>), dim3(grid), dim3(kBlock), lds_bytes, stream, P);
     err = hipGetLastError();
-    if (err != hipSuccess || TAB) return err;
+    if (err != hipSuccess || TABULATE) return err;
     return launch_assemble_hits(P, FLASHER, dev, stream);
 }
 
@@ -936,6 +959,29 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     const bool fast = v.fast && P.history_n == 0 && !(no_fast && no_fast[0] == '1');
     switch (key) {
 #define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 0, true>(P, stream) : launch_variant<a, b, c, d, 0, false>(P, stream);
+#define CASES(m) \
+    CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
+    CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
+    CASE(8 * m + 4, m, true, false, false)  CASE(8 * m + 5, m, true, false, true)  \
+    CASE(8 * m + 6, m, true, true, false)   CASE(8 * m + 7, m, true, true, true)
+    CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
+#undef CASES
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+#elif defined(CLSIMHIP_KEEP_UNIT)
+// propagation without STOP_PHOTONS_ON_DETECTION (TAB = 3)
+hipError_t launch_keep_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
+{
+    if (P.n_steps == 0) return hipSuccess;
+    if (!v.keep_detected || v.tabulate) return hipErrorInvalidValue;
+    if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
+    if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
+    const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
+    switch (key) {
+#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, 3>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \

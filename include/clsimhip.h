@@ -194,7 +194,7 @@ int clsimhip_set_geometry_from_text_file(clsimhip_converter *c, const char *file
                                          int32_t string_id_min, int32_t string_id_max, uint32_t dom_id_min, uint32_t dom_id_max);
 int clsimhip_set_enable_double_buffering(clsimhip_converter *c, int value);
 int clsimhip_set_double_precision(clsimhip_converter *c, int value);           /* only 0 */
-int clsimhip_set_stop_detected_photons(clsimhip_converter *c, int value);      /* only 1 */
+int clsimhip_set_stop_detected_photons(clsimhip_converter *c, int value);      /* 0 (the default, as in the reference class, OpenCL.cxx:86; initializeOpenCL's callers pass 1): every DOM on a photon's way records it and the photon travels on (no STOP_PHOTONS_ON_DETECTION) */
 int clsimhip_set_save_all_photons(clsimhip_converter *c, int value);           /* only 0 */
 int clsimhip_set_save_all_photons_prescale(clsimhip_converter *c, double value);
 int clsimhip_set_fixed_number_of_absorption_lengths(clsimhip_converter *c, double value); /* NaN = off */

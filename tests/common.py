@@ -70,17 +70,17 @@ def config(name):
     return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=name.startswith("flasher"))
 
 
-def oracle_tables(cfg, pancake=5.0):
+def oracle_tables(cfg, pancake=5.0, stop_detected=True):
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     bias = B.icecube_dom_acceptance()
     gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
     if cfg["flasher"]:
         gens.append(dict(kind="const", value=FLASHER_WLEN))
-    return capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake)
+    return capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, stop_detected=stop_detected)
 
 
-def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345, double_buffering=False):
+def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345, double_buffering=False, stop_detected=True):
     bias = CV.GetIceCubeDOMAcceptance()
     gens = [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])]
     if cfg["flasher"]:
@@ -90,9 +90,10 @@ def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, se
         conv = CV.I3CLSimStepToPhotonConverterHIP(device)
         conv.SetWlenGenerators(gens); conv.SetWlenBias(bias); conv.SetMediumProperties(cfg["med_p"])
         conv.SetGeometry(geom); conv.SetDOMPancakeFactor(pancake)
+        conv.SetStopDetectedPhotons(stop_detected)          # (the class's own default is false, OpenCL.cxx:86)
         return conv
     return CV.initializeHIP(device, geom, cfg["med_p"], bias, gens, pancakeFactor=pancake, enableDoubleBuffering=double_buffering,
-                            approximateNumberOfWorkItems=max_items, streams=streams(max_items, seed))
+                            stopDetectedPhotons=stop_detected, approximateNumberOfWorkItems=max_items, streams=streams(max_items, seed))
 
 
 def steps_for(cfg, n, seed=3, pad_to=256):

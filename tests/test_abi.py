@@ -52,8 +52,7 @@ def test_use_before_initialize_raises_like_the_reference():
 
 def test_unsupported_modes_are_refused_at_compile():
     cfg = common.config("c1")
-    for setter, value in (("SetDoublePrecision", True), ("SetStopDetectedPhotons", False), ("SetSaveAllPhotons", True),
-                          ("SetPhotonHistoryEntries", 5000)):
+    for setter, value in (("SetDoublePrecision", True), ("SetSaveAllPhotons", True), ("SetPhotonHistoryEntries", 5000)):
         conv = common.product_converter(cfg, 512, initialize=False)
         getattr(conv, setter)(value)
         with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception) as e:
@@ -63,6 +62,7 @@ def test_unsupported_modes_are_refused_at_compile():
     conv = common.product_converter(cfg, 512, initialize=False)
     conv.SetPhotonHistoryEntries(4)
     conv.SetFixedNumberOfAbsorptionLengths(46.0)
+    conv.SetStopDetectedPhotons(False)
     conv.Compile()
 
 

@@ -117,13 +117,11 @@ def test_oracle_table_maker_equals_the_verbatim_kernel(case):
 def test_hip_path_equals_the_verbatim_kernel(case):
     cfg, opt, steps, x, a, f = inputs(case)
     hits = np.frombuffer(f["hits"].tobytes(), dtype=PHOTON_DTYPE)
-    conv = common.product_converter(cfg, len(steps), pancake=opt.get("pancake", 5.0), initialize=False)
+    conv = common.product_converter(cfg, len(steps), pancake=opt.get("pancake", 5.0), initialize=False, stop_detected=opt.get("stop_detected", True))
     if opt.get("fixed_abs"):
         conv.SetFixedNumberOfAbsorptionLengths(opt["fixed_abs"])
     if opt.get("history"):
         conv.SetPhotonHistoryEntries(opt["history"])
-    if not opt.get("stop_detected", True):
-        conv.SetStopDetectedPhotons(False)
     conv.SetMaxNumWorkitems(len(steps))
     conv.Compile()
     conv.InitializeWithStreams(x, a)
