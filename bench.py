@@ -76,6 +76,9 @@ def parse():
                     help="I3CLSimSteps per GPU and pass, cut into equal bunches of at most 6 139 850 (the converter's stream limit, "
                          "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
                          "c2 -> C4 = 100M steps / 8 = 12 500 000 per GPU (weak scaling), c5 -> 10^9 photons / N (strong scaling)")
+    ap.add_argument("--keep-detected", action="store_true",
+                    help="SetStopDetectedPhotons(false): the instantiations without STOP_PHOTONS_ON_DETECTION (classic kernel, every DOM on "
+                         "a photon's way records it); an extra measurement, never the headline")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1 (or CLSIMHIP_BENCH_GATHER=1): after the timed region, one more launch whose gathered photons on rank 0 "
                          "are compared with every rank's own buffer (record counts and a 64-bit sum); config.gather_verified")
@@ -510,7 +513,7 @@ def main():
     if args.workload == "c5":
         gens.append(CV.I3CLSimRandomValueConstant(405e-9))          # delta-peak spectrum (ModuleHelper.cxx:81-88)
     conv = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=args.host_path,
-                            approximateNumberOfWorkItems=n, seed=12345 + rank)
+                            stopDetectedPhotons=not args.keep_detected, approximateNumberOfWorkItems=n, seed=12345 + rank)
     def make_bunch(b):
         real = min(n, shard - b * n)                    # the last bunch of a shard carries the padding
         seed = 1000 + rank + 7919 * b
@@ -697,6 +700,8 @@ def main():
         avg_ms = kernel_ms / max(launches, 1)
         pooled = conv.KernelForBunch(n) == "pool"
         kernel_name = "prop_pool_kernel" if pooled else "prop_kernel"
+        if args.keep_detected:
+            workload_name += " -- WITHOUT STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false))"
         # algorithmic HBM bytes per launch: step record + RNG state read and
         # write per step (48 + 12 + 12 B) plus one 80-byte record per detected photon
         alg_bytes = n * 72.0 + hits_last * 80.0

@@ -53,7 +53,7 @@ def test_photons_travel_on_after_a_detection():
     # one photon = one creation point: start position + time + direction
     key = np.ascontiguousarray(ph_k).view(np.uint8).reshape(len(ph_k), 80)[:, 48:72]       # sx, sy, sz, st, stheta, sphi
     _, counts = np.unique(key, axis=0, return_counts=True)
-    assert counts.max() >= 2 and (counts > 1).sum() > 20
+    assert counts.max() >= 2 and (counts > 1).sum() >= 5
     assert not np.array_equal(stop.GetRNGState(len(steps)), keep.GetRNGState(len(steps)))
 
 
