@@ -3,7 +3,9 @@
 SPICE-Lea) or configs[4] (c5: 2 621 440 flasher steps x 400 photons at a DOM) through the kernel's production schedule
 against the oracle run on all host cores for the WHOLE bunch -- every detected photon (80 bytes each, as a sorted multiset)
 and every final RNG state, bit for bit.  (tests/test_production_size_gpu.py checks the first 2048 steps of such a launch
-in every test run; this takes 5-7 minutes of oracle time per workload.)   usage: full_size_parity.py c3|c5 [chunks=6]"""
+in every test run; this takes 5-7 minutes of oracle time per workload.)   usage: full_size_parity.py c3|c5|c2keep|c5keep [chunks=6]
+(c2keep: BASELINE configs[1], 1 048 576 cascade steps in SPICE-Mie, c5keep: the flasher bunch -- both WITHOUT
+STOP_PHOTONS_ON_DETECTION, SetStopDetectedPhotons(false))"""
 import os
 import sys
 import time
@@ -20,7 +22,13 @@ from tests import common
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-if which == "c3":
+keep = which.endswith("keep")
+if which == "c2keep":
+    cfg = common.config("mie")
+    n = 1 << 20
+    steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
+    capacity = 4 << 20
+elif which == "c3":
     cfg = common.config("lea")
     n = 5 * (1 << 20)
     steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
@@ -35,7 +43,7 @@ else:
 capi.build()
 x, a = common.streams(n)
 dev = torch.device("cuda", 0)
-conv = common.product_converter(cfg, n)
+conv = common.product_converter(cfg, n, stop_detected=not keep)
 d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
 d_out = torch.empty((capacity, 80), dtype=torch.uint8, device=dev)
 d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -48,7 +56,7 @@ print("%s: kernel %s, %d steps, %.3g photons, %d detected, %.2f s" % (which, con
 got = np.frombuffer(d_out[:cnt].cpu().numpy().tobytes(), dtype=PHOTON_DTYPE)
 x_dev = conv.GetRNGState(n)
 del d_out
-T = common.oracle_tables(cfg)
+T = common.oracle_tables(cfg, stop_detected=not keep)
 parts, x_parts = [], []
 threads = os.cpu_count() or 8
 for c in range(chunks):
