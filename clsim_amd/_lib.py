@@ -17,12 +17,12 @@ DP = C.POINTER(C.c_double)
 
 class Function(C.Structure):        # clsimhip_function
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("start", C.c_double), ("step", C.c_double),
-                ("values", DP), ("value", C.c_double)]
+                ("values", DP), ("value", C.c_double), ("wavelengths", DP)]
 
 
 class RandomValue(C.Structure):     # clsimhip_random_value
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("first", C.c_double), ("spacing", C.c_double),
-                ("y", DP), ("value", C.c_double)]
+                ("y", DP), ("value", C.c_double), ("x", DP)]
 
 
 class StepRequest(C.Structure):     # clsimhip_step_request
@@ -83,7 +83,7 @@ class MediumDesc(C.Structure):      # clsimhip_medium_desc
 SYMBOLS = [
     "clsimhip_medium_create", "clsimhip_medium_create_from_ppc",
     "clsimhip_medium_create_from_photonics", "clsimhip_medium_describe", "clsimhip_medium_destroy",
-    "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator",
+    "clsimhip_icecube_dom_acceptance", "clsimhip_make_cherenkov_wlen_generator", "clsimhip_make_wlen_generator",
     "clsimhip_mwc_multipliers", "clsimhip_mwc_multipliers_from_file", "clsimhip_seed_streams",
     "clsimhip_create", "clsimhip_destroy", "clsimhip_last_error", "clsimhip_set_device", "clsimhip_get_device", "clsimhip_uses_pooled_kernel", "clsimhip_kernel_for_bunch",
     "clsimhip_step_series_blob_size", "clsimhip_encode_step_series", "clsimhip_decode_step_series",
@@ -149,6 +149,7 @@ def load():
         "clsimhip_medium_destroy": (None, [vp]),
         "clsimhip_icecube_dom_acceptance": (i32, [dbl, dbl, DP, DP, DP]),
         "clsimhip_make_cherenkov_wlen_generator": (i32, [C.POINTER(Function), vp, DP, DP, DP]),
+        "clsimhip_make_wlen_generator": (i32, [C.POINTER(Function), C.POINTER(Function), vp, C.POINTER(RandomValue), DP, DP, C.c_size_t]),
         "clsimhip_mwc_multipliers": (i32, [vp, sz]),
         "clsimhip_mwc_multipliers_from_file": (i32, [C.c_char_p, vp, sz]),
         "clsimhip_seed_streams": (i32, [vp, sz, u64, vp]),

@@ -10,6 +10,7 @@ marshals numpy arrays.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -38,14 +39,45 @@ def _dp(a):
 
 
 class I3CLSimFunctionFromTable:
-    """private/clsim/function/I3CLSimFunctionFromTable.cxx:70-90 (equal spacing)."""
+    """private/clsim/function/I3CLSimFunctionFromTable.cxx: (startWlen, wlenStep, values) :70-90, equal spacing, or
+    (wlens, values) :57-70, the table's own wavelengths -- host side only, like the reference (:169-170): an emission
+    spectrum for makeWavelengthGenerator."""
 
-    def __init__(self, startWlen, wlenStep, values):
-        self.startWlen, self.wlenStep = float(startWlen), float(wlenStep)
-        self.values = np.ascontiguousarray(values, dtype=np.float64)
+    def __init__(self, *args):
+        if len(args) == 3:
+            self.startWlen, self.wlenStep = float(args[0]), float(args[1])
+            self.values = np.ascontiguousarray(args[2], dtype=np.float64)
+            self.wlens = None
+        elif len(args) == 2:
+            self.wlens = np.ascontiguousarray(args[0], dtype=np.float64)
+            self.values = np.ascontiguousarray(args[1], dtype=np.float64)
+            if len(self.wlens) < 2:
+                raise I3CLSimStepToPhotonConverter_exception("wlens must contain at least 2 elements!")
+            if len(self.wlens) != len(self.values):
+                raise I3CLSimStepToPhotonConverter_exception("wlens and values must have the same size!")
+        else:
+            raise TypeError("I3CLSimFunctionFromTable(startWlen, wlenStep, values) or (wlens, values)")
+
+    def GetInEqualSpacingMode(self):
+        return self.wlens is None
 
     def _desc(self):
-        return _lib.Function(0, len(self.values), self.startWlen, self.wlenStep, _dp(self.values), 0.0)
+        if self.wlens is None:
+            return _lib.Function(0, len(self.values), self.startWlen, self.wlenStep, _dp(self.values), 0.0, None)
+        return _lib.Function(2, len(self.values), 0.0, 0.0, _dp(self.values), 0.0, _dp(self.wlens))
+
+
+class I3CLSimFunctionDeltaPeak:
+    """function/I3CLSimFunctionDeltaPeak: a single-wavelength emission spectrum (the standard candles)"""
+
+    def __init__(self, peakPosition):
+        self.peakPosition = float(peakPosition)
+
+    def GetPeakPosition(self):
+        return self.peakPosition
+
+    def _desc(self):
+        return _lib.Function(3, 0, 0.0, 0.0, None, self.peakPosition, None)
 
 
 class I3CLSimFunctionConstant:
@@ -53,18 +85,29 @@ class I3CLSimFunctionConstant:
         self.value = float(value)
 
     def _desc(self):
-        return _lib.Function(1, 0, 0.0, 0.0, None, self.value)
+        return _lib.Function(1, 0, 0.0, 0.0, None, self.value, None)
 
 
 class I3CLSimRandomValueInterpolatedDistribution:
-    """...InterpolatedDistribution.cxx:57-74: (xFirst, xSpacing, y)."""
+    """...InterpolatedDistribution.cxx: (xFirst, xSpacing, y) :57-74, or (x, y) :40-55."""
 
-    def __init__(self, xFirst, xSpacing, y):
-        self.first, self.spacing = float(xFirst), float(xSpacing)
-        self.y = np.ascontiguousarray(y, dtype=np.float64)
+    def __init__(self, *args):
+        if len(args) == 3:
+            self.first, self.spacing = float(args[0]), float(args[1])
+            self.y = np.ascontiguousarray(args[2], dtype=np.float64)
+            self.x = None
+        elif len(args) == 2:
+            self.x = np.ascontiguousarray(args[0], dtype=np.float64)
+            self.y = np.ascontiguousarray(args[1], dtype=np.float64)
+            if len(self.x) != len(self.y):
+                raise I3CLSimStepToPhotonConverter_exception('The "x" and "y" vectors must have the same size!')
+        else:
+            raise TypeError("I3CLSimRandomValueInterpolatedDistribution(xFirst, xSpacing, y) or (x, y)")
 
     def _desc(self):
-        return _lib.RandomValue(0, len(self.y), self.first, self.spacing, _dp(self.y), 0.0)
+        if self.x is None:
+            return _lib.RandomValue(0, len(self.y), self.first, self.spacing, _dp(self.y), 0.0, None)
+        return _lib.RandomValue(3, len(self.y), 0.0, 0.0, _dp(self.y), 0.0, _dp(self.x))
 
 
 class I3CLSimRandomValueWlenCherenkovNoDispersion:
@@ -74,7 +117,7 @@ class I3CLSimRandomValueWlenCherenkovNoDispersion:
         self.fromWlen, self.toWlen = float(fromWlen), float(toWlen)
 
     def _desc(self):
-        return _lib.RandomValue(2, 0, self.fromWlen, self.toWlen, None, 0.0)
+        return _lib.RandomValue(2, 0, self.fromWlen, self.toWlen, None, 0.0, None)
 
 
 class I3CLSimRandomValueConstant:
@@ -82,7 +125,7 @@ class I3CLSimRandomValueConstant:
         self.value = float(value)
 
     def _desc(self):
-        return _lib.RandomValue(1, 0, 0.0, 0.0, None, self.value)
+        return _lib.RandomValue(1, 0, 0.0, 0.0, None, self.value, None)
 
 
 class I3CLSimMediumProperties:
@@ -191,6 +234,53 @@ def makeCherenkovWavelengthGenerator(wavelengthGenerationBias, mediumProperties)
     _check(_lib.load().clsimhip_make_cherenkov_wlen_generator(C.byref(desc), mediumProperties._h, _dp(y),
                                                                C.byref(first), C.byref(spacing)))
     return I3CLSimRandomValueInterpolatedDistribution(first.value, spacing.value, y)
+
+
+def makeWavelengthGenerator(unbiasedSpectrum, wavelengthGenerationBias, mediumProperties):
+    """I3CLSimModuleHelper::makeWavelengthGenerator (ModuleHelper.cxx:73-171): a delta peak becomes a constant, a tabulated
+    spectrum an InterpolatedDistribution on the table's own binning with the bias folded in."""
+    n = max(len(getattr(unbiasedSpectrum, "values", ())), 1)
+    x = np.zeros(n, dtype=np.float64)
+    y = np.zeros(n, dtype=np.float64)
+    out = _lib.RandomValue()
+    spectrum, bias = unbiasedSpectrum._desc(), wavelengthGenerationBias._desc()
+    _check(_lib.load().clsimhip_make_wlen_generator(C.byref(spectrum), C.byref(bias), mediumProperties._h, C.byref(out), _dp(x), _dp(y), n))
+    if out.kind == 1:
+        return I3CLSimRandomValueConstant(out.value)
+    if out.kind == 3:
+        return I3CLSimRandomValueInterpolatedDistribution(x[:out.n].copy(), y[:out.n].copy())
+    return I3CLSimRandomValueInterpolatedDistribution(out.first, out.spacing, y[:out.n].copy())
+
+
+FLASHER_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "flasher_data")
+_FLASHER_LED_SPECTRA = {
+    # python/GetIceCubeFlasherSpectrum.py:38-60: file under resources/flasher_data/, normalisation constant
+    "LED340nm": ("flasher_led_340nm_emission_spectrum_cw_measured_20mA_pulseCurrent.txt", 24.306508),
+    "LED370nm": ("flasher_led_370nm_emission_spectrum_cw_measured.txt", 15.7001863),
+    "LED405nm": ("flasher_led_405nm_emission_spectrum_datasheet.txt", 8541585.10324),
+    "LED450nm": ("flasher_led_450nm_emission_spectrum_datasheet.txt", 21.9792812618),
+    "LED505nm": ("flasher_led_505nm_emission_spectrum_cw_measured.txt", 38.1881),
+}
+
+
+def GetIceCubeFlasherSpectrumData(spectrumType):
+    """python/GetIceCubeFlasherSpectrum.py:38-70: (wavelengths [m], values) of an LED's emission spectrum"""
+    if spectrumType not in _FLASHER_LED_SPECTRA:
+        raise RuntimeError("invalid spectrumType")
+    name, norm = _FLASHER_LED_SPECTRA[spectrumType]
+    data = np.loadtxt(os.path.join(FLASHER_DATA, name), unpack=True)
+    data[0] *= NANOMETER
+    data[1] /= norm
+    return data
+
+
+def GetIceCubeFlasherSpectrum(spectrumType="LED405nm"):
+    """python/GetIceCubeFlasherSpectrum.py:72-82; spectrumType: 'LED340nm' ... 'LED505nm', 'SC1', 'SC2'
+    (I3CLSimFlasherPulse::FlasherPulseType)"""
+    if spectrumType in ("SC1", "SC2"):
+        return I3CLSimFunctionDeltaPeak(337.0 * NANOMETER)
+    data = GetIceCubeFlasherSpectrumData(spectrumType)
+    return I3CLSimFunctionFromTable(data[0], data[1])
 
 
 def mwc_multipliers(count):

@@ -70,8 +70,13 @@ FunctionData function_from(const clsimhip_function *f)
         if (f->n < 2 || !f->values) throw Error(CLSIMHIP_ERR_ARGUMENT, "values must contain at least 2 elements!");
         d.start = f->start; d.step = f->step;
         d.values.assign(f->values, f->values + f->n);
-    } else if (f->kind == CLSIMHIP_FUNCTION_CONSTANT) {
+    } else if (f->kind == CLSIMHIP_FUNCTION_CONSTANT || f->kind == CLSIMHIP_FUNCTION_DELTA_PEAK) {
         d.value = f->value;
+    } else if (f->kind == CLSIMHIP_FUNCTION_TABLE_X) {              // FromTable.cxx:57-70
+        if (f->n < 2 || !f->wavelengths) throw Error(CLSIMHIP_ERR_ARGUMENT, "wlens must contain at least 2 elements!");
+        if (!f->values) throw Error(CLSIMHIP_ERR_ARGUMENT, "wlens and values must have the same size!");
+        d.wavelengths.assign(f->wavelengths, f->wavelengths + f->n);
+        d.values.assign(f->values, f->values + f->n);
     } else
         throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown function kind");
     return d;
@@ -179,6 +184,22 @@ int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const 
         std::memcpy(y_out, g.y.data(), g.y.size() * sizeof(double));
         if (first_out) *first_out = g.first;
         if (spacing_out) *spacing_out = g.spacing;
+    });
+}
+int clsimhip_make_wlen_generator(const clsimhip_function *spectrum, const clsimhip_function *bias, const clsimhip_medium *m,
+                                 clsimhip_random_value *out, double *x_out, double *y_out, size_t capacity)
+{
+    return guarded(nullptr, [&] {
+        need(m, "medium"); need(out, "out"); need(y_out, "y_out"); need(x_out, "x_out");
+        const RandomValueData g = make_wlen_generator(function_from(spectrum), function_from(bias), m->data);
+        if (g.y.size() > capacity) throw Error(CLSIMHIP_ERR_ARGUMENT, "clsimhip_make_wlen_generator: the output arrays are too small");
+        std::memset(out, 0, sizeof *out);
+        out->kind = g.kind; out->n = static_cast<int32_t>(g.y.size());
+        out->first = g.first; out->spacing = g.spacing; out->value = g.value;
+        std::memcpy(y_out, g.y.data(), g.y.size() * sizeof(double));
+        std::memcpy(x_out, g.x.data(), g.x.size() * sizeof(double));
+        out->y = g.y.empty() ? nullptr : y_out;
+        out->x = g.x.empty() ? nullptr : x_out;
     });
 }
 struct clsimhip_ppc_converter { std::unique_ptr<clsimhip::PPCConverter> impl; };
@@ -412,6 +433,10 @@ int clsimhip_set_wlen_generators(clsimhip_converter *c, const clsimhip_random_va
             if (gens[i].kind == CLSIMHIP_RANDOM_INTERPOLATED) {
                 if (gens[i].n < 2 || !gens[i].y) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified in the vector passed to I3CLSimRandomValueInterpolatedDistribution().");
                 v[i].first = gens[i].first; v[i].spacing = gens[i].spacing;
+                v[i].y.assign(gens[i].y, gens[i].y + gens[i].n);
+            } else if (gens[i].kind == CLSIMHIP_RANDOM_INTERPOLATED_X) {       // InterpolatedDistribution.cxx:40-55
+                if (gens[i].n < 2 || !gens[i].y || !gens[i].x) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified in the vectors passed to I3CLSimRandomValueInterpolatedDistribution().");
+                v[i].x.assign(gens[i].x, gens[i].x + gens[i].n);
                 v[i].y.assign(gens[i].y, gens[i].y + gens[i].n);
             } else if (gens[i].kind == CLSIMHIP_RANDOM_CONSTANT) {
                 v[i].value = gens[i].value;

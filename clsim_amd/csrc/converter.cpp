@@ -129,7 +129,12 @@ void Converter::set_wlen_generators(std::vector<RandomValueData> g)
             if (r.first > r.spacing) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"fromWlen\" argument must not be greater than \"toWlen\".");
             if (!(r.first > 0.) || !std::isfinite(r.spacing)) throw Error(CLSIMHIP_ERR_ARGUMENT, "the wavelength range must be positive and finite");
         } else {
-            if (!std::isfinite(r.first) || !(r.first > 0.) || !std::isfinite(r.spacing) || !(r.spacing > 0.))
+            if (r.kind == CLSIMHIP_RANDOM_INTERPOLATED_X) {
+                if (r.x.size() != r.y.size()) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"x\" and \"y\" vectors must have the same size!");
+                for (size_t i = 0; i < r.x.size(); ++i)
+                    if (!std::isfinite(r.x[i]) || !(r.x[i] > 0.) || (i > 0 && !(r.x[i] > r.x[i - 1])))
+                        throw Error(CLSIMHIP_ERR_ARGUMENT, "the wavelengths of a distribution must be positive, finite and ascending");
+            } else if (!std::isfinite(r.first) || !(r.first > 0.) || !std::isfinite(r.spacing) || !(r.spacing > 0.))
                 throw Error(CLSIMHIP_ERR_ARGUMENT, "a wavelength distribution needs a positive first wavelength and spacing");
             double sum = 0.;
             for (double y : r.y) {
@@ -142,7 +147,12 @@ void Converter::set_wlen_generators(std::vector<RandomValueData> g)
     compiled_ = false;
     generators_ = std::move(g);
 }
-void Converter::set_wlen_bias(FunctionData b) { guard(); compiled_ = false; bias_ = std::move(b); have_bias_ = true; }
+void Converter::set_wlen_bias(FunctionData b)
+{
+    guard();
+    if (!b.on_device()) throw Error(CLSIMHIP_ERR_ARGUMENT, "the wavelength bias must be a table with equal spacing or a constant (FromTable.cxx:169-170)");
+    compiled_ = false; bias_ = std::move(b); have_bias_ = true;
+}
 void Converter::set_medium(MediumData m) { guard(); m.validate(); compiled_ = false; medium_ = std::move(m); have_medium_ = true; }
 void Converter::set_geometry(GeometryInput g) { guard(); compiled_ = false; geometry_ = std::move(g); have_geometry_ = true; }
 

@@ -36,17 +36,18 @@ constexpr double deg = 3.14159265358979323846 / 180.0;
 constexpr double c_light = 0.299792458; // m/ns
 }
 
-struct FunctionData {                   // I3CLSimFunctionFromTable / Constant
+struct FunctionData {                   // I3CLSimFunctionFromTable / Constant (+ on the host: FromTable with its own wavelengths, DeltaPeak)
     int kind = CLSIMHIP_FUNCTION_CONSTANT;
     double start = 0, step = 0, value = 1.0;
-    std::vector<double> values;
+    std::vector<double> values, wavelengths;
     double eval(double wlen) const;     // host GetValue()
+    bool on_device() const { return kind == CLSIMHIP_FUNCTION_TABLE || kind == CLSIMHIP_FUNCTION_CONSTANT; }
 };
 
 struct RandomValueData {                // InterpolatedDistribution / Constant
     int kind = CLSIMHIP_RANDOM_CONSTANT;
     double first = 0, spacing = 0, value = 0;
-    std::vector<double> y;
+    std::vector<double> y, x;           // x: INTERPOLATED_X only
 };
 
 struct MediumData {                     // I3CLSimMediumProperties (IceCube function classes)
@@ -82,6 +83,7 @@ MediumData medium_from_ppc(const std::string &dir, double detector_center_depth,
 MediumData medium_from_photonics(const std::string &table_file, double detector_center_depth);
 void dom_acceptance(double dom_radius, double efficiency, std::vector<double> &values, double &start, double &step);
 RandomValueData make_cherenkov_generator(const FunctionData &bias, const MediumData &m);
+RandomValueData make_wlen_generator(const FunctionData &spectrum, const FunctionData &bias, const MediumData &m);    // makeWavelengthGenerator
 
 struct GeometryInput {                  // I3CLSimSimpleGeometry
     std::vector<int32_t> string_ids;

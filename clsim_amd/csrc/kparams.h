@@ -160,6 +160,7 @@ struct KParams {
     int32_t gen_kind[kMaxGenerators], gen_n[kMaxGenerators];
     float gen_first[kMaxGenerators], gen_spacing[kMaxGenerators], gen_value[kMaxGenerators];
     uint32_t off_gen_yv[kMaxGenerators], off_gen_ycum[kMaxGenerators];
+    uint32_t off_gen_xv[kMaxGenerators];        // kind 3 (InterpolatedDistribution with its own x values): _distXValues
     int32_t bias_kind, bias_n;
     float bias_start, bias_step, bias_value;
     uint32_t off_bias;

@@ -50,6 +50,16 @@ double FunctionData::eval(double wlen) const
 {
     // I3CLSimFunctionFromTable::GetValue, equal spacing (FromTable.cxx:105-122)
     if (kind == CLSIMHIP_FUNCTION_CONSTANT) return value;
+    if (kind == CLSIMHIP_FUNCTION_DELTA_PEAK) return (wlen == value) ? INFINITY : 0.;      // FunctionDeltaPeak.cxx (never sampled: makeWavelengthGenerator turns it into a constant)
+    if (kind == CLSIMHIP_FUNCTION_TABLE_X) {                // FromTable.cxx:123-145
+        if (wlen <= wavelengths[0]) return values[0];
+        for (size_t i = 1; i < wavelengths.size(); ++i)
+            if (wlen <= wavelengths[i]) {
+                const double fraction = (wlen - wavelengths[i - 1]) / (wavelengths[i] - wavelengths[i - 1]);
+                return values[i - 1] + (values[i] - values[i - 1]) * fraction;
+            }
+        return values[wavelengths.size() - 1];
+    }
     double fbin;
     double fraction = std::modf((wlen - start) / step, &fbin);
     int ibin = static_cast<int>(fbin);
@@ -486,6 +496,40 @@ RandomValueData make_cherenkov_generator(const FunctionData &bias, const MediumD
         const double yield = (2. * M_PI / (137. * (wlen * wlen))) * (1. - 1. / (std::pow(beta * n_phase, 2.)));
         g.y[i] = bias.values[i] * yield;
     }
+    return g;
+}
+
+// I3CLSimModuleHelper.cxx:73-171 for the spectrum classes its callers pass (GetIceCubeFlasherSpectrum.py: a FromTable with the
+// LED's measured wavelengths, or a DeltaPeak for the standard candles)
+RandomValueData make_wlen_generator(const FunctionData &spectrum, const FunctionData &bias, const MediumData &)
+{
+    RandomValueData g;
+    if (spectrum.kind == CLSIMHIP_FUNCTION_DELTA_PEAK) {        // :78-89
+        g.kind = CLSIMHIP_RANDOM_CONSTANT;
+        g.value = spectrum.value;
+        return g;
+    }
+    if (spectrum.kind != CLSIMHIP_FUNCTION_TABLE && spectrum.kind != CLSIMHIP_FUNCTION_TABLE_X)
+        throw Error(CLSIMHIP_ERR_CONFIG, "makeWavelengthGenerator: the spectrum must be a table or a delta peak");
+    if (!bias.on_device()) throw Error(CLSIMHIP_ERR_CONFIG, "makeWavelengthGenerator: the bias must be a table with equal spacing or a constant");
+    const size_t n = spectrum.values.size();
+    const bool own_x = (spectrum.kind == CLSIMHIP_FUNCTION_TABLE_X);
+    // a tabulated spectrum keeps its whole range (no clipping to the medium's, :100-106); the bias has to cover it (:111-114)
+    const double min_wlen = own_x ? spectrum.wavelengths.front() : spectrum.start;
+    const double max_wlen = own_x ? spectrum.wavelengths.back() : spectrum.start + spectrum.step * static_cast<double>(n - 1);
+    if (max_wlen - min_wlen <= 0.) throw Error(CLSIMHIP_ERR_CONFIG, "Internal error, wavelength range <= 0!");
+    if (bias.kind == CLSIMHIP_FUNCTION_TABLE) {
+        const double bias_min = bias.start, bias_max = bias.start + bias.step * static_cast<double>(bias.values.size() - 1);
+        if (bias_min > min_wlen || bias_max < max_wlen)
+            throw Error(CLSIMHIP_ERR_CONFIG, "wavelength generation bias has to have a wavelength range larger or equal to the spectrum wavelength range!");
+    }
+    g.y.resize(n);
+    for (size_t i = 0; i < n; ++i) {                            // :120-133
+        const double wavelength = own_x ? spectrum.wavelengths[i] : spectrum.start + static_cast<double>(i) * spectrum.step;
+        g.y[i] = bias.eval(wavelength) * spectrum.values[i];
+    }
+    if (own_x) { g.kind = CLSIMHIP_RANDOM_INTERPOLATED_X; g.x = spectrum.wavelengths; }
+    else { g.kind = CLSIMHIP_RANDOM_INTERPOLATED; g.first = spectrum.start; g.spacing = spectrum.step; }
     return g;
 }
 

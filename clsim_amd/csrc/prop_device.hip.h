@@ -318,7 +318,7 @@ DM float tilt_z_shift(KP P, float px, float py, float pz)
     return (val_at_upper * frac_at_upper + val_at_lower * frac_at_lower);
 }
 
-// InterpolatedDistribution.cxx:236-336 (constant spacing).  The reference scans
+// InterpolatedDistribution.cxx:236-336 (constant spacing, or kind 3: its own x values, :292-297).  The reference scans
 // the cumulative table linearly for the first entry >= r; the table is
 // non-decreasing, so a bisection lands on the same bin.
 DM float generate_wavelength(KP P, int gen, uint64_t &x, uint32_t a)
@@ -338,8 +338,9 @@ DM float generate_wavelength(KP P, int gen, uint64_t &x, uint32_t a)
     const int k = lo - 1;
     const float this_acu = (k == 0) ? 0.0f : ldsf(cum + k);
     const float b = ldsf(yv + k);
-    const float sp = P->gen_spacing[gen];
-    const float x0 = (float)k * sp + P->gen_first[gen];
+    const bool own_x = (P->gen_kind[gen] == 3);                // wave-uniform where the generator is (Cherenkov steps: always)
+    const float x0 = own_x ? ldsf(P->off_gen_xv[gen] + (uint32_t)k) : (float)k * P->gen_spacing[gen] + P->gen_first[gen];
+    const float sp = own_x ? (ldsf(P->off_gen_xv[gen] + (uint32_t)k + 1u) - x0) : P->gen_spacing[gen];
     const float slope = (ldsf(yv + k + 1) - b) / sp;
     const float dy = r - this_acu;
     if ((b == 0.0f) && (slope == 0.0f)) return x0;

@@ -323,21 +323,31 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         }
         // InterpolatedDistribution.cxx:134-175 (InitTables) and :177-234 (WriteTableCode)
         const size_t n = g.y.size();
+        const bool own_x = (g.kind == CLSIMHIP_RANDOM_INTERPOLATED_X);
         if (n < 2) throw Error(CLSIMHIP_ERR_ARGUMENT, "At least two entries have to be specified for an interpolated distribution.");
-        if (!(g.spacing > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "\"xSpacing\" must not be <= 0!");
+        if (own_x && g.x.size() != n) throw Error(CLSIMHIP_ERR_ARGUMENT, "The \"x\" and \"y\" vectors must have the same size!");
+        if (!own_x && !(g.spacing > 0.)) throw Error(CLSIMHIP_ERR_ARGUMENT, "\"xSpacing\" must not be <= 0!");
         std::vector<double> acu(n, 0.), beta(n, 0.);
-        for (size_t j = 1; j < n; ++j) acu[j] = acu[j - 1] + (g.spacing) * (g.y[j] + g.y[j - 1]) / 2.;
+        if (own_x) for (size_t j = 1; j < n; ++j) acu[j] = acu[j - 1] + (g.x[j] - g.x[j - 1]) * (g.y[j] + g.y[j - 1]) / 2.;     // :148-154
+        else for (size_t j = 1; j < n; ++j) acu[j] = acu[j - 1] + (g.spacing) * (g.y[j] + g.y[j - 1]) / 2.;
         const double total = acu[n - 1];
         for (size_t j = 0; j < n; ++j) { beta[j] = g.y[j] / total; acu[j] = acu[j] / total; }
         const std::vector<float> yv = literals(beta), ycum = literals(acu);
         for (size_t j = 0; j + 1 < n; ++j)
             if (ycum[j] > ycum[j + 1]) throw Error(CLSIMHIP_ERR_CONFIG, "cumulative spectrum is not monotonic (negative density?)");
         P.gen_n[k] = static_cast<int>(n);
-        P.gen_first[k] = to_float_literal(g.first);
-        P.gen_spacing[k] = to_float_literal(g.spacing);
+        P.gen_first[k] = own_x ? 0.f : to_float_literal(g.first);
+        P.gen_spacing[k] = own_x ? 0.f : to_float_literal(g.spacing);
         P.off_gen_yv[k] = img.add_floats(yv);
         P.off_gen_ycum[k] = img.add_floats(ycum);
         const std::string prefix = "_generateWavelength_" + std::to_string(k);
+        if (own_x) {                                        // WriteTableCode, :203-211
+            const std::vector<float> xv = literals(g.x);
+            for (size_t j = 0; j + 1 < n; ++j)
+                if (!(xv[j] < xv[j + 1])) throw Error(CLSIMHIP_ERR_CONFIG, "the wavelengths of a distribution do not ascend in single precision");
+            P.off_gen_xv[k] = img.add_floats(xv);
+            name(prefix + "distXValues", as_doubles(xv));
+        }
         name(prefix + "distYValues", as_doubles(yv));
         name(prefix + "distYCumulativeValues", as_doubles(ycum));
     }
@@ -349,6 +359,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         for (const RandomValueData &g : generators) {
             double a = g.value, b = g.value;
             if (g.kind == CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION) { a = std::min(g.first, g.spacing); b = std::max(g.first, g.spacing); }
+            else if (g.kind == CLSIMHIP_RANDOM_INTERPOLATED_X) { a = g.x.empty() ? 0. : g.x.front(); b = g.x.empty() ? 0. : g.x.back(); }
             else if (g.kind != CLSIMHIP_RANDOM_CONSTANT) { a = g.first - g.spacing; b = g.first + g.spacing * static_cast<double>(g.y.size()); }
             w_lo = std::min(w_lo, a); w_hi = std::max(w_hi, b);
         }

@@ -113,26 +113,31 @@ inline FunctionHolder MakeHIPFunction(const I3CLSimFunction &fn, const char *wha
 
 struct RandomValueHolder {
     clsimhip_random_value r;
-    std::vector<double> y;
+    std::vector<double> y, x;
     RandomValueHolder() { std::memset(&r, 0, sizeof r); }
-    RandomValueHolder(const RandomValueHolder &o) : r(o.r), y(o.y) { r.y = y.empty() ? 0 : y.data(); }
-    RandomValueHolder &operator=(const RandomValueHolder &o) { r = o.r; y = o.y; r.y = y.empty() ? 0 : y.data(); return *this; }
+    RandomValueHolder(const RandomValueHolder &o) : r(o.r), y(o.y), x(o.x) { r.y = y.empty() ? 0 : y.data(); r.x = x.empty() ? 0 : x.data(); }
+    RandomValueHolder &operator=(const RandomValueHolder &o) { r = o.r; y = o.y; x = o.x; r.y = y.empty() ? 0 : y.data(); r.x = x.empty() ? 0 : x.data(); return *this; }
 };
 
-// wavelength generators (I3CLSimModuleHelper.cxx:175-298 builds them): InterpolatedDistribution with constant spacing,
+// wavelength generators (I3CLSimModuleHelper.cxx:73-298 builds them): InterpolatedDistribution with constant spacing or its own x values,
 // Constant (delta peak), WlenCherenkovNoDispersion
 inline RandomValueHolder MakeHIPWlenGenerator(const I3CLSimRandomValue &rv, std::size_t index)
 {
     RandomValueHolder h;
     if (const I3CLSimRandomValueInterpolatedDistribution *d = dynamic_cast<const I3CLSimRandomValueInterpolatedDistribution *>(&rv)) {
         const double spacing = CLSIMHIP_PARAM(*d, interp_spacing, GetConstantXSpacing);
-        if (std::isnan(spacing)) log_fatal("HIP propagator: wavelength generator %zu has tabulated x values (constant spacing required)", index);
-        h.r.kind = CLSIMHIP_RANDOM_INTERPOLATED;
         h.y = CLSIMHIP_PARAM(*d, interp_y, GetYValues);
         h.r.n = static_cast<int32_t>(h.y.size());
-        h.r.first = CLSIMHIP_PARAM(*d, interp_first, GetFirstX);
-        h.r.spacing = spacing;
         h.r.y = h.y.data();
+        if (std::isnan(spacing)) {              // (x, y): the flasher LEDs' measured spectra (InterpolatedDistribution.cxx:40-55)
+            h.r.kind = CLSIMHIP_RANDOM_INTERPOLATED_X;
+            h.x = CLSIMHIP_PARAM(*d, interp_x, GetXValues);
+            h.r.x = h.x.data();
+        } else {
+            h.r.kind = CLSIMHIP_RANDOM_INTERPOLATED;
+            h.r.first = CLSIMHIP_PARAM(*d, interp_first, GetFirstX);
+            h.r.spacing = spacing;
+        }
     } else if (const I3CLSimRandomValueConstant *c = dynamic_cast<const I3CLSimRandomValueConstant *>(&rv)) {
         h.r.kind = CLSIMHIP_RANDOM_CONSTANT;
         h.r.value = CLSIMHIP_PARAM(*c, rconst_value, GetValue);

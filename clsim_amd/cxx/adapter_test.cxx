@@ -41,9 +41,9 @@ int main(int argc, char **argv)
     std::vector<double> acc(43), y(43);
     double start = 0, step = 0, first = 0, spacing = 0;
     clsimhip_icecube_dom_acceptance(0.16510, 1.0, acc.data(), &start, &step);
-    clsimhip_function bias = {CLSIMHIP_FUNCTION_TABLE, 43, start, step, acc.data(), 0.};
+    clsimhip_function bias = {CLSIMHIP_FUNCTION_TABLE, 43, start, step, acc.data(), 0., nullptr};
     clsimhip_make_cherenkov_wlen_generator(&bias, medium, y.data(), &first, &spacing);
-    clsimhip_random_value gen = {CLSIMHIP_RANDOM_INTERPOLATED, 43, first, spacing, y.data(), 0.};
+    clsimhip_random_value gen = {CLSIMHIP_RANDOM_INTERPOLATED, 43, first, spacing, y.data(), 0., nullptr};
 
     std::vector<int32_t> sid; std::vector<uint32_t> did; std::vector<double> x, yy, z; std::vector<std::string> sub;
     for (int k = 0; k < 60; ++k) { sid.push_back(1); did.push_back(k + 1); x.push_back(20.); yy.push_back(20.); z.push_back(500. - 17. * k); sub.push_back("IceCube"); }

@@ -197,7 +197,7 @@ int MakeSpectra(clsimhip_medium *medium, Inputs &in)
     std::vector<double> acc(43), y(43);
     double start = 0, step = 0, first = 0, spacing = 0;
     REQUIRE(clsimhip_icecube_dom_acceptance(0.16510, 1.0, acc.data(), &start, &step) == CLSIMHIP_OK);
-    const clsimhip_function bias = {CLSIMHIP_FUNCTION_TABLE, 43, start, step, acc.data(), 0.};
+    const clsimhip_function bias = {CLSIMHIP_FUNCTION_TABLE, 43, start, step, acc.data(), 0., nullptr};
     REQUIRE(clsimhip_make_cherenkov_wlen_generator(&bias, medium, y.data(), &first, &spacing) == CLSIMHIP_OK);
     in.bias.reset(new I3CLSimFunctionFromTable(start, step, acc));
     in.generators.assign(1, I3CLSimRandomValueConstPtr(new I3CLSimRandomValueInterpolatedDistribution(first, spacing, y)));

@@ -63,31 +63,39 @@ typedef struct {
 /* ---- value descriptions (doubles, like the reference's function objects) ---- */
 
 /* I3CLSimFunction: FromTable (equal spacing) or Constant.
- * private/clsim/function/I3CLSimFunctionFromTable.cxx:70-90, ...Constant.cxx:40-44 */
+ * private/clsim/function/I3CLSimFunctionFromTable.cxx:70-90, ...Constant.cxx:40-44.
+ * Two more kinds exist on the host only, as the emission spectra handed to clsimhip_make_wlen_generator -- like the reference,
+ * whose FromTable has no device code for unequal spacing (FromTable.cxx:169-170) and whose DeltaPeak is turned into a constant
+ * generator (I3CLSimModuleHelper.cxx:78-89): a converter refuses them as wavelength bias, a medium as refractive index. */
 #define CLSIMHIP_FUNCTION_TABLE 0
 #define CLSIMHIP_FUNCTION_CONSTANT 1
+#define CLSIMHIP_FUNCTION_TABLE_X 2     /* FromTable(wlens, values), FromTable.cxx:57-70: n wavelengths (ascending) + n values */
+#define CLSIMHIP_FUNCTION_DELTA_PEAK 3  /* I3CLSimFunctionDeltaPeak: value = the peak's wavelength */
 typedef struct {
     int32_t kind;
-    int32_t n;               /* TABLE: number of entries (>=2)            */
+    int32_t n;               /* TABLE, TABLE_X: number of entries (>=2)   */
     double start, step;      /* TABLE: first wavelength, spacing [m]      */
-    const double *values;    /* TABLE: n values                           */
-    double value;            /* CONSTANT                                  */
+    const double *values;    /* TABLE, TABLE_X: n values                  */
+    double value;            /* CONSTANT; DELTA_PEAK: peak position [m]   */
+    const double *wavelengths; /* TABLE_X: n wavelengths [m]              */
 } clsimhip_function;
 
 /* I3CLSimRandomValue used as wavelength generator: InterpolatedDistribution
- * (constant x spacing) or Constant (delta peak).
- * private/clsim/random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:57-74 */
+ * (constant x spacing, or with its own x values: the flasher LEDs' measured spectra) or Constant (delta peak).
+ * private/clsim/random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:40-74 */
 #define CLSIMHIP_RANDOM_INTERPOLATED 0
 #define CLSIMHIP_RANDOM_CONSTANT 1
 #define CLSIMHIP_RANDOM_CHERENKOV_NO_DISPERSION 2 /* I3CLSimRandomValueWlenCherenkovNoDispersion(fromWlen, toWlen)
                                                     (random_value/…WlenCherenkovNoDispersion.cxx:40-98): first = fromWlen,
                                                     spacing = toWlen */
+#define CLSIMHIP_RANDOM_INTERPOLATED_X 3 /* InterpolatedDistribution(x, y), InterpolatedDistribution.cxx:40-55 */
 typedef struct {
     int32_t kind;
     int32_t n;
     double first, spacing;   /* INTERPOLATED: x of first point, x spacing  */
-    const double *y;         /* INTERPOLATED: n unnormalised densities      */
+    const double *y;         /* INTERPOLATED, INTERPOLATED_X: n unnormalised densities */
     double value;            /* CONSTANT                                    */
+    const double *x;         /* INTERPOLATED_X: n abscissae, ascending      */
 } clsimhip_random_value;
 
 /* I3CLSimMediumProperties restricted to the function classes of the IceCube
@@ -155,6 +163,13 @@ int clsimhip_icecube_dom_acceptance(double dom_radius, double efficiency, double
  * (I3CLSimModuleHelper.cxx:175-263): y_out[bias->n] */
 int clsimhip_make_cherenkov_wlen_generator(const clsimhip_function *bias, const clsimhip_medium *m,
                                            double *y_out, double *first_out, double *spacing_out);
+
+/* I3CLSimModuleHelper::makeWavelengthGenerator (I3CLSimModuleHelper.cxx:73-171) for the spectrum classes its callers pass
+ * (python/GetIceCubeFlasherSpectrum.py): DELTA_PEAK -> CONSTANT; TABLE / TABLE_X -> INTERPOLATED / INTERPOLATED_X on the
+ * table's own binning, every entry multiplied by the bias at its wavelength.  `out` is filled in with out->y = y_out and
+ * out->x = x_out (x_out only written for INTERPOLATED_X); both arrays hold `capacity` >= spectrum->n doubles. */
+int clsimhip_make_wlen_generator(const clsimhip_function *spectrum, const clsimhip_function *bias, const clsimhip_medium *m,
+                                 clsimhip_random_value *out, double *x_out, double *y_out, size_t capacity);
 
 /* ---- RNG set-up (private/opencl/mwcrng_init.h:26-117, private/make_safeprimes/main.cxx) ---- */
 /* first `count` MWC multipliers (a*2^32-1 and (a*2^32-2)/2 prime, descending from 4294967118) */

@@ -91,6 +91,57 @@ def from_table_host(tab, wlen):
     return v[ibin] + (v[ibin + 1] - v[ibin]) * fraction
 
 
+def from_table_x_host(tab, wlen):
+    """I3CLSimFunctionFromTable::GetValue with the table's own wavelengths (FromTable.cxx:123-145)."""
+    w, v = tab["wavelengths"], tab["values"]
+    if wlen <= w[0]:
+        return v[0]
+    for i in range(1, len(w)):
+        if wlen <= w[i]:
+            fraction = (wlen - w[i - 1]) / (w[i] - w[i - 1])
+            return v[i - 1] + (v[i] - v[i - 1]) * fraction
+    return v[len(w) - 1]
+
+
+FLASHER_LED_SPECTRA = {
+    # python/GetIceCubeFlasherSpectrum.py:38-60: file under resources/flasher_data/, normalisation constant
+    "LED340nm": ("flasher_led_340nm_emission_spectrum_cw_measured_20mA_pulseCurrent.txt", 24.306508),
+    "LED370nm": ("flasher_led_370nm_emission_spectrum_cw_measured.txt", 15.7001863),
+    "LED405nm": ("flasher_led_405nm_emission_spectrum_datasheet.txt", 8541585.10324),
+    "LED450nm": ("flasher_led_450nm_emission_spectrum_datasheet.txt", 21.9792812618),
+    "LED505nm": ("flasher_led_505nm_emission_spectrum_cw_measured.txt", 38.1881),
+}
+
+
+def flasher_spectrum(kind, data_dir):
+    """python/GetIceCubeFlasherSpectrum.py:38-82: the LED's emission spectrum as an I3CLSimFunctionFromTable with its own
+    wavelengths (numpy.loadtxt, wavelengths * nanometer, values / constant); SC1 / SC2: a delta peak at 337 nm."""
+    if kind in ("SC1", "SC2"):
+        return dict(kind="delta", value=337.0 * NANOMETER)
+    name, norm = FLASHER_LED_SPECTRA[kind]
+    data = np.loadtxt(os.path.join(data_dir, name), unpack=True)
+    w = data[0] * NANOMETER
+    v = data[1] / norm
+    return dict(kind="table_x", wavelengths=w, values=v)
+
+
+def make_wavelength_generator(spectrum, bias, medium):
+    """I3CLSimModuleHelper::makeWavelengthGenerator (I3CLSimModuleHelper.cxx:73-171) for the spectrum classes its callers
+    pass: a delta peak -> RandomValueConstant; a table -> InterpolatedDistribution on the table's own binning, every
+    entry multiplied by the bias at its wavelength (no clipping to the medium's range, :100-106)."""
+    if spectrum["kind"] == "delta":
+        return dict(kind="const", value=spectrum["value"])
+    bias_at = (lambda wl: from_table_host(bias, wl)) if bias["kind"] == "table" else (lambda wl: bias["value"])
+    if spectrum["kind"] == "table_x":
+        w = np.asarray(spectrum["wavelengths"], dtype=np.float64)
+        y = np.array([bias_at(w[i]) * spectrum["values"][i] for i in range(len(w))])
+        return dict(kind="interp_x", x=w, y=y)
+    assert spectrum["kind"] == "table"
+    n = len(spectrum["values"])
+    y = np.array([bias_at(spectrum["start"] + float(i) * spectrum["step"]) * spectrum["values"][i] for i in range(n)])
+    return dict(kind="interp", first=spectrum["start"], spacing=spectrum["step"], y=y)
+
+
 def cherenkov_wlen_generator(bias, medium, beta=1.0):
     """I3CLSimModuleHelper::makeCherenkovWavelengthGenerator with a tabulated
     bias and dispersion on (I3CLSimModuleHelper.cxx:175-263, 52-63).  Returns an
@@ -114,8 +165,13 @@ def interp_dist_tables(gen):
     y = np.asarray(gen["y"], dtype=np.float64)
     n = len(y)
     acu = np.zeros(n, dtype=np.float64)
-    for j in range(1, n):
-        acu[j] = acu[j - 1] + (gen["spacing"]) * (y[j] + y[j - 1]) / 2.0
+    if gen["kind"] == "interp_x":                         # :148-154
+        x = np.asarray(gen["x"], dtype=np.float64)
+        for j in range(1, n):
+            acu[j] = acu[j - 1] + (x[j] - x[j - 1]) * (y[j] + y[j - 1]) / 2.0
+    else:
+        for j in range(1, n):
+            acu[j] = acu[j - 1] + (gen["spacing"]) * (y[j] + y[j - 1]) / 2.0
     total = acu[n - 1]
     beta = np.empty(n)
     for j in range(n):

@@ -35,7 +35,7 @@ FP = C.POINTER(C.c_float)
 
 class WlenGen(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("first", C.c_float), ("spacing", C.c_float),
-                ("yv", FP), ("ycum", FP), ("value", C.c_float)]
+                ("yv", FP), ("ycum", FP), ("value", C.c_float), ("xv", FP)]
 
 
 class Tables(C.Structure):
@@ -289,6 +289,13 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
             t.gen[k].spacing = fl(gdesc["spacing"])
             t.gen[k].yv = O._ptr("gen%d_yv" % k, yv, C.c_float)
             t.gen[k].ycum = O._ptr("gen%d_ycum" % k, ycum, C.c_float)
+        elif gdesc["kind"] == "interp_x":                     # its own x values (InterpolatedDistribution.cxx:41-55)
+            yv, ycum = B.interp_dist_tables(gdesc)
+            t.gen[k].kind = 3
+            t.gen[k].n = len(yv)
+            t.gen[k].yv = O._ptr("gen%d_yv" % k, yv, C.c_float)
+            t.gen[k].ycum = O._ptr("gen%d_ycum" % k, ycum, C.c_float)
+            t.gen[k].xv = O._ptr("gen%d_xv" % k, B.float_literals(gdesc["x"]), C.c_float)
         elif gdesc["kind"] == "nodispersion":                # WlenCherenkovNoDispersion.cxx:72-77
             min_val = 1.0 / gdesc["to"]
             t.gen[k].kind = 2
@@ -573,3 +580,12 @@ def eval_rng(x, a, n):
     out = np.empty(n, dtype=np.float32)
     L.oracle_eval_rng(C.byref(xs), C.c_uint32(int(a)), C.c_int(n), out.ctypes.data_as(C.c_void_p))
     return out, xs.value
+
+
+def generate_wavelengths(tables, generator, n, seed=1):
+    """n draws of generateWavelength_<generator> from one MWC stream (oracle_eval_wlen)"""
+    L = lib()
+    xs = C.c_uint64(0x9E3779B97F4A7C15 ^ int(seed) * 0x100000001B3 & 0xFFFFFFFFFFFFFFFF | 1)
+    out = np.empty(n, dtype=np.float32)
+    L.oracle_eval_wlen(C.byref(tables.t), C.c_int(int(generator)), C.byref(xs), C.c_uint32(4294967118), C.c_int(n), out.ctypes.data_as(C.c_void_p))
+    return out

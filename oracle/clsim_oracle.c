@@ -66,12 +66,14 @@ _Static_assert(sizeof(oracle_photon) == 80, "photon size");
 #define ORACLE_MAX_SUBDET 9
 
 typedef struct {
-    int32_t kind;               /* 0 interpolated (const spacing), 1 constant, 2 Cherenkov without dispersion */
+    int32_t kind;               /* 0 interpolated (const spacing), 1 constant, 2 Cherenkov without dispersion,
+                                   3 interpolated with its own x values (InterpolatedDistribution.cxx:41-55, :292-297) */
     int32_t n;
     float first, spacing;       /* literals of InterpolatedDistribution.cxx:250-266 */
     const float *yv;            /* _distYValues */
     const float *ycum;          /* _distYCumulativeValues */
     float value;                /* RandomValueConstant */
+    const float *xv;            /* _distXValues (kind 3) */
 } oracle_wlen_gen;
 
 typedef struct {
@@ -366,8 +368,14 @@ static inline float generateWavelength_k(const oracle_tables *T, int kgen, rng_t
         ++k;
     }
     const float b = G->yv[k];
-    const float x0 = (float)k * (G->spacing) + (G->first);
-    const float slope = (G->yv[k + 1] - b) / (G->spacing);
+    float x0, slope;
+    if (G->kind == 3) {                             /* :292-297 */
+        x0 = G->xv[k];
+        slope = (G->yv[k + 1] - b) / (G->xv[k + 1] - x0);
+    } else {                                        /* :298-303 */
+        x0 = (float)k * (G->spacing) + (G->first);
+        slope = (G->yv[k + 1] - b) / (G->spacing);
+    }
     const float dy = randomNumber - this_acu;
     if ((b == 0.0f) && (slope == 0.0f)) return x0;
     else if (b == 0.0f) return x0 + om_sqrt(2.0f * dy / slope);

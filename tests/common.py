@@ -67,24 +67,41 @@ def config(name):
         d = os.path.join(ICE, "spice_mie" if name == "mie" else "spice_lea")
         med_o = B.load_ppc_ice(d)
         med_p = CV.MakeIceCubeMediumProperties(iceDataDirectory=d)
-    return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=name.startswith("flasher"))
+    # 'flasher': the second generator is a 405 nm delta peak; 'flasher_led405': the LED's measured emission spectrum, a table with
+    # its own wavelengths (GetIceCubeFlasherSpectrum.py -> makeWavelengthGenerator -> InterpolatedDistribution(x, y))
+    return dict(name=name, geom=geom, med_o=med_o, med_p=med_p, flasher=name.startswith("flasher"),
+                led=("LED405nm" if name.startswith("flasher_led405") else None))
+
+
+def oracle_generators(cfg, bias):
+    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
+    if cfg.get("led"):
+        gens.append(B.make_wavelength_generator(B.flasher_spectrum(cfg["led"], CV.FLASHER_DATA), bias, cfg["med_o"]))
+    elif cfg["flasher"]:
+        gens.append(dict(kind="const", value=FLASHER_WLEN))
+    return gens
+
+
+def product_generators(cfg, bias):
+    gens = [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])]
+    if cfg.get("led"):
+        gens.append(CV.makeWavelengthGenerator(CV.GetIceCubeFlasherSpectrum(cfg["led"]), bias, cfg["med_p"]))
+    elif cfg["flasher"]:
+        gens.append(CV.I3CLSimRandomValueConstant(FLASHER_WLEN))
+    return gens
 
 
 def oracle_tables(cfg, pancake=5.0, stop_detected=True):
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     bias = B.icecube_dom_acceptance()
-    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
-    if cfg["flasher"]:
-        gens.append(dict(kind="const", value=FLASHER_WLEN))
+    gens = oracle_generators(cfg, bias)
     return capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, stop_detected=stop_detected)
 
 
 def product_converter(cfg, max_items, pancake=5.0, initialize=True, device=0, seed=12345, double_buffering=False, stop_detected=True):
     bias = CV.GetIceCubeDOMAcceptance()
-    gens = [CV.makeCherenkovWavelengthGenerator(bias, cfg["med_p"])]
-    if cfg["flasher"]:
-        gens.append(CV.I3CLSimRandomValueConstant(FLASHER_WLEN))
+    gens = product_generators(cfg, bias)
     geom = CV.I3CLSimSimpleGeometry.from_dict(cfg["geom"])
     if not initialize:
         conv = CV.I3CLSimStepToPhotonConverterHIP(device)

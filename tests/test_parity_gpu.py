@@ -32,7 +32,9 @@ def run_both(name, n_steps, max_items=None, seed=3, threads=8):
 @pytest.mark.parametrize("name,n_steps", [("c1", 1000), ("mie", 4096), ("lea", 4096), ("flasher", 2048),
                                           ("photonics_mie", 4096), ("photonics_wham", 2048),
                                           # DOMs exactly on the string axes: 86 strings share two position templates
-                                          ("mie_regular", 4096), ("flasher_regular", 2048)])
+                                          ("mie_regular", 4096), ("flasher_regular", 2048),
+                                          # second generator = the 405 nm LED's measured spectrum, a table with its own wavelengths
+                                          ("flasher_led405", 2048)])
 def test_hit_multiset_bit_exact(name, n_steps):
     steps, (ph_o, cnt_o, x_o), (ph_p, x_p), conv = run_both(name, n_steps)
     assert cnt_o > 10, "workload too small to be a test"

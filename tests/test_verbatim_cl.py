@@ -8,7 +8,7 @@ item over seeded step bunches.  They hold outputs only (sorted 80-byte hit recor
 the table maker: entry counts, the SHA-256 of the entry stream and the table it adds up to); the inputs are regenerated here
 from the same seeds.  Cases = the #ifdef branches of the static kernel files in use: plain (C1, SPICE-Mie, SPICE-Lea, flasher),
 per-layer tables in 16 bits with tabulated refractive indices, SAVE_PHOTON_HISTORY, a fixed absorption budget, no pancake
-factor, -DTABULATE with 4 axes / full azimuth / the impact-angle axis / too little entry space, and the search without
+factor, a flasher LED's measured spectrum (InterpolatedDistribution with its own x values), -DTABULATE with 4 axes / full azimuth / the impact-angle axis / too little entry space, and the search without
 STOP_PHOTONS_ON_DETECTION (`*_keep`: SetStopDetectedPhotons(false) -- every DOM on a segment's way is saved and the photon
 travels on; `clear*` = ice with a 600 m scattering length, where the quirks of that branch's bit masks decide 5 % of the hits).
 
@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # case -> (configuration, converter options)   [tools/verbatim_cl_check.py: CASES]
 CASES = {"c1": ("c1", {}), "mie": ("mie", {}), "lea": ("lea", {}), "flasher": ("flasher", {}), "photonics_mie": ("photonics_mie", {}),
          "mie_history": ("mie", dict(history=4)), "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)), "lea_no_pancake": ("lea", dict(pancake=1.0)),
+         "flasher_led405": ("flasher_led405", {}),
          "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
          "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
          "clear_keep": ("clear", dict(stop_detected=False)), "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4))}
@@ -59,7 +60,7 @@ def test_oracle_equals_the_verbatim_kernel(case):
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     bias = B.icecube_dom_acceptance()
-    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])] + ([dict(kind="const", value=common.FLASHER_WLEN)] if cfg["flasher"] else [])
+    gens = common.oracle_generators(cfg, bias)
     T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=opt.get("pancake", 5.0), stop_detected=opt.get("stop_detected", True),
                          fixed_abs_lengths=opt.get("fixed_abs"), history_entries=opt.get("history", 0))
     hits = np.frombuffer(f["hits"].tobytes(), dtype=PHOTON_DTYPE)

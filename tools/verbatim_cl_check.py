@@ -74,23 +74,31 @@ def emit_preamble(pancake, stop_detected=True, fixed_abs=None, history_n=0):
 
 
 def emit_interpolated_distribution(name, gen):
-    """random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:177-336, constant spacing"""
+    """random_value/I3CLSimRandomValueInterpolatedDistribution.cxx:177-336, constant spacing or (kind interp_x) with a table of
+    x values (:203-211, :292-297)"""
     from oracle import builders as B
     yv, ycum = B.interp_dist_tables(gen)
     n = len(yv)
     p = "_" + name
+    own_x = gen["kind"] == "interp_x"
     s = "#define %sNUM_DIST_ENTRIES %d\n" % (p, n)
+    if own_x:
+        s += "__constant float %sdistXValues[%sNUM_DIST_ENTRIES] = {%s};\n" % (p, p, ", ".join(hexf(v) for v in B.float_literals(gen["x"])))
     s += "__constant float %sdistYValues[%sNUM_DIST_ENTRIES] = {%s};\n" % (p, p, ", ".join(hexf(v) for v in yv))
     s += "__constant float %sdistYCumulativeValues[%sNUM_DIST_ENTRIES] = {%s};\n" % (p, p, ", ".join(hexf(v) for v in ycum))
-    sp, first = fl(gen["spacing"]), fl(gen["first"])
+    sp, first = (None, None) if own_x else (fl(gen["spacing"]), fl(gen["first"]))
     s += "inline float %s(RNG_ARGS);\ninline float %s(RNG_ARGS)\n{\n" % (name, name)
     s += "    const float randomNumber = RNG_CALL_UNIFORM_OC;\n"
     s += "    unsigned int k=0;\n    float this_acu = 0.f;\n"
     s += "    for (;;)\n    {\n        float next_acu = %sdistYCumulativeValues[k+1];\n" % p
     s += "        if (next_acu >= randomNumber) break;\n        this_acu = next_acu;\n        ++k;\n    }\n"
     s += "    const float b = %sdistYValues[k];\n" % p
-    s += "    const float x0 = convert_float_rtz(k)*(%s) + (%s);\n" % (sp, first)
-    s += "    const float slope = (%sdistYValues[k+1]-b)/(%s);\n" % (p, sp)
+    if own_x:
+        s += "    const float x0 = %sdistXValues[k];\n" % p
+        s += "    const float slope = (%sdistYValues[k+1]-b)/(%sdistXValues[k+1]-x0);\n" % (p, p)
+    else:
+        s += "    const float x0 = convert_float_rtz(k)*(%s) + (%s);\n" % (sp, first)
+        s += "    const float slope = (%sdistYValues[k+1]-b)/(%s);\n" % (p, sp)
     s += "    const float dy = randomNumber-this_acu;\n"
     s += "    if ((b==0.f) && (slope==0.f))\n    {\n        return x0;\n    }\n"
     s += "    else if (b==0.f)\n    {\n        return x0 + sqrt(2.f*dy/slope);\n    }\n"
@@ -104,7 +112,7 @@ def emit_wavelength_generators(generators):
     s = ""
     for i, g in enumerate(generators):
         name = "generateWavelength_%d" % i
-        if g["kind"] == "interp":
+        if g["kind"] in ("interp", "interp_x"):
             s += emit_interpolated_distribution(name, g) + "\n"
         elif g["kind"] == "const":                            # I3CLSimRandomValueConstant.cxx:75-103 (a fixed value)
             s += "inline float %s(RNG_ARGS);\ninline float %s(RNG_ARGS)\n{\n    return %s;\n}\n\n" % (name, name, fl(g["value"]))
@@ -525,6 +533,7 @@ CASES = {
     # and has (GEO_MAX_DOM_INDEX+63)/64 = 1 word here, so a 65th string makes it read and write past its array
     "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
     "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
+    "flasher_led405": ("flasher_led405", {}),                       # the LED's measured spectrum: InterpolatedDistribution with its own x values
     "clear_keep": ("clear", dict(stop_detected=False)),             # 86 strings: strings 64-85 index the DOM mask out of bounds (informational)
     "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4)),
     # the table maker's kernel (-DTABULATE, spherical_coordinates.c.cl): 4 axes; azimuth to 360 degrees; impact-angle axis;
@@ -612,9 +621,7 @@ def check_config(case, n_steps, write_fixtures):
     g = cfg["geom"]
     geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
     bias = B.icecube_dom_acceptance()
-    gens = [B.cherenkov_wlen_generator(bias, cfg["med_o"])]
-    if cfg["flasher"]:
-        gens.append(dict(kind="const", value=common.FLASHER_WLEN))
+    gens = common.oracle_generators(cfg, bias)
     steps = common.steps_for(cfg, n_steps, seed=3)
     x, a = common.streams(len(steps))
     T = capi.make_tables(cfg["med_o"], geo, gens, bias, pancake=pancake, stop_detected=stop_detected, fixed_abs_lengths=fixed_abs, history_entries=history)
