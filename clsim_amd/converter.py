@@ -504,6 +504,36 @@ class I3CLSimStepToPhotonConverterHIP:
         self._call("clsimhip_uses_pooled_kernel", C.byref(v))
         return bool(v.value)
 
+    # ---- the reference's tester classes (private/test/I3CLSim*Tester): single functions evaluated on the device ----
+    EVAL = {"lengths": 0, "refraction": 1, "wavelength_bias": 2, "tilt": 3, "abs_len_scaling": 4, "pre_scatter_transform": 5,
+            "post_scatter_transform": 6}
+    EVAL_RANDOM = {"uniform": 0, "wavelength": 1, "scattering_cosine": 2}
+
+    def EvaluateOnDevice(self, what, values, layer=0, fast=False):
+        """what: 'lengths' (values = wavelengths -> columns absorption, scattering length of `layer`), 'refraction' (-> phase
+        index, group velocity), 'wavelength_bias', 'tilt' (values = positions (n, 3)), 'abs_len_scaling', 'pre_scatter_transform',
+        'post_scatter_transform' (values = directions (n, 3) -> (n, 3)).  Returns float32 (n, 4)."""
+        v = np.asarray(values, dtype=np.float32)
+        inp = np.zeros((len(v), 4), dtype=np.float32)
+        if v.ndim == 1:
+            inp[:, 0] = v
+        else:
+            inp[:, :v.shape[1]] = v
+        out = np.zeros_like(inp)
+        self._call("clsimhip_eval_device_function", self.EVAL[what], int(layer), int(bool(fast)), inp.ctypes.data_as(C.c_void_p), len(inp),
+                   out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def SampleOnDevice(self, what, x, a, draws, generator=0, fast=False):
+        """what: 'uniform', 'wavelength' (of `generator`), 'scattering_cosine'; one work item per stream (x[i], a[i]), `draws`
+        values each.  Returns (values (n_streams, draws), final stream states)."""
+        xs = np.ascontiguousarray(x, dtype=np.uint64).copy()
+        a32 = np.ascontiguousarray(a, dtype=np.uint32)
+        out = np.zeros((len(xs), int(draws)), dtype=np.float32)
+        self._call("clsimhip_eval_device_random", self.EVAL_RANDOM[what], int(generator), int(bool(fast)), xs.ctypes.data_as(C.c_void_p),
+                   a32.ctypes.data_as(C.c_void_p), len(xs), int(draws), out.ctypes.data_as(C.c_void_p))
+        return out, xs
+
     def GetRNGState(self, count):
         x = np.zeros(count, dtype=np.uint64)
         self._call("clsimhip_get_rng_state", x.ctypes.data_as(C.c_void_p), count)

@@ -572,6 +572,15 @@ int clsimhip_debug_counters(clsimhip_converter *c, uint32_t out[4])
 {
     return guarded(c, [&] { need(c, "converter"); c->impl.debug_counters(out); });
 }
+int clsimhip_eval_device_function(clsimhip_converter *c, int what, int layer, int fast, const float *in4, size_t n, float *out4)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.eval_device_function(what, layer, fast != 0, in4, n, out4); });
+}
+int clsimhip_eval_device_random(clsimhip_converter *c, int what, int generator, int fast, uint64_t *x, const uint32_t *a, size_t n_streams, size_t draws,
+                                float *out)
+{
+    return guarded(c, [&] { need(c, "converter"); c->impl.eval_device_random(what, generator, fast != 0, x, a, n_streams, draws, out); });
+}
 int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out)
 {
     return guarded(nullptr, [&] {

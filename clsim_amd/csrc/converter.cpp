@@ -711,6 +711,62 @@ void Converter::propagate_device(const void *d_steps, size_t n, size_t rng_offse
     pending_events_.push_back(ev);
 }
 
+namespace {
+struct Scratch {                       // device memory of one tester call
+    void *p = nullptr;
+    explicit Scratch(size_t bytes)
+    {
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    ~Scratch() { if (p) (void)hipFree(p); }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+};
+} // namespace
+
+void Converter::eval_device_function(int what, int layer, bool fast, const float *in4, size_t n, float *out4)
+{
+    need_init();
+    if (!in4 || !out4) throw Error(CLSIMHIP_ERR_ARGUMENT, "in4 / out4 are (null)");
+    if (what < CLSIMHIP_EVAL_LENGTHS || what > CLSIMHIP_EVAL_POST_SCATTER_TRANSFORM) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown function");
+    if (what == CLSIMHIP_EVAL_LENGTHS && (layer < 0 || layer >= tables_.params.num_layers)) throw Error(CLSIMHIP_ERR_ARGUMENT, "no such layer");
+    if (fast && !tables_.variant.fast) throw Error(CLSIMHIP_ERR_STATE, "this configuration has no FAST instantiation (Compile() could not prove its ranges)");
+    if (n > 0xffffffffull) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many points");
+    DeviceGuard on_device(device_);
+    Scratch in(n * 16), out(n * 16);
+    hip_check(hipMemcpy(in.p, in4, n * 16, hipMemcpyHostToDevice), "hipMemcpy");
+    KParams P = tables_.params;
+    P.tables = d_tables_;
+    P.len_table = d_len_table_;
+    hip_check(launch_eval_function(P, tables_.variant.lengths, tables_.variant.tilt, fast, what, layer, static_cast<const float4 *>(in.p), static_cast<uint32_t>(n),
+                                   static_cast<float4 *>(out.p), nullptr), "function tester launch");
+    hip_check(hipDeviceSynchronize(), "function tester");
+    hip_check(hipMemcpy(out4, out.p, n * 16, hipMemcpyDeviceToHost), "hipMemcpy");
+}
+
+void Converter::eval_device_random(int what, int generator, bool fast, uint64_t *x, const uint32_t *a, size_t n_streams, size_t draws, float *out)
+{
+    need_init();
+    if (!x || !a || !out) throw Error(CLSIMHIP_ERR_ARGUMENT, "x / a / out are (null)");
+    if (what < CLSIMHIP_EVAL_RANDOM_UNIFORM || what > CLSIMHIP_EVAL_RANDOM_SCATTERING_COSINE) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown distribution");
+    if (what == CLSIMHIP_EVAL_RANDOM_WAVELENGTH && (generator < 0 || generator >= tables_.params.num_gen)) throw Error(CLSIMHIP_ERR_ARGUMENT, "no such wavelength generator");
+    if (fast && !tables_.variant.fast) throw Error(CLSIMHIP_ERR_STATE, "this configuration has no FAST instantiation (Compile() could not prove its ranges)");
+    if (n_streams > 0xffffffffull || draws > 0xffffffffull) throw Error(CLSIMHIP_ERR_ARGUMENT, "too many draws");
+    DeviceGuard on_device(device_);
+    Scratch dx(n_streams * 8), da(n_streams * 4), dout(n_streams * draws * 4);
+    hip_check(hipMemcpy(dx.p, x, n_streams * 8, hipMemcpyHostToDevice), "hipMemcpy");
+    hip_check(hipMemcpy(da.p, a, n_streams * 4, hipMemcpyHostToDevice), "hipMemcpy");
+    KParams P = tables_.params;
+    P.tables = d_tables_;
+    P.len_table = d_len_table_;
+    hip_check(launch_eval_random(P, fast, what, generator, static_cast<uint64_t *>(dx.p), static_cast<const uint32_t *>(da.p), static_cast<uint32_t>(n_streams),
+                                 static_cast<uint32_t>(draws), static_cast<float *>(dout.p), nullptr), "distribution tester launch");
+    hip_check(hipDeviceSynchronize(), "distribution tester");
+    hip_check(hipMemcpy(out, dout.p, n_streams * draws * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+    hip_check(hipMemcpy(x, dx.p, n_streams * 8, hipMemcpyDeviceToHost), "hipMemcpy");
+}
+
 void Converter::kernel_time(bool reset, double *total_ms, uint64_t *launches)
 {
     std::lock_guard<std::mutex> lk(ev_mutex_);

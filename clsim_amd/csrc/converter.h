@@ -31,6 +31,10 @@ hipError_t launch_generate_flasher_steps(const clsimhip_flasher_config &cfg, con
 hipError_t launch_generate_steps(const clsimhip_step_request *d_requests, const uint64_t *d_first_step, uint32_t n_requests,
                                  uint64_t total_real, uint64_t total_padded, uint64_t seed, void *d_out, hipStream_t stream);
 hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
+hipError_t launch_eval_function(const KParams &P, int lengths_kind, bool has_tilt, bool fast, int what, int layer, const float4 *in, uint32_t n, float4 *out,
+                                hipStream_t stream);
+hipError_t launch_eval_random(const KParams &P, bool fast, int what, int generator, uint64_t *x, const uint32_t *a, uint32_t n_streams, uint32_t draws,
+                              float *out, hipStream_t stream);
 hipError_t launch_keep_kernel(const KParams &P, const KVariant &v, hipStream_t stream);     // prop_keep_kernel.hip: without STOP_PHOTONS_ON_DETECTION
 size_t prop_kernel_max_lanes();
 size_t prop_kernel_lds_budget();
@@ -174,6 +178,9 @@ public:
     void kernel_time(bool reset, double *total_ms, uint64_t *launches);
     long get_table(const std::string &name, double *out, size_t cap) const;
     void get_rng_state(uint64_t *x, size_t count);
+    // the reference's tester classes (prop_eval_kernel.hip)
+    void eval_device_function(int what, int layer, bool fast, const float *in4, size_t n, float *out4);
+    void eval_device_random(int what, int generator, bool fast, uint64_t *x, const uint32_t *a, size_t n_streams, size_t draws, float *out);
     void debug_counters(uint32_t out[4]);
     // SetDevice (OpenCL.cxx:1322-1331): the HIP device ordinal, before Initialize()
     void set_device(int device);

@@ -332,6 +332,28 @@ int clsimhip_get_rng_state(clsimhip_converter *c, uint64_t *x_out, size_t count)
  * 5 acos,6 atan2(x,y),7 rsqrt,8 sqrt,9 x/y,10 acos (single precision),11 rcp_,12 sqrt_near_,13 rsqrt_near_,
  * 14 powr_unit_(x,y),15 cbrt_,16 div_near_(x,y) */
 int clsimhip_eval_math(int device_ordinal, int what, const float *x, const float *y, size_t n, float *out);
+
+/* Single functions of an initialised converter evaluated ON THE DEVICE, from the table image its kernels read: what the
+ * reference's tester classes do (private/test/I3CLSimFunctionTester, ...ScalarFieldTester, ...VectorTransformTester,
+ * ...MediumPropertiesTester, ...RandomDistributionTester; used by resources/tests/testScalarFields.py,
+ * testScalarFieldIceTiltZShift.py, testVectorTransforms.py to compare device with host).  in4 / out4: n x 4 floats.
+ * fast != 0: the forms the standard configuration's kernels use (exact reciprocals; only valid when Compile() proved their
+ * ranges: CLSIMHIP_ERR_STATE otherwise), 0: the IEEE sequences.  Same values either way (tests/test_device_functions_gpu.py). */
+#define CLSIMHIP_EVAL_LENGTHS 0                 /* in.x = wavelength [m]; out.x = absorption, out.y = scattering length of `layer` */
+#define CLSIMHIP_EVAL_REFRACTION 1              /* in.x = wavelength; out.x = phase refractive index, out.y = group velocity [m/ns] */
+#define CLSIMHIP_EVAL_WAVELENGTH_BIAS 2         /* in.x = wavelength; out.x = getWavelengthBias */
+#define CLSIMHIP_EVAL_TILT 3                    /* in.xyz = position; out.x = getTiltZShift */
+#define CLSIMHIP_EVAL_ABS_LEN_SCALING 4         /* in.xyz = direction; out.x = getDirectionalAbsLenCorrFactor */
+#define CLSIMHIP_EVAL_PRE_SCATTER_TRANSFORM 5   /* in.xyz = direction; out.xyz = transformDirectionPreScatter */
+#define CLSIMHIP_EVAL_POST_SCATTER_TRANSFORM 6  /* in.xyz = direction; out.xyz = transformDirectionPostScatter */
+int clsimhip_eval_device_function(clsimhip_converter *c, int what, int layer, int fast, const float *in4, size_t n, float *out4);
+/* n_streams work items, each with its own MWC stream (x[i], a[i]) -- x is updated --, draw `draws` values:
+ * out[i * draws + k] (RandomDistributionTester.cxx:43-199) */
+#define CLSIMHIP_EVAL_RANDOM_UNIFORM 0              /* rand_MWC_co */
+#define CLSIMHIP_EVAL_RANDOM_WAVELENGTH 1           /* generateWavelength_<generator> */
+#define CLSIMHIP_EVAL_RANDOM_SCATTERING_COSINE 2    /* makeScatteringCosAngle */
+int clsimhip_eval_device_random(clsimhip_converter *c, int what, int generator, int fast, uint64_t *x, const uint32_t *a, size_t n_streams,
+                                size_t draws, float *out);
 /* exhaustive device-side check of the range-restricted operations of the kernel's math library (what = 11 reciprocal,
  * 12 square root, 13 reciprocal square root) against the IEEE divide / sqrt: all 2^23 significands x every binary
  * exponent in [exp_lo, exp_hi].  result[0] = number of mismatches, result[1..cap) = bit patterns of the first ones.

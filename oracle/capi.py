@@ -589,3 +589,28 @@ def generate_wavelengths(tables, generator, n, seed=1):
     out = np.empty(n, dtype=np.float32)
     L.oracle_eval_wlen(C.byref(tables.t), C.c_int(int(generator)), C.byref(xs), C.c_uint32(4294967118), C.c_int(n), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def sample(tables, what, x, a, draws, generator=0):
+    """`draws` values from every stream (x[i], a[i]): what = 'uniform' (rand_MWC_co), 'wavelength' (generateWavelength_<generator>),
+    'scattering_cosine' (makeScatteringCosAngle).  Returns (values (n, draws), final states) -- oracle_eval_rng / _wlen / _scatcos."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.empty((len(x), draws), dtype=np.float32)
+    x_out = np.empty_like(x)
+    row = np.empty(draws, dtype=np.float32)
+    for i in range(len(x)):
+        xs = C.c_uint64(int(x[i]))
+        p = row.ctypes.data_as(C.c_void_p)
+        if what == "uniform":
+            L.oracle_eval_rng(C.byref(xs), C.c_uint32(int(a[i])), C.c_int(draws), p)
+        elif what == "wavelength":
+            L.oracle_eval_wlen(C.byref(tables.t), C.c_int(int(generator)), C.byref(xs), C.c_uint32(int(a[i])), C.c_int(draws), p)
+        elif what == "scattering_cosine":
+            L.oracle_eval_scatcos(C.byref(tables.t), C.byref(xs), C.c_uint32(int(a[i])), C.c_int(draws), p)
+        else:
+            raise ValueError(what)
+        out[i] = row
+        x_out[i] = xs.value
+    return out, x_out
