@@ -466,6 +466,27 @@ class I3CLSimStepToPhotonConverterHIP:
                 "TotalNumPhotonsAtDOMs", "AverageDeviceTimePerPhoton", "AverageHostTimePerPhoton", "DeviceUtilization"]
         return dict(zip(keys, list(out)))
 
+    # the accessors of the concrete class (OpenCL.h:138-258, :377-381; times in nanoseconds)
+    def GetTotalDeviceTime(self): return self.GetStatistics()["TotalDeviceTime"]
+    def GetTotalHostTime(self): return self.GetStatistics()["TotalHostTime"]
+    def GetNumKernelCalls(self): return int(self.GetStatistics()["NumKernelCalls"])
+    def GetTotalNumPhotonsGenerated(self): return int(self.GetStatistics()["TotalNumPhotonsGenerated"])
+    def GetTotalNumPhotonsAtDOMs(self): return int(self.GetStatistics()["TotalNumPhotonsAtDOMs"])
+
+    def _option(self, which):
+        v = C.c_double()
+        self._call("clsimhip_get_option", int(which), C.byref(v))
+        return v.value
+
+    def GetEnableDoubleBuffering(self): return self._option(0) != 0.0
+    def GetDoublePrecision(self): return self._option(1) != 0.0
+    def GetStopDetectedPhotons(self): return self._option(2) != 0.0
+    def GetSaveAllPhotons(self): return self._option(3) != 0.0
+    def GetSaveAllPhotonsPrescale(self): return self._option(4)
+    def GetFixedNumberOfAbsorptionLengths(self): return self._option(5)
+    def GetDOMPancakeFactor(self): return self._option(6)
+    def GetPhotonHistoryEntries(self): return int(self._option(7))
+
     # ---- device-resident path / introspection ----
     def PropagateDevice(self, d_steps, n, d_photons, capacity, d_hit_count, stream=0, rng_offset=0):
         self._call("clsimhip_propagate_device", C.c_void_p(d_steps), int(n), int(rng_offset), C.c_void_p(d_photons),

@@ -541,6 +541,10 @@ int clsimhip_get_statistics(const clsimhip_converter *c, double out[8])
 {
     return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); c->impl.statistics(out); });
 }
+int clsimhip_get_option(const clsimhip_converter *c, int option, double *out)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.option(option); });
+}
 int clsimhip_propagate_device(clsimhip_converter *c, const void *d_steps, size_t n, size_t rng_offset, void *d_photons,
                               size_t capacity, void *d_hit_count, void *stream)
 {

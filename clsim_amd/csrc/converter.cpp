@@ -667,6 +667,21 @@ void Converter::statistics(double out[8]) const
     out[5] = dev / gen; out[6] = host / gen; out[7] = dev / host;
 }
 
+double Converter::option(int which) const
+{
+    switch (which) {
+    case CLSIMHIP_OPTION_ENABLE_DOUBLE_BUFFERING: return double_buffering_ ? 1. : 0.;
+    case CLSIMHIP_OPTION_DOUBLE_PRECISION: return double_precision_ ? 1. : 0.;
+    case CLSIMHIP_OPTION_STOP_DETECTED_PHOTONS: return stop_detected_ ? 1. : 0.;
+    case CLSIMHIP_OPTION_SAVE_ALL_PHOTONS: return save_all_ ? 1. : 0.;
+    case CLSIMHIP_OPTION_SAVE_ALL_PHOTONS_PRESCALE: return save_all_prescale_;
+    case CLSIMHIP_OPTION_FIXED_NUMBER_OF_ABSORPTION_LENGTHS: return fixed_abs_lengths_;
+    case CLSIMHIP_OPTION_DOM_PANCAKE_FACTOR: return pancake_;
+    case CLSIMHIP_OPTION_PHOTON_HISTORY_ENTRIES: return static_cast<double>(history_entries_);
+    }
+    throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown option");
+}
+
 // OpenCL.cxx:1565-1600
 void Converter::replace_indices(clsimhip_photon *photons, size_t n) const
 {

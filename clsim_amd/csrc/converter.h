@@ -171,6 +171,7 @@ public:
     size_t queue_size() const;
     bool more_photons_available() const;
     void statistics(double out[8]) const;
+    double option(int which) const;
 
     void propagate_device(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity,
                           void *d_hit_count, hipStream_t stream);

@@ -238,7 +238,23 @@ public:
         return m;
     }
 
-    // ---- concrete setters of the OpenCL converter (OpenCL.h:78-258) ----
+    // the statistics accessors I3CLSimModule::Finish reads from the concrete class (OpenCL.h:377-381, I3CLSimModule.cxx:1626-1634):
+    // times in nanoseconds
+    double GetTotalDeviceTime() const { return stat(0); }
+    double GetTotalHostTime() const { return stat(1); }
+    uint64_t GetNumKernelCalls() const { return static_cast<uint64_t>(stat(2)); }
+    uint64_t GetTotalNumPhotonsGenerated() const { return static_cast<uint64_t>(stat(3)); }
+    uint64_t GetTotalNumPhotonsAtDOMs() const { return static_cast<uint64_t>(stat(4)); }
+
+    // ---- concrete setters and getters of the OpenCL converter (OpenCL.h:78-258) ----
+    bool GetEnableDoubleBuffering() const { return option(CLSIMHIP_OPTION_ENABLE_DOUBLE_BUFFERING) != 0.; }
+    bool GetDoublePrecision() const { return option(CLSIMHIP_OPTION_DOUBLE_PRECISION) != 0.; }
+    bool GetStopDetectedPhotons() const { return option(CLSIMHIP_OPTION_STOP_DETECTED_PHOTONS) != 0.; }
+    bool GetSaveAllPhotons() const { return option(CLSIMHIP_OPTION_SAVE_ALL_PHOTONS) != 0.; }
+    double GetSaveAllPhotonsPrescale() const { return option(CLSIMHIP_OPTION_SAVE_ALL_PHOTONS_PRESCALE); }
+    double GetFixedNumberOfAbsorptionLengths() const { return option(CLSIMHIP_OPTION_FIXED_NUMBER_OF_ABSORPTION_LENGTHS); }
+    double GetDOMPancakeFactor() const { return option(CLSIMHIP_OPTION_DOM_PANCAKE_FACTOR); }
+    uint32_t GetPhotonHistoryEntries() const { return static_cast<uint32_t>(option(CLSIMHIP_OPTION_PHOTON_HISTORY_ENTRIES)); }
     void SetDevice(int hipDeviceOrdinal) { check(clsimhip_set_device(handle_, hipDeviceOrdinal)); }
     void SetEnableDoubleBuffering(bool v) { check(clsimhip_set_enable_double_buffering(handle_, v)); }
     void SetDoublePrecision(bool v) { check(clsimhip_set_double_precision(handle_, v)); }
@@ -264,6 +280,8 @@ private:
 #endif
         throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(handle_));
     }
+    double stat(int i) const { double v[8]; check(clsimhip_get_statistics(handle_, v)); return v[i]; }
+    double option(int which) const { double v = 0.; check(clsimhip_get_option(handle_, which, &v)); return v; }
     clsimhip_converter *handle_;
     uint64_t seed_;
 #ifdef CLSIMHIP_WITH_ICETRAY

@@ -250,6 +250,17 @@ int clsimhip_more_photons_available(const clsimhip_converter *c, int *out);
  * [3] TotalNumPhotonsGenerated, [4] TotalNumPhotonsAtDOMs, [5] AverageDeviceTimePerPhoton,
  * [6] AverageHostTimePerPhoton, [7] DeviceUtilization */
 int clsimhip_get_statistics(const clsimhip_converter *c, double out[8]);
+/* the option getters of the concrete class (GetEnableDoubleBuffering ... GetDOMPancakeFactor, OpenCL.h:138-258): what the
+ * setters stored */
+#define CLSIMHIP_OPTION_ENABLE_DOUBLE_BUFFERING 0
+#define CLSIMHIP_OPTION_DOUBLE_PRECISION 1
+#define CLSIMHIP_OPTION_STOP_DETECTED_PHOTONS 2
+#define CLSIMHIP_OPTION_SAVE_ALL_PHOTONS 3
+#define CLSIMHIP_OPTION_SAVE_ALL_PHOTONS_PRESCALE 4
+#define CLSIMHIP_OPTION_FIXED_NUMBER_OF_ABSORPTION_LENGTHS 5    /* NaN: not set */
+#define CLSIMHIP_OPTION_DOM_PANCAKE_FACTOR 6
+#define CLSIMHIP_OPTION_PHOTON_HISTORY_ENTRIES 7
+int clsimhip_get_option(const clsimhip_converter *c, int option, double *out);
 
 /* ---- device-resident path (no reference counterpart: the reference always
  * stages through host memory, OpenCL.cxx:824-911, 994-1086) ----

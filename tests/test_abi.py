@@ -155,3 +155,20 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                            str(src), "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_option_getters_and_the_class_defaults():
+    """GetEnableDoubleBuffering ... GetDOMPancakeFactor (OpenCL.h:138-258); a fresh converter holds the defaults of the reference's
+    constructor (OpenCL.cxx:83-92), initializeHIP what its caller passed (I3CLSimModuleHelper.cxx:319-369)"""
+    import math
+    conv = CV.I3CLSimStepToPhotonConverterHIP(0)
+    assert conv.GetEnableDoubleBuffering() is False and conv.GetDoublePrecision() is False
+    assert conv.GetStopDetectedPhotons() is False and conv.GetSaveAllPhotons() is False
+    assert math.isnan(conv.GetFixedNumberOfAbsorptionLengths()) and conv.GetDOMPancakeFactor() == 1.0
+    assert conv.GetPhotonHistoryEntries() == 0
+    conv.SetEnableDoubleBuffering(True); conv.SetStopDetectedPhotons(True); conv.SetFixedNumberOfAbsorptionLengths(46.0)
+    conv.SetDOMPancakeFactor(5.0); conv.SetPhotonHistoryEntries(3); conv.SetSaveAllPhotonsPrescale(0.25)
+    assert conv.GetEnableDoubleBuffering() is True and conv.GetStopDetectedPhotons() is True
+    assert conv.GetFixedNumberOfAbsorptionLengths() == 46.0 and conv.GetDOMPancakeFactor() == 5.0
+    assert conv.GetPhotonHistoryEntries() == 3 and conv.GetSaveAllPhotonsPrescale() == 0.25
+    assert conv.GetNumKernelCalls() == 0 and conv.GetTotalNumPhotonsGenerated() == 0 and conv.GetTotalNumPhotonsAtDOMs() == 0
