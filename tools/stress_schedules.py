@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress test (GPU): the propagation result must not depend on the schedule.  Random bunch sizes, photon counts, grids,
 slice counts and batching thresholds; every case is compared with the same bunch run as whole steps on a small grid
-(hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases]"""
+(hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases] [keep]
+(keep: the instantiations without STOP_PHOTONS_ON_DETECTION, classic kernel only; `clear` ice among the configurations)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,7 @@ from clsim_amd import converter as CV, synthetic as S
 from tests import common
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+KEEP = len(sys.argv) > 2 and sys.argv[2] == "keep"
 rng = np.random.Generator(np.random.PCG64(2024))
 dev = torch.device("cuda", 0)
 cap = 1 << 21
@@ -23,7 +25,7 @@ def run(cfg, steps, env):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in env.items()})
     n = len(steps)
-    conv = common.product_converter(cfg, n)
+    conv = common.product_converter(cfg, n, stop_detected=not KEEP)
     d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
     conv.PropagateDevice(d_steps.data_ptr(), n, out.data_ptr(), cap, cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -34,7 +36,7 @@ def run(cfg, steps, env):
 
 
 for case in range(cases):
-    name = ["mie", "lea", "c1", "flasher"][case % 4]
+    name = (["mie", "lea", "clear", "flasher"] if KEEP else ["mie", "lea", "c1", "flasher"])[case % 4]
     cfg = common.config(name)
     n = 256 * int(rng.integers(1, [40, 400, 1200][case % 3]))
     steps = common.steps_for(cfg, n, seed=100 + case)
@@ -48,7 +50,7 @@ for case in range(cases):
         steps["num"][rng.integers(0, n, 5)] = 3000
     env = dict(CLSIMHIP_GRID=int(rng.integers(1, 1793)), CLSIMHIP_SLICES=int(rng.choice([1, 2, 3, 5, 16, 33, 64])),
                CLSIMHIP_K_NEW=int(rng.choice([1, 4, 12, 40, 64])), CLSIMHIP_K_SEARCH=int(rng.choice([1, 3, 5, 20])))
-    if case % 2:        # the pooled kernel: ring size, service threshold, specialised or generic instantiation
+    if (case % 2) and not KEEP:        # the pooled kernel: ring size, service threshold, specialised or generic instantiation
         env.update(CLSIMHIP_KERNEL="pool", CLSIMHIP_POOL_R=int(rng.choice([4, 7, 16, 34])), CLSIMHIP_K_POP=int(rng.choice([1, 4, 17, 64])),
                    CLSIMHIP_NO_FAST=int(rng.integers(0, 2)), CLSIMHIP_GRID=int(rng.integers(1, 513)))
     ref = run(cfg, steps, dict(CLSIMHIP_GRID=64, CLSIMHIP_SLICES=1, CLSIMHIP_K_NEW=1, CLSIMHIP_K_SEARCH=1))
