@@ -178,7 +178,20 @@ def test_hip_table_maker_equals_the_verbatim_kernel(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/resources/kernels"), reason="the reference tree is not on this machine")
 def test_fixture_is_what_the_reference_kernel_text_yields_today():
     """build container only: recompile the reference's .cl files and run the smallest configuration again (the tool exits
-    non-zero unless the verbatim kernel and the oracle agree bit for bit); `tools/verbatim_cl_check.py` runs all twelve"""
+    non-zero unless the verbatim kernel and the oracle agree bit for bit); `tools/verbatim_cl_check.py` runs all nineteen"""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verbatim_cl_check.py"), "--configs", "c1"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "hit records IDENTICAL | final RNG states IDENTICAL" in p.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/resources/kernels"), reason="the reference tree is not on this machine")
+def test_the_two_refused_modes_do_not_compile_in_the_reference_either():
+    """build container only.  Compile() refuses DoublePrecision and SaveAllPhotons because the reference's own
+    program cannot be built in them at this revision: with DOUBLE_PRECISION propagation_kernel.c.cl:872 hands the double4 direction
+    to a function taking float4* -- for every medium, the call is unconditional --, and with SAVE_ALL_PHOTONS the geometry source is
+    left out (OpenCL.cxx:459-470) while saveHit still calls geometryGetDomPosition (c.cl:339)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verbatim_cl_check.py"), "--refused-modes"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = {l.split()[0]: l for l in p.stdout.splitlines() if l.startswith(("DOUBLE_PRECISION", "SAVE_ALL_PHOTONS"))}
+    assert "DOES NOT COMPILE" in lines["DOUBLE_PRECISION"] and "double4" in lines["DOUBLE_PRECISION"] and "float4" in lines["DOUBLE_PRECISION"]
+    assert "DOES NOT COMPILE" in lines["SAVE_ALL_PHOTONS"] and "geometryGetDomPosition" in lines["SAVE_ALL_PHOTONS"]

@@ -658,14 +658,64 @@ def check_config(case, n_steps, write_fixtures):
     return same_hits and same_rng
 
 
+def check_refused_modes():
+    """The two modes the HIP converter refuses at Compile(): does the reference's own program compile in them?  (SPICE-Mie: no
+    direction transforms, the friendliest case.)  Returns {mode: first compiler error or None}."""
+    from oracle import builders as B
+    from tests import common
+    cfg = common.config("mie")
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    bias = B.icecube_dom_acceptance()
+    gens = common.oracle_generators(cfg, bias)
+    single = ("typedef float floating_t;\ntypedef float2 floating2_t;\ntypedef float4 floating4_t;\n"
+              "#define convert_floating_t convert_float\n#define ZERO 0.f\n#define ONE 1.f\n")
+    # I3CLSimHelperMath.cxx:16-25
+    double = ("#pragma OPENCL EXTENSION cl_khr_fp64 : enable\ntypedef double floating_t;\ntypedef double2 floating2_t;\n"
+              "typedef double4 floating4_t;\n#define convert_floating_t convert_double\n#define DOUBLE_PRECISION\n#define ZERO 0.\n#define ONE 1.\n")
+    programs = {}
+    text = emit_program(cfg["med_o"], geo, gens, bias, 5.0)
+    assert single in text
+    programs["DOUBLE_PRECISION"] = text.replace(single, double)
+    # OpenCL.cxx:395-412 (no STOP_PHOTONS_ON_DETECTION, SAVE_ALL_PHOTONS + prescale), :459-470 and :655-657 (no geometry source),
+    # :522-527 (no collision detection sources)
+    text = emit_program(cfg["med_o"], geo, gens, bias, 5.0, stop_detected=False)
+    geometry = emit_geometry(geo)
+    assert geometry in text
+    text = text.replace(geometry, "").replace(single, single + "#define SAVE_ALL_PHOTONS\n#define SAVE_ALL_PHOTONS_PRESCALE 0.01f\n")
+    for name in ("sparse_collision_kernel.h.cl", "sparse_collision_kernel.c.cl"):
+        with open(os.path.join(KERNELS, name)) as f:
+            part = f.read()
+        assert part in text
+        text = text.replace(part, "")
+    programs["SAVE_ALL_PHOTONS"] = text
+    out = {}
+    for mode, program in programs.items():
+        with tempfile.TemporaryDirectory() as d:
+            cl = os.path.join(d, "program.cl")
+            with open(cl, "w") as f:
+                f.write(program)
+            r = subprocess.run([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header", "-target", "x86_64-unknown-linux-gnu", "-O2",
+                                "-ffp-contract=off", "-fPIC", "-Dinline=static inline", "-DNO_FLASHER", "-c", cl, "-o", os.path.join(d, "p.o")],
+                               capture_output=True, text=True)
+            errors = [l.split("error: ", 1)[1] for l in r.stderr.splitlines() if "error: " in l]
+            out[mode] = (errors[0] if errors else "compiler failed") if r.returncode != 0 else None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default=",".join(CASES))
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--write-fixtures", action="store_true")
+    ap.add_argument("--refused-modes", action="store_true", help="try to compile the reference's program with DOUBLE_PRECISION and with SAVE_ALL_PHOTONS")
     args = ap.parse_args()
     if not os.path.isdir(KERNELS):
         raise SystemExit("the reference tree is not on this machine: this check runs in the build container only")
+    if args.refused_modes:
+        for mode, error in check_refused_modes().items():
+            print("%-18s %s" % (mode, "compiles" if error is None else "DOES NOT COMPILE: " + error))
+        return
     ok = True
     for name in args.configs.split(","):
         ok = check_config(name, 1000 if name == "c1" else (2048 if name in ("mie_history", "photonics_mie") else args.steps), args.write_fixtures) and ok
