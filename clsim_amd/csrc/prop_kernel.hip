@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             if (!TABULATE && !(distance < free_flight)) {
-                const uint32_t kind = dom_search_needed(fresh_params(P0), ph, distance);
+                const uint32_t kind = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (kind != kSearchNone) {
                     parked = true;
                     search_kind = kind;
@@ -937,7 +937,9 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         if (P.k_new <= 0) P.k_new = 12;
         // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1.5M steps: 3 -> 5 is
         // +1.6 %), costs when they are scarce (0.8M steps: -1.7 %)
-        if (P.k_search <= 0) P.k_search = (r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
+        // (flasher instantiations: searches are rare since the filter knows about photons inside their DOM of birth, prop_device.hip.h:
+        // 312 500 flasher steps, 1 parked lane 1.53e9 photons/s, 2: 1.49, 3: 1.46, 5: 1.40)
+        if (P.k_search <= 0) P.k_search = (FLASHER || r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }
     hipError_t err = launch_scan_steps(P, stream);

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
             if (!(distance < free_flight)) {
-                const uint32_t need = dom_search_needed(fresh_params(P0), ph, distance);
+                const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (need != kSearchNone) {
                     st = kParked + need - kSearchFull;                   // kParked, or kParked + 1 + id
                     parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
@@ -550,7 +550,10 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // lanes parked per DOM search: with the two-level proximity filter about 1 % of the lanes need one per trip (cascade
         // steps: 3 parked lanes 2.55e9 photons/s, 1: 2.49, 5: 2.53, 8: 2.27 at 1M steps); photons born at a DOM need one on
         // most trips whatever the filter (flasher steps: 3 parked lanes 1.50e9, 5: 1.58, 7: 1.615, 9: 1.625, 12: 1.616, 16: 1.57)
-        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 8 : 3);
+        // Since round 3 the filter itself discards the photons that are still inside the DOM they were born in (dom_search_needed<INSIDE>):
+        // flasher steps now need 0.005 searches per trip instead of 0.28, and a lane that waits for company waits long
+        // (2.6M flasher steps: 1 parked lane 2.32e9 photons/s, 2: 2.30, 3: 2.28, 4: 2.25, 8: 2.13; profiles/r03/c5_inside_filter.txt)
+        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 1 : 3);
         // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
         if (P.k_pop <= 0) P.k_pop = FLASHER ? 8 : 4;
         if (P.k_pop > 64) P.k_pop = 64;
