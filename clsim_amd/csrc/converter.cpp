@@ -302,7 +302,7 @@ void Converter::setup_device_buffers()
     };
     upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
     upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
-    upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size(), "string proximity map");
+    upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size() * sizeof(uint32_t), "string proximity map");
     upload(reinterpret_cast<void **>(&d_dom_prox_), tables_.dom_prox.data(), tables_.dom_prox.size() * 4, "DOM proximity map");
     upload(reinterpret_cast<void **>(&d_dom_centres_), tables_.dom_centres.data(), tables_.dom_centres.size() * 4, "DOM centres");
     upload(reinterpret_cast<void **>(&d_dom_named_), tables_.dom_named.data(), tables_.dom_named.size() * 4, "named-DOM records");
@@ -359,6 +359,8 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_POP")) k_pop_ = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_WAIT")) k_wait_ = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_AIM")) k_aim_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
     use_pool_ = true;
     pool_min_steps_ = kPooledKernelMinSteps;
@@ -393,6 +395,8 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.k_search = k_search_;
     P.slices = k_slices_;
     P.k_pop = k_pop_;
+    P.k_wait = k_wait_;
+    P.k_aim = k_aim_;
     P.pool_ready = pool_ready_;
     P.chip_share = concurrent_launches_;
 #ifdef CLSIMHIP_CENSUS

@@ -54,7 +54,7 @@ struct CompiledTables {
     KVariant variant{};
     std::vector<uint32_t> lds_image;
     std::vector<float> len_table;       // KParams::len_table (TABLE lengths)
-    std::vector<uint8_t> prox_map;      // KParams::prox_map
+    std::vector<uint32_t> prox_map;     // KParams::prox_map
     std::vector<uint32_t> dom_prox;     // KParams::dom_prox
     std::vector<float> dom_centres;     // KParams::dom_centres (4 floats per DOM)
     std::vector<uint32_t> dom_named;    // KParams::dom_named (4 words per DOM)
@@ -236,7 +236,7 @@ private:
     uint32_t *d_tables_ = nullptr;
     int16_t *d_dom_tx_ = nullptr, *d_dom_ty_ = nullptr;
     float *d_len_table_ = nullptr;
-    uint8_t *d_prox_map_ = nullptr;
+    uint32_t *d_prox_map_ = nullptr;
     uint32_t *d_dom_prox_ = nullptr;
     uint32_t *d_dom_named_ = nullptr;
     float *d_dom_centres_ = nullptr;
@@ -281,6 +281,7 @@ private:
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *d_census_ = nullptr;
 #endif
+    int k_wait_ = 0, k_aim_ = 0;                 // 0 = automatic (CLSIMHIP_K_WAIT, CLSIMHIP_K_AIM)
     int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
     int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)

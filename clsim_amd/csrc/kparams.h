@@ -64,7 +64,9 @@ struct KParams {
     // steps, [3] debug; the heads of the kSubQueues sub-queues sit on cache lines of their own at [kQueueHeadStride*(q+1)]
     uint32_t *queue;
     int32_t k_new;                      // lanes that must be waiting before photons are created
-    int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search
+    int32_t k_search;                   // lanes that must be parked before the wave runs the DOM search ...
+    int32_t k_wait;                     // ... or trips the first of them has waited (whichever comes first)
+    int32_t k_aim;                      // segment_misses_string is asked when at most this many lanes of the wave reach a string's cylinder
     int32_t slices;                     // a step is handed out in this many slices (1 = whole steps)
     // pooled kernel (prop_pool_kernel.hip): entries of a wave's ring of ready photons, and how many lanes must be
     // without a photon before the wave services them; k_new is its creation batch there (0 = automatic everywhere)
@@ -85,13 +87,15 @@ struct KParams {
     int32_t history_n;
     int32_t has_fixed_abs;              // PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS (c.cl:582-588)
     float fixed_abs;
-    // String proximity map: prox_n x prox_n bytes over the xy bounding box of the string axes; entry * 0.25 m is a
-    // proven lower bound of the xy distance from anywhere in that cell to the surface of the nearest string cylinder
-    // (axis + largest DOM offset + OM radius).  A step shorter than the bound cannot reach a DOM: the DOM search,
-    // which would find nothing, is skipped (64 KB, L2 resident).
-    const uint8_t *prox_map;
+    // String proximity map: prox_n x prox_n words over the xy bounding box of the string axes.  Bits 0-7 * 0.25 m: a proven
+    // lower bound of the xy distance from anywhere in that cell to the surface of the nearest string cylinder (axis + largest
+    // DOM offset + OM radius = prox_reach).  A step shorter than the bound cannot reach a DOM: the DOM search, which would find
+    // nothing, is skipped.  Bits 8-15: the same bound for the SECOND nearest string; bits 16-31: the index of the nearest one
+    // (0xffff: no string) -- a step shorter than the second bound can touch that string only, and only if its xy projection comes
+    // within prox_reach of its axis (prop_device.hip.h: segment_misses_string).  64 KB, L2 resident.
+    const uint32_t *prox_map;
     int32_t prox_n;
-    float prox_x0, prox_y0, prox_inv_cell;
+    float prox_x0, prox_y0, prox_inv_cell, prox_reach;
     // DOM proximity map, the second level of the search filter: dprox_nx x dprox_ny x dprox_nz words (cubic cells, z fastest) over
     // the bounding box of the DOMs.  A word names the DOM nearest to the cell (bits 0-15: index into dom_centres, 0xffff =
     // none within 64 m) and carries in bits 16-23, in 0.25 m units, a proven lower bound of the 3D distance from anywhere

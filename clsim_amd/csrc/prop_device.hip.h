@@ -681,12 +681,40 @@ DM void collide_with_string(KP P, const Detector &D, uint32_t s, float dir_len_x
 }
 
 // String proximity map (kparams.h): xy distance [m] that a photon at (x, y) can travel before it could touch a DOM
-DM float free_flight_bound(KP P, float x, float y)
+DM uint32_t free_flight_bound(KP P, float x, float y)
 {
     const int n = P->prox_n;
     const int ix = clamp_index((int)((x - P->prox_x0) * P->prox_inv_cell), n - 1);
     const int iy = clamp_index((int)((y - P->prox_y0) * P->prox_inv_cell), n - 1);
-    return (float)P->prox_map[(uint32_t)iy * (uint32_t)n + (uint32_t)ix] * 0.25f;
+    return P->prox_map[(uint32_t)iy * (uint32_t)n + (uint32_t)ix];
+}
+DM float free_flight_of(uint32_t word) { return (float)(word & 0xffu) * 0.25f; }
+
+// Between the first level (the step reaches the nearest string's cylinder) and the second (the DOM proximity map): when the step
+// is too short to reach any OTHER string (bits 8-15 of the map word), a DOM can only be hit on the string the word names, and
+// only at a point of the segment whose xy distance from that string's axis is at most prox_reach (the hit point lies on a DOM
+// sphere, whose centre is within the largest DOM offset of the axis; a pancaked DOM keeps its lateral extent).  The xy
+// projection of the segment comes that close unless
+//   * the string lies behind: (axis - start) . d_xy <= 0 and the start is farther away than prox_reach, or
+//   * the infinite line misses the cylinder: cross(axis - start, d_xy)^2 > |d_xy|^2 reach^2
+// (the case of a segment that ends before it gets there is what the first level tested).  Both with the margin of
+// collide_with_string's early-out (1 mm + 4 ulp of the coordinates).  A photon that passes a string at 10 m has a chance of
+// reach / (pi * 10 m) = 6 % to be aimed at it: the rest needs neither the DOM proximity map nor a search.
+DM bool segment_misses_string(KP P, const Photon &ph, float len, uint32_t word)
+{
+    const uint32_t s = word >> 16;
+    if (s == 0xffffu) return false;
+    if (!(len < (float)((word >> 8) & 0xffu) * 0.25f)) return false;         // another string is within reach
+    const Rec4 str = lds_rec4(P->off_strings + 8u * s);        // x, y, ...
+    const float wx = str.a - ph.px, wy = str.b - ph.py;
+    const float reach = P->prox_reach + (1e-3f + 9.5367431640625e-7f * (__builtin_fabsf(ph.px) + __builtin_fabsf(ph.py) + __builtin_fabsf(str.a) + __builtin_fabsf(str.b)));
+    const float reach_sq = reach * reach;
+    const float along = wx * ph.d.x + wy * ph.d.y;
+    const float cross = wx * ph.d.y - wy * ph.d.x;
+    const float m = ph.d.x * ph.d.x + ph.d.y * ph.d.y;
+    const bool behind = (along <= 0.0f) && (wx * wx + wy * wy > reach_sq);
+    const bool beside = cross * cross > (m * reach_sq) * 1.0001f;
+    return behind || beside;
 }
 
 // Second and third level of the search filter (kparams.h: DOM proximity map), for a lane whose step of length `len` reaches a

@@ -305,6 +305,10 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
 // 3 = photon propagation without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false)): every DOM on a segment's way is
 // saved and the photon travels on (find_collisions_keep); a translation unit of its own as well (prop_keep_kernel.hip)
 // FAST: prop_device.hip.h (the standard configuration with every proof in hand; propagation only)
+// (the pooled kernel reads these two from its parameters, KParams::k_aim / k_wait: constants here, the classic kernel has no scalar
+// register to spare)
+constexpr uint32_t kAimLanes = 8u, kParkedWait = 16u;
+
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
 __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kernel(const KParams Pvalue)
 {
@@ -351,6 +355,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     uint32_t sub_queue = (blockIdx.x * (uint32_t)kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) % (uint32_t)kSubQueues;     // wave-uniform, and known to be
     uint32_t used_up = 0;                                                                                          // in a row
     uint32_t n_staged = 0;     // hit stubs waiting in the wave's staging area
+    uint32_t parked_trips = 0; // trips since the first of the parked lanes parked
     uint32_t sidx = kNoStep;
     uint64_t rx = 0;
     uint32_t ra = 0;
@@ -507,10 +512,16 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
-            const float free_flight = TABULATE ? 0.0f : free_flight_bound(fresh_params(P0), ph.px, ph.py);
+            const uint32_t near_string = TABULATE ? 0u : free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
-            if (!TABULATE && !(distance < free_flight)) {
+            // ... second: a step that can reach no other string touches this one only if it is aimed at it (not asked of photons
+            // born at a DOM: they live inside the string's cylinder)
+            // (asked when few lanes of the wave are at a string, prop_pool_kernel.hip)
+            bool at_string = !TABULATE && !(distance < free_flight_of(near_string));
+            if (!TABULATE && !FLASHER && (uint32_t)__popcll(ballot(at_string)) <= kAimLanes)
+                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            if (at_string) {
                 const uint32_t kind = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (kind != kSearchNone) {
                     parked = true;
@@ -522,7 +533,12 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         bool advance = run && !parked;
         if (!TABULATE) {
             const uint64_t m_parked = ballot(parked);
-            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull))) {
+            // (a parked lane waits for company at most kParkedWait trips -- in the instantiations without STOP_PHOTONS_ON_DETECTION,
+            // which take bunches of every size; the others run the bunches the pooled kernel leaves them, where k_search is 1)
+            if (KEEP) parked_trips = (m_parked != 0ull) ? parked_trips + 1u : 0u;
+            if ((m_parked != 0ull) && (((int)__popcll(m_parked) >= fresh_params(P0)->k_search) || (ballot(advance) == 0ull) ||
+                                       (KEEP && (parked_trips > kParkedWait)))) {
+                if (KEEP) parked_trips = 0u;
                 if (KEEP && parked) {
                     // without STOP_PHOTONS_ON_DETECTION (c.cl:704-750): the search saves what it finds, nothing is shortened or absorbed
                     const KP P = fresh_params(P0);

@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     uint32_t sub_queue = (blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group) % (uint32_t)kSubQueues;
     uint32_t used_up = 0;                       // sub-queues found used up in a row
     uint32_t n_staged = 0;                      // hit stubs waiting in the staging area
+    uint32_t parked_trips = 0;                  // trips since the first of the parked lanes parked
     uint32_t n_ready = 0, ready_head = 0, n_pend = 0, n_wait = 0, n_empty = U, n_left = U;     // n_wait: pending units that wait for a predecessor; n_left: unit slots not yet retired
 
     // per lane: the photon it carries and the unit that photon belongs to
@@ -353,11 +354,18 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
         if (run) {
-            const float free_flight = free_flight_bound(fresh_params(P0), ph.px, ph.py);
+            const uint32_t near_string = free_flight_bound(fresh_params(P0), ph.px, ph.py);
             distance = propagate_through_layers<MED, TILT, ANISO, FAST>(fresh_params(P0), ph, rx, ra);
             // the search cannot find a DOM closer than the nearest string cylinder: skipped when the step ends before
             // ... and of the lanes that do reach a string, most pass between two of its DOMs (second level: 3D map)
-            if (!(distance < free_flight)) {
+            // ... a step that can reach no other string touches this one only if it is aimed at it (segment_misses_string; not asked
+            // of photons born at a DOM, which live inside the string's cylinder)
+            // Asked when few lanes of the wave are at a string (a cascade in the bulk: 2 of 60); when many are (a source at a
+            // string: the reference's benchmark, flashers) most of them are inside the cylinder and the question only costs.
+            bool at_string = !(distance < free_flight_of(near_string));
+            if (!FLASHER && (uint32_t)__popcll(ballot(at_string)) <= (uint32_t)fresh_params(P0)->k_aim)
+                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            if (at_string) {
                 const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (need != kSearchNone) {
                     st = kParked + need - kSearchFull;                   // kParked, or kParked + 1 + id
@@ -370,7 +378,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // the DOM search runs when k_search lanes are parked, or for any parked lane when nothing else can advance
             const uint32_t n_parked = (uint32_t)__popcll(ballot(st >= kParked));
             const uint32_t enough = (ballot(advance) == 0ull) ? 1u : (uint32_t)fresh_params(P0)->k_search;
-            if (n_parked >= enough) {
+            // (flasher instantiations search for the first parked lane: nothing to count)
+            if (!FLASHER) parked_trips = (n_parked != 0u) ? parked_trips + 1u : 0u;
+            if ((n_parked >= enough) || (!FLASHER && (parked_trips > (uint32_t)fresh_params(P0)->k_wait))) {
+                if (!FLASHER) parked_trips = 0u;
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
 #endif
@@ -553,8 +564,16 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // Since round 3 the filter itself discards the photons that are still inside the DOM they were born in (dom_search_needed<INSIDE>):
         // flasher steps now need 0.005 searches per trip instead of 0.28, and a lane that waits for company waits long
         // (2.6M flasher steps: 1 parked lane 2.32e9 photons/s, 2: 2.30, 3: 2.28, 4: 2.25, 8: 2.13; profiles/r03/c5_inside_filter.txt)
-        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 1 : 3);
+        // Cascade steps, since the filter asks whether a photon that passes a string is aimed at it (segment_misses_string): 0.009
+        // searches per trip in the bulk (was 0.076), where a parked lane would wait a hundred trips for two more -- so it waits
+        // k_wait trips at most; next to a source on a string (the reference's benchmark.py in this detector) lanes arrive every
+        // other trip and a batch of 5 fills in time.  1M cascade steps / benchmark.py, 1e9 photons/s: k_search, k_wait = 3, 4: 3.72 / 2.81;
+        // 3, 16: 3.71 / 2.84; 5, 16: 3.72 / 2.87; 8, 16: 3.71 / 2.85; 1, -: 3.72 / 2.68; 3, none: 3.39 / 2.84
+        // (profiles/r03/string_aimed_filter.txt)
+        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 1 : 5);
         // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
+        if (P.k_wait <= 0) P.k_wait = 16;
+        if (P.k_aim <= 0) P.k_aim = 8;
         if (P.k_pop <= 0) P.k_pop = FLASHER ? 8 : 4;
         if (P.k_pop > 64) P.k_pop = 64;
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon

@@ -504,6 +504,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.prox_x0 = static_cast<float>(x_lo);
         P.prox_y0 = static_cast<float>(y_lo);
         P.prox_inv_cell = static_cast<float>(1. / cell);
+        P.prox_reach = static_cast<float>(reach * 1.00001);
         // cell the kernel computes for a point: (int)((x - x0) * inv_cell) in float; each cell is grown by `slack`
         // for that arithmetic (relative error < 4e-7 of |x| + |x0|, n cells) and border cells reach to infinity
         const double x0f = P.prox_x0, y0f = P.prox_y0, cellf = 1. / double(P.prox_inv_cell);
@@ -513,19 +514,27 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
             for (int ix = 0; ix < n; ++ix) {
                 const double rx0 = (ix == 0) ? -INFINITY : x0f + ix * cellf - slack, rx1 = (ix == n - 1) ? INFINITY : x0f + (ix + 1) * cellf + slack;
                 const double ry0 = (iy == 0) ? -INFINITY : y0f + iy * cellf - slack, ry1 = (iy == n - 1) ? INFINITY : y0f + (iy + 1) * cellf + slack;
-                double nearest = INFINITY;
+                double nearest = INFINITY, second = INFINITY;
+                int which = -1;
                 for (int s = 0; s < G.num_strings; ++s) {
                     const double ax = G.str_x[s], ay = G.str_y[s];
                     const double dx = std::max(std::max(rx0 - ax, ax - rx1), 0.), dy = std::max(std::max(ry0 - ay, ay - ry1), 0.);
-                    nearest = std::min(nearest, std::sqrt(dx * dx + dy * dy));
+                    const double d = std::sqrt(dx * dx + dy * dy);
+                    if (d < nearest) { second = nearest; nearest = d; which = s; }
+                    else if (d < second) second = d;
                 }
                 // a segment of length L moves at most L * |d_xy| <= L * (1 + 1e-5) in xy
-                const double bound = (nearest - reach) / 1.00001;
-                const double q = std::floor(bound / 0.25);
-                C.prox_map[static_cast<size_t>(iy) * n + ix] = static_cast<uint8_t>(q < 0. ? 0. : (q > 255. ? 255. : q));
+                auto quantised = [&](double distance) {
+                    const double q = std::floor(((distance - reach) / 1.00001) / 0.25);
+                    return static_cast<uint32_t>(q < 0. ? 0. : (q > 255. ? 255. : q));
+                };
+                // (the string the cell names is the one whose bound is `nearest`; every other string is at least `second` away from
+                // every point of the cell)
+                const uint32_t id = (which >= 0 && which < 0xffff) ? static_cast<uint32_t>(which) : 0xffffu;
+                C.prox_map[static_cast<size_t>(iy) * n + ix] = quantised(nearest) | ((id == 0xffffu ? 0u : quantised(second)) << 8) | (id << 16);
             }
         name("string_proximity_map", as_doubles(C.prox_map));
-        name("STRING_PROXIMITY_GRID", {double(n), P.prox_x0, P.prox_y0, P.prox_inv_cell, reach});
+        name("STRING_PROXIMITY_GRID", {double(n), P.prox_x0, P.prox_y0, P.prox_inv_cell, reach, double(P.prox_reach)});
     }
     {   // DOM proximity map (kparams.h), the second level of the search filter.  Everything in double, rounded towards
         // "search anyway".  Cubic cells; at most 256 per axis (64 MB); border cells reach to infinity.

@@ -187,34 +187,49 @@ def test_tabulated_medium_tables(tmp_path):
 
 
 def test_string_proximity_map_is_a_lower_bound():
-    """The DOM search is skipped for steps shorter than the map's entry (prop_kernel.hip: free_flight_bound): the
-    entry must never exceed the true xy distance from any point of its cell to the nearest DOM sphere."""
-    for name in ("mie", "c1"):
+    """The DOM search is skipped for steps shorter than the map's entry (prop_device.hip.h: free_flight_bound): bits 0-7 of a
+    word must never exceed the true xy distance from any point of its cell to the nearest DOM sphere.  Bits 16-31 name a string,
+    bits 8-15 bound the distance to every OTHER string's DOMs (segment_misses_string relies on it: a step shorter than that can
+    only touch the named string, and only within `reach` of its axis)."""
+    for name in ("mie", "c1", "mie_regular"):
         cfg = common.config(name)
         conv = common.product_converter(cfg, 512, initialize=False)
         conv.Compile()
-        n, x0, y0, inv_cell, reach = conv.GetTable("STRING_PROXIMITY_GRID")
+        n, x0, y0, inv_cell, reach, reach_f = conv.GetTable("STRING_PROXIMITY_GRID")
         n = int(n)
-        m = conv.GetTable("string_proximity_map").reshape(n, n)
+        words = conv.GetTable("string_proximity_map").astype(np.uint64).astype(np.uint32).reshape(n, n)
         g = cfg["geom"]
         rng = np.random.Generator(np.random.PCG64(7))
         lo = min(g["x"].min(), g["y"].min()) - 200.0
         hi = max(g["x"].max(), g["y"].max()) + 200.0
-        pts = rng.uniform(lo, hi, size=(40000, 2))
-        near = rng.integers(0, len(g["x"]), size=20000)                 # and points close to DOMs
-        pts = np.concatenate([pts, np.stack([g["x"][near], g["y"][near]], axis=1) + rng.normal(0, 6.0, size=(20000, 2))])
+        pts = rng.uniform(lo, hi, size=(20000, 2))
+        near = rng.integers(0, len(g["x"]), size=10000)                 # and points close to DOMs
+        pts = np.concatenate([pts, np.stack([g["x"][near], g["y"][near]], axis=1) + rng.normal(0, 6.0, size=(10000, 2))])
         xf, yf = pts[:, 0].astype(np.float32), pts[:, 1].astype(np.float32)
         ix = np.clip(((xf - np.float32(x0)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1)   # the kernel's arithmetic
         iy = np.clip(((yf - np.float32(y0)) * np.float32(inv_cell)).astype(np.int32), 0, n - 1)
-        bound = m[iy, ix] * 0.25
-        dom_xy = np.unique(np.stack([g["x"], g["y"]], axis=1), axis=0)
-        true = np.full(len(pts), np.inf)
-        for k in range(0, len(dom_xy), 256):
-            d = np.hypot(xf[:, None].astype(np.float64) - dom_xy[None, k:k + 256, 0], yf[:, None].astype(np.float64) - dom_xy[None, k:k + 256, 1])
-            true = np.minimum(true, d.min(axis=1))
-        true -= g["om_radius"]
+        w = words[iy, ix]
+        bound, second, named = (w & 0xff) * 0.25, ((w >> 8) & 0xff) * 0.25, (w >> 16).astype(np.int64)
+        # the strings as the converter numbers them (sorted string IDs) and every DOM's distance in xy
+        ids = np.unique(g["string_ids"])
+        string_of_dom = np.searchsorted(ids, g["string_ids"])
+        true, other = np.empty(len(pts)), np.empty(len(pts))
+        for k in range(0, len(pts), 2000):
+            sl = slice(k, k + 2000)
+            d = np.hypot(xf[sl, None].astype(np.float64) - g["x"][None, :], yf[sl, None].astype(np.float64) - g["y"][None, :]) - g["om_radius"]
+            true[sl] = d.min(axis=1)
+            other[sl] = np.where(string_of_dom[None, :] == named[sl, None], np.inf, d).min(axis=1)
         assert np.all(bound <= np.maximum(true, 0.0)), name
         assert (bound > 0).mean() > 0.5          # and it is useful: most of the volume is free flight
+        assert np.all(named < len(ids))          # (every cell of these detectors names a string)
+        # DOMs of strings other than the named one: never closer than the second bound
+        if len(ids) > 1:
+            assert np.all(second <= np.maximum(other, 0.0)), name
+            assert np.all(second >= bound) and (second > 20.0).mean() > 0.5       # useful: the next string is 125 m away
+        # every DOM of the named string lies within `reach` - radius of the axis the kernel reads (string mean position)
+        axis = np.array([[g["x"][string_of_dom == s].mean(), g["y"][string_of_dom == s].mean()] for s in range(len(ids))])
+        off = np.hypot(g["x"] - axis[string_of_dom, 0], g["y"] - axis[string_of_dom, 1])
+        assert off.max() + g["om_radius"] < reach_f and reach_f >= reach
 
 
 def test_dom_proximity_map_is_a_lower_bound():

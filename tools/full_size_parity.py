@@ -3,7 +3,7 @@
 SPICE-Lea) or configs[4] (c5: 2 621 440 flasher steps x 400 photons at a DOM) through the kernel's production schedule
 against the oracle run on all host cores for the WHOLE bunch -- every detected photon (80 bytes each, as a sorted multiset)
 and every final RNG state, bit for bit.  (tests/test_production_size_gpu.py checks the first 2048 steps of such a launch
-in every test run; this takes 5-7 minutes of oracle time per workload.)   usage: full_size_parity.py c3|c5|c2keep|c5keep [chunks=6]
+in every test run; this takes 5-7 minutes of oracle time per workload.)   usage: full_size_parity.py c2|c3|c5|c2keep|c5keep [chunks=6]
 (c2keep: BASELINE configs[1], 1 048 576 cascade steps in SPICE-Mie, c5keep: the flasher bunch -- both WITHOUT
 STOP_PHOTONS_ON_DETECTION, SetStopDetectedPhotons(false))"""
 import os
@@ -23,7 +23,7 @@ from tests import common
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 keep = which.endswith("keep")
-if which == "c2keep":
+if which in ("c2keep", "c2"):
     cfg = common.config("mie")
     n = 1 << 20
     steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
