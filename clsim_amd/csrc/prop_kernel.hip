@@ -955,7 +955,11 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         // +1.6 %), costs when they are scarce (0.8M steps: -1.7 %)
         // (flasher instantiations: searches are rare since the filter knows about photons inside their DOM of birth, prop_device.hip.h:
         // 312 500 flasher steps, 1 parked lane 1.53e9 photons/s, 2: 1.49, 3: 1.46, 5: 1.40)
-        if (P.k_search <= 0) P.k_search = (FLASHER || r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
+        // Since the filter asks whether a photon is aimed at the string it passes, searches are rare (0.009 per trip on cascade steps)
+        // and a lane that waits for company waits long: this kernel, which has no scalar register left for the pooled kernel's
+        // waiting limit, searches for the first parked lane (0.5M cascade steps: threshold 3 2.29e9 photons/s, 1: below; the
+        // instantiations without STOP_PHOTONS_ON_DETECTION have the limit and keep the thresholds)
+        if (P.k_search <= 0) P.k_search = (TAB != 3 || FLASHER || r < 1.5) ? 1 : (r < 2.2) ? 3 : 5;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }
     hipError_t err = launch_scan_steps(P, stream);
