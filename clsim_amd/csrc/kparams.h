@@ -92,7 +92,7 @@ struct KParams {
     // DOM offset + OM radius = prox_reach).  A step shorter than the bound cannot reach a DOM: the DOM search, which would find
     // nothing, is skipped.  Bits 8-15: the same bound for the SECOND nearest string; bits 16-31: the index of the nearest one
     // (0xffff: no string) -- a step shorter than the second bound can touch that string only, and only if its xy projection comes
-    // within prox_reach of its axis (prop_device.hip.h: segment_misses_string).  64 KB, L2 resident.
+    // within prox_reach of its axis (prop_device.hip.h: segment_misses_string).  512 x 512 words = 1 MB, L2 resident.
     const uint32_t *prox_map;
     int32_t prox_n;
     float prox_x0, prox_y0, prox_inv_cell, prox_reach;

@@ -476,9 +476,13 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         }
     }
     {   // string proximity map (kparams.h).  Everything in double, rounded towards "search anyway".
-        // resolution hardly matters (measured 32^2 ... 1024^2: within 1.5 %); a 64^2 copy in LDS was 1.5 % SLOWER
-        // than the L2-resident map (the load is issued before the layer walk and is long back when it is needed)
-        int n = 128;
+        // Resolution: the bound of a cell is taken at its far corner, so a 10 m cell (128^2) gives away up to 14 m of free flight.
+        // That hardly mattered (32^2 ... 1024^2 within 1.5 %) while a lane that got through the first level cost a DOM-map look-up
+        // anyway; since the level behind it asks whether the photon is aimed at the string (segment_misses_string) it does:
+        // 1M cascade steps 64^2 3.60e9 photons/s, 128^2 3.70, 256^2 3.73, 512^2 3.77, 768^2 3.78, 1024^2 3.78, 2048^2 (16 MB) 3.42;
+        // SPICE-Lea 3.09 / 3.15 / 3.19 / 3.21 / - / 3.22.  512^2 words = 1 MB, L2 resident.  (A 64^2 copy in LDS was 1.5 % SLOWER
+        // than the L2-resident map: the load is issued before the layer walk and is long back when it is needed.)
+        int n = 512;
         if (const char *e = std::getenv("CLSIMHIP_PROX_N")) n = std::max(8, std::min(4096, std::atoi(e)));
         double x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY, reach = 0.;
         for (int s = 0; s < G.num_strings; ++s) {
