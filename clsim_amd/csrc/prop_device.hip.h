@@ -56,7 +56,7 @@ struct Rec4 { float a, b, c, d; };
 // Analysis build (make EXTRA=-DCLSIMHIP_CENSUS, tools/exp_pool_census.py): one visit of a divergent region and the lanes that
 // are active in it, per wave, in the census buffer behind the per-wave records (word 32768 + 32 x wave + 2 x region).
 enum CensusRegion { kCensusCrossing = 0, kCensusFilter = 1, kCensusLiu = 2, kCensusHG = 3, kCensusSearchFull = 4, kCensusSearchNamed = 5,
-                    kCensusCreation = 6, kCensusService = 7, kCensusScatter = 8, kCensusWalk = 9, kCensusRegions = 16 };
+                    kCensusCreation = 6, kCensusService = 7, kCensusScatter = 8, kCensusWalk = 9, kCensusAim = 10, kCensusRegions = 16 };
 #ifdef CLSIMHIP_CENSUS
 #define CENSUS_REGION(P, region)                                                                                                 \
     do {                                                                                                                          \
@@ -702,6 +702,7 @@ DM float free_flight_of(uint32_t word) { return (float)(word & 0xffu) * 0.25f; }
 // reach / (pi * 10 m) = 6 % to be aimed at it: the rest needs neither the DOM proximity map nor a search.
 DM bool segment_misses_string(KP P, const Photon &ph, float len, uint32_t word)
 {
+    CENSUS_REGION(P, kCensusAim);
     const uint32_t s = word >> 16;
     if (s == 0xffffu) return false;
     if (!(len < (float)((word >> 8) & 0xffu) * 0.25f)) return false;         // another string is within reach

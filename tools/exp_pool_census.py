@@ -23,13 +23,15 @@ for spec in sys.argv[1:]:
             os.environ[e] = kv[k]
     os.environ.setdefault("CLSIMHIP_KERNEL", "pool")
     n = int(kv.get("n", 1 << 20))
-    workload = kv.get("workload", "c2")           # bench.py's workloads: c2 (SPICE-Mie), c3 (SPICE-Lea), c5 (flasher steps at a DOM)
+    workload = kv.get("workload", "c2")           # bench.py's workloads: c2 (SPICE-Mie), c3 (SPICE-Lea), c5 (flasher steps at a DOM); origin: a c3 bunch with every vertex at the origin (the reference's benchmark.py: a cascade on the central string)
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie" if workload == "c2" else "spice_lea"))
     gens = [CV.makeCherenkovWavelengthGenerator(bias, medium)]
     if workload == "c5":
         gens.append(CV.I3CLSimRandomValueConstant(405e-9))
         k = int(np.argmin(np.abs(g86["x"]) + np.abs(g86["y"]) + np.abs(g86["z"] + 100.0)))
         steps = S.flasher_steps(n, seed=1000, photons_per_step=400, position=(float(g86["x"][k]), float(g86["y"][k]), float(g86["z"][k])))
+    elif workload == "origin":
+        steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0))
     else:
         steps = S.cascade_steps(n, seed=1000)
     conv = CV.initializeHIP(0, geom, medium, bias, gens, pancakeFactor=5.0, approximateNumberOfWorkItems=n, seed=12345)
@@ -60,7 +62,7 @@ for spec in sys.argv[1:]:
              q(end, 1), q(end, 50), q(end, 99), end.max(), q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
     # divergent regions (prop_device.hip.h: CENSUS_REGION): visits per wave trip and active lanes per visit
     names = ["layer crossing body", "search filter levels 2-3", "Liu branch", "HG branch", "full DOM search", "named DOM search", "photon creation",
-             "service (free lanes)", "scattering (all)", "layer walk (all)"]
+             "service (free lanes)", "scattering (all)", "layer walk (all)", "aimed at the string?"]
     reg = buf[32768:32768 + 32 * 8192].reshape(-1, 16, 2).astype(np.float64).sum(axis=0)
     print("   region                      visits/trip   lanes/visit   lane-visits/trip")
     for k, nm in enumerate(names):
