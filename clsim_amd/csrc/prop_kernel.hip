@@ -1002,8 +1002,10 @@ hipError_t launch_keep_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
+    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
+    const bool fast = v.fast && P.history_n == 0 && !(no_fast && no_fast[0] == '1');       // (as launch_prop_kernel)
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return launch_variant<a, b, c, d, 3>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 3, true>(P, stream) : launch_variant<a, b, c, d, 3, false>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \

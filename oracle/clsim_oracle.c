@@ -1125,17 +1125,24 @@ uint32_t oracle_propagate_mt(const oracle_tables *T, const oracle_step *steps, u
         uint64_t it = 0;
 #pragma omp for schedule(dynamic, 16)
         for (uint32_t i = 0; i < n; ++i) {
-            rng_t r = { x[i], a[i] };
-            /* a step of P photons can record at most P hits */
-            const uint32_t need = cnt + steps[i].numPhotons;
-            if (need > cap) {
-                cap = need * 2 + 4096;
-                buf = (oracle_photon *)realloc(buf, (size_t)cap * sizeof(oracle_photon));
+            /* a step of P photons records at most P hits -- with STOP_PHOTONS_ON_DETECTION; without it a photon is recorded
+             * by every DOM on its way, so the step is run again with more room if its records did not fit */
+            uint32_t need = cnt + steps[i].numPhotons;
+            for (;;) {
+                if (need > cap) {
+                    cap = need * 2 + 4096;
+                    buf = (oracle_photon *)realloc(buf, (size_t)cap * sizeof(oracle_photon));
+                }
+                rng_t r = { x[i], a[i] };
+                uint64_t it_step = 0;
+                hit_sink sink = { buf + cnt, cap - cnt, 0, NULL, NULL };
+                propagate_step(T, &steps[i], &r, &sink, &it_step, NULL);
+                if (sink.count > cap - cnt) { need = cnt + sink.count; continue; }
+                cnt += sink.count;
+                it += it_step;
+                x[i] = r.x;
+                break;
             }
-            hit_sink sink = { buf + cnt, cap - cnt, 0, NULL, NULL };
-            propagate_step(T, &steps[i], &r, &sink, &it, NULL);
-            cnt += sink.count;
-            x[i] = r.x;
         }
 #pragma omp critical
         {

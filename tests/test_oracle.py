@@ -193,3 +193,21 @@ def test_cube_root_of_the_power_axes_is_within_opencl_bounds(oracle_lib):
     ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
     assert np.max(np.abs(got - want) / ulp) <= 2.0
     assert capi.eval_math(15, np.array([0.0, 8.0, -27.0], dtype=np.float32)).tolist() == [0.0, 2.0, -3.0]
+
+
+def test_threaded_driver_without_stop_keeps_every_record():
+    """oracle_propagate_mt gives every step room for numPhotons records; without STOP_PHOTONS_ON_DETECTION a photon is recorded
+    by every DOM on its way, so a step can need more -- the driver runs such a step again with more room.  Steps placed at DOMs
+    (tests/test_search_filter_gpu.py: boundary_steps), threaded against the serial driver."""
+    from tests.test_search_filter_gpu import boundary_steps
+    cfg = common.config("mie")
+    steps = boundary_steps(cfg, 8192, seed=5, reach=1.9, photons=4)           # few photons per step: several records per photon matter
+    x, a = common.streams(len(steps))
+    T = common.oracle_tables(cfg, stop_detected=False)
+    ph_1, cnt_1, x_1, _ = capi.propagate(T, steps, x, a, threads=1)
+    for rep in range(3):
+        ph_n, cnt_n, x_n, _ = capi.propagate(T, steps, x, a, threads=8)
+        assert cnt_n == cnt_1 and np.array_equal(x_n, x_1)
+        assert common.sort_photons(ph_n).tobytes() == common.sort_photons(ph_1).tobytes()
+    per_step = np.bincount(ph_1["id"], minlength=1)
+    assert per_step.max() > 4                                                  # some step recorded more hits than it has photons
