@@ -296,6 +296,26 @@ int Check(const char *ice_dir, const char *photonics_file)
     double aDust[512];
     REQUIRE(clsimhip_get_table(conv.Handle(), "aDust400", aDust, 512) == d.num_layers);
     for (int i = 0; i < d.num_layers; ++i) REQUIRE(static_cast<float>(aDust[i]) != 0.f);
+    REQUIRE(conv.GetStopDetectedPhotons() && !conv.GetSaveAllPhotons() && conv.GetDOMPancakeFactor() == 5. && conv.GetPhotonHistoryEntries() == 0);
+    REQUIRE(conv.GetNumKernelCalls() == 0 && conv.GetTotalNumPhotonsGenerated() == 0);
+    {   // an emission spectrum with its own wavelengths (a flasher LED): InterpolatedDistribution(x, y), as makeWavelengthGenerator
+        // builds it (I3CLSimModuleHelper.cxx:142-147), reaches the library with its abscissae
+        const std::vector<double> x = {350e-9, 361.139e-9, 365.918e-9, 373.362e-9, 400e-9, 455e-9};
+        const std::vector<double> y = {0.1, 0.4, 0.9, 1.0, 0.5, 0.0};
+        const I3CLSimRandomValueInterpolatedDistribution led(x, y);
+        const clsimhip_glue::RandomValueHolder h = clsimhip_glue::MakeHIPWlenGenerator(led, 1);
+        REQUIRE(h.r.kind == CLSIMHIP_RANDOM_INTERPOLATED_X && h.r.n == 6 && h.r.x == h.x.data() && h.r.y == h.y.data());
+        for (std::size_t i = 0; i < x.size(); ++i) REQUIRE(h.x[i] == x[i] && h.y[i] == y[i]);
+        std::vector<I3CLSimRandomValueConstPtr> two = in.generators;
+        two.push_back(I3CLSimRandomValueConstPtr(new I3CLSimRandomValueInterpolatedDistribution(x, y)));
+        I3CLSimStepToPhotonConverterHIP flasher(I3RandomServicePtr(new TestRandomService(1)));
+        I3CLSimStepToPhotonConverter &fi = flasher;
+        fi.SetWlenGenerators(two); fi.SetWlenBias(in.bias); fi.SetMediumProperties(MediumFromDescription(d)); fi.SetGeometry(SingleString());
+        flasher.Compile();
+        double xs[8];
+        REQUIRE(clsimhip_get_table(flasher.Handle(), "_generateWavelength_1distXValues", xs, 8) == 6);
+        REQUIRE(static_cast<float>(xs[1]) == static_cast<float>(361.139e-9));
+    }
     {   // a generator class without a kernel
         std::vector<I3CLSimRandomValueConstPtr> bad(1, I3CLSimRandomValueConstPtr(new I3CLSimRandomValueHenyeyGreenstein(0.9)));
         REQUIRE(Fatal([&] { iface.SetWlenGenerators(bad); }, "without a HIP implementation"));
