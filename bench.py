@@ -437,9 +437,68 @@ def emit(line):
 JSON_FD = 1
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK in the environment): this process becomes the launcher.
+    It starts N fresh children of the same command line, one rank per GPU, with the rendezvous variables torchrun would set
+    (127.0.0.1, a free port), waits for all of them and exits with the largest return code.  The parent never imports torch
+    and never touches the GPU; nothing is re-exec'ed.  Rank 0's JSON line goes to the stdout the children inherit.  If a rank
+    dies the others (which would wait for it in a collective) are ended by their own process IDs."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    sys.stdout.flush()
+    children = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLSIMHIP_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, failed_at = 0, None
+    while any(c.poll() is None for c in children):
+        for c in children:
+            rc = c.poll()
+            if rc is not None and rc not in (0, 3) and failed_at is None:
+                failed_at = time.time()                 # (3 = the line was printed for the torch.distributed fallback)
+        if failed_at is not None and time.time() - failed_at > 20.0:
+            for c in children:
+                if c.poll() is None:
+                    c.terminate()
+            for c in children:
+                try:
+                    c.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    c.kill()
+            break
+        time.sleep(0.2)
+    for r, c in enumerate(children):
+        rc = c.wait()
+        rc = rc if rc >= 0 else 128 - rc
+        if rc:
+            sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, rc))
+        worst = max(worst, rc)
+    sys.exit(worst)
+
+
 def main():
     global JSON_FD
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if "RANK" not in os.environ:
+        if env_world is not None and int(env_world) != args.gpus:
+            sys.stderr.write("bench.py: WORLD_SIZE=%s but --gpus %d (and no RANK): refusing to guess\n" % (env_world, args.gpus))
+            sys.exit(2)
+        if args.gpus > 1:
+            return launch_ranks(args)                   # does not return
+    elif int(env_world or "1") != args.gpus:
+        # a launcher started W ranks of a command that asks for N GPUs: a line printed from here would carry the wrong n_gpus
+        sys.stderr.write("bench.py: started as rank %s of WORLD_SIZE=%s but --gpus %d: the two must agree\n"
+                         % (os.environ["RANK"], env_world, args.gpus))
+        sys.exit(2)
     # Native libraries print banners to the C stdout (RCCL: version / library path at communicator creation, flushed at
     # exit): file descriptor 1 becomes stderr for everything but the result line, which is written to a duplicate of
     # the original stdout.
@@ -465,6 +524,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CLSIMHIP_BENCH_ECHO_RANK") == "1":
+        sys.stderr.write("bench.py: rank %d of %d (local rank %d)\n" % (rank, world, local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the propagator has no CPU path")
     # CLSIMHIP_BENCH_REHEARSAL=1: a FUNCTIONAL rehearsal of the --gpus N path on a box with one GPU -- every rank uses
@@ -752,6 +813,26 @@ def main():
                          "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
                                  (photons_per_pass / n_bunches / (avg_ms * 1e-3))},
         }
+        if world > 1 or args.shard_steps > 0:
+            # the like-for-like N = 1 point of a scaling curve: ONE GPU running this very per-GPU shard (same bunches, gather
+            # path on), measured by the builder with `python bench.py --gpus 1 --shard-steps <shard> [--workload ...]` under
+            # CLSIMHIP_BENCH_GATHER=1 and stored with its git revision.  The default N = 1 line is C2 (one bunch of 1M steps,
+            # the configuration the metric is quoted on), which is NOT the shard the N > 1 lines run.
+            spath = os.path.join(ROOT, "profiles", "single_gpu_shard_rates.json")
+            same = None
+            if os.path.exists(spath):
+                with open(spath) as f:
+                    same = json.load(f).get("%s:%d" % (args.workload, shard))
+            out["config"]["single_gpu_rate_same_shard"] = same if same is not None else {
+                "value": None, "note": "no stored one-GPU measurement of a %d-step shard of %s; take it with --gpus 1 --shard-steps %d"
+                                       % (shard, args.workload, shard)}
+            if same is not None and same.get("value"):
+                out["config"]["predicted_value_if_ranks_scale_ideally"] = same["value"] * world
+            if args.workload == "c5":
+                out["config"]["stream_count_note"] = (
+                    "one RNG stream per step (the reference's definition) makes a step sequential work: %d steps per GPU against "
+                    "393 216 resident unit slots%s" % (shard, "; fewer steps than lanes, so this GPU runs at its small-bunch rate "
+                                                       "and N GPUs cannot reach N x the whole-bunch rate" if shard < 393216 else ""))
         if rehearsal:
             out["rehearsal"] = ("FUNCTIONAL REHEARSAL, NOT A MEASUREMENT: %d ranks time-share one GPU, torch.distributed over gloo, "
                                 "RCCL library = %s" % (world, os.environ.get("CLSIMHIP_RCCL_LIBRARY", "(default)")))

@@ -21,13 +21,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "libfake_rccl.so")
 
 
-def _run(world, workload, shard_steps, port):
+def _run(world, workload, shard_steps, port, launcher="torchrun"):
     scratch = tempfile.mkdtemp(prefix="fake_rccl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     env = dict(os.environ, CLSIMHIP_BENCH_REHEARSAL="1", CLSIMHIP_RCCL_LIBRARY=FAKE, FAKE_RCCL_DIR=scratch,
                MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--workload", workload, "--verify-gather"] + (["--shard-steps", str(shard_steps)] if shard_steps else [])
+    front = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+             "--master-port", str(port)] if launcher == "torchrun" else [sys.executable]     # "self": bench.py starts its own ranks
+    if launcher == "self":
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+    cmd = front + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+                   "--workload", workload, "--verify-gather"] + (["--shard-steps", str(shard_steps)] if shard_steps else [])
     try:
         p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     finally:
@@ -39,12 +43,16 @@ def _run(world, workload, shard_steps, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,workload,shard,port", [(2, "c2", 700000, 29711), (4, "c2", 300000, 29713), (2, "c5", 100000, 29715),
-                                                      (2, "c2", None, 29717)])   # None: the driver's own command, C4's shard of 12.5M steps per rank
-def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port):
+@pytest.mark.parametrize("world,workload,shard,port,launcher", [
+    (2, "c2", 700000, 29711, "torchrun"), (4, "c2", 300000, 29713, "torchrun"), (2, "c5", 100000, 29715, "torchrun"),
+    (2, "c2", None, 29717, "torchrun"),      # None: the driver's own command, C4's shard of 12.5M steps per rank
+    (2, "c2", 700000, None, "self"),         # plain `python bench.py --gpus 2`: bench.py is its own launcher
+    (4, "c5", 100000, None, "self")])
+def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port, launcher):
     from tests.test_comm_fake_rccl import build_fake
     assert build_fake() == FAKE
-    out = _run(world, workload, shard, port)
+    out = _run(world, workload, shard, port, launcher)
+    assert "single_gpu_rate_same_shard" in out["config"]
     assert out["n_gpus"] == world and out["steps"] == 1
     assert out["value"] is None and "REHEARSAL" in out["rehearsal"]
     cfg = out["config"]
@@ -58,3 +66,33 @@ def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port):
     assert cfg["overflowed_buffers"] == 0
     assert cfg["hits_gathered_per_pass"] > cfg["hits_last_pass_rank0"] > 0                  # more than rank 0's own photons arrived
     assert cfg["photons_per_pass_all_gpus"] == world * shard * cfg["photons_per_step"]
+
+
+def _plain(argv, **env_changes):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_changes)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_and_world_size_must_agree():
+    """`--gpus` is never ignored: a launcher's world that differs from it is refused before anything else happens."""
+    p = _plain(["--gpus", "8"], RANK="0", WORLD_SIZE="1")
+    assert p.returncode == 2 and "must agree" in p.stderr and "{" not in p.stdout
+    p = _plain(["--gpus", "1"], RANK="0", WORLD_SIZE="4")
+    assert p.returncode == 2 and "must agree" in p.stderr
+    p = _plain(["--gpus", "2"], WORLD_SIZE="4")
+    assert p.returncode == 2 and "refusing to guess" in p.stderr
+    p = _plain(["--gpus", "0"])
+    assert p.returncode != 0
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="the no-GPU behaviour of the launcher")
+def test_plain_gpus_n_starts_n_ranks_of_its_own():
+    """Without a GPU every rank stops at "bench.py needs a GPU": the launcher must have started --gpus ranks, each with its own
+    RANK, and must hand back their failure instead of printing a one-GPU line."""
+    p = _plain(["--gpus", "3", "--no-cpu-baseline"], CLSIMHIP_BENCH_ECHO_RANK="1")
+    assert p.returncode != 0 and "{" not in p.stdout
+    for r in range(3):
+        assert "bench.py: rank %d of 3" % r in p.stderr, p.stderr[-2000:]
+        assert "bench.py: rank %d exited with" % r in p.stderr
+    assert p.stderr.count("needs a GPU") == 3
