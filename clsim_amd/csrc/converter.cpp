@@ -24,7 +24,8 @@ constexpr size_t kPooledKernelMinSteps = 614400;   // 0.52M steps: classic 2.54e
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
-    if (tables_.variant.keep_detected) return launch_keep_kernel(P, tables_.variant, stream);
+    if (tables_.variant.keep_detected)
+        return pooled_for(P.n_steps) ? launch_pool_keep_kernel(P, tables_.variant, stream) : launch_keep_kernel(P, tables_.variant, stream);
     return pooled_for(P.n_steps) ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
 }
 
@@ -371,7 +372,9 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_POOL_MIN_STEPS")) pool_min_steps_ = static_cast<size_t>(std::max(0ll, std::atoll(e)));
     // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
     // leaves its pools no LDS
-    if (history_entries_ != 0 || !stop_detected_ || !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()))) use_pool_ = false;
+    if (history_entries_ != 0 ||
+        !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()), stop_detected_ ? 0u : static_cast<uint32_t>(tables_.params.num_strings)))
+        use_pool_ = false;
 }
 
 KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)

@@ -53,9 +53,15 @@ constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // uni
 constexpr int kPoolMinReady = 4;                // smallest ready ring the kernel runs with
 constexpr int kPoolWorthwhileReady = 8;         // smallest ring with which it is chosen over the classic kernel
 
-__host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R) { return kPoolFixedWords + kReadyWords * R + kPendWords * (64u + R); }
+// `extra`: KEEP only -- the words of find_collisions_keep's string mask beyond the first, which lives in the lane's parked_len word
+// (the step length is in a register by the time the search clears its mask): 64 lanes x (ceil(strings / 64) - 1)
+__host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R, uint32_t extra) { return kPoolFixedWords + extra + kReadyWords * R + kPendWords * (64u + R); }
+__host__ __device__ constexpr uint32_t pool_keep_extra_words(uint32_t num_strings) { return (num_strings > 64u) ? 64u * (((num_strings + 63u) >> 6) - 1u) : 0u; }
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST>
+// KEEP: without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false), the reference class's default, OpenCL.cxx:86): the search
+// saves every DOM the segment enters from inside (find_collisions_keep) and the photon travels on; instantiated in a translation
+// unit of its own (prop_pool_keep_kernel.hip)
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST, bool KEEP>
 __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(const KParams Pvalue)
 {
     const KP P0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -70,10 +76,11 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes, and everything derived from it --
     // the sub-queue, hence every unit count below and the loop's exit -- would be treated as lane-varying)
     const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *wave_lds = lds_words + P0->table_words + wave_in_group * pool_wave_words(R);
+    const uint32_t keep_extra = KEEP ? pool_keep_extra_words((uint32_t)P0->num_strings) : 0u;
+    uint32_t *wave_lds = lds_words + P0->table_words + wave_in_group * pool_wave_words(R, keep_extra);
     uint32_t *stage = wave_lds;
     uint32_t *parked_len = wave_lds + kStageRecords * kStubWords;
-    uint32_t *ready = wave_lds + kPoolFixedWords;
+    uint32_t *ready = wave_lds + kPoolFixedWords + keep_extra;
     uint32_t *pend = ready + kReadyWords * R;
     __syncthreads();
 
@@ -385,7 +392,24 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
 #endif
-                if (st >= kParked) {
+                if (KEEP && (st >= kParked)) {
+                    // without STOP_PHOTONS_ON_DETECTION (c.cl:704-750): the search saves what it finds, nothing is shortened or absorbed.
+                    // The lane's string mask (one word per 64 strings) starts in its parked_len word -- the step length is in a register
+                    // now -- and goes on behind the 64 parked_len words.
+                    const KP P = fresh_params(P0);
+                    distance = __builtin_bit_cast(float, parked_len[lane]);
+                    KeepSink K;
+                    K.step_index = sidx;
+                    K.history_n = 0u;                           // (photon histories run the classic kernel)
+                    K.ring = nullptr;
+                    K.string_mask = parked_len + lane;
+                    K.mask_stride = 64u;
+                    K.mask_words = ((uint32_t)P->num_strings + 63u) >> 6;
+                    find_collisions_keep(P, ph, distance, K);
+                    st = kLive;
+                    advance = true;
+                }
+                if (!KEEP && (st >= kParked)) {
                     distance = __builtin_bit_cast(float, parked_len[lane]);
                     // Lanes with only one DOM in reach take the search confined to it (find_collision_named: what the
                     // reference's search does for that DOM, and nothing else) -- in the flasher instantiations, and when
@@ -491,11 +515,20 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #endif
 }
 
+// ring entries per wave that fit beside a table image of `table_words` words (two workgroups per CU share 160 KB; the image is per
+// workgroup, the rest goes to the waves' pools); keep_strings: the detector's strings without STOP_PHOTONS_ON_DETECTION, else 0
+static int pool_ring_that_fits(uint32_t table_words, uint32_t keep_strings)
+{
+    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)table_words;         // per workgroup
+    const int per_wave = budget_words / kPoolWavesPerBlock;
+    return (per_wave - (int)kPoolFixedWords - (int)pool_keep_extra_words(keep_strings) - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
+}
+
 // ---- host-side launcher (called from launch_prop_kernel) ----
 hipError_t launch_scan_steps(const KParams &P, hipStream_t stream);
 hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream);
 
-template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST>
+template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST, bool KEEP>
 static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
 {
     KParams P = Pin;
@@ -507,9 +540,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     // LDS: two workgroups per CU share 160 KB; the image is per workgroup, the rest goes to the waves' pools
     int R = P.pool_ready;
     {
-        const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)P.table_words;         // per workgroup
-        const int per_wave = budget_words / kPoolWavesPerBlock;
-        const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
+        const int fit = pool_ring_that_fits(P.table_words, KEEP ? (uint32_t)P.num_strings : 0u);
         if (R <= 0 || R > fit) R = fit;
         if (R > 64) R = 64;
         // a ring the user asked for (CLSIMHIP_POOL_R) below the smallest one the kernel runs with is raised to it; an image
@@ -519,7 +550,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         if (R > fit) return hipErrorInvalidValue;
         P.pool_ready = R;
     }
-    const size_t lds_bytes = (size_t)(P.table_words + kPoolWavesPerBlock * pool_wave_words((uint32_t)R)) * 4;
+    const size_t lds_bytes = (size_t)(P.table_words + kPoolWavesPerBlock * pool_wave_words((uint32_t)R, KEEP ? pool_keep_extra_words((uint32_t)P.num_strings) : 0u)) * 4;
     struct Plan { int cus = 0, resident = 0; };
     static std::mutex plan_mutex;
     static std::map<std::pair<int, size_t>, Plan> plans;
@@ -531,10 +562,10 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
             int cus = 0, per_cu = 0;
             hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (e == hipSuccess && lds_bytes > 64 * 1024)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST, KEEP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e == hipSuccess)
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>, kPoolBlock, lds_bytes);
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST, KEEP>, kPoolBlock, lds_bytes);
             if (e != hipSuccess) return e;
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 1;
@@ -584,24 +615,31 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     }
     hipError_t err = launch_scan_steps(P, stream);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST, KEEP>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
     return launch_assemble_hits(P, FLASHER, dev, stream);
 }
 
-hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream)
+#ifndef CLSIMHIP_POOL_KEEP_UNIT
+#define CLSIMHIP_POOL_LAUNCHER launch_pool_kernel
+#define CLSIMHIP_POOL_KEEP false
+#else       // prop_pool_keep_kernel.hip: the instantiations without STOP_PHOTONS_ON_DETECTION
+#define CLSIMHIP_POOL_LAUNCHER launch_pool_keep_kernel
+#define CLSIMHIP_POOL_KEEP true
+#endif
+hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream_t stream)
 {
     if (P.n_steps == 0) return hipSuccess;
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
-    if (P.history_n != 0 || v.tabulate) return hipErrorInvalidValue;
+    if (P.history_n != 0 || v.tabulate || (v.keep_detected != CLSIMHIP_POOL_KEEP)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     // CLSIMHIP_NO_FAST=1: the generic instantiation also where Compile() found every proof (tests compare the two)
     const char *no_fast = getenv("CLSIMHIP_NO_FAST");
     const bool fast = v.fast && !(no_fast && no_fast[0] == '1');
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return fast ? launch_pool_variant<a, b, c, d, true>(P, stream) : launch_pool_variant<a, b, c, d, false>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_pool_variant<a, b, c, d, true, CLSIMHIP_POOL_KEEP>(P, stream) : launch_pool_variant<a, b, c, d, false, CLSIMHIP_POOL_KEEP>(P, stream);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
@@ -614,14 +652,14 @@ hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-// smallest table image the pooled kernel cannot serve (its waves would get fewer than 4 ring entries)
-bool pool_kernel_fits(uint32_t table_words)
+#ifndef CLSIMHIP_POOL_KEEP_UNIT
+// does the pooled kernel pay for this table image (its waves need at least kPoolWorthwhileReady ring entries)?  keep_strings: the
+// number of strings when the converter runs without STOP_PHOTONS_ON_DETECTION (the search's string masks share the pool's LDS), else 0
+bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings)
 {
-    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)table_words;
-    const int per_wave = budget_words / kPoolWavesPerBlock;
-    const int fit = (per_wave - (int)kPoolFixedWords - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
     static_assert(kPoolWorthwhileReady >= kPoolMinReady, "an image the pooled kernel is chosen for must be one it can run");
-    return fit >= kPoolWorthwhileReady;
+    return pool_ring_that_fits(table_words, keep_strings) >= kPoolWorthwhileReady;
 }
+#endif
 
 } // namespace clsimhip

@@ -2,7 +2,7 @@
 """Stress test (GPU): the propagation result must not depend on the schedule.  Random bunch sizes, photon counts, grids,
 slice counts and batching thresholds; every case is compared with the same bunch run as whole steps on a small grid
 (hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases] [keep]
-(keep: the instantiations without STOP_PHOTONS_ON_DETECTION, classic kernel only; `clear` ice among the configurations)"""
+(keep: the instantiations without STOP_PHOTONS_ON_DETECTION, classic and pooled kernel; `clear` ice among the configurations)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,7 +50,7 @@ for case in range(cases):
         steps["num"][rng.integers(0, n, 5)] = 3000
     env = dict(CLSIMHIP_GRID=int(rng.integers(1, 1793)), CLSIMHIP_SLICES=int(rng.choice([1, 2, 3, 5, 16, 33, 64])),
                CLSIMHIP_K_NEW=int(rng.choice([1, 4, 12, 40, 64])), CLSIMHIP_K_SEARCH=int(rng.choice([1, 3, 5, 20])))
-    if (case % 2) and not KEEP:        # the pooled kernel: ring size, service threshold, specialised or generic instantiation
+    if case % 2:        # the pooled kernel: ring size, service threshold, specialised or generic instantiation
         env.update(CLSIMHIP_KERNEL="pool", CLSIMHIP_POOL_R=int(rng.choice([4, 7, 16, 34])), CLSIMHIP_K_POP=int(rng.choice([1, 4, 17, 64])),
                    CLSIMHIP_NO_FAST=int(rng.integers(0, 2)), CLSIMHIP_GRID=int(rng.integers(1, 513)))
     ref = run(cfg, steps, dict(CLSIMHIP_GRID=64, CLSIMHIP_SLICES=1, CLSIMHIP_K_NEW=1, CLSIMHIP_K_SEARCH=1))
