@@ -370,6 +370,35 @@ def propagate(tables, steps, x, a, max_hits=None, threads=1, history=False):
     return out[:min(cnt, max_hits)], cnt, x, it.value
 
 
+# ---- the counting build (count_ops.hpp): the enumerations oc_op / oc_region / oc_event, in their order ----
+COUNT_OPS = ["add", "mul", "div", "cmp", "neg", "cvt", "sqrt", "rsqrt", "log", "exp", "powr", "powr_unit", "sin", "cos", "sincos", "acos", "atan2",
+             "rng_draw", "floor_trunc", "fabs", "other_math"]
+COUNT_REGIONS = ["other", "create", "wavelength", "medium_per_photon", "tilt", "layer_lengths", "walk", "aniso", "scatter_angle", "rotate",
+                 "transform", "search_cells", "search_string", "search_dom", "hit_record", "advance", "rng_internal", "per_step"]
+COUNT_EVENTS = ["photons", "trips", "scatters", "layer_crossings", "liu", "hg", "search_calls", "cells", "strings", "dom_tests", "hits",
+                "layer_length_evals", "steps"]
+
+
+def count_ops(tables, steps, x, a, threads=1):
+    """MEASUREMENT ONLY: the same propagation through liboracle_count.so, whose float operators count themselves.
+    Returns (propagate()'s tuple, ops[region][op] as a dict of dicts, events as a dict)."""
+    use_variant("liboracle_count.so")
+    try:
+        L = lib()
+        shape = [C.c_int32(), C.c_int32(), C.c_int32()]
+        L.oracle_count_shape(*[C.byref(v) for v in shape])
+        assert [v.value for v in shape] == [len(COUNT_REGIONS), len(COUNT_OPS), len(COUNT_EVENTS)], "count_ops.hpp enumerations changed"
+        L.oracle_count_reset()
+        result = propagate(tables, steps, x, a, threads=threads)
+        ops = np.zeros((len(COUNT_REGIONS), len(COUNT_OPS)), dtype=np.uint64)
+        events = np.zeros(len(COUNT_EVENTS), dtype=np.uint64)
+        L.oracle_count_get(ops.ctypes.data_as(C.c_void_p), events.ctypes.data_as(C.c_void_p))
+    finally:
+        use_variant(None)
+    by_region = {r: {o: int(ops[i, j]) for j, o in enumerate(COUNT_OPS) if ops[i, j]} for i, r in enumerate(COUNT_REGIONS) if ops[i].any()}
+    return result, by_region, {e: int(events[k]) for k, e in enumerate(COUNT_EVENTS)}
+
+
 REQUEST_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("time", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"),
                           ("length", "<f4"), ("pa", "<f4"), ("pb", "<f4"), ("kind", "<u4"), ("identifier", "<u4"),
                           ("photons_per_step", "<u4"), ("num_photons_in_last_step", "<u4"), ("num_steps", "<u8")])

@@ -30,6 +30,20 @@
 #include <string.h>
 #include "oracle_math.h"
 
+/* Counting build (make liboracle_count.so, -DORACLE_COUNT_OPS; count_ops.hpp): this file compiled as C++ with its `float`s
+ * replaced by a counting type.  REGION() names the part of the kernel the operations that follow belong to (until the end
+ * of the enclosing block), EVENT() counts an occurrence; both vanish from the normal build, whose code is unchanged. */
+#ifdef ORACLE_COUNT_OPS
+#include "count_ops.hpp"
+#include "count_ops_calls.hpp"
+#else
+#define REGION(r) ((void)0)
+#define REGION_UNLESS_CREATING(r) ((void)0)
+#define EVENT(e, n) ((void)0)
+#define COUNT_OP(op) ((void)0)
+#define COUNT_FOLD() ((void)0)
+#endif
+
 /* ---- wire structs: public/clsim/I3CLSimStep.h:141-155, I3CLSimPhoton.h:194-213;
  *      propagation_kernel.h.cl:52-81 ---- */
 typedef struct __attribute__((packed)) {
@@ -178,6 +192,8 @@ static __thread uint8_t g_cur[8];
 /* mwcrng_kernel.cl:12-20 */
 static inline float rand_co(rng_t *r)
 {
+    COUNT_OP(OC_RNG);                               /* the draw is the unit; its conversion and scaling go to a region of their own */
+    REGION(OCR_RNG_INTERNAL);
     r->x = (r->x & 0xffffffffull) * (uint64_t)r->a + (r->x >> 32);
     const uint32_t lo = (uint32_t)(r->x & 0xffffffffull);
     /* convert_float_rtz(uint): keep the top 24 significant bits */
@@ -235,12 +251,14 @@ static inline float fromTable16(float start, float step, int n, const uint16_t *
 /* RefIndexIceCube.cxx:128-180 */
 static inline float getPhaseRefIndex(const oracle_tables *T, float wlen)
 {
+    REGION(OCR_MEDIUM_PER_PHOTON);
     if (T->phase_mode == 1) return fromTableFloat(T->phase_start, T->phase_step, T->phase_n, T->phase_data, wlen);
     const float x = wlen / T->micrometer;
     return T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
 }
 static inline float getGroupRefIndex(const oracle_tables *T, float wlen)
 {
+    REGION(OCR_MEDIUM_PER_PHOTON);
     if (T->group_mode == 1) return fromTableFloat(T->group_start, T->group_step, T->group_n, T->group_data, wlen);
     const float x = wlen / T->micrometer;
     const float np = T->n[0] + x * (T->n[1] + x * (T->n[2] + x * (T->n[3] + x * T->n[4])));
@@ -250,11 +268,14 @@ static inline float getGroupRefIndex(const oracle_tables *T, float wlen)
 /* MediumPropertiesSource.cxx:255-272 (group index override path) */
 static inline float getGroupVelocity(const oracle_tables *T, float wlen)
 {
+    REGION(OCR_MEDIUM_PER_PHOTON);
     return T->c_light / getGroupRefIndex(T, wlen);
 }
 /* _Optimizers.cxx:195-250 / FunctionConstant.cxx:81-100 */
 static inline float getScatteringLength(const oracle_tables *T, int layer, float wlen)
 {
+    REGION(OCR_LAYER_LENGTHS);
+    EVENT(OCE_LAYER_LENGTH_EVALS, 1);
     if (T->len_mode == 0) return T->sca_const[layer];
     if (T->len_mode == 2) {                         /* MediumPropertiesSource.cxx:89-123: switch(layer) over _func<k> */
         const size_t o = (size_t)layer * (size_t)T->tab_n;
@@ -266,6 +287,7 @@ static inline float getScatteringLength(const oracle_tables *T, int layer, float
 /* _Optimizers.cxx:123-190 */
 static inline float getAbsorptionLength(const oracle_tables *T, int layer, float wlen)
 {
+    REGION(OCR_LAYER_LENGTHS);
     if (T->len_mode == 0) return T->abs_const[layer];
     if (T->len_mode == 2) {
         const size_t o = (size_t)layer * (size_t)T->tab_n;
@@ -293,15 +315,18 @@ static inline float liu_cos(const oracle_tables *T, float rnd_co)
 /* Mixed.cxx:115-157 (single random number form) */
 static inline float makeScatteringCosAngle(const oracle_tables *T, rng_t *rng)
 {
+    REGION(OCR_SCATTER_ANGLE);
     if (T->scat_kind == 0) return hg_cos(T, rand_co(rng));
     if (T->scat_kind == 1) return liu_cos(T, rand_co(rng));
     const float rr = rand_co(rng);
-    if (rr < T->mix_frac) { TR(5, 1); return liu_cos(T, rr / T->mix_frac); }
+    if (rr < T->mix_frac) { TR(5, 1); EVENT(OCE_LIU, 1); return liu_cos(T, rr / T->mix_frac); }
+    EVENT(OCE_HG, 1);
     return hg_cos(T, (1.0f - rr) / T->mix_frac_rest);
 }
 /* ScalarFieldAnisotropyAbsLenScaling.cxx:92-140 / ScalarFieldConstant.cxx:61-80 */
 static inline float getDirectionalAbsLenCorrFactor(const oracle_tables *T, const float d[4])
 {
+    REGION(OCR_ANISO);
     if (!T->has_abs_corr) return T->abs_corr_const;
     const float n0 = (T->an_azx * d[0]) + (T->an_azy * d[1]);
     const float n1 = (T->an_mazy * d[0]) + (T->an_azx * d[1]);
@@ -315,6 +340,7 @@ static inline float getDirectionalAbsLenCorrFactor(const oracle_tables *T, const
 /* VectorTransformMatrix.cxx:101-135 / VectorTransformConstant.cxx:58-74 */
 static inline void transformDirection(int has, int renorm, const float m[9], float d[4])
 {
+    REGION(OCR_TRANSFORM);
     if (!has) return;
     const float x = (m[0] * d[0]) + (m[1] * d[1]) + (m[2] * d[2]);
     const float y = (m[3] * d[0]) + (m[4] * d[1]) + (m[5] * d[2]);
@@ -328,6 +354,7 @@ static inline void transformDirection(int has, int renorm, const float m[9], flo
 /* ScalarFieldIceTiltZShift.cxx:145-213 */
 static inline float getTiltZShift(const oracle_tables *T, const float p[4])
 {
+    REGION(OCR_TILT);
     const float z_rescaled = (p[2] - T->tilt_first_z) / T->tilt_dz;
     const int k = imin(imax((int)__builtin_floorf(z_rescaled), 0), T->tilt_nz - 2);
     const float fraction_z_above = z_rescaled - (float)k;
@@ -352,6 +379,7 @@ static inline float getTiltZShift(const oracle_tables *T, const float p[4])
 /* InterpolatedDistribution.cxx:236-336 / RandomValueConstant.cxx */
 static inline float generateWavelength_k(const oracle_tables *T, int kgen, rng_t *rng)
 {
+    REGION(OCR_WAVELENGTH);
     const oracle_wlen_gen *G = &T->gen[kgen];
     if (G->kind == 1) return G->value;
     if (G->kind == 2) {                             /* WlenCherenkovNoDispersion.cxx:72-92: first = minVal, spacing = range */
@@ -432,6 +460,7 @@ static inline float mediumLayerBoundary(const oracle_tables *T, int layer)
 /* c.cl:83-129 */
 static void scatterDirectionByAngle(float cosa, float sina, float d[4], float randomNumber)
 {
+    REGION_UNLESS_CREATING(OCR_ROTATE);
     const float b = 2.0f * PI_F * randomNumber;
     float cosb, sinb;
     om_sincos(b, &sinb, &cosb);
@@ -442,7 +471,7 @@ static void scatterDirectionByAngle(float cosa, float sina, float d[4], float ra
         d[1] = oy * cosa + ((ox * cosb - oz * oy * sinb) * sina) / sinth;
         d[2] = oz * cosa + sina * sinb * sinth;
     } else {
-        const float sgn = (d[2] > 0.0f) ? 1.0f : ((d[2] < 0.0f) ? -1.0f : d[2]);
+        const float sgn = (d[2] > 0.0f) ? (float)1.0f : ((d[2] < 0.0f) ? (float)-1.0f : d[2]);
         d[0] = sina * cosb;
         d[1] = sina * sinb;
         d[2] = cosa * sgn;
@@ -457,6 +486,7 @@ static void scatterDirectionByAngle(float cosa, float sina, float d[4], float ra
 static void createPhotonFromTrack(const oracle_tables *T, const oracle_step *step, const float stepDir[4],
                                   rng_t *rng, float pos[4], float dirw[4])
 {
+    REGION(OCR_CREATE);
     const float shiftMultiplied = step->dir[2] * rand_co(rng);
     const float inverseParticleSpeed = 1.0f / (SPEED_OF_LIGHT * step->dir[3]);
     pos[0] = step->pos[0] + stepDir[0] * shiftMultiplied;
@@ -506,6 +536,8 @@ static void saveHit(const oracle_tables *T, const float pos[4], const float dirw
                     const float startPos[4], const float startDirw[4], const oracle_step *step,
                     unsigned hitOnString, unsigned hitOnDom, hit_sink *sink)
 {
+    REGION(OCR_HIT_RECORD);
+    EVENT(OCE_HITS, 1);
     const uint32_t myIndex = sink->count++;
     if (myIndex >= sink->max_hits) return;
     oracle_photon *o = &sink->out[myIndex];
@@ -546,6 +578,8 @@ static void checkForCollision_OnString(const oracle_tables *T, unsigned stringNu
                                        const float pos[4], const float dirw[4], float *thisStepLength,
                                        int *hitRecorded, unsigned *hitOnString, unsigned *hitOnDom)
 {
+    REGION(OCR_SEARCH_STRING);
+    EVENT(OCE_STRINGS, 1);
     const unsigned stringSet = T->str_set[stringNum];
     {
         const float smin = sqr(((pos[0] - T->str_x[stringNum]) * dirw[1]
@@ -568,6 +602,8 @@ static void checkForCollision_OnString(const oracle_tables *T, unsigned stringNu
         TR(4, 1);
         const unsigned domNum = *geoLayerToOMNumIndex;
         if (domNum == 0xFFFF) continue;
+        REGION(OCR_SEARCH_DOM);
+        EVENT(OCE_DOM_TESTS, 1);
         float domPosX, domPosY, domPosZ;
         geometryGetDomPosition(T, stringNum, domNum, &domPosX, &domPosY, &domPosZ);
         float urdot, discr;
@@ -601,6 +637,7 @@ static void checkForCollision_InCell(const oracle_tables *T, int sd, float dirLe
                                      const float dirw[4], float *thisStepLength, int *hitRecorded,
                                      unsigned *hitOnString, unsigned *hitOnDom)
 {
+    REGION(OCR_SEARCH_CELLS);
     const float sx = T->cell_sx[sd], sy = T->cell_sy[sd], wx = T->cell_wx[sd], wy = T->cell_wy[sd];
     const int nx = T->cell_nx[sd], ny = T->cell_ny[sd];
     int lowCellX = (int)((pos[0] - sx) / wx);
@@ -616,6 +653,7 @@ static void checkForCollision_InCell(const oracle_tables *T, int sd, float dirLe
     for (int cell_y = lowCellY; cell_y <= highCellY; ++cell_y) {
         for (int cell_x = lowCellX; cell_x <= highCellX; ++cell_x) {
             TR(2, 1);
+            EVENT(OCE_CELLS, 1);
             const unsigned stringNum = T->cell_index[sd][cell_y * nx + cell_x];
             if (stringNum == 0xFFFF) continue;
             checkForCollision_OnString(T, stringNum, dirLenXYSqr, pos, dirw, thisStepLength,
@@ -630,6 +668,8 @@ static int checkForCollision(const oracle_tables *T, const float pos[4], const f
                              const float startDirw[4], const oracle_step *step, float *thisStepLength,
                              hit_sink *sink)
 {
+    REGION(OCR_SEARCH_CELLS);
+    EVENT(OCE_SEARCH_CALLS, 1);
     const float dirLenXYSqr = sqr(dirw[0]) + sqr(dirw[1]);
     if (dirLenXYSqr <= 0.0f) return 0;
     int hitRecorded = 0;
@@ -663,6 +703,8 @@ static inline uint64_t opencl_int_bit(unsigned n) { return (uint64_t)(int64_t)(i
 static void checkForCollision_OnString_keep(const oracle_tables *T, unsigned stringNum, float dirLenXYSqr,
                                             const float pos[4], const float dirw[4], float thisStepLength, const keep_ctx *K)
 {
+    REGION(OCR_SEARCH_STRING);
+    EVENT(OCE_STRINGS, 1);
     const unsigned stringSet = T->str_set[stringNum];
     {
         const float smin = sqr(((pos[0] - T->str_x[stringNum]) * dirw[1]
@@ -690,6 +732,8 @@ static void checkForCollision_OnString_keep(const oracle_tables *T, unsigned str
         if (domNum == 0xFFFF) continue;
         if (dom_bitmask & opencl_int_bit(domNum)) continue;         /* a DOM named by several layers is tested once */
         dom_bitmask |= opencl_int_bit(domNum);
+        REGION(OCR_SEARCH_DOM);
+        EVENT(OCE_DOM_TESTS, 1);
         float domPosX, domPosY, domPosZ;
         geometryGetDomPosition(T, stringNum, domNum, &domPosX, &domPosY, &domPosZ);
         float urdot, discr;
@@ -718,6 +762,7 @@ static void checkForCollision_OnString_keep(const oracle_tables *T, unsigned str
 static void checkForCollision_InCell_keep(const oracle_tables *T, int sd, float dirLenXYSqr, const float pos[4],
                                           const float dirw[4], float thisStepLength, const keep_ctx *K)
 {
+    REGION(OCR_SEARCH_CELLS);
     const float sx = T->cell_sx[sd], sy = T->cell_sy[sd], wx = T->cell_wx[sd], wy = T->cell_wy[sd];
     const int nx = T->cell_nx[sd], ny = T->cell_ny[sd];
     int lowCellX = (int)((pos[0] - sx) / wx);
@@ -736,6 +781,7 @@ static void checkForCollision_InCell_keep(const oracle_tables *T, int sd, float 
     for (int i = 0; i < words; ++i) string_bitmask[i] = 0;
     for (int cell_y = lowCellY; cell_y <= highCellY; ++cell_y) {
         for (int cell_x = lowCellX; cell_x <= highCellX; ++cell_x) {
+            EVENT(OCE_CELLS, 1);
             const unsigned stringNum = T->cell_index[sd][cell_y * nx + cell_x];
             if (stringNum == 0xFFFF) continue;
             if (string_bitmask[stringNum / 64] & opencl_int_bit(stringNum)) continue;      /* :252 */
@@ -750,6 +796,8 @@ static int checkForCollision_keep(const oracle_tables *T, const float pos[4], co
                                   float totalPath, uint32_t numScatters, float distAbsLens, const float startPos[4],
                                   const float startDirw[4], const oracle_step *step, float thisStepLength, hit_sink *sink)
 {
+    REGION(OCR_SEARCH_CELLS);
+    EVENT(OCE_SEARCH_CALLS, 1);
     const float dirLenXYSqr = sqr(dirw[0]) + sqr(dirw[1]);
     if (dirLenXYSqr <= 0.0f) return 0;
     const keep_ctx K = { inv_groupvel, totalPath, distAbsLens, numScatters, startPos, startDirw, step, sink };
@@ -795,7 +843,7 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
     if (T->tab_axes_kind == 0) {
         const float n_rho = magnitude(rho);
         coords[0] = magnitude(pos);
-        const float azimuth = (n_rho > 0) ? om_acos_f(dot4(rho, source->perpDir) / n_rho) / (PI_F / 180) : 0;
+        const float azimuth = (n_rho > 0) ? om_acos_f(dot4(rho, source->perpDir) / n_rho) / (PI_F / 180) : (float)0.0f;
         if (T->tab_full_azimuth) {
             /* cross(rho, perpDir) . dir */
             const float cx = rho[1] * source->perpDir[2] - rho[2] * source->perpDir[1];
@@ -807,11 +855,11 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
         } else {
             coords[1] = azimuth;
         }
-        coords[2] = (coords[0] > 0) ? (l / coords[0]) : 0;
+        coords[2] = (coords[0] > 0) ? (l / coords[0]) : (float)0.0f;
         coords[3] = pos[3] - coords[0] * T->tab_min_inv_groupvel;
     } else {
         coords[0] = magnitude(rho);
-        coords[1] = (coords[0] > 0) ? om_acos_f(dot4(rho, source->perpDir) / coords[0]) : 0;
+        coords[1] = (coords[0] > 0) ? om_acos_f(dot4(rho, source->perpDir) / coords[0]) : (float)0.0f;
         coords[2] = source->posAndTime[2] + l * source->dir[2];
         coords[3] = pos[3] - (l + coords[0] * T->tab_tan_thetac) * 3.33564095f;
     }
@@ -822,7 +870,7 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
         const float sina = om_sqrt(rand_co(rng));
         scatterDirectionByAngle(om_sqrt(1 - sina * sina), sina, dirw, rand_co(rng));
         if (T->tab_axes_kind == 0) {
-            coords[4] = (coords[0] > 0) ? (dot4(dirw, pos) / coords[0]) : 1;
+            coords[4] = (coords[0] > 0) ? (dot4(dirw, pos) / coords[0]) : (float)1.0f;
         } else {
             /* cylindrical :70-75: (l - rho*recip(tan_thetaC))*source->dir is evaluated component by component
              * (scalar - vector, vector * vector), as OpenCL does for this expression */
@@ -831,7 +879,7 @@ static inline void getCoordinates(const oracle_tables *T, const float absPos[4],
             for (int k = 0; k < 4; ++k)
                 cpos[k] = absPos[k] - (source->posAndTime[k] + (l - rho[k] * recip_tan) * source->dir[k]);
             const float cdist = magnitude(cpos);
-            coords[4] = (cdist > 0) ? (dot4(dirw, cpos) / cdist) : 1;
+            coords[4] = (cdist > 0) ? (dot4(dirw, cpos) / cdist) : (float)1.0f;
         }
     }
 }
@@ -898,7 +946,9 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
 {
     oracle_step step = *stepIn;
     float stepDir[4];
+    EVENT(OCE_STEPS, 1);
     {
+        REGION(OCR_PER_STEP);
         float st, ct, sp, cp;
         om_sincos(step.dir[0], &st, &ct);
         om_sincos(step.dir[1], &sp, &cp);
@@ -925,10 +975,13 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
     float prevStepRemainder = 0.0f, depthPropagated = 0.0f;
     while (photonsLeftToPropagate > 0) {
         ++iters;
+        EVENT(OCE_TRIPS, 1);
 #ifdef ORACLE_TRACE
         memset(g_cur, 0, 8);
 #endif
         if (abs_lens_left < EPSILON) {
+            REGION(OCR_CREATE);
+            EVENT(OCE_PHOTONS, 1);
             TR(0, 1);
             prev_rng = *rng;                                                /* c.cl:540-545 */
             createPhotonFromTrack(T, &step, stepDir, rng, pos, dirw);
@@ -945,6 +998,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         }
         float distancePropagated;
         {
+            REGION(OCR_WALK);
             float effective_z; int currentPhotonLayer;
             if (!T->has_tilt) {
                 effective_z = pos[2] - T->tilt_const;
@@ -970,14 +1024,14 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
                      currentScaLen = getScatteringLength(T, j, dirw[3]),
                      currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
                      ais += 1.0f / currentScaLen,
-                     aia += 1.0f / currentAbsLen) { --j; TR(1, 1); }
+                     aia += 1.0f / currentAbsLen) { --j; TR(1, 1); EVENT(OCE_LAYER_CROSSINGS, 1); }
             } else {
                 for (; (j < T->num_layers - 1) && (ais > 0.0f) && (aia > 0.0f);
                      mediumBoundary += thickness,
                      currentScaLen = getScatteringLength(T, j, dirw[3]),
                      currentAbsLen = getAbsorptionLength(T, j, dirw[3]),
                      ais -= 1.0f / currentScaLen,
-                     aia -= 1.0f / currentAbsLen) { ++j; TR(1, 1); }
+                     aia -= 1.0f / currentAbsLen) { ++j; TR(1, 1); EVENT(OCE_LAYER_CROSSINGS, 1); }
             }
             float distanceToAbsorption;
             if ((currentPhotonLayer == j) || ((om_fabs(photon_dz)) < EPSILON)) {
@@ -1018,6 +1072,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
             }
             depthPropagated = abs_lens_initial - abs_lens_left;
         }
+        REGION(OCR_ADVANCE);                                                /* (to the end of the loop body) */
         pos[0] += dirw[0] * distancePropagated;
         pos[1] += dirw[1] * distancePropagated;
         pos[2] += dirw[2] * distancePropagated;
@@ -1026,6 +1081,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
         if (abs_lens_left < EPSILON) {
             --photonsLeftToPropagate;
         } else {
+            EVENT(OCE_SCATTERS, 1);
             if (T->history_n > 0) {                                         /* c.cl:833-837 */
                 float *h = currentPhotonHistory[numScatters % (uint32_t)T->history_n];
                 h[0] = pos[0]; h[1] = pos[1]; h[2] = pos[2];
@@ -1048,6 +1104,9 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
 }
 
 /* ---------------- exported entry points (ctypes) ---------------- */
+#ifdef __cplusplus
+extern "C" {
+#endif
 
 /* One launch of the TABULATE kernel over steps[0..n): entries[i*EPS ..] / num_entries[i] per stream, photons_left[i] =
  * what the kernel writes back into inputSteps[i].numPhotons, x[] updated (restored to the photon's start on a miss). */
@@ -1100,6 +1159,7 @@ uint32_t oracle_propagate_hist(const oracle_tables *T, const oracle_step *steps,
         x[i] = r.x;
     }
     if (iterations) *iterations = it;
+    COUNT_FOLD();
     return sink.count;
 }
 uint32_t oracle_propagate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x,
@@ -1151,6 +1211,7 @@ uint32_t oracle_propagate_mt(const oracle_tables *T, const oracle_step *steps, u
                 ++total;
             }
             it_total += it;
+            COUNT_FOLD();
         }
         free(buf);
     }
@@ -1213,7 +1274,7 @@ void oracle_eval_scatcos(const oracle_tables *T, uint64_t *x, uint32_t a, int n,
 void oracle_eval_math(int what, const float *xs, const float *ys, int n, float *out)
 {
     for (int i = 0; i < n; ++i) {
-        const float x = xs[i], y = ys ? ys[i] : 0.0f;
+        const float x = xs[i], y = ys ? ys[i] : (float)0.0f;
         switch (what) {
         case 0: out[i] = om_log(x); break;
         case 1: out[i] = om_exp(x); break;
@@ -1246,4 +1307,13 @@ uint64_t oracle_trace_step(const oracle_tables *T, const oracle_step *step, uint
     g_trace = 0;
     return g_trace_n;
 }
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#ifdef ORACLE_COUNT_OPS
+/* counting build: totals over all threads since the last reset (the multi-threaded driver above folds each thread's counters
+ * in when its loop ends; the serial entry points fold the caller's) */
+#include "count_ops_api.hpp"
 #endif
