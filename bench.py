@@ -426,6 +426,46 @@ def benchmark_host_workload(args, torch, device):
         "limiting_stage": min(stages, key=stages.get), "stage_rates_photons_per_s": stages}))
 
 
+VALU_PEAK_LANE_OPS = 256 * 4 * 2.4e9 * 32       # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, a wave64 vector operation holds a SIMD for 2 cycles
+                                                # at 2.4 GHz: 7.86e13 single-precision lane operations per second (157 TFLOP/s counting an fma as two)
+
+
+def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, kernel_ms=None):
+    """The operative roofline (the kernel is vector-issue bound, not HBM bound).  USEFUL work: the reference's arithmetic per photon,
+    counted by the instrumented oracle on a sample of this very bunch and priced in gfx950 vector instructions
+    (tools/count_reference_ops.py -> profiles/r04/reference_ops.json: `as_written` = every operation of the reference's
+    expressions at the device's generic sequences, search arithmetic on every trip included; `transformed` = the same photon
+    histories after the bit-preserving transformations of DESIGN.md section 2, every division and root at the cheapest form proven
+    exact for its site, no search arithmetic: the floor) x the measured photons per second, against the chip's vector peak.
+    ISSUED work (only where a rocprofv3 --pmc pass of this workload is stored): SQ_INSTS_VALU per launch -> issue slots and
+    lanes, whose ratio to the floor is the overhead (filter, searches, scheduling, creation bookkeeping, idle lanes)."""
+    path = os.path.join(ROOT, "profiles", "r04", "reference_ops.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        stored = json.load(f)
+    w = stored["workloads"].get(workload)
+    if w is None:
+        return None
+    floor = w["valu_per_photon"]["transformed"]
+    out = {"reference_ops_per_photon": {"as_written": w["valu_per_photon"]["as_written"],
+                                        "as_written_without_search": w["valu_per_photon"]["as_written_without_search"],
+                                        "transformed": floor, "unit": "gfx950 vector instructions per lane",
+                                        "source": "profiles/r04/reference_ops.json (oracle %s, %s)" % (stored["oracle_sha16"], w["sample"])},
+           "trips_per_photon": w["events_per_photon"]["trips"],
+           "useful_lane_ops_per_s": floor * photons_per_s, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+           "useful_frac": floor * photons_per_s / VALU_PEAK_LANE_OPS}
+    if pmc and photons_per_launch and kernel_ms:
+        insts, lanes = pmc["sq_insts_valu_per_launch"], pmc.get("valu_lane_utilisation")
+        out.update({"insts_per_launch": insts, "lane_utilisation": lanes,
+                    "issue_slot_frac": insts * 2.0 / (1024 * 2.4e9 * kernel_ms * 1e-3),
+                    "issued_lane_slots_per_photon": insts * 64.0 / photons_per_launch,
+                    "issued_live_lane_ops_per_photon": (insts * 64.0 * lanes / photons_per_launch) if lanes else None,
+                    "overhead_ratio": (insts * 64.0 * lanes / photons_per_launch / floor) if lanes else None,
+                    "pmc_source": "rocprofv3 --pmc pass of this command (profiles/latest_traffic.json) x the live kernel time"})
+    return out
+
+
 WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
@@ -768,7 +808,7 @@ def main():
         alg_bytes = n * 72.0 + hits_last * 80.0
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
-        valu = None
+        pmc = None
         traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.workload == "c2" and n == (1 << 20) and n_bunches == 1 and args.photons_per_step == 200:
@@ -782,12 +822,13 @@ def main():
             if kernel_name + "<" in str(prof.get("kernel")):
                 traffic = prof.get("bytes_per_launch")
                 if prof.get("sq_insts_valu_per_launch"):
-                    # the operative bound: VALU issue slots (a wave64 operation holds a SIMD for 2 cycles; 1024 SIMDs at 2.4 GHz)
-                    valu = {"insts_per_launch": prof["sq_insts_valu_per_launch"], "lane_utilisation": prof.get("valu_lane_utilisation"),
-                            "issue_slot_frac": prof["sq_insts_valu_per_launch"] * 2.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
-                            "source": "rocprofv3 --pmc pass of this command at the revision above x the live kernel time"}
+                    pmc = prof
             else:
                 traffic_source["stale"] = "profiled kernel differs from the one this run launched (%s)" % kernel_name
+        kernel_rate = photons_per_pass / n_bunches / (avg_ms * 1e-3)
+        valu = None
+        if not args.keep_detected and args.photons_per_step == {"c2": 200, "c3": 200, "c5": 400}[args.workload]:
+            valu = valu_roofline(args.workload, kernel_rate, pmc, photons_per_pass / n_bunches, avg_ms)
         out = {
             "metric": "propagated photons/sec (whole node)", "value": value, "unit": "photons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -810,8 +851,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "avg_kernel_ms": avg_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu,
-                         "note": "VALU/divergence-bound kernel; kernel-only rate %.4g photons/s" %
-                                 (photons_per_pass / n_bunches / (avg_ms * 1e-3))},
+                         "note": "VALU/divergence-bound kernel (`valu`: useful_frac = the reference's arithmetic per photon x photons/s over the "
+                                 "chip's vector peak); kernel-only rate %.4g photons/s" % kernel_rate},
         }
         if world > 1 or args.shard_steps > 0:
             # the like-for-like N = 1 point of a scaling curve: ONE GPU running this very per-GPU shard (same bunches, gather

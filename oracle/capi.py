@@ -376,7 +376,7 @@ COUNT_OPS = ["add", "mul", "div", "cmp", "neg", "cvt", "sqrt", "rsqrt", "log", "
 COUNT_REGIONS = ["other", "create", "wavelength", "medium_per_photon", "tilt", "layer_lengths", "walk", "aniso", "scatter_angle", "rotate",
                  "transform", "search_cells", "search_string", "search_dom", "hit_record", "advance", "rng_internal", "per_step"]
 COUNT_EVENTS = ["photons", "trips", "scatters", "layer_crossings", "liu", "hg", "search_calls", "cells", "strings", "dom_tests", "hits",
-                "layer_length_evals", "steps"]
+                "layer_length_evals", "steps", "crossing_trips"]
 
 
 def count_ops(tables, steps, x, a, threads=1):

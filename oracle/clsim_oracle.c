@@ -1033,6 +1033,7 @@ static void propagate_step(const oracle_tables *T, const oracle_step *stepIn, rn
                      ais -= 1.0f / currentScaLen,
                      aia -= 1.0f / currentAbsLen) { ++j; TR(1, 1); EVENT(OCE_LAYER_CROSSINGS, 1); }
             }
+            if (currentPhotonLayer != j) EVENT(OCE_CROSSING_TRIPS, 1);
             float distanceToAbsorption;
             if ((currentPhotonLayer == j) || ((om_fabs(photon_dz)) < EPSILON)) {
                 distancePropagated = sca_step_left * currentScaLen;

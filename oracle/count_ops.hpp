@@ -24,7 +24,7 @@ enum oc_op { OC_ADD = 0, OC_MUL, OC_DIV, OC_CMP, OC_NEG, OC_CVT, OC_SQRT, OC_RSQ
 enum oc_region { OCR_OTHER = 0, OCR_CREATE, OCR_WAVELENGTH, OCR_MEDIUM_PER_PHOTON, OCR_TILT, OCR_LAYER_LENGTHS, OCR_WALK, OCR_ANISO, OCR_SCATTER_ANGLE,
                  OCR_ROTATE, OCR_TRANSFORM, OCR_SEARCH_CELLS, OCR_SEARCH_STRING, OCR_SEARCH_DOM, OCR_HIT_RECORD, OCR_ADVANCE, OCR_RNG_INTERNAL, OCR_PER_STEP, OCR_NUM_REGIONS };
 enum oc_event { OCE_PHOTONS = 0, OCE_TRIPS, OCE_SCATTERS, OCE_LAYER_CROSSINGS, OCE_LIU, OCE_HG, OCE_SEARCH_CALLS, OCE_CELLS, OCE_STRINGS, OCE_DOM_TESTS, OCE_HITS,
-                OCE_LAYER_LENGTH_EVALS, OCE_STEPS, OCE_NUM_EVENTS };
+                OCE_LAYER_LENGTH_EVALS, OCE_STEPS, OCE_CROSSING_TRIPS, OCE_NUM_EVENTS };
 
 struct oc_counters {
     uint64_t ops[OCR_NUM_REGIONS][OC_NUM_OPS];
