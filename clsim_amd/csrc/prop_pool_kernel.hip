@@ -119,6 +119,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0) atomicMin(fresh_params(P0)->census + 8, wall_clock64());
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
+    // shader-clock cycles of the wave inside the service block, its publication of finished units, the unit take and the creation chunks
+    unsigned long long t_service = 0, t_publish = 0, t_take = 0, t_create = 0;
+    const unsigned long long t_wave_start = __builtin_readcyclecounter();
 #endif
     // who holds what, as lane masks; taken at the end of a trip for the next one (and for the loop's exit, a plain backward branch)
     uint64_t m_spent = 0ull, m_vacant = ~0ull, m_live = 0ull;
@@ -151,6 +154,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #ifdef CLSIMHIP_CENSUS
             ++c_services;
             if (st != kLive) CENSUS_REGION(P, kCensusService);
+            const unsigned long long t_s0 = __builtin_readcyclecounter();
 #endif
             if (m_spent != 0ull) {
                 const bool mine = (st == kSpent);
@@ -158,6 +162,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 const bool next = mine && (photons_left != 0u);
                 const uint64_t m_finished = ballot(finished), m_next = ballot(next);
                 if (m_finished != 0ull) {
+#ifdef CLSIMHIP_CENSUS
+                    const unsigned long long t_p0 = __builtin_readcyclecounter();
+#endif
                     // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
                     // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
                     // state first, then the slice counter, both write-through so that a lane on another XCD that sees
@@ -171,6 +178,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     if (finished && !last)
                         __hip_atomic_store(&work[sidx].done, (uflags & 0xffffu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     n_empty += (uint32_t)__popcll(m_finished);
+#ifdef CLSIMHIP_CENSUS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    t_publish += __builtin_readcyclecounter() - t_p0;
+#endif
                 }
                 if (next) {     // the unit goes to `pending` with its stream where the photon left it
                     uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_next & lanes_below));
@@ -195,6 +206,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             if (((batch != 0u) && ((batch >= (uint32_t)P->k_new) || starving)) || look_again) {
 #ifdef CLSIMHIP_CENSUS
                 ++c_creations;
+                const unsigned long long t_a0 = __builtin_readcyclecounter();
 #endif
                 // (a) new units for the empty slots: one atomic per wave and round on the wave's sub-queue
                 for (uint32_t round = 0; (n_empty != 0u) && (used_up < (uint32_t)kSubQueues) && (round < (uint32_t)kSubQueues + 2u); ++round) {
@@ -240,6 +252,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+#ifdef CLSIMHIP_CENSUS
+                const unsigned long long t_b0 = __builtin_readcyclecounter();
+                t_take += t_b0 - t_a0;
+#endif
                 // (b) the pending units, 64 at a time: look for the predecessor's state where needed, create the next
                 // photon while the ring has room; what stays is compacted to the front of the list in its order
                 uint32_t kept = 0, created = 0, still_waiting = 0;
@@ -314,6 +330,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 n_ready += created;
 #ifdef CLSIMHIP_CENSUS
                 c_created += created;
+                t_create += __builtin_readcyclecounter() - t_b0;
 #endif
             }
 
@@ -348,6 +365,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             }
             // nothing runnable in this wave: every unit it holds waits for another wave's slice
             if (ballot(st != kVacant) == 0ull) __builtin_amdgcn_s_sleep(16);
+#ifdef CLSIMHIP_CENSUS
+            t_service += __builtin_readcyclecounter() - t_s0;
+#endif
         }
 
         // ---- one reference loop iteration for the lanes that hold a live photon ----
@@ -507,6 +527,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_services); atomicAdd(d + 3, c_creations);
         atomicAdd(d + 4, c_created); atomicAdd(d + 5, c_vacant); atomicAdd(d + 6, c_polls); atomicAdd(d + 7, c_parked);
         atomicAdd(d + 9, c_searches); atomicAdd(d + 10, c_chunks); atomicAdd(d + 11, c_empty_ring);
+        atomicAdd(d + 12, t_service); atomicAdd(d + 13, t_publish); atomicAdd(d + 14, t_take); atomicAdd(d + 15, t_create);
+        atomicAdd(d + 24600, (unsigned long long)__builtin_readcyclecounter() - t_wave_start);
         const uint32_t w = blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group;
         d[16 + 3 * w] = wall_clock64();
         d[16 + 3 * w + 1] = 0;

@@ -60,6 +60,13 @@ for spec in sys.argv[1:]:
           % (spec, ms, len(rec), (run + parked) / photons, trips * 64.0 / photons, 100 * run / lanes, 100 * parked / lanes, 100 * vacant / lanes, services / trips, creations / trips,
              created / max(creations, 1), chunks / max(creations, 1), searches / trips, 100 * empty_ring / trips, polls / trips,
              q(end, 1), q(end, 50), q(end, 99), end.max(), q(rec[:, 2], 10), q(rec[:, 2], 50), q(rec[:, 2], 90)), flush=True)
+    t_service, t_publish, t_take, t_create = (float(v) for v in buf[12:16])
+    t_total = float(buf[24600])
+    if t_total > 0:
+        print("   wave time (shader clock, summed over waves) inside the service block %.1f%% -- of it: publishing finished units %.1f%%, taking new units (queue atomic + "
+              "first look at the work record) %.1f%%, creation chunks (polls, record reads, creation, compaction) %.1f%%, the rest (retire, hand-out) %.1f%%"
+              % (100 * t_service / t_total, 100 * t_publish / t_total, 100 * t_take / t_total, 100 * t_create / t_total,
+                 100 * (t_service - t_publish - t_take - t_create) / t_total), flush=True)
     # divergent regions (prop_device.hip.h: CENSUS_REGION): visits per wave trip and active lanes per visit
     names = ["layer crossing body", "search filter levels 2-3", "Liu branch", "HG branch", "full DOM search", "named DOM search", "photon creation",
              "service (free lanes)", "scattering (all)", "layer walk (all)", "aimed at the string?"]
