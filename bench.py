@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--keep-detected", action="store_true",
                     help="SetStopDetectedPhotons(false): the instantiations without STOP_PHOTONS_ON_DETECTION (classic kernel, every DOM on "
                          "a photon's way records it); an extra measurement, never the headline")
+    ap.set_defaults(c3_as_written=False)
     ap.add_argument("--verify-gather", action="store_true",
                     help="N>1 (or CLSIMHIP_BENCH_GATHER=1): after the timed region, one more launch whose gathered photons on rank 0 "
                          "are compared with every rank's own buffer (record counts and a 64-bit sum); config.gather_verified")
@@ -466,7 +467,7 @@ def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, ke
     return out
 
 
-WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 = BASELINE configs[2]", "c5": "C5 = BASELINE configs[4] (flasher half)"}
+WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 (the ice and detector of BASELINE configs[2])", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
 def emit(line):
@@ -551,8 +552,11 @@ def main():
         from oracle import capi
         capi.build()
     if args.workload == "c3":
-        args.ice, args.bunch = "spice_lea", (args.bunch if args.bunch != (1 << 20) else 5 * (1 << 20))   # 10M steps = 2 such bunches:
-        # a converter holds at most 6 139 850 streams (all 32-bit safeprime multipliers, OpenCL.cxx:250)
+        # BASELINE configs[2] as written: 10 000 000 steps -- two bunches of 5 000 192 per pass, because a converter holds at most
+        # 6 139 850 streams (all 32-bit safeprime multipliers, OpenCL.cxx:250); `--bunch N`: one bunch of N instead
+        args.ice = "spice_lea"
+        if args.bunch == (1 << 20) and args.shard_steps == 0:
+            args.shard_steps, args.c3_as_written = 10000000, True
     elif args.workload == "c5":
         args.ice, args.photons_per_step = "spice_lea", (400 if args.photons_per_step == 200 else args.photons_per_step)
     import torch
@@ -794,6 +798,8 @@ def main():
             "" if world == 8 else " (this run: %d GPU%s, the same per-GPU shard)" % (world, "" if world == 1 else "s"))
     elif args.workload == "c5" and world > 1:
         workload_name = "C5 = BASELINE configs[4] (flasher half): 10^9 photons / %d GPUs, hits gathered on rank 0" % world
+    elif args.workload == "c3" and shard == 10000000 and world == 1:
+        workload_name = "C3 = BASELINE configs[2]: 10 000 000 steps"
     else:
         workload_name = WORKLOAD_NAMES[args.workload]
     if rank == 0:
@@ -854,7 +860,7 @@ def main():
                          "note": "VALU/divergence-bound kernel (`valu`: useful_frac = the reference's arithmetic per photon x photons/s over the "
                                  "chip's vector peak); kernel-only rate %.4g photons/s" % kernel_rate},
         }
-        if world > 1 or args.shard_steps > 0:
+        if world > 1 or (args.shard_steps > 0 and not args.c3_as_written):
             # the like-for-like N = 1 point of a scaling curve: ONE GPU running this very per-GPU shard (same bunches, gather
             # path on), measured by the builder with `python bench.py --gpus 1 --shard-steps <shard> [--workload ...]` under
             # CLSIMHIP_BENCH_GATHER=1 and stored with its git revision.  The default N = 1 line is C2 (one bunch of 1M steps,

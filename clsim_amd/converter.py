@@ -414,6 +414,11 @@ class I3CLSimStepToPhotonConverterHIP:
         histories = None
         if n.value:
             buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
+            if out is not None:
+                # a recycled buffer is written through its raw address: it must be exactly what the records are
+                if not (isinstance(out, np.ndarray) and out.dtype == PHOTON_DTYPE and out.ndim == 1 and out.flags.c_contiguous and out.flags.writeable):
+                    self._call("clsimhip_release_result", ptr)
+                    raise ValueError("GetConversionResult(out=...): a writeable, C-contiguous one-dimensional array of PHOTON_DTYPE (80-byte records) is required")
             if out is not None and len(out) >= n.value:
                 C.memmove(out.ctypes.data, ptr.value, n.value * 80)
                 photons = out[:n.value]

@@ -225,7 +225,7 @@ private:
     bool have_bias_ = false, have_medium_ = false, have_geometry_ = false;
     bool double_buffering_ = false, double_precision_ = false, stop_detected_ = false, save_all_ = false;     // (OpenCL.cxx:83-87: the class's own defaults;
                                                                                                           // initializeOpenCL's callers pass stopDetectedPhotons = true)
-    double save_all_prescale_ = 0.01, fixed_abs_lengths_ = NAN, pancake_ = 1.0;
+    double save_all_prescale_ = 0.001, fixed_abs_lengths_ = NAN, pancake_ = 1.0;
     uint32_t history_entries_ = 0;
     size_t workgroup_size_ = 0, max_workitems_ = 0;
     uint32_t max_output_photons_ = 0;

@@ -519,8 +519,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             // born at a DOM: they live inside the string's cylinder)
             // (asked when few lanes of the wave are at a string, prop_pool_kernel.hip)
             bool at_string = !TABULATE && !(distance < free_flight_of(near_string));
-            if (!TABULATE && !FLASHER && (uint32_t)__popcll(ballot(at_string)) <= kAimLanes)
-                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            if (!TABULATE && !FLASHER) {
+                const uint32_t n_aim = (uint32_t)__popcll(ballot(at_string && ((near_string & 0xffu) != 0u)));       // (lanes outside the cylinder)
+                if ((n_aim - 1u) < kAimLanes) at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            }
             if (at_string) {
                 const uint32_t kind = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (kind != kSearchNone) {

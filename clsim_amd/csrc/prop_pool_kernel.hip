@@ -170,6 +170,18 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     // state first, then the slice counter, both write-through so that a lane on another XCD that sees
                     // the counter sees the state
                     const bool last = (uflags & kFlagLast) != 0u;
+#ifdef CLSIMHIP_EXP_PUBLISH16
+                    // experiment (profiles/r04/ab_service_latency.txt): state, multiplier and slice counter are the last 16 bytes of the work
+                    // record -- ONE write-through store instead of store, wait for its acknowledgement, store
+                    if (finished) {
+                        if (last) P->rng_x[sidx] = rx;
+                        else {
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 tail = {(uint32_t)rx, (uint32_t)(rx >> 32), ra, (uflags & 0xffffu) + 1u};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&work[sidx].x), "v"(tail) : "memory");
+                        }
+                    }
+#else
                     if (finished) {
                         if (last) P->rng_x[sidx] = rx;
                         else __hip_atomic_store(&work[sidx].x, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -177,6 +189,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (finished && !last)
                         __hip_atomic_store(&work[sidx].done, (uflags & 0xffffu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     n_empty += (uint32_t)__popcll(m_finished);
 #ifdef CLSIMHIP_CENSUS
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -186,6 +199,11 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 if (next) {     // the unit goes to `pending` with its stream where the photon left it
                     uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_next & lanes_below));
                     e[0] = sidx; e[1] = (uint32_t)rx; e[2] = (uint32_t)(rx >> 32); e[3] = photons_left; e[4] = uflags;
+#ifdef CLSIMHIP_EXP_PREFETCH
+                    // experiment (profiles/r04/ab_service_latency.txt): touch the unit's work record now, one or more services before the
+                    // creation of its next photon reads it
+                    { const volatile uint32_t *touch = &work[sidx].a; (void)*touch; }
+#endif
                 }
                 n_pend += (uint32_t)__popcll(m_next);
                 if (mine) st = kVacant;
@@ -271,6 +289,20 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         e_sidx = e[0]; e_rx = (uint64_t)e[1] | ((uint64_t)e[2] << 32); e_left = e[3]; e_flags = e[4];
                     }
                     bool waiting = have && ((e_flags & kFlagWaiting) != 0u);
+#ifdef CLSIMHIP_EXP_PUBLISH16
+                    if (waiting) {
+                        WorkRecord *rec = work + e_sidx;
+                        const uint32_t slice = e_flags & 0xffffu;
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 tail = {0u, 0u, 0u, 0u};
+                        if (slice != 0u) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tail) : "v"(&rec->x) : "memory");
+                        if (tail.w >= slice) {
+                            e_rx = (slice == 0u) ? rec->x : ((uint64_t)tail.x | ((uint64_t)tail.y << 32));
+                            e_flags &= ~kFlagWaiting;
+                            waiting = false;
+                        }
+                    }
+#else
                     if (waiting) {
                         WorkRecord *rec = work + e_sidx;
                         const uint32_t slice = e_flags & 0xffffu;
@@ -285,6 +317,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                             waiting = false;
                         }
                     }
+#endif
                     still_waiting += (uint32_t)__popcll(ballot(waiting));
                     const bool can = have && !waiting;
                     const uint64_t m_can = ballot(can);
@@ -389,9 +422,14 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // of photons born at a DOM, which live inside the string's cylinder)
             // Asked when few lanes of the wave are at a string (a cascade in the bulk: 2 of 60); when many are (a source at a
             // string: the reference's benchmark, flashers) most of them are inside the cylinder and the question only costs.
+            // (round 4: counted are the lanes OUTSIDE the cylinder -- a photon inside it, bound 0, cannot miss it -- and no such lane, no question:
+            // next to a source on a string 9 lanes of a wave are at the string in every trip, 8 of them inside)
             bool at_string = !(distance < free_flight_of(near_string));
-            if (!FLASHER && (uint32_t)__popcll(ballot(at_string)) <= (uint32_t)fresh_params(P0)->k_aim)
-                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            if (!FLASHER) {
+                const uint32_t n_aim = (uint32_t)__popcll(ballot(at_string && ((near_string & 0xffu) != 0u)));
+                if ((n_aim - 1u) < (uint32_t)fresh_params(P0)->k_aim)          // 1 <= n_aim <= k_aim
+                    at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
+            }
             if (at_string) {
                 const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (need != kSearchNone) {

@@ -382,6 +382,12 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         if (len_lo > 1e-15 && len_hi < 1e15) P.div_ok |= 32u;
         scalar("length_bounds_lo", len_lo); scalar("length_bounds_hi", len_hi);
     }
+    // a wavelength bias the DEVICE evaluates: an equally spaced table or a constant.  The host-only kinds (a table with its own
+    // wavelengths, a delta peak: spectra for make_wlen_generator / the flasher front end) have no device form -- the reference's
+    // FromTable throws for unequal spacing when its OpenCL code is asked for (FromTable.cxx:169-170).  Every caller ends here
+    // (converter, table maker), so this is where it is refused.
+    if (!bias.on_device())
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "the wavelength bias / acceptance must be a table with equal spacing or a constant (FromTable.cxx:169-170)");
     P.bias_kind = bias.kind;
     if (bias.kind == CLSIMHIP_FUNCTION_TABLE) {
         // FunctionFromTable.cxx:167-300

@@ -166,6 +166,7 @@ def test_option_getters_and_the_class_defaults():
     assert conv.GetStopDetectedPhotons() is False and conv.GetSaveAllPhotons() is False
     assert math.isnan(conv.GetFixedNumberOfAbsorptionLengths()) and conv.GetDOMPancakeFactor() == 1.0
     assert conv.GetPhotonHistoryEntries() == 0
+    assert conv.GetSaveAllPhotonsPrescale() == 0.001                 # OpenCL.cxx:88
     conv.SetEnableDoubleBuffering(True); conv.SetStopDetectedPhotons(True); conv.SetFixedNumberOfAbsorptionLengths(46.0)
     conv.SetDOMPancakeFactor(5.0); conv.SetPhotonHistoryEntries(3); conv.SetSaveAllPhotonsPrescale(0.25)
     assert conv.GetEnableDoubleBuffering() is True and conv.GetStopDetectedPhotons() is True

@@ -1,5 +1,5 @@
 """GPU: BASELINE configs[2] (C3) and configs[4] (C5, flasher half) at their production bunch sizes -- the launch
-geometry bench.py measures (5 242 880 cascade steps x 200 photons on SPICE-Lea; 2 621 440 flasher steps x 400 photons
+geometry bench.py measures (10 000 000 cascade steps x 200 photons on SPICE-Lea in two bunches; 2 621 440 flasher steps x 400 photons
 from a point source at a DOM, 48 Mi-record photon buffer).  Pattern of test_baseline_size_properties: the whole bunch
 runs once on each of two converters (determinism: the multiset of all 80-byte records through an order-independent
 64-bit checksum computed on the device, and every final stream state), and the records of the first 2048 steps are
@@ -46,50 +46,63 @@ def prefix_records(records, m):
     return np.frombuffer(sub.tobytes(), dtype=PHOTON_DTYPE).copy()
 
 
-def check_at_size(cfg, steps, capacity, hit_fraction_range, m=2048):
-    n = len(steps)
+def check_at_size(cfg, bunches, capacity, hit_fraction_range, m=2048):
+    """bunches: step arrays of one size, run back to back on ONE converter (the RNG streams persist from bunch to bunch,
+    propagation_kernel.c.cl:458-461, 911-912) -- and once more on a second converter."""
+    if isinstance(bunches, np.ndarray):
+        bunches = [bunches]
+    n = len(bunches[0])
+    assert all(len(b) == n for b in bunches)
     dev = torch.device("cuda", 0)
-    d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
     x, a = common.streams(n)
     conv = common.product_converter(cfg, n)
-    rec1, cnt1 = big_run(conv, d_steps, n, capacity)
-    x1 = conv.GetRNGState(n)
-    sum1 = multiset_checksum(rec1)
-    sub = prefix_records(rec1, m)
-    string_ok = bool((rec1.view(torch.int16)[:, 22] < 86).all()) and bool((rec1.view(torch.int16)[:, 22] >= 0).all())
-    dom_ok = bool((rec1.view(torch.int16)[:, 23] < 60).all())
-    del rec1
-    torch.cuda.empty_cache()
-    # determinism across converters (and across queue schedules: the order lanes take units in is not reproducible)
     conv_b = common.product_converter(cfg, n)
-    rec2, cnt2 = big_run(conv_b, d_steps, n, capacity)
-    assert cnt1 == cnt2
-    assert multiset_checksum(rec2) == sum1
-    assert np.array_equal(x1, conv_b.GetRNGState(n))
-    del rec2
-    torch.cuda.empty_cache()
-    live = steps["num"] > 0
-    assert np.all(x1[live] != x[live])                               # every stream with photons advanced
-    photons = float(steps["num"].sum())
-    assert hit_fraction_range[0] < cnt1 / photons < hit_fraction_range[1], cnt1 / photons
-    assert string_ok and dom_ok
-    # the first m steps inside the big launch == the oracle on those steps alone
     T = common.oracle_tables(cfg)
-    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps[:m], x[:m], a[:m], threads=16)
-    assert len(sub) == cnt_o
-    assert common.sort_photons(sub).tobytes() == common.sort_photons(ph_o).tobytes()
-    assert np.array_equal(x1[:m], x_o)
-    return cnt1
+    x_before, x_oracle, total = x, x[:m], 0
+    for steps in bunches:
+        d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
+        rec1, cnt1 = big_run(conv, d_steps, n, capacity)
+        x1 = conv.GetRNGState(n)
+        sum1 = multiset_checksum(rec1)
+        sub = prefix_records(rec1, m)
+        string_ok = bool((rec1.view(torch.int16)[:, 22] < 86).all()) and bool((rec1.view(torch.int16)[:, 22] >= 0).all())
+        dom_ok = bool((rec1.view(torch.int16)[:, 23] < 60).all())
+        del rec1
+        torch.cuda.empty_cache()
+        # determinism across converters (and across queue schedules: the order lanes take units in is not reproducible)
+        rec2, cnt2 = big_run(conv_b, d_steps, n, capacity)
+        assert cnt1 == cnt2
+        assert multiset_checksum(rec2) == sum1
+        assert np.array_equal(x1, conv_b.GetRNGState(n))
+        del rec2, d_steps
+        torch.cuda.empty_cache()
+        live = steps["num"] > 0
+        assert np.all(x1[live] != x_before[live])                    # every stream with photons advanced
+        assert np.array_equal(x1[~live], x_before[~live])            # a padding step leaves its stream alone
+        photons = float(steps["num"].sum())
+        assert hit_fraction_range[0] < cnt1 / photons < hit_fraction_range[1], cnt1 / photons
+        assert string_ok and dom_ok
+        # the first m steps inside the big launch == the oracle on those steps alone, continued from the previous bunch's streams
+        ph_o, cnt_o, x_oracle, _ = capi.propagate(T, steps[:m], x_oracle, a[:m], threads=16)
+        assert len(sub) == cnt_o
+        assert common.sort_photons(sub).tobytes() == common.sort_photons(ph_o).tobytes()
+        assert np.array_equal(x1[:m], x_oracle)
+        x_before = x1
+        total += cnt1
+    return total
 
 
 @pytest.mark.timeout(900)
-def test_c3_spice_lea_production_bunch():
-    """bench.py --workload c3: one of the two 5 242 880-step bunches of BASELINE configs[2] (tilt + anisotropy + direction
-    transforms), 1.05e9 photons; about 11 steps per resident lane."""
+def test_c3_spice_lea_production_bunches():
+    """bench.py --workload c3 = BASELINE configs[2] as written: 10 000 000 cascade steps on SPICE-Lea (tilt + anisotropy + direction
+    transforms) as TWO bunches of 5 000 192 (a converter holds at most 6 139 850 streams, OpenCL.cxx:250; the second bunch carries 384
+    padding steps), back to back on one converter: 2.0e9 photons, about 11 steps per resident lane and bunch.  The second bunch's
+    prefix is compared with the oracle continued from the first bunch's final streams."""
     cfg = common.config("lea")
-    n = 5 * (1 << 20)
-    steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
-    check_at_size(cfg, steps, capacity=8 << 20, hit_fraction_range=(2e-4, 3e-3))
+    shard, n = 10000000, 5000192
+    bunches = [S.cascade_steps(min(n, shard - b * n), seed=1000 + 7919 * b, photons_per_step=200, pad_to=n) for b in range(2)]
+    assert int((bunches[1]["num"] == 0).sum()) == 2 * n - shard
+    check_at_size(cfg, bunches, capacity=8 << 20, hit_fraction_range=(2e-4, 3e-3))
 
 
 @pytest.mark.timeout(900)

@@ -243,3 +243,19 @@ def test_fits_file_has_the_structure_the_reference_writes(tmp_path):
         assert he["BITPIX"] == -64 and np.array_equal(edges.astype(np.float64), tab.GetBinEdges(i))
     with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception, match="Could not create"):
         tab.WriteFITSFile(path)                       # fits_create_diskfile does not overwrite
+
+
+def test_table_maker_refuses_an_acceptance_without_a_device_form():
+    """FromTable(wlens, values) and a delta peak are host-only spectra (FromTable.cxx:169-170 throws when OpenCL code is asked of a
+    table without equal spacing): as the table maker's wavelength acceptance they must be refused, not turned into a garbage
+    device table.  Host-only configuration: no GPU needed."""
+    medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(common.ICE, "spice_mie"))
+    axes = TB.SphericalAxes([TB.PowerAxis(0, 580, 20, 2), TB.LinearAxis(0, 180, 6), TB.LinearAxis(-1, 1, 10), TB.PowerAxis(0, 7e3, 15, 2)])
+    ang = TB.I3CLSimFunctionPolynomial([0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435])
+    a = CV.mwc_multipliers(256)
+    x = CV.seed_streams(a)
+    wl, v = np.array([300e-9, 350e-9, 420e-9, 600e-9]), np.array([0.1, 0.3, 0.2, 0.05])
+    for acceptance in (CV.I3CLSimFunctionFromTable(wl, v), CV.I3CLSimFunctionDeltaPeak(405e-9)):
+        with pytest.raises(Exception) as err:
+            TB.I3CLSimStepToTableConverterHIP(0, axes, False, medium, math.pi * 0.16510 ** 2, acceptance, ang, (x, a))
+        assert "bias" in str(err.value) or "acceptance" in str(err.value)
