@@ -313,7 +313,7 @@ void Converter::setup_device_buffers()
     {   // index -> ID tables for assemble_hits_kernel; an ID that does not fit the record's short / ushort keeps the
         // conversion on the host, which reports it when a photon carries it (OpenCL.cxx:1577-1586)
         std::vector<int16_t> sid(G.string_index_to_id.size());
-        std::vector<uint32_t> start(G.string_index_to_id.size());
+        std::vector<uint32_t> start(G.string_index_to_id.size() + 1);         // (+ the end of the last string's run)
         std::vector<uint16_t> did;
         bool fits = true;
         for (size_t k = 0; k < G.string_index_to_id.size(); ++k) {
@@ -322,6 +322,7 @@ void Converter::setup_device_buffers()
             start[k] = static_cast<uint32_t>(did.size());
             for (uint32_t v : G.dom_index_to_id[k]) { fits = fits && v <= 65535u; did.push_back(static_cast<uint16_t>(v)); }
         }
+        start.back() = static_cast<uint32_t>(did.size());
         if (fits && !sid.empty()) {
             upload(reinterpret_cast<void **>(&d_id_strings_), sid.data(), sid.size() * 2, "string IDs");
             upload(reinterpret_cast<void **>(&d_id_doms_), did.data(), did.size() * 2, "OM IDs");
@@ -360,8 +361,10 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_POP")) k_pop_ = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_WAIT")) k_wait_ = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_AIM")) k_aim_ = std::max(0, std::atoi(e));
+    // (pooled kernel only -- the classic kernels have no scalar register to spare for them; -1 or unset: automatic; 0: a parked lane
+    // never waits for company / the string-aimed filter level is off, for A/B runs and the filter-off parity point)
+    if (const char *e = std::getenv("CLSIMHIP_K_WAIT")) k_wait_ = std::max(-1, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_K_AIM")) k_aim_ = std::max(-1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
     use_pool_ = true;
     pool_min_steps_ = kPooledKernelMinSteps;
@@ -457,7 +460,7 @@ void Converter::submit(Slot &s, const Job &job)
     hip_check(launch(P, stream_), "propagation kernel launch");
     hip_check(hipEventRecord(s.stop, stream_), "event");
     hip_check(hipMemcpyAsync(s.h_hit_count, s.d_hit_count, 4, hipMemcpyDeviceToHost, stream_), "download hit counter");
-    hip_check(hipMemcpyAsync(s.h_hit_count + 1, P.queue + 2, 4, hipMemcpyDeviceToHost, stream_), "download skipped-step counter");
+    hip_check(hipMemcpyAsync(s.h_hit_count + 1, P.queue + 2, 12, hipMemcpyDeviceToHost, stream_), "download skipped-step and bad-record counters");
     hip_check(hipEventRecord(s.counted, stream_), "event");
 }
 
@@ -470,6 +473,8 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
     if (s.h_hit_count[1] != 0)
         std::fprintf(stderr, "clsimhip: %u steps of bunch %u have non-finite position/direction/length/beta or a source type without spectrum and were not propagated\n",
                      s.h_hit_count[1], s.id);
+    if (s.h_hit_count[3] != 0)           // (queue[4]: assemble_hits_kernel met records whose string / DOM indices name no DOM)
+        throw Error(CLSIMHIP_ERR_DEVICE, "photon record with out-of-range string/DOM index");
     if (hits > max_output_photons_) {
         // OpenCL.cxx:1027-1032: logged, truncated
         std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);

@@ -282,7 +282,8 @@ private:
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *d_census_ = nullptr;
 #endif
-    int k_wait_ = 0, k_aim_ = 0;                 // 0 = automatic (CLSIMHIP_K_WAIT, CLSIMHIP_K_AIM)
+    int k_wait_ = -1, k_aim_ = -1;               // -1 = automatic; CLSIMHIP_K_WAIT, CLSIMHIP_K_AIM (pooled kernel only: the classic and keep
+                                                 // kernels have them as constants); 0 is honoured: never wait / never ask
     int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
     int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
     int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)

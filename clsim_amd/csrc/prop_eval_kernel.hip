@@ -98,9 +98,13 @@ hipError_t launch_eval_function(const KParams &P, int lengths_kind, bool has_til
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)P.table_words * 4;
     const dim3 grid((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), block(256);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    // (an image beyond 64 KB -- a detector of several hundred strings -- needs the attribute, like the propagation kernels' launch_variant)
+#define BIG(kernel) \
+    if (lds > 64u * 1024u) { const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
 #define GO(m) \
-    if (fast) hipLaunchKernelGGL((eval_function_kernel<m, true>), grid, block, lds, stream, P, what, layer, (int)has_tilt, in, n, out); \
-    else hipLaunchKernelGGL((eval_function_kernel<m, false>), grid, block, lds, stream, P, what, layer, (int)has_tilt, in, n, out);
+    if (fast) { BIG((eval_function_kernel<m, true>)) hipLaunchKernelGGL((eval_function_kernel<m, true>), grid, block, lds, stream, P, what, layer, (int)has_tilt, in, n, out); } \
+    else { BIG((eval_function_kernel<m, false>)) hipLaunchKernelGGL((eval_function_kernel<m, false>), grid, block, lds, stream, P, what, layer, (int)has_tilt, in, n, out); }
     switch (lengths_kind) {
     case CLSIMHIP_LENGTHS_CONSTANT: GO(CLSIMHIP_LENGTHS_CONSTANT) break;
     case CLSIMHIP_LENGTHS_ICECUBE: GO(CLSIMHIP_LENGTHS_ICECUBE) break;
@@ -117,9 +121,11 @@ hipError_t launch_eval_random(const KParams &P, bool fast, int what, int generat
     if (n_streams == 0 || draws == 0) return hipSuccess;
     const size_t lds = (size_t)P.table_words * 4;
     const dim3 grid((n_streams + 255) / 256 < 1024 ? (n_streams + 255) / 256 : 1024), block(256);
-    if (fast) hipLaunchKernelGGL((eval_random_kernel<true>), grid, block, lds, stream, P, what, generator, x, a, n_streams, draws, out);
-    else hipLaunchKernelGGL((eval_random_kernel<false>), grid, block, lds, stream, P, what, generator, x, a, n_streams, draws, out);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    if (fast) { BIG((eval_random_kernel<true>)) hipLaunchKernelGGL((eval_random_kernel<true>), grid, block, lds, stream, P, what, generator, x, a, n_streams, draws, out); }
+    else { BIG((eval_random_kernel<false>)) hipLaunchKernelGGL((eval_random_kernel<false>), grid, block, lds, stream, P, what, generator, x, a, n_streams, draws, out); }
     return hipGetLastError();
+#undef BIG
 }
 
 } // namespace clsimhip

@@ -519,10 +519,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             // born at a DOM: they live inside the string's cylinder)
             // (asked when few lanes of the wave are at a string, prop_pool_kernel.hip)
             bool at_string = !TABULATE && !(distance < free_flight_of(near_string));
-            if (!TABULATE && !FLASHER) {
-                const uint32_t n_aim = (uint32_t)__popcll(ballot(at_string && ((near_string & 0xffu) != 0u)));       // (lanes outside the cylinder)
-                if ((n_aim - 1u) < kAimLanes) at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
-            }
+            if (!TABULATE && !FLASHER && (uint32_t)__popcll(ballot(at_string)) <= kAimLanes)
+                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
             if (at_string) {
                 const uint32_t kind = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (kind != kSearchNone) {
@@ -735,8 +733,12 @@ __global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue
         uint32_t rec[20];
         const float abs_lens_initial = make_hit_record<FLASHER>(P, h, rec);
         if (P->id_strings) {                 // index -> ID (OpenCL.cxx:1565-1600), same for every record: wave-uniform branch
+            // (id_dom_start has one entry more than there are strings; a record whose indices do not name a DOM -- a corrupted stub -- keeps
+            // them and is counted in queue[4]: the host then fails the bunch like its own conversion would, converter.cpp: replace_indices)
             const uint32_t s_index = rec[11] & 0xffffu, d_index = rec[11] >> 16;
-            rec[11] = (uint32_t)(uint16_t)P->id_strings[s_index] | ((uint32_t)P->id_doms[P->id_dom_start[s_index] + d_index] << 16);
+            const bool named = (s_index < (uint32_t)P->num_strings) && (d_index < P->id_dom_start[s_index + 1u] - P->id_dom_start[s_index]);
+            if (named) rec[11] = (uint32_t)(uint16_t)P->id_strings[s_index] | ((uint32_t)P->id_doms[P->id_dom_start[s_index] + d_index] << 16);
+            else atomicAdd(P->queue + 4, 1u);
         }
 #pragma unroll
         for (int w = 0; w < 20; ++w) slot[w] = rec[w];
@@ -1030,8 +1032,16 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     if (P.tab_ndim != 4 && P.tab_ndim != 5) return hipErrorInvalidValue;
     const int key = 4 * v.lengths + (v.tilt ? 2 : 0) + (v.aniso ? 1 : 0);
+    // (round 4) FAST: the instantiation without the wave-uniform tests of the medium's proofs, as in the propagation kernels.  Built, tested
+    // (tests/test_tabulator.py) and measured -- 200x36x100x105 table: 2.15e7 photons/s against 2.24e7 for the generic instantiation, the
+    // impact-angle table 1.92e7 both (profiles/r04/tab_fast_vs_generic.txt): this kernel waits for its memory-side fp64 atomics in 55 % of
+    // its wave cycles and issues vector instructions in 37 % of the slots, fewer scalar branches buy nothing and the other register
+    // allocation costs.  So the generic instantiation runs; CLSIMHIP_TAB_FAST=1 selects the other one.
+    const char *tab_fast = getenv("CLSIMHIP_TAB_FAST");
+    const bool fast = v.fast && tab_fast && tab_fast[0] == '1';
     switch (key) {
-#define CASE(k, m, t, a) case k: return (P.tab_ndim > 4) ? launch_variant<m, t, a, true, 2>(P, stream) : launch_variant<m, t, a, true, 1>(P, stream);
+#define CASE(k, m, t, a) case k: return (P.tab_ndim > 4) ? (fast ? launch_variant<m, t, a, true, 2, true>(P, stream) : launch_variant<m, t, a, true, 2, false>(P, stream)) \
+                                                         : (fast ? launch_variant<m, t, a, true, 1, true>(P, stream) : launch_variant<m, t, a, true, 1, false>(P, stream));
 #define CASES(m) CASE(4 * m + 0, m, false, false) CASE(4 * m + 1, m, false, true) CASE(4 * m + 2, m, true, false) CASE(4 * m + 3, m, true, true)
     CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
 #undef CASES

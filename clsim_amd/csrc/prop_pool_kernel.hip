@@ -422,14 +422,13 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // of photons born at a DOM, which live inside the string's cylinder)
             // Asked when few lanes of the wave are at a string (a cascade in the bulk: 2 of 60); when many are (a source at a
             // string: the reference's benchmark, flashers) most of them are inside the cylinder and the question only costs.
-            // (round 4: counted are the lanes OUTSIDE the cylinder -- a photon inside it, bound 0, cannot miss it -- and no such lane, no question:
-            // next to a source on a string 9 lanes of a wave are at the string in every trip, 8 of them inside)
+            // (round 4, profiles/r04/aim_question.txt: two other triggers measured and dropped.  Asked whenever 1 to 8 lanes lie outside a
+            // cylinder's cell (map bound > 0): the reference's benchmark.py -2.5 % -- lanes in the cylinder's cell keep the wave in the DOM map
+            // whatever the others are told.  Not asked when any lane lies in a cylinder's cell: C2 -2.0 % -- a 2 m cell that touches a cylinder
+            // is mostly outside it, 34 % of C2's wave trips hold such a lane, and it can very well be sent back.)
             bool at_string = !(distance < free_flight_of(near_string));
-            if (!FLASHER) {
-                const uint32_t n_aim = (uint32_t)__popcll(ballot(at_string && ((near_string & 0xffu) != 0u)));
-                if ((n_aim - 1u) < (uint32_t)fresh_params(P0)->k_aim)          // 1 <= n_aim <= k_aim
-                    at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
-            }
+            if (!FLASHER && (uint32_t)__popcll(ballot(at_string)) <= (uint32_t)fresh_params(P0)->k_aim)
+                at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
             if (at_string) {
                 const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (need != kSearchNone) {
@@ -663,8 +662,8 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // (profiles/r03/string_aimed_filter.txt)
         if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 1 : 5);
         // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
-        if (P.k_wait <= 0) P.k_wait = 16;
-        if (P.k_aim <= 0) P.k_aim = 8;
+        if (P.k_wait < 0) P.k_wait = 16;          // (0 is honoured: search as soon as a lane is parked)
+        if (P.k_aim < 0) P.k_aim = 8;             // (0 is honoured: the string-aimed level is off)
         if (P.k_pop <= 0) P.k_pop = FLASHER ? 8 : 4;
         if (P.k_pop > 64) P.k_pop = 64;
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon

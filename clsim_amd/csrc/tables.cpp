@@ -403,8 +403,26 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         P.bias_value = to_float_literal(bias.value);
     }
 
+    // KVariant::fast (prop_device.hip.h: FAST), the medium's part: the standard configuration with every proof in hand
+    auto medium_proofs_complete = [&]() {
+        bool fast = (m.scatter_kind == CLSIMHIP_SCATTER_MIXED) && (P.liu_beta <= 0.09f) && ((P.div_ok & (2u | 4u | 8u | 16u | 32u | 64u)) == (2u | 4u | 8u | 16u | 32u | 64u));
+        if (m.has_aniso && !(P.div_ok & 128u)) fast = false;
+        // hg_cos divides 1 - g^2 by 1 + g s, |s| <= 1, with dm::div_near_: numerator >= 2^-40, divisors in [2^-50, 2^50]
+        if (!(P.hg_one_minus_g2 >= 9.094947017729282e-13f) || !(1.0f - std::abs(P.hg_g) >= 8.881784197001252e-16f) || !(std::abs(P.hg_g) <= 1.0f)) fast = false;
+        if (m.has_tilt) {
+            if (!(P.div_ok & 1u) || m.tilt_distances.size() > 8) fast = false;      // kTiltScalarBins + 2
+            for (size_t j = 1; j < m.tilt_distances.size(); ++j) {
+                float rcp = 0.f;
+                const float lo = to_float_literal(m.tilt_distances[j - 1]), hi = to_float_literal(m.tilt_distances[j]);
+                if (!division_by_reciprocal_is_exact(hi - lo, rcp)) fast = false;
+            }
+        }
+        return fast;
+    };
     if (geometry.string_ids.empty()) {
         // the tabulator has no detector (tabulator/I3CLSimStepToTableConverter.cxx:196-207 assembles no geometry source)
+        C.variant.fast = medium_proofs_complete();         // (round 4: the TABULATE kernels have FAST instantiations too)
+        scalar("fast_variant", C.variant.fast ? 1. : 0.);
         P.table_words = static_cast<uint32_t>(img.words.size());
         C.lds_image = std::move(img.words);
         return C;
@@ -703,19 +721,8 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         for (size_t k = 0; k < G.cells.size(); ++k) flags.push_back(subdet[12 * k + 7]);
         name("div_ok_cells", flags);
     }
-    {   // KVariant::fast (prop_device.hip.h: FAST): the standard configuration with every proof in hand
-        bool fast = (m.scatter_kind == CLSIMHIP_SCATTER_MIXED) && (P.liu_beta <= 0.09f) && ((P.div_ok & (2u | 4u | 8u | 16u | 32u | 64u)) == (2u | 4u | 8u | 16u | 32u | 64u));
-        if (m.has_aniso && !(P.div_ok & 128u)) fast = false;
-        // hg_cos divides 1 - g^2 by 1 + g s, |s| <= 1, with dm::div_near_: numerator >= 2^-40, divisors in [2^-50, 2^50]
-        if (!(P.hg_one_minus_g2 >= 9.094947017729282e-13f) || !(1.0f - std::abs(P.hg_g) >= 8.881784197001252e-16f) || !(std::abs(P.hg_g) <= 1.0f)) fast = false;
-        if (m.has_tilt) {
-            if (!(P.div_ok & 1u) || m.tilt_distances.size() > 8) fast = false;      // kTiltScalarBins + 2
-            for (size_t j = 1; j < m.tilt_distances.size(); ++j) {
-                float rcp = 0.f;
-                const float lo = to_float_literal(m.tilt_distances[j - 1]), hi = to_float_literal(m.tilt_distances[j]);
-                if (!division_by_reciprocal_is_exact(hi - lo, rcp)) fast = false;
-            }
-        }
+    {   // KVariant::fast: the medium's proofs (above the detector section) and every cell width proven
+        bool fast = medium_proofs_complete();
         for (size_t k = 0; k < G.cells.size(); ++k)
             if (subdet[12 * k + 7] != 3u) fast = false;
         C.variant.fast = fast;

@@ -111,3 +111,37 @@ def test_filter_rules_without_stopping_detected_photons():
     assert len(ph_p) == cnt_o and cnt_o > 10000
     assert common.sort_photons(ph_p).tobytes() == common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes()
     assert np.array_equal(conv.GetRNGState(n), x_o)
+
+
+@pytest.mark.parametrize("stop", [True, False])
+def test_pooled_kernel_on_the_boundaries_with_the_aim_level_on_and_off(monkeypatch, stop):
+    """the same boundary steps through the POOLED kernel (its filter reads k_aim / k_wait from the launch parameters) with the
+    string-aimed level at its default, switched off (CLSIMHIP_K_AIM=0) and with parked lanes never waiting (CLSIMHIP_K_WAIT=0):
+    every setting must give the oracle's records -- the filter is conservative, no result depends on it (a filter-off
+    point in the bit-identical tests); with and without STOP_PHOTONS_ON_DETECTION"""
+    cfg = common.config("mie")
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    reach = float(conv.GetTable("STRING_PROXIMITY_GRID")[5])
+    del conv
+    n = 1 << 16
+    steps = boundary_steps(cfg, n, seed=33, reach=reach)
+    x, a = common.streams(n)
+    T = common.oracle_tables(cfg, stop_detected=stop)
+    ph_o, cnt_o, x_o, _ = capi.propagate(T, steps, x, a, threads=16)
+    expect = common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes()
+    assert cnt_o > 10000
+    monkeypatch.setenv("CLSIMHIP_KERNEL", "pool")
+    for env in ({}, {"CLSIMHIP_K_AIM": "0"}, {"CLSIMHIP_K_AIM": "64", "CLSIMHIP_K_WAIT": "0"}):
+        for k in ("CLSIMHIP_K_AIM", "CLSIMHIP_K_WAIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        conv = common.product_converter(cfg, n, stop_detected=stop)
+        assert conv.UsesPooledKernel()
+        conv.EnqueueSteps(steps, 3)
+        _, ph_p = conv.GetConversionResult()
+        assert len(ph_p) == cnt_o, env
+        assert common.sort_photons(ph_p).tobytes() == expect, env
+        assert np.array_equal(conv.GetRNGState(n), x_o), env
+        del conv

@@ -105,6 +105,19 @@ def test_oracle_tabulator_entries_and_misses():
                                                   ("spherical", "lea", 0.2), ("spherical5", "mie", 1.0), ("cylindrical5", "lea", 1.0),
                                                   ("spherical5", "lea", 0.2), ("spherical_cuberoot", "mie", 1.0)])
 def test_table_matches_the_oracle(kind, ice, step_length):
+    check_table_against_the_oracle(kind, ice, step_length)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,ice", [("spherical", "mie"), ("cylindrical5", "lea")])
+def test_fast_table_instantiations_match_the_oracle_too(monkeypatch, kind, ice):
+    """round 4: the TABULATE kernels have FAST instantiations (the medium's proofs compiled in, as in the propagation kernels);
+    measured slower than the generic ones, so they run only with CLSIMHIP_TAB_FAST=1 -- under the same check"""
+    monkeypatch.setenv("CLSIMHIP_TAB_FAST", "1")
+    check_table_against_the_oracle(kind, ice, 1.0)
+
+
+def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by medium"):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
     the reference's in-order float accumulation to float accuracy.  step_length 0.2 m makes most waves exceed the
@@ -142,6 +155,8 @@ def test_table_matches_the_oracle(kind, ice, step_length):
     tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=step_length)
     assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
+    if expect_fast == "by medium":
+        assert int(tab.GetTable("fast_variant")[0]) == (0 if ice.startswith("photonics") else 1)
     for k in range(len(o)):
         assert np.array_equal(tab.GetBinEdges(k), B.axis_bin_edges(o[k]))
     assert np.array_equal(tab.GetTable("TABULATOR_SCALE"), np.array(tb["scale"], dtype=np.float64))
