@@ -9,6 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_FILES = ["clsim_amd/csrc/prop_kernel.hip", "clsim_amd/csrc/prop_pool_kernel.hip", "clsim_amd/csrc/prop_tab_kernel.hip",
+                "clsim_amd/csrc/prop_keep_kernel.hip", "clsim_amd/csrc/prop_pool_keep_kernel.hip",
                 "clsim_amd/csrc/prop_device.hip.h", "clsim_amd/csrc/detmath.hip.h", "clsim_amd/csrc/kparams.h", "clsim_amd/csrc/Makefile"]
 
 
@@ -28,4 +29,4 @@ def test_traffic_profile_was_taken_at_the_shipped_kernels():
     # uncommitted edits count as well
     changed += git("diff", "--name-only", "HEAD", "--", *KERNEL_FILES).stdout.split()
     assert not changed, "kernel sources changed since the profile of %s was taken: %s -- rerun tools/profile_round.sh + tools/make_latest_traffic.py" % (rev, sorted(set(changed)))
-    assert "prop_pool_kernel<1, true, false, false, true>" in prof["kernel"]
+    assert "prop_pool_kernel<1, true, false, false, true, false>" in prof["kernel"]        # (MED, TILT, ANISO, FLASHER, FAST, KEEP)
