@@ -49,6 +49,19 @@ DM float rcp_(float x)
     const float e0 = fma_(-x, r0, 1.0f);
     return fma_(e0, r0, r0);
 }
+// rcp_of_rcp_(b, x) = RN(1/b) for b = RN(1/x) -- the reciprocal of a reciprocal whose argument is still at hand (round 4).  The layer walk
+// forms a length as RN(1/x) (x = b400 * lambda^-alpha, ...) and then divides by that length, i.e. needs RN(1/RN(1/x)) -- which is x itself
+// or a neighbour.  With x as the seed one Newton step in fma arithmetic gives it exactly: for EVERY significand of x,
+// fma(fma(-b, x, 1), x, x) == RN(1/b) (the residual 1 - b x is below 2^-23 and exact in the fma; the step's value is (1/b)(1 - r^2) with
+// r^2 <= 2^-46, and no significand puts it within that of a rounding boundary).  Scaling x by a power of two scales every intermediate
+// exactly, so one binade proves all -- away from the ends of the exponent range: |x| in [2^-100, 2^100].  Not argued, TESTED: all 2^23
+// significands on the host when the idea was tried, and on the device against the IEEE divide, every exponent of the range, both signs
+// (clsimhip_check_math_exhaustive(17), tests/test_detmath_gpu.py).  Two full-rate instructions in place of v_rcp_f32 (quarter rate) + two.
+DM float rcp_of_rcp_(float b, float x)
+{
+    const float e = fma_(-b, x, 1.0f);
+    return fma_(e, x, x);
+}
 // div_near_(a, b) = RN(a / b) for 2^-50 <= |b| <= 2^50 and 2^-40 <= |a| <= 2^60, in 8 instructions without the IEEE
 // sequence's VCC-carried scaling (11, and stalls: measured +3.4 % for four call sites).  Markstein's scheme on the exact
 // reciprocal: y = RN(1/b) (rcp_ above, tested exhaustively); q0 = RN(a y) is within 2^-23 |a/b|; one correction
@@ -88,6 +101,22 @@ DM float sqrt_near_(float x)
     return u2f(dn + m_dn + m_up);
 }
 DM float rsqrt_near_(float x) { return rcp_(sqrt_near_(x)); }
+// rsqrt_unit_(x) = RN(1 / RN(sqrt x)) for x within 1023 ulps of one (rsqrt_unit_ok_) -- the renormalisation of a vector that a rotation has
+// just left within rounding errors of unit length (round 4).  So close to one both roundings are decided by the argument's distance from
+// one in ulps: x = 1 + k 2^-23: sqrt x = 1 + (k/2) 2^-23 - k^2 2^-49 rounds to 1 + floor(k/2) 2^-23 =: 1 + m 2^-23, and 1 / that =
+// 1 - m 2^-23 + m^2 2^-46 rounds to 1 - m 2^-23, which is 2m ulps below one (ulps below one are half as wide); x = 1 - j 2^-24: the root
+// rounds to 1 - ceil(j/2) 2^-24 =: 1 - c 2^-24, its reciprocal 1 + (c/2) 2^-23 + ... to 1 + ceil(c/2) 2^-23.  Integer arithmetic on the bit
+// pattern, full rate, in place of v_sqrt_f32 + 8 + v_rcp_f32 + 2.  The argument holds while the squared terms stay below a quarter ulp (k
+// below 2896); not trusted, TESTED: every pattern of the window on the host, and on the device against the IEEE operations
+// (clsimhip_check_math_exhaustive(18), tests/test_detmath_gpu.py).
+DM bool rsqrt_unit_ok_(float x) { return (f2u(x) - (0x3f800000u - 1023u)) <= 2046u; }
+DM float rsqrt_unit_(float x)
+{
+    const int d = (int)(f2u(x) - 0x3f800000u);
+    const uint32_t above = 0x3f800000u - ((uint32_t)d & ~1u);          // d >= 0
+    const uint32_t below = 0x3f800000u + ((uint32_t)(3 - d) >> 2);     // d < 0: ceil(ceil(j / 2) / 2) = (j + 3) >> 2, j = -d
+    return u2f((d < 0) ? below : above);
+}
 
 constexpr float LN2_HI = 0.693359375f;
 constexpr float LN2_LO = -2.12194440e-4f;

@@ -198,8 +198,13 @@ DM IceFactors ice_factors(KP P, float wlen)
 }
 // scattering and absorption length of one layer (_Optimizers.cxx:123-250, FunctionConstant.cxx:81-100,
 // FunctionFromTable.cxx:262-291 behind the switch(layer) of MediumPropertiesSource.cxx:89-123)
+// rcp_sca / rcp_abs: RN(1 / length), which the layer walk needs next to a length (the divisions by it, the crossing updates).
+// ICECUBE lengths ARE reciprocals -- 1 / (b400 x^-alpha) ... -- and the reciprocal of a reciprocal whose argument is at hand is two fma
+// (dm::rcp_of_rcp_: exact for every argument, tested exhaustively) instead of v_rcp_f32 + two: formed here, together with the length,
+// when Compile() has bounded the lengths (`fast`).  Every other case: length_reciprocals() below, where they are needed.
 template <int MED, bool FAST = false>
-DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len, bool fast)
+DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len,
+                      float &rcp_sca, float &rcp_abs, bool fast)
 {
     if (MED == CLSIMHIP_LENGTHS_TABLE) {
         const float4 r = *reinterpret_cast<const float4 *>(len_table + 4u * (__builtin_bit_cast(uint32_t, f.abs_pow) + (uint32_t)layer));
@@ -209,12 +214,25 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
     }
     const Rec4 r = lds_rec4(off_layers + 4u * (uint32_t)layer);
     if (MED == CLSIMHIP_LENGTHS_ICECUBE) {
-        sca_len = rcp_t<FAST>(r.c * f.sca_pow, fast);
-        abs_len = rcp_t<FAST>(r.a * f.abs_pow + f.abs_exp * r.b, fast);
+        const float x_sca = r.c * f.sca_pow, x_abs = r.a * f.abs_pow + f.abs_exp * r.b;
+        sca_len = rcp_t<FAST>(x_sca, fast);
+        abs_len = rcp_t<FAST>(x_abs, fast);
+        if (FAST || fast) {                             // lengths within [1e-15, 1e15] (Compile()): inside rcp_of_rcp_'s range
+            rcp_sca = dm::rcp_of_rcp_(sca_len, x_sca);
+            rcp_abs = dm::rcp_of_rcp_(abs_len, x_abs);
+        }
     } else {
         sca_len = r.c;
         abs_len = r.a;
     }
+}
+// ... for the lengths layer_lengths() did not give reciprocals with
+template <int MED, bool FAST = false>
+DM void length_reciprocals(float sca_len, float abs_len, float &rcp_sca, float &rcp_abs, bool fast)
+{
+    if ((MED == CLSIMHIP_LENGTHS_ICECUBE) && (FAST || fast)) return;
+    rcp_sca = rcp_t<FAST>(sca_len, fast);
+    rcp_abs = rcp_t<FAST>(abs_len, fast);
 }
 
 // HenyeyGreenstein.cxx:69-92
@@ -416,7 +434,10 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
         d.y = along_z ? sina * sinb : d.y;
         d.z = along_z ? cosa * sgn : d.z;
     }
-    const float recip_length = dm::rsqrt_near_(sqr(d.x) + sqr(d.y) + sqr(d.z));     // a rotated unit vector: ~1
+    // a rotated unit vector: its squared length is one to within a few ulps -- the integer form of the reciprocal root (detmath.hip.h:
+    // rsqrt_unit_) when every lane's is within 1023, the general one for the whole wave otherwise
+    const float len2 = sqr(d.x) + sqr(d.y) + sqr(d.z);
+    const float recip_length = (ballot(!dm::rsqrt_unit_ok_(len2)) == 0ull) ? dm::rsqrt_unit_(len2) : dm::rsqrt_near_(len2);
     d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
 }
 
@@ -554,8 +575,9 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const float lower = ((float)current_layer * thickness) + bottom;
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
-    float sca_len, abs_len;
-    layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, fast);
+    float sca_len, abs_len, rcp_sca = 0.0f, rcp_abs = 0.0f;     // the current layer's lengths and RN(1 / length)
+    layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, rcp_sca, rcp_abs, fast);
+    if (fast) length_reciprocals<MED, FAST>(sca_len, abs_len, rcp_sca, rcp_abs, fast);       // (the exact divides below take them)
     const float recip_thickness = P->recip_thickness;
     // Two divides of one numerator by lengths that Compile() has bounded to (2^-50, 2^50) (`fast`): the 8-instruction exact
     // divide when every lane's height above the boundary is inside its range (a photon ON a boundary, or within 1e-12 m of
@@ -563,8 +585,8 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const float to_boundary = boundary - effective_z;
     float over_sca, over_abs;
     if (fast && (ballot(!dm::div_near_ok_(to_boundary)) == 0ull)) {
-        over_sca = dm::div_near_(to_boundary, sca_len);
-        over_abs = dm::div_near_(to_boundary, abs_len);
+        over_sca = dm::div_near_with_(to_boundary, sca_len, rcp_sca);
+        over_abs = dm::div_near_with_(to_boundary, abs_len, rcp_abs);
     } else {
         over_sca = to_boundary / sca_len;
         over_abs = to_boundary / abs_len;
@@ -585,9 +607,10 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
             CENSUS_REGION(P, kCensusCrossing);
             j += step;
             boundary += signed_thickness;
-            layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, j, sca_len, abs_len, fast);
-            ais -= sgn * rcp_t<FAST>(sca_len, fast);
-            aia -= sgn * rcp_t<FAST>(abs_len, fast);
+            layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, j, sca_len, abs_len, rcp_sca, rcp_abs, fast);
+            length_reciprocals<MED, FAST>(sca_len, abs_len, rcp_sca, rcp_abs, fast);
+            ais -= sgn * rcp_sca;
+            aia -= sgn * rcp_abs;
         }
     }
     float distance, to_absorption;
@@ -605,7 +628,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         ph.abs_lens_left = 0.0f;
     } else {
         const float left = to_absorption - distance;       // >= +0, below 2^55
-        ph.abs_lens_left = (fast && (ballot(!dm::div_near_ok_(left)) == 0ull)) ? dm::div_near_(left, abs_len) : left / abs_len;
+        ph.abs_lens_left = (fast && (ballot(!dm::div_near_ok_(left)) == 0ull)) ? dm::div_near_with_(left, abs_len, rcp_abs) : left / abs_len;
     }
     if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;       // (the exact divide with its range test gains nothing here: measured)
     return distance;
@@ -686,6 +709,8 @@ DM uint32_t free_flight_bound(KP P, float x, float y)
     const int n = P->prox_n;
     const int ix = clamp_index((int)((x - P->prox_x0) * P->prox_inv_cell), n - 1);
     const int iy = clamp_index((int)((y - P->prox_y0) * P->prox_inv_cell), n - 1);
+    // (24-bit multiplies -- full rate where the 32-bit one is a quarter -- in this and the two other index computations of the loop: measured
+    // 0.4 % SLOWER, profiles/r04/ab_quarter_rate.txt: v_mad_u64_u32 forms the product and the sum in one instruction)
     return P->prox_map[(uint32_t)iy * (uint32_t)n + (uint32_t)ix];
 }
 DM float free_flight_of(uint32_t word) { return (float)(word & 0xffu) * 0.25f; }

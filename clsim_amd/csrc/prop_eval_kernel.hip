@@ -32,10 +32,11 @@ __global__ void __launch_bounds__(256) eval_function_kernel(const KParams Pvalue
         switch (what) {
         case CLSIMHIP_EVAL_LENGTHS: {            // x = wavelength: absorption length, scattering length of `layer`
             const IceFactors f = ice_factors<MED>(P, v.x);
-            float sca = 0.0f, ab = 0.0f;
-            layer_lengths<MED, FAST>(P->off_layers, (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr, f, layer, sca, ab,
-                                     FAST || (P->div_ok & kFastLengths) != 0u);
-            r.x = ab; r.y = sca;
+            float sca = 0.0f, ab = 0.0f, rcp_sca = 0.0f, rcp_ab = 0.0f;
+            const bool bounded = FAST || (P->div_ok & kFastLengths) != 0u;
+            layer_lengths<MED, FAST>(P->off_layers, (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr, f, layer, sca, ab, rcp_sca, rcp_ab, bounded);
+            length_reciprocals<MED, FAST>(sca, ab, rcp_sca, rcp_ab, bounded);
+            r.x = ab; r.y = sca; r.z = rcp_ab; r.w = rcp_sca;        // (z, w: RN(1 / length) as the layer walk takes them)
             break;
         }
         case CLSIMHIP_EVAL_REFRACTION:           // x = wavelength: phase refractive index, group velocity

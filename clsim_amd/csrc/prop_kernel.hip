@@ -783,7 +783,7 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 
 // Exhaustive proof runs for the range-restricted operations of detmath.hip.h: every significand (2^23) x every binary
 // exponent in [exp_lo, exp_hi], both signs for the reciprocal, against the IEEE operation.  what: 11 rcp_, 12 sqrt_near_,
-// 13 rsqrt_near_; 16 div_near_ (two-argument: see the kernel).
+// 13 rsqrt_near_; 16 div_near_ (two-argument: see the kernel); 17 rcp_of_rcp_(rcp_(x), x) against 1/(1/x); 18 rsqrt_unit_ on its window.
 // result[0] = mismatches, result[1..] = bit patterns of the first few mismatching arguments.
 __global__ void check_math_kernel(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap)
 {
@@ -833,10 +833,19 @@ __global__ void check_math_kernel(int what, int exp_lo, int exp_hi, uint32_t *re
     }
     for (int e = exp_lo; e <= exp_hi; ++e) {
         const uint32_t bits = ((uint32_t)(e + 127) << 23) | m;
-        for (int sign = 0; sign < ((what == 11) ? 2 : 1); ++sign) {
+        for (int sign = 0; sign < ((what == 11 || what == 17) ? 2 : 1); ++sign) {
             const float x = dm::u2f(bits | ((uint32_t)sign << 31));
             float want, got;
-            if (what == 11) { want = 1.0f / x; got = dm::rcp_(x); }
+            if (what == 18) {       // rsqrt_unit_: the 2047 patterns of its window (exponents and the rest of the significands do not apply)
+                if (e != exp_lo || sign != 0 || m > 2046u) continue;
+                const float xx = dm::u2f(0x3f800000u - 1023u + m);
+                want = 1.0f / __builtin_sqrtf(xx); got = dm::rsqrt_unit_(xx);
+                if (!dm::rsqrt_unit_ok_(xx) || dm::rsqrt_unit_ok_(dm::u2f(0x3f800000u + 1024u)) || dm::rsqrt_unit_ok_(dm::u2f(0x3f800000u - 1024u))) got = 0.0f;
+                if (dm::f2u(want) != dm::f2u(got)) { const uint32_t k = atomicAdd(result, 1u); if (k + 1u < result_cap) result[k + 1u] = dm::f2u(xx); }
+                continue;
+            }
+            if (what == 17) { const float b = 1.0f / x; want = 1.0f / b; got = dm::rcp_of_rcp_(dm::rcp_(x), x); }       // (rcp_(x) == b: what = 11)
+            else if (what == 11) { want = 1.0f / x; got = dm::rcp_(x); }
             else if (what == 12) { want = __builtin_sqrtf(x); got = dm::sqrt_near_(x); }
             else { want = 1.0f / __builtin_sqrtf(x); got = dm::rsqrt_near_(x); }
             if (dm::f2u(want) != dm::f2u(got)) {

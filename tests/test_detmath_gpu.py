@@ -122,3 +122,20 @@ def test_range_restricted_operations_equal_the_ieee_ones_on_every_input(what, ex
 def test_square_root_of_zero_stays_zero():
     x = np.array([0.0, 1.0, 4.0, 2.0, 5.9604645e-8], dtype=np.float32)
     assert np.array_equal(bits(device_eval(12, x)), bits(np.sqrt(x)))
+
+
+def test_reciprocal_of_a_reciprocal_from_its_argument():
+    """dm::rcp_of_rcp_(b, x) with b = RN(1/x): one Newton step from the seed x is RN(1/b) -- for all 2^23 significands of x, every
+    exponent -100 ... 100 and both signs, against the IEEE divides on the device (round 4: the layer walk's 1 / length)"""
+    bad, args = check_exhaustive(17, -100, 100)
+    assert bad == 0, "%d mismatches, first arguments %s" % (bad, args[:8])
+    # and the harness bites: beyond the admitted range the reciprocals leave the normal numbers
+    bad, _ = check_exhaustive(17, 126, 127)
+    assert bad > 0
+
+
+def test_reciprocal_root_next_to_one_in_integer_arithmetic():
+    """dm::rsqrt_unit_: RN(1 / RN(sqrt x)) for the 2047 floats within 1023 ulps of one, from the bit pattern alone (the
+    renormalisation after a rotation), against the IEEE operations on the device; its range test admits exactly that window"""
+    bad, args = check_exhaustive(18, 0, 0)
+    assert bad == 0, "%d mismatches, first arguments %s" % (bad, args[:8])
