@@ -470,13 +470,16 @@ def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, ke
     if w is None:
         return None
     floor = w["valu_per_photon"]["transformed"]
+    slots = w["issue_slots_per_photon"]["transformed"]      # the floor's instructions, a quarter-rate one (v_rcp_f32, v_sqrt_f32, 32-bit integer multiply) as four
     out = {"reference_ops_per_photon": {"as_written": w["valu_per_photon"]["as_written"],
                                         "as_written_without_search": w["valu_per_photon"]["as_written_without_search"],
                                         "transformed": floor, "unit": "gfx950 vector instructions per lane",
+                                        "transformed_issue_slots": slots,
                                         "source": "profiles/r04/reference_ops.json (oracle %s, %s)" % (stored["oracle_sha16"], w["sample"])},
            "trips_per_photon": w["events_per_photon"]["trips"],
-           "useful_lane_ops_per_s": floor * photons_per_s, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-           "useful_frac": floor * photons_per_s / VALU_PEAK_LANE_OPS}
+           "useful_lane_slots_per_s": slots * photons_per_s, "peak_lane_slots_per_s": VALU_PEAK_LANE_OPS,
+           "useful_frac": slots * photons_per_s / VALU_PEAK_LANE_OPS,
+           "useful_frac_counting_instructions": floor * photons_per_s / VALU_PEAK_LANE_OPS}
     if pmc and photons_per_launch and kernel_ms:
         insts, lanes = pmc["sq_insts_valu_per_launch"], pmc.get("valu_lane_utilisation")
         out.update({"insts_per_launch": insts, "lane_utilisation": lanes,

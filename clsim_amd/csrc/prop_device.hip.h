@@ -424,7 +424,7 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     d.z = oz * cosa + sina * sinb * sinth;
     const bool along_z = !(sinth > 0.0f);
     const bool ieee = !(dm::div_near_ok_(num_x) && dm::div_near_ok_(num_y));
-    if (ballot(along_z || ieee) != 0ull) {
+    if (__builtin_expect(ballot(along_z || ieee) != 0ull, 0)) {
         if (ieee) {
             d.x = ox * cosa - num_x / sinth;
             d.y = oy * cosa + num_y / sinth;
@@ -437,7 +437,11 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     // a rotated unit vector: its squared length is one to within a few ulps -- the integer form of the reciprocal root (detmath.hip.h:
     // rsqrt_unit_) when every lane's is within 1023, the general one for the whole wave otherwise
     const float len2 = sqr(d.x) + sqr(d.y) + sqr(d.z);
-    const float recip_length = (ballot(!dm::rsqrt_unit_ok_(len2)) == 0ull) ? dm::rsqrt_unit_(len2) : dm::rsqrt_near_(len2);
+#ifdef CLSIMHIP_NO_RSQRT_UNIT      // (A/B builds, profiles/r04/ab_quarter_rate.txt)
+    const float recip_length = dm::rsqrt_near_(len2);
+#else
+    const float recip_length = __builtin_expect(ballot(!dm::rsqrt_unit_ok_(len2)) == 0ull, 1) ? dm::rsqrt_unit_(len2) : dm::rsqrt_near_(len2);
+#endif
     d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
 }
 
@@ -584,7 +588,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     // one at z = 0, sends its wave through the IEEE sequence instead; positions stay below 2^55 m with those lengths)
     const float to_boundary = boundary - effective_z;
     float over_sca, over_abs;
-    if (fast && (ballot(!dm::div_near_ok_(to_boundary)) == 0ull)) {
+    if (__builtin_expect(fast && (ballot(!dm::div_near_ok_(to_boundary)) == 0ull), 1)) {
         over_sca = dm::div_near_with_(to_boundary, sca_len, rcp_sca);
         over_abs = dm::div_near_with_(to_boundary, abs_len, rcp_abs);
     } else {
@@ -628,7 +632,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         ph.abs_lens_left = 0.0f;
     } else {
         const float left = to_absorption - distance;       // >= +0, below 2^55
-        ph.abs_lens_left = (fast && (ballot(!dm::div_near_ok_(left)) == 0ull)) ? dm::div_near_with_(left, abs_len, rcp_abs) : left / abs_len;
+        ph.abs_lens_left = __builtin_expect(fast && (ballot(!dm::div_near_ok_(left)) == 0ull), 1) ? dm::div_near_with_(left, abs_len, rcp_abs) : left / abs_len;
     }
     if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;       // (the exact divide with its range test gains nothing here: measured)
     return distance;

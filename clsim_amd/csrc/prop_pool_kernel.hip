@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 
-            if (used_up >= (uint32_t)kSubQueues) { n_left -= n_empty; n_empty = 0u; }          // the queues are dry: empty slots retire
+            if (__builtin_expect(used_up >= (uint32_t)kSubQueues, 0)) { n_left -= n_empty; n_empty = 0u; }          // the queues are dry: empty slots retire
 
             // photon creation: when a batch fits the ring, or when lanes would otherwise go without a photon.  A wave
             // whose pending units all wait for predecessors elsewhere looks again every fourth trip.
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             const uint32_t batch = (creatable < room) ? creatable : room;
             const bool starving = (n_ready < n_free);
             const bool look_again = starving && (n_wait != 0u) && (room != 0u) && (((trip & 3u) == 0u) || (m_live == 0ull));
-            if (((batch != 0u) && ((batch >= (uint32_t)P->k_new) || starving)) || look_again) {
+            if (__builtin_expect(((batch != 0u) && ((batch >= (uint32_t)P->k_new) || starving)) || look_again, 0)) {
 #ifdef CLSIMHIP_CENSUS
                 ++c_creations;
                 const unsigned long long t_a0 = __builtin_readcyclecounter();
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             const uint32_t enough = (ballot(advance) == 0ull) ? 1u : (uint32_t)fresh_params(P0)->k_search;
             // (flasher instantiations search for the first parked lane: nothing to count)
             if (!FLASHER) parked_trips = (n_parked != 0u) ? parked_trips + 1u : 0u;
-            if ((n_parked >= enough) || (!FLASHER && (parked_trips > (uint32_t)fresh_params(P0)->k_wait))) {
+            if (__builtin_expect((n_parked >= enough) || (!FLASHER && (parked_trips > (uint32_t)fresh_params(P0)->k_wait)), 0)) {
                 if (!FLASHER) parked_trips = 0u;
 #ifdef CLSIMHIP_CENSUS
                 ++c_searches;
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 // address for the whole chip and sustains about 1e8 additions per second (like the queue heads, section 5):
                 // a cascade next to a string (the reference's benchmark: 4 % of the photons detected) asked for that many.
                 const uint64_t hit_mask = ballot(hit);
-                if (hit_mask != 0ull) {
+                if (__builtin_expect(hit_mask != 0ull, 0)) {
                     const uint32_t total = (uint32_t)__popcll(hit_mask);
                     const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
                     for (uint32_t done = 0; done < total;) {
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         m_spent = ballot(st == kSpent);
         m_vacant = ballot(st == kVacant);
         m_live = ballot(st >= kLive);
-        if ((m_live | m_spent | (uint64_t)n_left) == 0ull) break;                // every unit slot has been retired (one test: the loop is scalar-issue bound)
+        if (__builtin_expect((m_live | m_spent | (uint64_t)n_left) == 0ull, 0)) break;                // every unit slot has been retired (one test: the loop is scalar-issue bound)
     }
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
 #ifdef CLSIMHIP_CENSUS

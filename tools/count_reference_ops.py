@@ -30,9 +30,13 @@ NAMED = {"div": "div", "sqrt": "sqrt", "rsqrt": "rsqrt", "log": "log", "exp": "e
          "sin": "sin", "cos": "sin", "acos": "acos", "atan2": "atan2", "rng_draw": "rng_draw"}
 
 
-def unit_costs():
+def unit_costs(cycles=False):
+    """vector instructions per unit; cycles=True: full-rate issue slots (a quarter-rate instruction -- v_rcp_f32, v_sqrt_f32, the 32-bit integer
+    multiplies -- holds the SIMD four times as long as an fma)"""
     with open(os.path.join(ROOT, "profiles", "r04", "math_unit_costs.json")) as f:
         u = json.load(f)["units"]
+    if cycles:
+        u = {k: dict(v, valu=v["valu"] + 3 * v["of_them_quarter_rate"]) for k, v in u.items()}
     c = dict(GENERIC)
     for op, name in NAMED.items():
         c[op] = u[name]["valu"]
@@ -40,6 +44,9 @@ def unit_costs():
     c["other_math"] = u["powr"]["valu"]
     proven = {k: u[k + "(range-restricted)"]["valu"] for k in ("rcp", "div_near", "sqrt_near", "rsqrt_near")}
     proven["div_inv"] = u["div_by_invariant(proven)"]["valu"]
+    proven["rcp_of_rcp"] = u["rcp_of_rcp(seeded)"]["valu"]
+    proven["div_with"] = u["div_near_with(reciprocal at hand)"]["valu"]
+    proven["rsqrt_unit"] = u["rsqrt_unit(next to one)"]["valu"]
     return c, proven
 
 
@@ -65,14 +72,15 @@ def price_transformed(ops, ev, cost, pv, aniso, tilt):
     c = g("create")
     cone = c.get("sincos", 0)                  # photons that are rotated onto a Cherenkov cone (flasher photons are not)
     out["create"] = simple(c) + named(c, ("log", "rng_draw", "sincos")) + (c.get("div", 0) - 2 * cone) * cost["div"] + cone * (pv["div_near"] + 5) \
-        + c.get("sqrt", 0) * pv["sqrt_near"] + c.get("rsqrt", 0) * pv["rsqrt_near"]
+        + c.get("sqrt", 0) * pv["sqrt_near"] + c.get("rsqrt", 0) * pv["rsqrt_unit"]
     w = g("wavelength")
     out["wavelength"] = simple(w) + named(w, ("div", "sqrt", "rng_draw"))
     m = g("medium_per_photon")
     out["medium_per_photon"] = simple(m) + named(m, ("div",))
     # layer lengths (ice_factors + layer_lengths): per photon x = wlen/nm, -B/x (IEEE), two powr, one exp and four multiplies; per layer
     # visit (D a + E and 1 + 0.01 dTau folded on the host) 3 multiplies, 1 add and two exact reciprocals (rcp_: lengths bounded at Compile())
-    out["layer_lengths"] = P * (2 * cost["div"] + 2 * cost["powr"] + cost["exp"] + 4) + EV * (4 + 2 * pv["rcp"]) if g("layer_lengths").get("powr") else simple(g("layer_lengths"))
+    # ... and RN(1 / length) from the length's own argument beside each of them (rcp_of_rcp_, round 4)
+    out["layer_lengths"] = P * (2 * cost["div"] + 2 * cost["powr"] + cost["exp"] + 4) + EV * (4 + 2 * pv["rcp"] + 2 * pv["rcp_of_rcp"]) if g("layer_lengths").get("powr") else simple(g("layer_lengths"))
     # tilt: both divisors are invariants with a proof (div_by: 3 each)
     t = g("tilt")
     out["tilt"] = simple(t) + t.get("div", 0) * pv["div_inv"]
@@ -80,7 +88,10 @@ def price_transformed(ops, ev, cost, pv, aniso, tilt):
     # (boundary - z) / scattering and absorption length (div_near, 8 each), 1 / length per crossing (rcp 3 each), 1 / dz on a trip that
     # crossed (rcp 3), the budget's division when the photon scatters (div_near 8); without anisotropy `budget *= 1; budget /= 1` vanish
     k = g("walk")
-    walk_div = (T * pv["div_inv"] if tilt else 0) + T * 2 * pv["div_near"] + CR * 2 * pv["rcp"] + CT * pv["rcp"] + SC * pv["div_near"] + (T * cost["div"] if aniso else 0)
+    # (round 4: the three divisions by a length take the reciprocal that came with the length, 5 each; the crossing updates need no reciprocal of their own)
+    icecube = bool(g("layer_lengths").get("powr"))
+    by_length = pv["div_with"] if icecube else pv["div_near"]
+    walk_div = (T * pv["div_inv"] if tilt else 0) + T * 2 * by_length + (0 if icecube else CR * 2 * pv["rcp"]) + CT * pv["rcp"] + SC * by_length + (T * cost["div"] if aniso else 0)
     out["walk"] = simple(k) - (0 if aniso else T * cost["mul"]) + named(k, ("log", "rng_draw")) + walk_div
     a = g("aniso")
     out["aniso"] = (simple(a) + a.get("div", 0) * (pv["rcp"] + 1)) if a else 0        # 2/x = 2 RN(1/x)
@@ -88,7 +99,7 @@ def price_transformed(ops, ev, cost, pv, aniso, tilt):
     s = g("scatter_angle")
     out["scatter_angle"] = simple(s) + named(s, ("powr_unit", "powr", "rng_draw")) + (ev["liu"] + ev["hg"]) * pv["div_inv"] + ev["hg"] * (pv["div_near"] + pv["div_inv"])
     r = g("rotate")
-    out["rotate"] = simple(r) + named(r, ("sincos",)) + SC * (pv["div_near"] + 5) + r.get("sqrt", 0) * pv["sqrt_near"] + r.get("rsqrt", 0) * pv["rsqrt_near"]
+    out["rotate"] = simple(r) + named(r, ("sincos",)) + SC * (pv["div_near"] + 5) + r.get("sqrt", 0) * pv["sqrt_near"] + r.get("rsqrt", 0) * pv["rsqrt_unit"]
     x = g("transform")
     out["transform"] = (simple(x) + x.get("rsqrt", 0) * pv["rsqrt_near"]) if x else 0
     d = g("advance")
@@ -125,8 +136,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "reference_ops.json"))
     args = ap.parse_args()
     cost, proven = unit_costs()
+    cost_c, proven_c = unit_costs(cycles=True)
     src = b"".join(open(os.path.join(ROOT, "oracle", f), "rb").read() for f in ("clsim_oracle.c", "oracle_math.h", "count_ops.hpp", "count_ops_calls.hpp"))
-    res = {"what": __doc__.split("\n\n")[0], "unit_costs_generic": cost, "unit_costs_proven": proven, "oracle_sha16": hashlib.sha256(src).hexdigest()[:16],
+    res = {"what": __doc__.split("\n\n")[0], "unit_costs_generic": cost, "unit_costs_proven": proven, "unit_issue_slots_generic": cost_c, "unit_issue_slots_proven": proven_c, "oracle_sha16": hashlib.sha256(src).hexdigest()[:16],
            "git_revision": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(), "workloads": {}}
     from clsim_amd import converter as CV
     for name in args.workloads:
@@ -141,6 +153,8 @@ def main():
         assert draws == birth * P + ev["trips"] + 2 * ev["scatters"], "SURVEY 9.1: draws per photon, trip and scatter"
         aw = price_as_written(ops, cost)
         tr = price_transformed(ops, ev, cost, proven, aniso=(ice == "spice_lea"), tilt=True)
+        aw_c = price_as_written(ops, cost_c)
+        tr_c = price_transformed(ops, ev, cost_c, proven_c, aniso=(ice == "spice_lea"), tilt=True)
         search = sum(v for k, v in aw.items() if k.startswith("search"))
         totals = {}
         for d in ops.values():
@@ -155,6 +169,8 @@ def main():
             "valu_per_photon_transformed_by_region": {k: v / P for k, v in tr.items()},
             "valu_per_photon": {"as_written": sum(aw.values()) / P, "as_written_without_search": (sum(aw.values()) - search) / P,
                                 "transformed": sum(tr.values()) / P},
+            "issue_slots_per_photon": {"as_written": sum(aw_c.values()) / P, "transformed": sum(tr_c.values()) / P,
+                                       "note": "the same sums with every quarter-rate instruction counted as four full-rate issue slots"},
             "valu_per_trip": {"as_written": sum(aw.values()) / ev["trips"], "transformed": sum(tr.values()) / ev["trips"]}}
         w = res["workloads"][name]
         print("%s: %s" % (name, w["sample"]))
@@ -163,6 +179,7 @@ def main():
         print("   VALU-equivalents per photon: as written %.0f (without the search %.0f), transformed %.0f  [per trip %.0f / %.0f]" %
               (w["valu_per_photon"]["as_written"], w["valu_per_photon"]["as_written_without_search"], w["valu_per_photon"]["transformed"],
                w["valu_per_trip"]["as_written"], w["valu_per_trip"]["transformed"]))
+        print("   full-rate issue slots per photon (quarter-rate instructions x 4): as written %.0f, transformed %.0f" % (sum(aw_c.values()) / P, sum(tr_c.values()) / P))
         for k in tr:
             print("     %-20s as written %8.1f   transformed %8.1f" % (k, aw.get(k, 0) / P, tr[k] / P))
         for k in aw:

@@ -14,6 +14,8 @@ UNITS = {
     "div_by_invariant(proven)": "{ const float q = x * y; o = dm::fma_(dm::fma_(-3.0f, q, x), y, q); }",
     "rcp(range-restricted)": "o = dm::rcp_(x);", "div_near(range-restricted)": "o = dm::div_near_(x, y);",
     "sqrt_near(range-restricted)": "o = dm::sqrt_near_(x);", "rsqrt_near(range-restricted)": "o = dm::rsqrt_near_(x);",
+    "rcp_of_rcp(seeded)": "o = dm::rcp_of_rcp_(x, y);", "div_near_with(reciprocal at hand)": "o = dm::div_near_with_(x, y, a[threadIdx.x + 64]);",
+    "rsqrt_unit(next to one)": "o = dm::rsqrt_unit_(x);",
     "log": "o = dm::log_(x);", "exp": "o = dm::exp_(x);", "powr": "o = dm::powr_(x, y);", "powr_unit": "o = dm::powr_unit_(x, y);",
     "sincos": "{ float s, c; dm::sincos_(x, s, c); o = s + c; }", "sin": "{ float s, c; dm::sincos_(x, s, c); o = s; }",
     "acos": "o = dm::acos_(x);", "atan2": "o = dm::atan2_(x, y);",
@@ -37,13 +39,14 @@ for k, name in names.items():
     m = re.search(r"^%s:[^\n]*\n(.*?)\n\.Lfunc_end" % k, text, re.S | re.M)
     body = m.group(1)
     insts = [l.strip().split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".", "//")) and not l.strip().endswith(":")]
+    quarter = re.compile(r"^v_(rcp|rsq|sqrt|exp|log|sin|cos)_|^v_mad_u64_u32|^v_mad_i64_i32|^v_mul_(lo|hi)_[ui]32")      # issue at a quarter of the full rate
     counts[name] = {"valu": sum(1 for i in insts if i.startswith("v_")), "salu": sum(1 for i in insts if i.startswith("s_") and not i.startswith(("s_waitcnt", "s_load", "s_nop"))),
-                    "f64": sum(1 for i in insts if i.startswith("v_") and "f64" in i)}
+                    "f64": sum(1 for i in insts if i.startswith("v_") and "f64" in i), "quarter": sum(1 for i in insts if quarter.match(i))}
 base = counts.pop("baseline")
 out = {}
 for name, c in counts.items():
     extra = 1 if name in ("add", "mul", "cmp", "neg", "cvt", "fabs", "floor_trunc") else 0      # (their bodies add one op on top of the unit: see UNITS)
-    out[name] = {"valu": c["valu"] - base["valu"], "salu": c["salu"] - base["salu"], "of_them_f64": c["f64"]}
+    out[name] = {"valu": c["valu"] - base["valu"], "salu": c["salu"] - base["salu"], "of_them_f64": c["f64"], "of_them_quarter_rate": c["quarter"] - base["quarter"]}
 # the one-instruction units are measured with a second operand folded in; normalise what the table is used for
 for name, v in (("add", 1), ("mul", 1), ("cmp", 2), ("neg", 1), ("cvt", 2), ("fabs", 1), ("floor_trunc", 1)):
     out[name]["note"] = "measured %d" % out[name]["valu"]
