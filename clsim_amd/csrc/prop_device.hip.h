@@ -201,7 +201,8 @@ DM IceFactors ice_factors(KP P, float wlen)
 // rcp_sca / rcp_abs: RN(1 / length), which the layer walk needs next to a length (the divisions by it, the crossing updates).
 // ICECUBE lengths ARE reciprocals -- 1 / (b400 x^-alpha) ... -- and the reciprocal of a reciprocal whose argument is at hand is two fma
 // (dm::rcp_of_rcp_: exact for every argument, tested exhaustively) instead of v_rcp_f32 + two: formed here, together with the length,
-// when Compile() has bounded the lengths (`fast`).  Every other case: length_reciprocals() below, where they are needed.
+// when Compile() has bounded the lengths (`fast`).  Every other case -- constant or tabulated lengths, unbounded ones -- forms a reciprocal
+// where it needs one, as before (two more live registers through the walk cost the classic kernel's 72-register instantiations a spill).
 template <int MED, bool FAST = false>
 DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFactors &f, int layer, float &sca_len, float &abs_len,
                       float &rcp_sca, float &rcp_abs, bool fast)
@@ -226,15 +227,6 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
         abs_len = r.a;
     }
 }
-// ... for the lengths layer_lengths() did not give reciprocals with
-template <int MED, bool FAST = false>
-DM void length_reciprocals(float sca_len, float abs_len, float &rcp_sca, float &rcp_abs, bool fast)
-{
-    if ((MED == CLSIMHIP_LENGTHS_ICECUBE) && (FAST || fast)) return;
-    rcp_sca = rcp_t<FAST>(sca_len, fast);
-    rcp_abs = rcp_t<FAST>(abs_len, fast);
-}
-
 // HenyeyGreenstein.cxx:69-92
 template <bool FAST = false>
 DM float hg_cos(KP P, float u)
@@ -579,9 +571,9 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const float lower = ((float)current_layer * thickness) + bottom;
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
     const float sca_step_left = -dm::log_(rng_oc(rx, ra));
-    float sca_len, abs_len, rcp_sca = 0.0f, rcp_abs = 0.0f;     // the current layer's lengths and RN(1 / length)
+    float sca_len, abs_len, rcp_sca = 0.0f, rcp_abs = 0.0f;     // the current layer's lengths and, when `seeded`, RN(1 / length)
+    const bool seeded = (MED == CLSIMHIP_LENGTHS_ICECUBE) && fast;
     layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, rcp_sca, rcp_abs, fast);
-    if (fast) length_reciprocals<MED, FAST>(sca_len, abs_len, rcp_sca, rcp_abs, fast);       // (the exact divides below take them)
     const float recip_thickness = P->recip_thickness;
     // Two divides of one numerator by lengths that Compile() has bounded to (2^-50, 2^50) (`fast`): the 8-instruction exact
     // divide when every lane's height above the boundary is inside its range (a photon ON a boundary, or within 1e-12 m of
@@ -589,8 +581,8 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     const float to_boundary = boundary - effective_z;
     float over_sca, over_abs;
     if (__builtin_expect(fast && (ballot(!dm::div_near_ok_(to_boundary)) == 0ull), 1)) {
-        over_sca = dm::div_near_with_(to_boundary, sca_len, rcp_sca);
-        over_abs = dm::div_near_with_(to_boundary, abs_len, rcp_abs);
+        over_sca = seeded ? dm::div_near_with_(to_boundary, sca_len, rcp_sca) : dm::div_near_(to_boundary, sca_len);
+        over_abs = seeded ? dm::div_near_with_(to_boundary, abs_len, rcp_abs) : dm::div_near_(to_boundary, abs_len);
     } else {
         over_sca = to_boundary / sca_len;
         over_abs = to_boundary / abs_len;
@@ -612,9 +604,8 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
             j += step;
             boundary += signed_thickness;
             layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, j, sca_len, abs_len, rcp_sca, rcp_abs, fast);
-            length_reciprocals<MED, FAST>(sca_len, abs_len, rcp_sca, rcp_abs, fast);
-            ais -= sgn * rcp_sca;
-            aia -= sgn * rcp_abs;
+            ais -= sgn * (seeded ? rcp_sca : rcp_t<FAST>(sca_len, fast));
+            aia -= sgn * (seeded ? rcp_abs : rcp_t<FAST>(abs_len, fast));
         }
     }
     float distance, to_absorption;
@@ -632,7 +623,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
         ph.abs_lens_left = 0.0f;
     } else {
         const float left = to_absorption - distance;       // >= +0, below 2^55
-        ph.abs_lens_left = __builtin_expect(fast && (ballot(!dm::div_near_ok_(left)) == 0ull), 1) ? dm::div_near_with_(left, abs_len, rcp_abs) : left / abs_len;
+        ph.abs_lens_left = __builtin_expect(fast && (ballot(!dm::div_near_ok_(left)) == 0ull), 1) ? (seeded ? dm::div_near_with_(left, abs_len, rcp_abs) : dm::div_near_(left, abs_len)) : left / abs_len;
     }
     if (ANISO) ph.abs_lens_left = ph.abs_lens_left / corr;       // (the exact divide with its range test gains nothing here: measured)
     return distance;

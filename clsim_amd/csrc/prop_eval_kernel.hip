@@ -35,8 +35,8 @@ __global__ void __launch_bounds__(256) eval_function_kernel(const KParams Pvalue
             float sca = 0.0f, ab = 0.0f, rcp_sca = 0.0f, rcp_ab = 0.0f;
             const bool bounded = FAST || (P->div_ok & kFastLengths) != 0u;
             layer_lengths<MED, FAST>(P->off_layers, (MED == CLSIMHIP_LENGTHS_TABLE) ? P->len_table : nullptr, f, layer, sca, ab, rcp_sca, rcp_ab, bounded);
-            length_reciprocals<MED, FAST>(sca, ab, rcp_sca, rcp_ab, bounded);
-            r.x = ab; r.y = sca; r.z = rcp_ab; r.w = rcp_sca;        // (z, w: RN(1 / length) as the layer walk takes them)
+            if (!((MED == CLSIMHIP_LENGTHS_ICECUBE) && bounded)) { rcp_sca = rcp_t<FAST>(sca, bounded); rcp_ab = rcp_t<FAST>(ab, bounded); }
+            r.x = ab; r.y = sca; r.z = rcp_ab; r.w = rcp_sca;        // (z, w: RN(1 / length): from the length's argument where the layer walk takes it that way)
             break;
         }
         case CLSIMHIP_EVAL_REFRACTION:           // x = wavelength: phase refractive index, group velocity

@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         // kernel): one atomic on the chip-wide hit counter per eight hits (prop_pool_kernel.hip).  A photon history is
         // copied next to its hit and needs the hit's final index at once: with histories every chunk leaves right away.
         const uint64_t hit_mask = ballot(hit);
-        if (__builtin_expect(hit_mask != 0ull, 0)) {
+        if (hit_mask != 0ull) {
             const uint32_t total = (uint32_t)__popcll(hit_mask);
             const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
             const uint32_t hn = (uint32_t)fresh_params(P0)->history_n;
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         need_next = alive && !parked && (ph.abs_lens_left < kEpsilon);
         m_need = ballot(need_next);
         m_ready = ballot(alive && !need_next);
-        if (__builtin_expect((m_need | m_ready) == 0ull, 0)) break;
+        if ((m_need | m_ready) == 0ull) break;
     }
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
 #ifdef CLSIMHIP_CENSUS

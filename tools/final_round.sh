@@ -3,10 +3,13 @@
 #   tools/final_round.sh <out dir under gpurun_out/>
 # bench.py lines of every workload DESIGN.md quotes + rocprofv3 kernel stats and PMC summaries (tools/profile_round.sh /
 # profile_workload.sh: --pmc passes separate, never combined with trace domains).  Copy the results into profiles/rNN/ by hand.
+#   tools/final_round.sh <out dir> bench | prof     (one part per gpurun call: together they exceed a call's 20 minutes)
 set -u
 OUT=gpurun_out/${1:-final}
+PART=${2:-all}
 mkdir -p $OUT
 B="timeout -k 10 400 python3 bench.py"
+if [ "$PART" != "prof" ]; then
 $B > $OUT/final_bench_default_line.json 2> $OUT/default.err; echo default rc=$?
 $B --workload c3 --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c3.json 2> $OUT/c3.err; echo c3 rc=$?
 $B --workload c5 --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c5.json 2> $OUT/c5.err; echo c5 rc=$?
@@ -17,6 +20,8 @@ $B --workload c3 --keep-detected --no-cpu-baseline --no-host-path --steps 5 --wa
 $B --workload c5 --keep-detected --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c5_keep.json 2> $OUT/c5_keep.err; echo c5keep rc=$?
 $B --workload tab --steps 3 --warmup 1 > $OUT/final_bench_tab.json 2> $OUT/tab.err; echo tab rc=$?
 $B --workload tab5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/final_bench_tab5.json 2> $OUT/tab5.err; echo tab5 rc=$?
+fi
+if [ "$PART" = "bench" ]; then ls $OUT; exit 0; fi
 timeout -k 10 500 bash tools/profile_round.sh ${1:-final}_c2 > $OUT/prof_c2.log 2>&1; echo prof c2 rc=$?
 for w in c3 c5; do timeout -k 10 600 bash tools/profile_workload.sh ${1:-final}_$w --workload $w > $OUT/prof_$w.log 2>&1; echo prof $w rc=$?; done
 timeout -k 10 500 bash tools/profile_workload.sh ${1:-final}_c2keep --keep-detected > $OUT/prof_c2keep.log 2>&1; echo prof c2keep rc=$?
