@@ -22,8 +22,10 @@ def load(name):
     if not os.path.exists(p):
         return None
     text = open(p).read().strip()
-    line = [l for l in text.splitlines() if l.startswith("{")]
-    return json.loads(line[-1] if line else text)
+    try:
+        return json.loads(text)                     # a JSON document (rocprofv3 summaries, pretty-printed)
+    except ValueError:
+        return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])       # a bench.py log: the line that is the result
 
 
 def sci(v):
