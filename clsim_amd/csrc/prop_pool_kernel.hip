@@ -47,15 +47,37 @@ constexpr int kPoolBlock = CLSIMHIP_POOL_BLOCK;
 constexpr int kPoolWavesPerBlock = kPoolBlock / 64;
 constexpr int kPoolMinWaves = CLSIMHIP_POOL_WAVES;
 constexpr uint32_t kReadyWords = 21;            // odd strides: consecutive entries fall into different LDS banks
-constexpr uint32_t kPendWords = 5;
-constexpr uint32_t kPoolFixedWords = kStageRecords * kStubWords + 64;      // hit stub staging + parked step lengths
+constexpr uint32_t kPendWords = 4;              // a pending unit in 16 bytes (round 4; five words before): see pend_store()
+#ifndef CLSIMHIP_POOL_STAGE
+#define CLSIMHIP_POOL_STAGE 4                  // (round 4: 8 -> 4 frees two ring entries; C2 / C5 / benchmark.py +0.3 % / +0.3 % / +0.2 %)
+#endif
+constexpr int kPoolStage = CLSIMHIP_POOL_STAGE;      // hit stubs a wave stages before it writes them out (one atomic on the hit counter per flush)
+constexpr uint32_t kPoolFixedWords = kPoolStage * kStubWords + 64;      // hit stub staging + parked step lengths
 constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // unit flags above the slice number
 constexpr int kPoolMinReady = 4;                // smallest ready ring the kernel runs with
 constexpr int kPoolWorthwhileReady = 8;         // smallest ring with which it is chosen over the classic kernel
 
 // `extra`: KEEP only -- the words of find_collisions_keep's string mask beyond the first, which lives in the lane's parked_len word
 // (the step length is in a register by the time the search clears its mask): 64 lanes x (ceil(strings / 64) - 1)
-__host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R, uint32_t extra) { return kPoolFixedWords + extra + kReadyWords * R + kPendWords * (64u + R); }
+__host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R, uint32_t extra) { return (kPoolFixedWords + extra + kReadyWords * R + kPendWords * (64u + R) + 3u) & ~3u; }
+
+// A pending unit: step index (below 2^23: a converter holds at most 6 139 850 streams), stream state, photons left in the slice (below 2^23: the
+// kernel's prologue caps the slice size), flags (slice number, last, waiting: 18 bits) -- 128 bits, one ds_read_b128 / ds_write_b128.  Every
+// word the ring does not need for the list is a ring entry more: 0.28 % per entry at 34 (profiles/r04/ab_ring_size.txt).
+typedef uint32_t pend_entry __attribute__((ext_vector_type(4)));
+DM void pend_store(uint32_t *list, uint32_t k, uint32_t sidx, uint64_t rx, uint32_t left, uint32_t flags)
+{
+    pend_entry e = {sidx | (flags << 23), (uint32_t)rx, (uint32_t)(rx >> 32), left | ((flags >> 9) << 23)};
+    *reinterpret_cast<pend_entry *>(list + kPendWords * k) = e;
+}
+DM void pend_load(const uint32_t *list, uint32_t k, uint32_t &sidx, uint64_t &rx, uint32_t &left, uint32_t &flags)
+{
+    const pend_entry e = *reinterpret_cast<const pend_entry *>(list + kPendWords * k);
+    sidx = e.x & 0x7fffffu;
+    rx = (uint64_t)e.y | ((uint64_t)e.z << 32);
+    left = e.w & 0x7fffffu;
+    flags = (e.x >> 23) | ((e.w >> 23) << 9);
+}
 __host__ __device__ constexpr uint32_t pool_keep_extra_words(uint32_t num_strings) { return (num_strings > 64u) ? 64u * (((num_strings + 63u) >> 6) - 1u) : 0u; }
 
 // KEEP: without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false), the reference class's default, OpenCL.cxx:86): the search
@@ -77,11 +99,11 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // the sub-queue, hence every unit count below and the loop's exit -- would be treated as lane-varying)
     const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t keep_extra = KEEP ? pool_keep_extra_words((uint32_t)P0->num_strings) : 0u;
-    uint32_t *wave_lds = lds_words + P0->table_words + wave_in_group * pool_wave_words(R, keep_extra);
+    uint32_t *wave_lds = lds_words + ((P0->table_words + 3u) & ~3u) + wave_in_group * pool_wave_words(R, keep_extra);      // (16-byte aligned)
     uint32_t *stage = wave_lds;
-    uint32_t *parked_len = wave_lds + kStageRecords * kStubWords;
-    uint32_t *ready = wave_lds + kPoolFixedWords + keep_extra;
-    uint32_t *pend = ready + kReadyWords * R;
+    uint32_t *parked_len = wave_lds + kPoolStage * kStubWords;
+    uint32_t *pend = wave_lds + kPoolFixedWords + keep_extra;              // (64-word multiples before it)
+    uint32_t *ready = pend + kPendWords * U;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -93,6 +115,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         const uint32_t target = (uint32_t)P0->slices;
         slice_photons = (max_photons + target - 1u) / target;
         if (slice_photons == 0u) slice_photons = 1u;
+        if (slice_photons > 0x7fffffu) slice_photons = 0x7fffffu;     // (a pending entry keeps the photons left in 23 bits; at most 513 rounds then)
         rounds = (max_photons + slice_photons - 1u) / slice_photons;
         if (rounds == 0u) rounds = 1u;
     }
@@ -197,8 +220,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #endif
                 }
                 if (next) {     // the unit goes to `pending` with its stream where the photon left it
-                    uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_next & lanes_below));
-                    e[0] = sidx; e[1] = (uint32_t)rx; e[2] = (uint32_t)(rx >> 32); e[3] = photons_left; e[4] = uflags;
+                    pend_store(pend, n_pend + (uint32_t)__popcll(m_next & lanes_below), sidx, rx, photons_left, uflags);
 #ifdef CLSIMHIP_EXP_PREFETCH
                     // experiment (profiles/r04/ab_service_latency.txt): touch the unit's work record now, one or more services before the
                     // creation of its next photon reads it
@@ -257,10 +279,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         }
                     }
                     const uint64_t m_got = ballot(got);
-                    if (got) {
-                        uint32_t *e = pend + kPendWords * (n_pend + (uint32_t)__popcll(m_got & lanes_below));
-                        e[0] = i_new; e[1] = 0u; e[2] = 0u; e[3] = left; e[4] = flags;
-                    }
+                    if (got) pend_store(pend, n_pend + (uint32_t)__popcll(m_got & lanes_below), i_new, 0ull, left, flags);
                     const uint32_t n_got = (uint32_t)__popcll(m_got);
                     n_pend += n_got;
                     n_empty -= n_got;
@@ -284,10 +303,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     const bool have = (c + lane) < n_pend;
                     uint32_t e_sidx = 0, e_left = 0, e_flags = 0;
                     uint64_t e_rx = 0;
-                    if (have) {
-                        const uint32_t *e = pend + kPendWords * (c + lane);
-                        e_sidx = e[0]; e_rx = (uint64_t)e[1] | ((uint64_t)e[2] << 32); e_left = e[3]; e_flags = e[4];
-                    }
+                    if (have) pend_load(pend, c + lane, e_sidx, e_rx, e_left, e_flags);
                     bool waiting = have && ((e_flags & kFlagWaiting) != 0u);
 #ifdef CLSIMHIP_EXP_PUBLISH16
                     if (waiting) {
@@ -348,10 +364,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (keep) {
-                        uint32_t *e = pend + kPendWords * (kept + (uint32_t)__popcll(m_keep & lanes_below));
-                        e[0] = e_sidx; e[1] = (uint32_t)e_rx; e[2] = (uint32_t)(e_rx >> 32); e[3] = e_left; e[4] = e_flags;
-                    }
+                    if (keep) pend_store(pend, kept + (uint32_t)__popcll(m_keep & lanes_below), e_sidx, e_rx, e_left, e_flags);
                     kept += (uint32_t)__popcll(m_keep);
                     created += (uint32_t)__popcll(ballot(make));
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -508,7 +521,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     const uint32_t total = (uint32_t)__popcll(hit_mask);
                     const uint32_t rank = (uint32_t)__popcll(hit_mask & lanes_below);
                     for (uint32_t done = 0; done < total;) {
-                        const uint32_t space = (uint32_t)kStageRecords - n_staged;
+                        const uint32_t space = (uint32_t)kPoolStage - n_staged;
                         const uint32_t take = (total - done < space) ? (total - done) : space;
                         if (hit && rank >= done && rank < done + take) {
                             uint32_t *st = stage + (n_staged + rank - done) * kStubWords;
@@ -524,7 +537,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (n_staged == (uint32_t)kStageRecords) {
+                        if (n_staged == (uint32_t)kPoolStage) {
                             flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
                             n_staged = 0u;
                         }
@@ -578,8 +591,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 // workgroup, the rest goes to the waves' pools); keep_strings: the detector's strings without STOP_PHOTONS_ON_DETECTION, else 0
 static int pool_ring_that_fits(uint32_t table_words, uint32_t keep_strings)
 {
-    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)table_words;         // per workgroup
-    const int per_wave = budget_words / kPoolWavesPerBlock;
+    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)((table_words + 3u) & ~3u);         // per workgroup
+    const int per_wave = (budget_words / kPoolWavesPerBlock) & ~3;                      // (a wave's region is a multiple of 16 bytes)
     return (per_wave - (int)kPoolFixedWords - (int)pool_keep_extra_words(keep_strings) - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
 }
 
@@ -609,7 +622,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         if (R > fit) return hipErrorInvalidValue;
         P.pool_ready = R;
     }
-    const size_t lds_bytes = (size_t)(P.table_words + kPoolWavesPerBlock * pool_wave_words((uint32_t)R, KEEP ? pool_keep_extra_words((uint32_t)P.num_strings) : 0u)) * 4;
+    const size_t lds_bytes = (size_t)(((P.table_words + 3u) & ~3u) + kPoolWavesPerBlock * pool_wave_words((uint32_t)R, KEEP ? pool_keep_extra_words((uint32_t)P.num_strings) : 0u)) * 4;
     struct Plan { int cus = 0, resident = 0; };
     static std::mutex plan_mutex;
     static std::map<std::pair<int, size_t>, Plan> plans;
