@@ -376,7 +376,7 @@ void Converter::setup_device_buffers()
     // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
     // leaves its pools no LDS
     if (history_entries_ != 0 ||
-        !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()), stop_detected_ ? 0u : static_cast<uint32_t>(tables_.params.num_strings)))
+        !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()), stop_detected_ ? 0u : static_cast<uint32_t>(tables_.params.num_strings), tables_.params.num_layers))
         use_pool_ = false;
 }
 

@@ -21,7 +21,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 // pooled scheduling (prop_pool_kernel.hip): same results, propagation without photon histories only
 hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
 hipError_t launch_pool_keep_kernel(const KParams &P, const KVariant &v, hipStream_t stream);     // prop_pool_keep_kernel.hip: without STOP_PHOTONS_ON_DETECTION
-bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings);
+bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings, int num_layers);
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 hipError_t launch_check_math(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);

@@ -46,7 +46,8 @@ namespace clsimhip {
 constexpr int kPoolBlock = CLSIMHIP_POOL_BLOCK;
 constexpr int kPoolWavesPerBlock = kPoolBlock / 64;
 constexpr int kPoolMinWaves = CLSIMHIP_POOL_WAVES;
-constexpr uint32_t kReadyWords = 21;            // odd strides: consecutive entries fall into different LDS banks
+constexpr uint32_t kReadyWords = 20;            // a created photon + its unit: five 16-byte words (round 4; 21 single words before -- the carried layer
+                                                // index, which only media without tilt use, now shares a word with the unit's flags)
 constexpr uint32_t kPendWords = 4;              // a pending unit in 16 bytes (round 4; five words before): see pend_store()
 #ifndef CLSIMHIP_POOL_STAGE
 #define CLSIMHIP_POOL_STAGE 4                  // (round 4: 8 -> 4 frees two ring entries; C2 / C5 / benchmark.py +0.3 % / +0.3 % / +0.2 %)
@@ -349,14 +350,12 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         uint32_t pos = ready_head + n_ready + slot;
                         if (pos >= R) pos -= R;
                         if (pos >= R) pos -= R;
-                        uint32_t *q = ready + kReadyWords * pos;
-                        q[0] = dm::f2u(born.px); q[1] = dm::f2u(born.py); q[2] = dm::f2u(born.pz); q[3] = dm::f2u(born.pt);
-                        q[4] = dm::f2u(born.d.x); q[5] = dm::f2u(born.d.y); q[6] = dm::f2u(born.d.z); q[7] = dm::f2u(born.inv_groupvel);
-                        q[8] = dm::f2u(born.abs_lens_left);
-                        q[9] = dm::f2u(born.ice.sca_pow); q[10] = dm::f2u(born.ice.abs_pow); q[11] = dm::f2u(born.ice.abs_exp);
-                        q[12] = (uint32_t)born.rx_start; q[13] = (uint32_t)(born.rx_start >> 32);
-                        q[14] = (uint32_t)born.layer;
-                        q[15] = e_sidx; q[16] = (uint32_t)e_rx; q[17] = (uint32_t)(e_rx >> 32); q[18] = e_ra; q[19] = e_left; q[20] = e_flags;
+                        pend_entry *q = reinterpret_cast<pend_entry *>(ready + kReadyWords * pos);      // (16-byte words)
+                        q[0] = pend_entry{dm::f2u(born.px), dm::f2u(born.py), dm::f2u(born.pz), dm::f2u(born.pt)};
+                        q[1] = pend_entry{dm::f2u(born.d.x), dm::f2u(born.d.y), dm::f2u(born.d.z), dm::f2u(born.inv_groupvel)};
+                        q[2] = pend_entry{dm::f2u(born.abs_lens_left), dm::f2u(born.ice.sca_pow), dm::f2u(born.ice.abs_pow), dm::f2u(born.ice.abs_exp)};
+                        q[3] = pend_entry{(uint32_t)born.rx_start, (uint32_t)(born.rx_start >> 32), e_sidx, e_ra};
+                        q[4] = pend_entry{(uint32_t)e_rx, (uint32_t)(e_rx >> 32), e_left, e_flags | ((uint32_t)born.layer << 18)};       // (flags: 18 bits; layers < 2^14, checked by the launcher)
                     }
                     const bool keep = have && !make;
                     const uint64_t m_keep = ballot(keep);
@@ -388,16 +387,17 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 if (want && (rank < n_ready)) {
                     uint32_t pos = ready_head + rank;
                     if (pos >= R) pos -= R;
-                    const uint32_t *q = ready + kReadyWords * pos;
-                    ph.px = dm::u2f(q[0]); ph.py = dm::u2f(q[1]); ph.pz = dm::u2f(q[2]); ph.pt = dm::u2f(q[3]);
-                    ph.d.x = dm::u2f(q[4]); ph.d.y = dm::u2f(q[5]); ph.d.z = dm::u2f(q[6]); ph.inv_groupvel = dm::u2f(q[7]);
-                    ph.abs_lens_left = dm::u2f(q[8]);
-                    ph.ice.sca_pow = dm::u2f(q[9]); ph.ice.abs_pow = dm::u2f(q[10]); ph.ice.abs_exp = dm::u2f(q[11]);
-                    ph.rx_start = (uint64_t)q[12] | ((uint64_t)q[13] << 32);
-                    ph.layer = (int)q[14];
+                    const pend_entry *q = reinterpret_cast<const pend_entry *>(ready + kReadyWords * pos);
+                    const pend_entry q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+                    ph.px = dm::u2f(q0.x); ph.py = dm::u2f(q0.y); ph.pz = dm::u2f(q0.z); ph.pt = dm::u2f(q0.w);
+                    ph.d.x = dm::u2f(q1.x); ph.d.y = dm::u2f(q1.y); ph.d.z = dm::u2f(q1.z); ph.inv_groupvel = dm::u2f(q1.w);
+                    ph.abs_lens_left = dm::u2f(q2.x);
+                    ph.ice.sca_pow = dm::u2f(q2.y); ph.ice.abs_pow = dm::u2f(q2.z); ph.ice.abs_exp = dm::u2f(q2.w);
+                    ph.rx_start = (uint64_t)q3.x | ((uint64_t)q3.y << 32);
+                    ph.layer = (int)(q4.w >> 18);
                     ph.num_scatters = 0;
                     ph.total_path = 0.0f;
-                    sidx = q[15]; rx = (uint64_t)q[16] | ((uint64_t)q[17] << 32); ra = q[18]; photons_left = q[19]; uflags = q[20];
+                    sidx = q3.z; rx = (uint64_t)q4.x | ((uint64_t)q4.y << 32); ra = q3.w; photons_left = q4.z; uflags = q4.w & 0x3ffffu;
                     st = kLive;
                 }
                 uint32_t taken = (uint32_t)__popcll(m_want);
@@ -706,6 +706,7 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     if (P.history_n != 0 || v.tabulate || (v.keep_detected != CLSIMHIP_POOL_KEEP)) return hipErrorInvalidValue;
+    if (P.num_layers >= (1 << 14)) return hipErrorInvalidValue;          // (a ring entry keeps the carried layer index in 14 bits: pool_kernel_fits() says so first)
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     // CLSIMHIP_NO_FAST=1: the generic instantiation also where Compile() found every proof (tests compare the two)
     const char *no_fast = getenv("CLSIMHIP_NO_FAST");
@@ -727,8 +728,9 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
 #ifndef CLSIMHIP_POOL_KEEP_UNIT
 // does the pooled kernel pay for this table image (its waves need at least kPoolWorthwhileReady ring entries)?  keep_strings: the
 // number of strings when the converter runs without STOP_PHOTONS_ON_DETECTION (the search's string masks share the pool's LDS), else 0
-bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings)
+bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings, int num_layers)
 {
+    if (num_layers >= (1 << 14)) return false;
     static_assert(kPoolWorthwhileReady >= kPoolMinReady, "an image the pooled kernel is chosen for must be one it can run");
     return pool_ring_that_fits(table_words, keep_strings) >= kPoolWorthwhileReady;
 }
