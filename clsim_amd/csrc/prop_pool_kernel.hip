@@ -53,13 +53,12 @@ constexpr uint32_t kPendWords = 4;              // a pending unit in 16 bytes (r
 #define CLSIMHIP_POOL_STAGE 4                  // (round 4: 8 -> 4 frees two ring entries; C2 / C5 / benchmark.py +0.3 % / +0.3 % / +0.2 %)
 #endif
 constexpr int kPoolStage = CLSIMHIP_POOL_STAGE;      // hit stubs a wave stages before it writes them out (one atomic on the hit counter per flush)
-constexpr uint32_t kPoolFixedWords = kPoolStage * kStubWords + 64;      // hit stub staging + parked step lengths
+constexpr uint32_t kPoolFixedWords = kPoolStage * kStubWords;           // hit stub staging (a parked lane keeps its step length in a register: round 4)
 constexpr uint32_t kFlagLast = 1u << 16, kFlagWaiting = 1u << 17;         // unit flags above the slice number
 constexpr int kPoolMinReady = 4;                // smallest ready ring the kernel runs with
 constexpr int kPoolWorthwhileReady = 8;         // smallest ring with which it is chosen over the classic kernel
 
-// `extra`: KEEP only -- the words of find_collisions_keep's string mask beyond the first, which lives in the lane's parked_len word
-// (the step length is in a register by the time the search clears its mask): 64 lanes x (ceil(strings / 64) - 1)
+// `extra`: KEEP only -- find_collisions_keep's string mask: 64 lanes x ceil(strings / 64) words
 __host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R, uint32_t extra) { return (kPoolFixedWords + extra + kReadyWords * R + kPendWords * (64u + R) + 3u) & ~3u; }
 
 // A pending unit: step index (below 2^23: a converter holds at most 6 139 850 streams), stream state, photons left in the slice (below 2^23: the
@@ -79,7 +78,7 @@ DM void pend_load(const uint32_t *list, uint32_t k, uint32_t &sidx, uint64_t &rx
     left = e.w & 0x7fffffu;
     flags = (e.x >> 23) | ((e.w >> 23) << 9);
 }
-__host__ __device__ constexpr uint32_t pool_keep_extra_words(uint32_t num_strings) { return (num_strings > 64u) ? 64u * (((num_strings + 63u) >> 6) - 1u) : 0u; }
+__host__ __device__ constexpr uint32_t pool_keep_extra_words(uint32_t num_strings) { return 64u * ((num_strings + 63u) >> 6); }
 
 // KEEP: without STOP_PHOTONS_ON_DETECTION (SetStopDetectedPhotons(false), the reference class's default, OpenCL.cxx:86): the search
 // saves every DOM the segment enters from inside (find_collisions_keep) and the photon travels on; instantiated in a translation
@@ -102,7 +101,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     const uint32_t keep_extra = KEEP ? pool_keep_extra_words((uint32_t)P0->num_strings) : 0u;
     uint32_t *wave_lds = lds_words + ((P0->table_words + 3u) & ~3u) + wave_in_group * pool_wave_words(R, keep_extra);      // (16-byte aligned)
     uint32_t *stage = wave_lds;
-    uint32_t *parked_len = wave_lds + kPoolStage * kStubWords;
+    uint32_t *keep_mask = wave_lds + kPoolFixedWords;                      // (KEEP only)
     uint32_t *pend = wave_lds + kPoolFixedWords + keep_extra;              // (64-word multiples before it)
     uint32_t *ready = pend + kPendWords * U;
     __syncthreads();
@@ -134,6 +133,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     constexpr uint32_t kVacant = 0u, kSpent = 1u, kLive = 2u, kParked = 3u;
     uint32_t st = kVacant;
     uint32_t sidx = kNoStep, ra = 0, photons_left = 0, uflags = 0;
+    float parked_dist = 0.0f;                   // the step length of a parked lane (a register: 64 LDS words per wave are 2.7 ring entries)
     uint64_t rx = 0;
     Photon ph;
     ph.abs_lens_left = 0.0f;
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
                 if (need != kSearchNone) {
                     st = kParked + need - kSearchFull;                   // kParked, or kParked + 1 + id
-                    parked_len[lane] = __builtin_bit_cast(uint32_t, distance);
+                    parked_dist = distance;
                 }
             }
         }
@@ -464,15 +464,14 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 #endif
                 if (KEEP && (st >= kParked)) {
                     // without STOP_PHOTONS_ON_DETECTION (c.cl:704-750): the search saves what it finds, nothing is shortened or absorbed.
-                    // The lane's string mask (one word per 64 strings) starts in its parked_len word -- the step length is in a register
-                    // now -- and goes on behind the 64 parked_len words.
+                    // The lane's string mask: one word per 64 strings in the wave's LDS region.
                     const KP P = fresh_params(P0);
-                    distance = __builtin_bit_cast(float, parked_len[lane]);
+                    distance = parked_dist;
                     KeepSink K;
                     K.step_index = sidx;
                     K.history_n = 0u;                           // (photon histories run the classic kernel)
                     K.ring = nullptr;
-                    K.string_mask = parked_len + lane;
+                    K.string_mask = keep_mask + lane;
                     K.mask_stride = 64u;
                     K.mask_words = ((uint32_t)P->num_strings + 63u) >> 6;
                     find_collisions_keep(P, ph, distance, K);
@@ -480,7 +479,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     advance = true;
                 }
                 if (!KEEP && (st >= kParked)) {
-                    distance = __builtin_bit_cast(float, parked_len[lane]);
+                    distance = parked_dist;
                     // Lanes with only one DOM in reach take the search confined to it (find_collision_named: what the
                     // reference's search does for that DOM, and nothing else) -- in the flasher instantiations, and when
                     // every parked lane of the wave is of that kind: a wave that has to run the full search for one lane runs
