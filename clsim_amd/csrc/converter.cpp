@@ -20,7 +20,10 @@ constexpr uint32_t kQueueSlots = 256;
 // The pooled kernel keeps 64 + R units per wave in flight (about 0.6M on the chip): it wins on bunches that hold more
 // steps than that by a margin (1M steps: +9 %, 4M: +8 %) and loses on smaller ones (0.5M: -17 %), where the classic
 // kernel's smaller grids apply.  Chosen per launch; results do not depend on the choice.
-constexpr size_t kPooledKernelMinSteps = 614400;   // 0.52M steps: classic 2.54e9 photons/s, pooled 2.29; 0.59M: 2.63 / 2.59; 0.66M: pooled 3.01
+// (round 4, with bunches just below the chip's unit slots sliced like larger ones -- prop_pool_kernel.hip -- and a ring of 45: cascade steps, classic /
+// pooled 1e9 photons/s: 0.39M 2.57 / 2.56, 0.49M 2.89 / 2.90, 0.56M 2.98 / 3.18, 0.59M 3.00 / 3.30, 0.62M 3.02 / 3.42, 0.66M 3.03 / 3.50; flasher steps 0.31M 1.62 / 1.55,
+// 0.63M 2.00 / 2.23.  Round 2's threshold was 614 400.)
+constexpr size_t kPooledKernelMinSteps = 524288;
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {

@@ -659,7 +659,9 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         const double r = (double)P.n_steps / ((double)grid * slots_per_group);
         // (1M steps: 8 slices 2.76e9 photons/s, 12: 2.84, 16: 2.84, 24: 2.85, 32: 2.87; fabric traffic 18.6 / 19.2 / 20.7 GB per
         // launch at 12 / 16 / 32 slices: the last per cent of speed is not worth a tenth more traffic)
-        if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
+        // (r < 1 only because the grid was cut to the workgroups the bunch fills: then r > 1 - 1 / grid and the bunch is sliced like a larger
+        // one -- with whole steps a bunch just below the chip's unit slots ran 10 % slower than one just above, profiles/r04/ab_ring_size.txt)
+        if (P.slices <= 0) P.slices = (r < 0.95) ? 1 : 16;
         // lanes parked per DOM search: with the two-level proximity filter about 1 % of the lanes need one per trip (cascade
         // steps: 3 parked lanes 2.55e9 photons/s, 1: 2.49, 5: 2.53, 8: 2.27 at 1M steps); photons born at a DOM need one on
         // most trips whatever the filter (flasher steps: 3 parked lanes 1.50e9, 5: 1.58, 7: 1.615, 9: 1.625, 12: 1.616, 16: 1.57)
@@ -672,7 +674,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // other trip and a batch of 5 fills in time.  1M cascade steps / benchmark.py, 1e9 photons/s: k_search, k_wait = 3, 4: 3.72 / 2.81;
         // 3, 16: 3.71 / 2.84; 5, 16: 3.72 / 2.87; 8, 16: 3.71 / 2.85; 1, -: 3.72 / 2.68; 3, none: 3.39 / 2.84
         // (profiles/r03/string_aimed_filter.txt)
-        if (P.k_search <= 0) P.k_search = (r < 1.0) ? 1 : (FLASHER ? 1 : 5);
+        if (P.k_search <= 0) P.k_search = (r < 0.95) ? 1 : (FLASHER ? 1 : 5);
         // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
         if (P.k_wait < 0) P.k_wait = 16;          // (0 is honoured: search as soon as a lane is parked)
         if (P.k_aim < 0) P.k_aim = 8;             // (0 is honoured: the string-aimed level is off)

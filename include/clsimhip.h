@@ -329,7 +329,7 @@ int clsimhip_gather_hits(clsimhip_comm *comm, const void *d_photons, const void 
 /* ---- introspection used by the parity tests ---- */
 /* Which scheduling the propagation kernel runs with (after Initialize): 1 = per-wave photon pools
  * (prop_pool_kernel.hip), 0 = one photon per lane (prop_kernel.hip).  Chosen per launch: pools for bunches large
- * enough to fill them (>= 614400 steps), never with photon histories or a table image that leaves the pools no LDS.
+ * enough to fill them (>= 524288 steps), never with photon histories or a table image that leaves the pools no LDS.
  * Results do not depend on it.  CLSIMHIP_KERNEL=pool|classic in the environment forces one for every bunch size
  * (clsimhip_uses_pooled_kernel then reports 1 / 0), CLSIMHIP_POOL_MIN_STEPS moves the threshold. */
 int clsimhip_kernel_for_bunch(const clsimhip_converter *c, size_t n_steps, int *out);
