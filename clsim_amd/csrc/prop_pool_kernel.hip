@@ -651,6 +651,20 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         const int g = atoi(e);
         if (g >= 1 && g <= plan.resident) grid = (uint32_t)g;
     }
+    // Fewer steps than the grid has unit slots: smaller rings on every CU rather than full rings on fewer CUs (round 4: with the ring of 45 a
+    // bunch of 625 000 flasher steps filled 478 of the 512 workgroups; a ring entry is worth 0.28 %, a workgroup 0.2 %) -- unless the ring
+    // was asked for (CLSIMHIP_POOL_R) or would fall below the size from which the pooled kernel pays
+    size_t lds_launch = lds_bytes;
+    if (Pin.pool_ready <= 0 && (uint64_t)grid * kPoolWavesPerBlock * (64u + (uint32_t)R) > (uint64_t)P.n_steps) {
+        const int smaller = (int)((uint64_t)P.n_steps / ((uint64_t)grid * kPoolWavesPerBlock)) - 64;
+        // (only a little smaller: cascade steps, photons/s, smaller rings on all CUs / full rings on fewer -- 0.49M steps, ring 16: 2.62 / 2.90e9; 0.56M, ring 26:
+        // 3.12 / 3.18; 0.62M, ring 37: 3.42 / 3.42; 625 000 flasher steps, ring 37: 2.30 / 2.23)
+        if (smaller >= kPoolWorthwhileReady && smaller < R && 5 * smaller >= 4 * R) {
+            R = smaller;
+            P.pool_ready = R;
+            lds_launch = (size_t)(((P.table_words + 3u) & ~3u) + kPoolWavesPerBlock * pool_wave_words((uint32_t)R, KEEP ? pool_keep_extra_words((uint32_t)P.num_strings) : 0u)) * 4;
+        }
+    }
     // never more unit slots than steps
     const uint32_t slots_per_group = (uint32_t)kPoolWavesPerBlock * (64u + (uint32_t)R);
     const uint32_t needed = (P.n_steps + slots_per_group - 1u) / slots_per_group;
@@ -688,7 +702,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     }
     hipError_t err = launch_scan_steps(P, stream);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST, KEEP>), dim3(grid), dim3(kPoolBlock), lds_bytes, stream, P);
+    hipLaunchKernelGGL((prop_pool_kernel<MED, TILT, ANISO, FLASHER, FAST, KEEP>), dim3(grid), dim3(kPoolBlock), lds_launch, stream, P);
     err = hipGetLastError();
     if (err != hipSuccess) return err;
     return launch_assemble_hits(P, FLASHER, dev, stream);
