@@ -81,13 +81,12 @@ void Converter::release_device()
         (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count); (void)hipFree(sl.d_hist_out);
         if (sl.h_hist) (void)hipHostFree(sl.h_hist);
         if (sl.h_steps) (void)hipHostFree(sl.h_steps);
-        if (sl.h_photons) (void)hipHostFree(sl.h_photons);
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
         sl = Slot();
     }
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_); (void)hipFree(d_id_strings_); (void)hipFree(d_id_doms_); (void)hipFree(d_id_dom_start_);
-    for (clsimhip_photon *b : free_result_buffers_) (void)hipHostFree(b);
-    free_result_buffers_.clear(); result_buffers_made_ = 0;
+    for (const PinnedBuffer &b : free_result_buffers_) (void)hipHostFree(b.p);
+    free_result_buffers_.clear(); result_buffers_made_ = 0; pinning_refused_ = false;
     // results nobody released, and results nobody fetched: their page-locked buffers go with the converter
     handed_out_.clear();
     if (out_queue_) {
@@ -346,7 +345,6 @@ void Converter::setup_device_buffers()
         hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_photons), static_cast<size_t>(max_output_photons_) * sizeof(DevPhoton)), "photons");
         hip_check(hipMalloc(reinterpret_cast<void **>(&sl.d_hit_count), 16), "hit counter");
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_steps), max_workitems_ * sizeof(clsimhip_step), hipHostMallocDefault), "pinned steps");
-        hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_photons), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault), "pinned photons");
         hip_check(hipHostMalloc(reinterpret_cast<void **>(&sl.h_hit_count), 16, hipHostMallocDefault), "pinned counter");
         if (history_entries_) {
             const size_t bytes = static_cast<size_t>(max_output_photons_) * history_entries_ * 16;
@@ -368,6 +366,7 @@ void Converter::setup_device_buffers()
     // never waits for company / the string-aimed filter level is off, for A/B runs and the filter-off parity point)
     if (const char *e = std::getenv("CLSIMHIP_K_WAIT")) k_wait_ = std::max(-1, std::atoi(e));
     if (const char *e = std::getenv("CLSIMHIP_K_AIM")) k_aim_ = std::max(-1, std::atoi(e));
+    if (const char *e = std::getenv("CLSIMHIP_RESULT_MIN_RECORDS")) min_result_records_ = static_cast<size_t>(std::max(1ll, std::atoll(e)));
     if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
     use_pool_ = true;
     pool_min_steps_ = kPooledKernelMinSteps;
@@ -483,23 +482,26 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
         std::fprintf(stderr, "clsimhip: maximum number of photons exceeded, only receiving %u of %u photons\n", max_output_photons_, hits);
         hits = max_output_photons_;
     }
-    // The download lands in the slot's page-locked buffer, which then IS the result: the slot takes a fresh buffer from the
-    // pool.  (Round 2 zero-filled a vector per result, copied the download into it and converted indices one by one on
-    // this thread: 0.4 s per bunch of 8.4 M photons in the reference's benchmark, the device idle 80 % of the time.)
+    // The download lands in a page-locked buffer of the result pool, which then IS the result (no copy, no conversion on this
+    // thread: round 2 zero-filled a vector per result, copied the download into it and converted indices one by one -- 0.4 s
+    // per bunch of 8.4 M photons in the reference's benchmark, the device idle 80 % of the time).  With every pool buffer in
+    // the caller's hands the records go into a plain vector.
     Result r;
     r.count = hits;
     std::unique_ptr<std::vector<clsimhip_photon>> photons;
-    clsimhip_photon *where = s.h_photons;
+    clsimhip_photon *where = nullptr;
     if (hits) {
-        hip_check(hipMemcpyAsync(s.h_photons, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
-        hip_check(hipStreamSynchronize(copy_stream_), "download photons");
-        if (clsimhip_photon *fresh = take_result_buffer()) {
-            r.pinned.reset(s.h_photons);
-            s.h_photons = fresh;
+        const PinnedBuffer buf = take_result_buffer(hits);
+        if (buf.p) {
+            r.pinned.reset(buf.p);
+            r.pinned_capacity = buf.capacity;
+            where = buf.p;
         } else {
-            photons.reset(new std::vector<clsimhip_photon>(s.h_photons, s.h_photons + hits));
+            photons.reset(new std::vector<clsimhip_photon>(hits));
             where = photons->data();
         }
+        hip_check(hipMemcpyAsync(where, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
+        hip_check(hipStreamSynchronize(copy_stream_), "download photons");
         if (!d_id_strings_) replace_indices(where, hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
     }
     std::unique_ptr<std::vector<float>> histories;
@@ -631,15 +633,16 @@ void Converter::result_histories(const clsimhip_photon *photons, const float **h
 
 void Converter::release_result(const clsimhip_photon *photons)
 {
-    clsimhip_photon *back = nullptr;
+    PinnedBuffer back;
     {
         std::lock_guard<std::mutex> lk(results_mutex_);
         auto it = handed_out_.find(photons);
         if (it == handed_out_.end()) return;
-        back = it->second.pinned.release();
+        back.capacity = it->second.pinned_capacity;
+        back.p = it->second.pinned.release();
         handed_out_.erase(it);
     }
-    if (back) {
+    if (back.p) {
         std::lock_guard<std::mutex> lk(result_pool_mutex_);
         free_result_buffers_.push_back(back);
     }
@@ -647,24 +650,42 @@ void Converter::release_result(const clsimhip_photon *photons)
 
 void Converter::Result::HostFree::operator()(clsimhip_photon *p) const { if (p) (void)hipHostFree(p); }
 
-clsimhip_photon *Converter::take_result_buffer()
+Converter::PinnedBuffer Converter::take_result_buffer(size_t records)
 {
+    clsimhip_photon *too_small = nullptr;
     {
         std::lock_guard<std::mutex> lk(result_pool_mutex_);
-        if (!free_result_buffers_.empty()) {
-            clsimhip_photon *b = free_result_buffers_.back();
-            free_result_buffers_.pop_back();
+        // the smallest free buffer that holds the records
+        size_t best = free_result_buffers_.size(), smallest = free_result_buffers_.size();
+        for (size_t i = 0; i < free_result_buffers_.size(); ++i) {
+            const size_t c = free_result_buffers_[i].capacity;
+            if (c >= records && (best == free_result_buffers_.size() || c < free_result_buffers_[best].capacity)) best = i;
+            if (smallest == free_result_buffers_.size() || c < free_result_buffers_[smallest].capacity) smallest = i;
+        }
+        if (best != free_result_buffers_.size()) {
+            const PinnedBuffer b = free_result_buffers_[best];
+            free_result_buffers_.erase(free_result_buffers_.begin() + static_cast<std::ptrdiff_t>(best));
             return b;
         }
-        if (result_buffers_made_ >= kResultBuffers) return nullptr;
+        if (pinning_refused_) return PinnedBuffer();
+        if (result_buffers_made_ >= kResultBuffers) {
+            if (free_result_buffers_.empty()) return PinnedBuffer();            // all of them are with the caller
+            too_small = free_result_buffers_[smallest].p;                       // a free one makes room for a larger one
+            free_result_buffers_.erase(free_result_buffers_.begin() + static_cast<std::ptrdiff_t>(smallest));
+            --result_buffers_made_;
+        }
         ++result_buffers_made_;
     }
-    clsimhip_photon *b = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&b), static_cast<size_t>(max_output_photons_) * sizeof(clsimhip_photon), hipHostMallocDefault) != hipSuccess) {
+    if (too_small) (void)hipHostFree(too_small);
+    PinnedBuffer b;
+    b.capacity = std::max(min_result_records_, (records + records / 4 + 4095) / 4096 * 4096);
+    b.capacity = std::max(records, std::min(b.capacity, static_cast<size_t>(max_output_photons_)));
+    if (hipHostMalloc(reinterpret_cast<void **>(&b.p), b.capacity * sizeof(clsimhip_photon), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(result_pool_mutex_);
-        result_buffers_made_ = kResultBuffers;      // the host will not pin more: results are copied out from now on
-        return nullptr;
+        --result_buffers_made_;
+        pinning_refused_ = true;
+        return PinnedBuffer();
     }
     return b;
 }

@@ -202,6 +202,7 @@ private:
         uint32_t id = 0;
         struct HostFree { void operator()(clsimhip_photon *p) const; };
         std::unique_ptr<clsimhip_photon, HostFree> pinned;  // pool buffer (returned to the pool by release_result; freed with a result nobody fetched)
+        size_t pinned_capacity = 0;                         // records `pinned` holds
         size_t count = 0;
         std::unique_ptr<std::vector<clsimhip_photon>> photons;
         std::unique_ptr<std::vector<float>> histories;     // [photons][history_entries_][4], forward order
@@ -254,7 +255,6 @@ private:
         float *d_hist_out = nullptr;            // photon histories of the slot's hits (history_entries_ float4 each)
         float *h_hist = nullptr;
         clsimhip_step *h_steps = nullptr;       // pinned staging
-        clsimhip_photon *h_photons = nullptr;
         uint32_t *h_hit_count = nullptr;
         hipEvent_t start = nullptr, stop = nullptr, counted = nullptr, uploaded = nullptr;
         uint32_t id = 0;
@@ -262,12 +262,18 @@ private:
     };
     Slot slots_[2];
     int num_slots_ = 1;
-    // page-locked result buffers not in use (each max_output_photons_ records); at most kResultBuffers exist besides the slots' own
-    static constexpr int kResultBuffers = 4;
-    std::vector<clsimhip_photon *> free_result_buffers_;
+    // Page-locked result buffers, sized by the photons that arrive: a bunch's download lands in a buffer of at least its own record
+    // count (a quarter more, at least min_result_records_, never more than max_output_photons_), which then IS the result until the
+    // caller releases it.  At most kResultBuffers exist at a time; a free one that is too small is given back to the host for a
+    // larger one.  (Rounds 3-4 kept buffers of max_output_photons_ records each -- 840 MB at a million work items, six of them.)
+    struct PinnedBuffer { clsimhip_photon *p = nullptr; size_t capacity = 0; };
+    static constexpr int kResultBuffers = 6;
+    size_t min_result_records_ = 65536;                 // (CLSIMHIP_RESULT_MIN_RECORDS: tests make the buffers grow with small bunches)
+    std::vector<PinnedBuffer> free_result_buffers_;
     int result_buffers_made_ = 0;
+    bool pinning_refused_ = false;                      // the host would not page-lock more: results are copied out from then on
     std::mutex result_pool_mutex_;
-    clsimhip_photon *take_result_buffer();              // nullptr when the pool is exhausted
+    PinnedBuffer take_result_buffer(size_t records);    // {nullptr, 0} when every buffer is with the caller (or the host refuses)
     // index -> ID tables on the device (host path: converted by assemble_hits_kernel); null when an ID does not fit the record
     int16_t *d_id_strings_ = nullptr;
     uint16_t *d_id_doms_ = nullptr;

@@ -444,3 +444,39 @@ def test_detector_of_576_strings_runs_with_fewer_workgroups_per_cu():
         assert ident == 5 and len(ph_p) == cnt_o, kernel
         assert common.sort_photons(ph_p).tobytes() == common.sort_photons(ph_o).tobytes(), kernel
         assert np.array_equal(conv.GetRNGState(len(steps)), x_o), kernel
+
+
+def test_result_buffers_follow_the_hit_counts_and_survive_a_caller_that_keeps_them(monkeypatch):
+    """The page-locked result pool (converter.cpp: take_result_buffer): buffers are sized by the photons that arrive and at
+    most six exist.  A caller that keeps nine results before releasing any gets the last ones from plain vectors; a bunch with
+    many more photons than its predecessors gets a larger buffer; every result equals the oracle's."""
+    monkeypatch.setenv("CLSIMHIP_RESULT_MIN_RECORDS", "64")        # (default 65 536 records: these bunches would never outgrow it)
+    cfg = common.config("flasher")
+    small, large = common.steps_for(cfg, 256, seed=5), common.steps_for(cfg, 4096, seed=6)
+    x, a = common.streams(4096)
+    T = common.oracle_tables(cfg)
+    conv = common.product_converter(cfg, 4096, double_buffering=True)
+    bunches = [small] * 4 + [large] + [small] * 4 + [large, small]
+    xo, expected = x, []
+    for steps in bunches:
+        ph_o, cnt_o, x_next, _ = capi.propagate(T, steps, xo[:len(steps)], a[:len(steps)], threads=8)
+        xo = np.concatenate([x_next, xo[len(steps):]])
+        expected.append(common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes())
+    assert len(expected[4]) > 8 * len(expected[0]) > 0, "the large bunch must need a larger buffer"
+    held = []
+    import threading                                    # (the input queue holds five bunches: a producer thread, like a real caller)
+    producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps, k) for k, steps in enumerate(bunches[:9])])
+    producer.start()
+    for k in range(9):
+        ident, view, release = conv.GetConversionResultInPlace()
+        assert ident == k
+        held.append((view, release))
+    producer.join()
+    for k, (view, _) in enumerate(held):                # all nine still readable, none overwritten by a later download
+        assert common.sort_photons(np.array(view)).tobytes() == expected[k], k
+    for _, release in held:
+        release()
+    for k in (9, 10):                                   # and the pool serves the next bunches from what came back
+        conv.EnqueueSteps(bunches[k], k)
+        ident, ph = conv.GetConversionResult()
+        assert ident == k and common.sort_photons(ph).tobytes() == expected[k]
