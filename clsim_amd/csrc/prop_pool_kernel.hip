@@ -689,10 +689,12 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
         // 3, 16: 3.71 / 2.84; 5, 16: 3.72 / 2.87; 8, 16: 3.71 / 2.85; 1, -: 3.72 / 2.68; 3, none: 3.39 / 2.84
         // (profiles/r03/string_aimed_filter.txt)
         if (P.k_search <= 0) P.k_search = (r < 0.95) ? 1 : (FLASHER ? 1 : 5);
-        // (flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96)
+        // (round 2, flasher steps, 2.6M: 4 free lanes per service 1.58e9 photons/s, 6: 1.60, 8: 1.61; cascade steps: 3 and 4 3.02e9, 6: 3.00, 8: 2.96.
+        // Round 4, ring of 45 and the inside-a-DOM filter: flasher steps 3, 4, 5: 2.48e9, 6: 2.47, 8: 2.44, 10: 2.41, 12: 2.37; cascade steps
+        // 3: 3.99, 4 - 6: 4.01 - 4.02, 8: 3.99; SPICE-Lea 4, 5: 3.42, 6: 3.41; benchmark.py 4: 3.00, 5: 2.99, 6: 2.98 -- profiles/r04/scan_k_pop.txt)
         if (P.k_wait < 0) P.k_wait = 16;          // (0 is honoured: search as soon as a lane is parked)
         if (P.k_aim < 0) P.k_aim = 8;             // (0 is honoured: the string-aimed level is off)
-        if (P.k_pop <= 0) P.k_pop = FLASHER ? 8 : 4;
+        if (P.k_pop <= 0) P.k_pop = 4;
         if (P.k_pop > 64) P.k_pop = 64;
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon
         // (ring of 34: threshold 20 2.76e9 photons/s, 26: 2.81, 30: 2.84, 33: 2.85)
