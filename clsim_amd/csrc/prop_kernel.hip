@@ -949,10 +949,14 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
         const int share = (P.chip_share > 1) ? P.chip_share : 1;
         const int cus = (plan.cus / share > 0) ? plan.cus / share : 1;
         const int per_cu = resident / plan.cus;
-        const int floor_per_cu = per_cu < 5 ? per_cu : 5;
+        // TABULATE (round 4, 200-photon steps at the origin, 4 axes): a lane that has a second unit to take balances the end of the launch;
+        // 262 144 steps on 3 workgroups per CU (r = 1.33) 2.306e7 photons/s, 3.5: 2.29, 4 (r = 1): 2.236, 2.5: 2.07; 524 288 steps on 5, 4, 3
+        // per CU: 2.34 / 2.25 / 2.35 (profiles/r04/tab_grid_scan.txt); with the impact-angle axis 3 and 4 per CU are level
+        const int floor_per_cu = TABULATE ? (per_cu < 3 ? per_cu : 3) : (per_cu < 5 ? per_cu : 5);
+        const double steps_per_lane_wanted = TABULATE ? 1.3 : 2.0;
         int chosen = floor_per_cu;
         for (int k = per_cu; k >= floor_per_cu; --k)
-            if ((double)P.n_steps / ((double)cus * k * kBlock) >= 2.0) { chosen = k; break; }
+            if ((double)P.n_steps / ((double)cus * k * kBlock) >= steps_per_lane_wanted) { chosen = k; break; }
         grid = (uint32_t)(cus * chosen);
     }
     if (const char *e = getenv("CLSIMHIP_GRID")) {
