@@ -967,7 +967,10 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     {
         const double r = (double)P.n_steps / ((double)grid * kBlock);
         if (P.slices <= 0) P.slices = (r < 1.0) ? 1 : 16;
-        if (P.k_new <= 0) P.k_new = 12;
+        // lanes without a photon before a wave creates (round 4, profiles/r04/scan_classic_k_new.txt: cascade steps, 262 144 / 393 216 per bunch,
+        // 12: 1.978 / 2.591e9 photons/s, 16: 1.985 / 2.607, 20: 1.973 / 2.611, 8: 1.92 / 2.48; flasher steps, 312 320 / 458 752: 8: 1.630 / 1.969,
+        // 10: 1.629 / 1.965, 12: 1.616 / 1.954, 16: 1.57 / -)
+        if (P.k_new <= 0) P.k_new = TABULATE ? 12 : (FLASHER ? 8 : 16);
         // lanes parked before a wave searches for DOMs: pays when lanes have plenty of steps (1.5M steps: 3 -> 5 is
         // +1.6 %), costs when they are scarce (0.8M steps: -1.7 %)
         // (flasher instantiations: searches are rare since the filter knows about photons inside their DOM of birth, prop_device.hip.h:
