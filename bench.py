@@ -77,12 +77,14 @@ def parse():
                          "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
                          "c2 -> C4 = 100M steps / 8 = 12 500 000 per GPU (weak scaling), c5 -> 10^9 photons / N (strong scaling)")
     ap.add_argument("--keep-detected", action="store_true",
-                    help="SetStopDetectedPhotons(false): the instantiations without STOP_PHOTONS_ON_DETECTION (classic kernel, every DOM on "
-                         "a photon's way records it); an extra measurement, never the headline")
+                    help="SetStopDetectedPhotons(false): the instantiations without STOP_PHOTONS_ON_DETECTION (every DOM on a photon's way "
+                         "records it; pooled kernel for large bunches like the default mode); an extra measurement, never the headline")
     ap.set_defaults(c3_as_written=False)
-    ap.add_argument("--verify-gather", action="store_true",
-                    help="N>1 (or CLSIMHIP_BENCH_GATHER=1): after the timed region, one more launch whose gathered photons on rank 0 "
-                         "are compared with every rank's own buffer (record counts and a 64-bit sum); config.gather_verified")
+    ap.add_argument("--verify-gather", dest="verify_gather", action="store_true", default=None,
+                    help="after the timed region, one more launch whose gathered photons on rank 0 are compared with every rank's own "
+                         "buffer (record counts and a 64-bit sum); config.gather_verified.  DEFAULT at N>1; at N=1 only with "
+                         "CLSIMHIP_BENCH_GATHER=1 and this flag")
+    ap.add_argument("--no-verify-gather", dest="verify_gather", action="store_false", help="N>1: skip the gather verification launch")
     return ap.parse_args()
 
 
@@ -500,6 +502,8 @@ def emit(line):
 
 
 JSON_FD = 1
+EXIT_PORT_TAKEN = 98            # a self-launched rank found MASTER_PORT in use (launch_ranks starts the world again)
+EXIT_NOT_N_DEVICES = 4          # an N>1 run whose ranks do not sit on N distinct devices (or whose communicator disagrees)
 
 
 def launch_ranks(args):
@@ -510,40 +514,52 @@ def launch_ranks(args):
     dies the others (which would wait for it in a collective) are ended by their own process IDs."""
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     sys.stdout.flush()
-    children = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLSIMHIP_BENCH_SELF_LAUNCHED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
-        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    worst, failed_at = 0, None
-    while any(c.poll() is None for c in children):
+    worst = 0
+    for attempt in range(4):
+        # a free port now is not a free port when rank 0 binds it: a child that finds it taken exits with EXIT_PORT_TAKEN
+        # and the whole world is started again on another port (ADVICE r4)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        children = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLSIMHIP_BENCH_SELF_LAUNCHED="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+            children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        failed_at = None
+        while any(c.poll() is None for c in children):
+            for c in children:
+                rc = c.poll()
+                if rc is not None and rc not in (0, 3) and failed_at is None:
+                    failed_at = time.time()             # (3 = the line was printed for the torch.distributed fallback)
+                    if rc == EXIT_PORT_TAKEN:
+                        failed_at -= 18.0               # nothing to wait for: the others are waiting for a store that is not ours
+            if failed_at is not None and time.time() - failed_at > 20.0:
+                for c in children:
+                    if c.poll() is None:
+                        c.terminate()
+                for c in children:
+                    try:
+                        c.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        c.kill()
+                break
+            time.sleep(0.2)
+        codes = []
         for c in children:
-            rc = c.poll()
-            if rc is not None and rc not in (0, 3) and failed_at is None:
-                failed_at = time.time()                 # (3 = the line was printed for the torch.distributed fallback)
-        if failed_at is not None and time.time() - failed_at > 20.0:
-            for c in children:
-                if c.poll() is None:
-                    c.terminate()
-            for c in children:
-                try:
-                    c.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    c.kill()
-            break
-        time.sleep(0.2)
-    for r, c in enumerate(children):
-        rc = c.wait()
-        rc = rc if rc >= 0 else 128 - rc
-        if rc:
-            sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, rc))
-        worst = max(worst, rc)
+            rc = c.wait()
+            codes.append(rc if rc >= 0 else 128 - rc)
+        if EXIT_PORT_TAKEN in codes and attempt < 3:
+            sys.stderr.write("bench.py: port %d was taken before rank 0 could bind it; starting the ranks again on another port\n" % port)
+            continue
+        for r, rc in enumerate(codes):
+            if rc:
+                sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, rc))
+        worst = max(codes)
+        break
     sys.exit(worst)
 
 
@@ -606,10 +622,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctl = torch.device("cpu") if rehearsal else dev     # where the control tensors of torch.distributed live
     if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        except Exception as exc:
+            if os.environ.get("CLSIMHIP_BENCH_SELF_LAUNCHED") == "1" and ("EADDRINUSE" in str(exc) or "address already in use" in str(exc).lower()):
+                sys.stderr.write("bench.py: rank %d: %s\n" % (rank, str(exc)[:200]))
+                sys.exit(EXIT_PORT_TAKEN)
+            raise
 
     if args.workload in ("tab", "tab5"):
         return tabulator_bench(args, torch, local_rank)
@@ -719,7 +741,7 @@ def main():
         comm_stream = torch.cuda.Stream(device=dev) if overlap else compute
     kernel_done = [torch.cuda.Event() for _ in range(n_buffers)]
     gather_done = [torch.cuda.Event() for _ in range(n_buffers)]
-    state = {"pending": None, "hits": 0, "pass": 0, "overflow": 0}
+    state = {"pending": None, "hits": 0, "pass": 0, "overflow": 0, "per_rank_hits": np.zeros(world, dtype=np.int64)}
 
     def do_gather(b):
         comm_stream.wait_event(kernel_done[b])
@@ -735,6 +757,7 @@ def main():
                     counts[rank] = raw
         gather_done[b].record(comm_stream)
         state["hits"] += int(np.minimum(counts, capacity).sum())
+        state["per_rank_hits"] += np.minimum(counts, capacity).astype(np.int64)
         state["overflow"] += int((counts > capacity).sum())
 
     def one_launch(bunch):
@@ -774,14 +797,19 @@ def main():
     flush()
     barrier()
     conv.KernelTimeMs(reset=True)
+    if gatherer is not None:
+        gatherer.statistics(reset=True)
     state["hits"] = 0
+    state["per_rank_hits"][:] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
     flush()
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     kernel_ms, launches = conv.KernelTimeMs(reset=True)
+    gather_stats = gatherer.statistics() if gatherer is not None else None
     counted_last = int(d_count[(state["pass"] - 1) % n_buffers].cpu().item())
     hits_last = min(counted_last, capacity)             # the counter keeps counting past the buffer; `capacity` records are stored
 
@@ -790,8 +818,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- who took part: every rank reports the device it ran on (PCI bus id as the LIBRARY's communicator
+    # sees it), what its RCCL communicator says about the world (ncclCommCount / ncclCommUserRank), its own kernel and
+    # gather times and its hits; all-gathered over the control group.  Outside a rehearsal an N>1 run whose ranks do not
+    # sit on N distinct devices, or whose communicator does not count N ranks, prints no line and exits non-zero.
+    identity = None
+    if use_gather:
+        info = gatherer.info() if gatherer is not None else {"rccl_ranks": None, "rccl_rank": None, "device": local_rank, "pci_bus_id": None}
+        if not info.get("pci_bus_id"):
+            props = torch.cuda.get_device_properties(dev)
+            if hasattr(props, "pci_bus_id"):
+                info["pci_bus_id"] = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+        mine = dict(info, rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid(),
+                    visible_devices=os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")),
+                    devices_visible_to_rank=torch.cuda.device_count(), device_name=torch.cuda.get_device_name(dev),
+                    kernel_ms=kernel_ms, launches=int(launches), seconds=own_elapsed,
+                    gather_ms=(gather_stats["gather_ms"] if gather_stats else None),
+                    gathers=(gather_stats["gathers"] if gather_stats else None),
+                    records_sent=(gather_stats["records_sent"] if gather_stats else None),
+                    records_received=(gather_stats["records_received"] if gather_stats else None))
+        everyone = [None] * world
+        if world > 1:
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
+        buses = [e["pci_bus_id"] for e in everyone]
+        counted = [e["rccl_ranks"] for e in everyone]
+        distinct = len(set(buses)) == world and None not in buses
+        agree = gatherer is None or (all(c == world for c in counted) and sorted(e["rccl_rank"] for e in everyone) == list(range(world)))
+        if world > 1 and not rehearsal and not (distinct and agree):
+            if rank == 0:
+                sys.stderr.write("bench.py: --gpus %d but the ranks sit on devices %s and their communicators count %s ranks: not an "
+                                 "N-GPU run, no line printed\n" % (world, buses, counted))
+            if gatherer is not None:
+                gatherer.close()
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(EXIT_NOT_N_DEVICES)
+
+        def spread(key):
+            v = [e[key] for e in everyone]
+            if any(x is None for x in v):
+                return None
+            return {"min": min(v), "max": max(v), "argmax_rank": int(np.argmax(v)), "mean": float(np.mean(v))}
+        identity = {"rccl_ranks": (counted[0] if gatherer is not None else None),
+                    "rccl_ranks_source": "ncclCommCount of the library's communicator on every rank (all equal)" if gatherer is not None else
+                                         "none: the torch.distributed fallback ran",
+                    "control_group": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1)},
+                    "rank_devices": buses, "distinct_devices": len(set(buses)),
+                    "rank_device_names": sorted(set(e["device_name"] for e in everyone)),
+                    "per_rank": {"kernel_ms": spread("kernel_ms"), "gather_ms": spread("gather_ms"), "seconds": spread("seconds"),
+                                 "launches": spread("launches"), "gathers": spread("gathers"),
+                                 "hits_stored_timed_region": [int(v) for v in state["per_rank_hits"]],
+                                 "records_sent": [e["records_sent"] for e in everyone],
+                                 "records_received_by_root": everyone[0]["records_received"],
+                                 "pids": [e["pid"] for e in everyone], "visible_devices": [e["visible_devices"] for e in everyone],
+                                 "devices_visible_to_rank": [e["devices_visible_to_rank"] for e in everyone]}}
+
     verified = None
-    if args.verify_gather and use_gather:
+    verify = use_gather and (args.verify_gather if args.verify_gather is not None else world > 1)
+    if verify:
         # outside the timed region: one more launch of the last bunch, gathered, and rank 0's buffer compared with what
         # each rank holds -- a 64-bit sum over every rank's records and the exact record counts
         hits_timed, state["hits"] = state["hits"], 0
@@ -877,6 +963,8 @@ def main():
                        "hits_gathered_per_pass": (state["hits"] / args.steps) if use_gather else None,
                        "overflowed_buffers": state["overflow"] + (1 if counted_last > capacity else 0),
                        "gather_verified": verified},
+            "multi_gpu_evidence": ("none: no run on more than one GPU exists yet; this line is one GPU" if world == 1 else
+                                   "this run: see config.rccl_ranks / rank_devices / per_rank; the scaling curve is the driver's to compute"),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "avg_kernel_ms": avg_ms, "launches": int(launches),
@@ -884,6 +972,19 @@ def main():
                          "note": "VALU/divergence-bound kernel (`valu`: useful_frac = the reference's arithmetic per photon x photons/s over the "
                                  "chip's vector peak); kernel-only rate %.4g photons/s" % kernel_rate},
         }
+        # the scalars of the operative (vector-issue) roofline directly in `roofline`: a parser that keeps scalars only still sees them
+        rf = out["roofline"]
+        rf["traffic_ratio"] = (traffic / alg_bytes) if traffic else None
+        rf["pmc_is_stored"] = bool(pmc)         # PMC-derived fields = stored rocprofv3 --pmc counts of this command x the LIVE kernel time
+        rf["valu_useful_frac"] = valu.get("useful_frac") if valu else None
+        rf["valu_useful_frac_counting_instructions"] = valu.get("useful_frac_counting_instructions") if valu else None
+        rf["valu_issue_slot_frac"] = valu.get("issue_slot_frac") if valu else None
+        rf["valu_lane_utilisation"] = valu.get("lane_utilisation") if valu else None
+        rf["valu_overhead_ratio"] = valu.get("overhead_ratio") if valu else None
+        rf["valu_floor_issue_slots_per_photon"] = valu["reference_ops_per_photon"]["transformed_issue_slots"] if valu else None
+        rf["kernel_photons_per_s"] = kernel_rate
+        if identity is not None:
+            out["config"].update(identity)
         if world > 1 or (args.shard_steps > 0 and not args.c3_as_written):
             # the like-for-like N = 1 point of a scaling curve: ONE GPU running this very per-GPU shard (same bunches, gather
             # path on), measured by the builder with `python bench.py --gpus 1 --shard-steps <shard> [--workload ...]` under

@@ -89,6 +89,7 @@ SYMBOLS = [
     "clsimhip_step_series_blob_size", "clsimhip_encode_step_series", "clsimhip_decode_step_series",
     "clsimhip_photon_series_blob_size", "clsimhip_encode_photon_series", "clsimhip_decode_photon_series", "clsimhip_encode_portable_uint",
     "clsimhip_comm_get_unique_id", "clsimhip_comm_create", "clsimhip_comm_destroy", "clsimhip_gather_hits",
+    "clsimhip_comm_info", "clsimhip_comm_statistics",
     "clsimhip_set_wlen_generators", "clsimhip_set_wlen_bias", "clsimhip_set_medium_properties", "clsimhip_set_geometry",
     "clsimhip_set_geometry_from_text_file",
     "clsimhip_set_enable_double_buffering", "clsimhip_set_double_precision", "clsimhip_set_stop_detected_photons",
@@ -171,6 +172,8 @@ def load():
         "clsimhip_comm_get_unique_id": (i32, [vp]),
         "clsimhip_comm_create": (i32, [i32, i32, i32, vp, C.POINTER(vp)]),
         "clsimhip_comm_destroy": (None, [vp]),
+        "clsimhip_comm_info": (i32, [vp, vp, vp, vp, vp, C.c_size_t]),
+        "clsimhip_comm_statistics": (i32, [vp, vp, vp, vp, vp, i32]),
         "clsimhip_gather_hits": (i32, [vp, vp, vp, sz, i32, vp, sz, vp, vp]),
         "clsimhip_set_wlen_generators": (i32, [vp, C.POINTER(RandomValue), sz]),
         "clsimhip_set_wlen_bias": (i32, [vp, C.POINTER(Function)]),

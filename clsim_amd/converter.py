@@ -409,16 +409,16 @@ class I3CLSimStepToPhotonConverterHIP:
         PhotonHistoryEntries); None when no histories are recorded).  The photons are copied out of the library's buffer
         (like the C++ adapter copies them into the I3CLSimPhotonSeries it hands to the caller): into `out`, a PHOTON_DTYPE
         array the caller recycles, when it is given and large enough -- a view of it is returned."""
+        # a recycled buffer is written through its raw address: it must be exactly what the records are -- checked before a
+        # result is taken, whatever that result holds (the contract does not depend on the data)
+        if out is not None and not (isinstance(out, np.ndarray) and out.dtype == PHOTON_DTYPE and out.ndim == 1 and out.flags.c_contiguous
+                                    and out.flags.writeable):
+            raise ValueError("GetConversionResult(out=...): a writeable, C-contiguous one-dimensional array of PHOTON_DTYPE (80-byte records) is required")
         ident, ptr, n = C.c_uint32(), C.c_void_p(), C.c_size_t()
         self._call("clsimhip_get_conversion_result", C.byref(ident), C.byref(ptr), C.byref(n))
         histories = None
         if n.value:
             buf = (C.c_char * (n.value * 80)).from_address(ptr.value)
-            if out is not None:
-                # a recycled buffer is written through its raw address: it must be exactly what the records are
-                if not (isinstance(out, np.ndarray) and out.dtype == PHOTON_DTYPE and out.ndim == 1 and out.flags.c_contiguous and out.flags.writeable):
-                    self._call("clsimhip_release_result", ptr)
-                    raise ValueError("GetConversionResult(out=...): a writeable, C-contiguous one-dimensional array of PHOTON_DTYPE (80-byte records) is required")
             if out is not None and len(out) >= n.value:
                 C.memmove(out.ctypes.data, ptr.value, n.value * 80)
                 photons = out[:n.value]

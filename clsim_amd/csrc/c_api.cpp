@@ -402,6 +402,14 @@ int clsimhip_comm_create(int device_ordinal, int rank, int world_size, const uin
     return guarded(nullptr, [&] { need(out, "out"); *out = reinterpret_cast<clsimhip_comm *>(comm_create(device_ordinal, rank, world_size, id)); });
 }
 void clsimhip_comm_destroy(clsimhip_comm *comm) { comm_destroy(reinterpret_cast<Comm *>(comm)); }
+int clsimhip_comm_info(clsimhip_comm *comm, int *rccl_ranks, int *rccl_rank, int *device_ordinal, char *pci_bus_id, size_t pci_bus_id_bytes)
+{
+    return guarded(nullptr, [&] { comm_info(reinterpret_cast<Comm *>(comm), rccl_ranks, rccl_rank, device_ordinal, pci_bus_id, pci_bus_id_bytes); });
+}
+int clsimhip_comm_statistics(clsimhip_comm *comm, uint64_t *gathers, double *gather_ms, uint64_t *records_sent, uint64_t *records_received, int reset)
+{
+    return guarded(nullptr, [&] { comm_statistics(reinterpret_cast<Comm *>(comm), gathers, gather_ms, records_sent, records_received, reset != 0); });
+}
 int clsimhip_gather_hits(clsimhip_comm *comm, const void *d_photons, const void *d_hit_count, size_t capacity, int root,
                          void *d_gathered, size_t gathered_capacity, uint64_t *counts_out, void *hip_stream)
 {

@@ -28,6 +28,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -60,6 +62,8 @@ const Rccl &rccl()
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
@@ -92,6 +96,35 @@ struct Comm {
     uint32_t *h_mine = nullptr;         // kWords, pinned
     uint32_t *h_all = nullptr;          // world x kWords, pinned
     hipEvent_t counted = nullptr;
+    // what the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank after ncclCommInitRank), not what the
+    // caller passed in: a multi-GPU record quotes these
+    int rccl_ranks = 0, rccl_rank = -1;
+    char pci_bus_id[32] = {0};
+    // per-gather timing on the caller's stream (events resolved lazily, in comm_statistics)
+    struct Timed { hipEvent_t begin, end; };
+    std::vector<Timed> in_flight, spare;
+    uint64_t gathers = 0, records_sent = 0, records_received = 0;
+    double gather_ms = 0.0;
+    std::mutex mutex;
+
+    void resolve_timers()
+    {
+        for (Timed &t : in_flight) {
+            float ms = 0.f;
+            if (hipEventSynchronize(t.end) == hipSuccess && hipEventElapsedTime(&ms, t.begin, t.end) == hipSuccess) gather_ms += ms;
+            spare.push_back(t);
+        }
+        in_flight.clear();
+    }
+    Timed take_timer()
+    {
+        if (in_flight.size() >= 256) resolve_timers();
+        if (!spare.empty()) { Timed t = spare.back(); spare.pop_back(); return t; }
+        Timed t{nullptr, nullptr};
+        hip_ok(hipEventCreate(&t.begin), "hipEventCreate");
+        hip_ok(hipEventCreate(&t.end), "hipEventCreate");
+        return t;
+    }
 };
 
 void comm_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES])
@@ -115,6 +148,16 @@ Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNI
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     nccl_check(rccl().CommInitRank(&c->comm, world, u, rank), "ncclCommInitRank");
+    // the communicator's own view must be the caller's: a record that says "N ranks" quotes ncclCommCount
+    nccl_check(rccl().CommCount(c->comm, &c->rccl_ranks), "ncclCommCount");
+    nccl_check(rccl().CommUserRank(c->comm, &c->rccl_rank), "ncclCommUserRank");
+    if (c->rccl_ranks != world || c->rccl_rank != rank) {
+        const std::string what = "the RCCL communicator reports rank " + std::to_string(c->rccl_rank) + " of " + std::to_string(c->rccl_ranks) +
+                                 ", asked for rank " + std::to_string(rank) + " of " + std::to_string(world);
+        (void)rccl().CommDestroy(c->comm);
+        throw Error(CLSIMHIP_ERR_DEVICE, what);
+    }
+    if (hipDeviceGetPCIBusId(c->pci_bus_id, static_cast<int>(sizeof c->pci_bus_id), device) != hipSuccess) c->pci_bus_id[0] = 0;
     const size_t words = Comm::kWords * static_cast<size_t>(world);
     hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_mine), sizeof(uint32_t) * Comm::kWords), "hipMalloc");
     hip_ok(hipMalloc(reinterpret_cast<void **>(&c->d_all), sizeof(uint32_t) * words), "hipMalloc");
@@ -122,6 +165,32 @@ Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNI
     hip_ok(hipHostMalloc(reinterpret_cast<void **>(&c->h_all), sizeof(uint32_t) * words, hipHostMallocDefault), "hipHostMalloc");
     hip_ok(hipEventCreateWithFlags(&c->counted, hipEventDisableTiming), "hipEventCreate");
     return c.release();
+}
+
+void comm_info(Comm *c, int *ranks, int *rank, int *device, char *pci_bus_id, size_t pci_bytes)
+{
+    if (!c) throw Error(CLSIMHIP_ERR_ARGUMENT, "communicator is (null)");
+    if (ranks) *ranks = c->rccl_ranks;
+    if (rank) *rank = c->rccl_rank;
+    if (device) *device = c->device;
+    if (pci_bus_id && pci_bytes) {
+        std::strncpy(pci_bus_id, c->pci_bus_id, pci_bytes - 1);
+        pci_bus_id[pci_bytes - 1] = 0;
+    }
+}
+
+// Blocks until the gathers issued so far have finished on their streams.
+void comm_statistics(Comm *c, uint64_t *gathers, double *gather_ms, uint64_t *records_sent, uint64_t *records_received, bool reset)
+{
+    if (!c) throw Error(CLSIMHIP_ERR_ARGUMENT, "communicator is (null)");
+    DeviceGuard on_device(c->device);
+    std::lock_guard<std::mutex> lock(c->mutex);
+    c->resolve_timers();
+    if (gathers) *gathers = c->gathers;
+    if (gather_ms) *gather_ms = c->gather_ms;
+    if (records_sent) *records_sent = c->records_sent;
+    if (records_received) *records_received = c->records_received;
+    if (reset) { c->gathers = c->records_sent = c->records_received = 0; c->gather_ms = 0.0; }
 }
 
 void comm_destroy(Comm *c)
@@ -136,6 +205,8 @@ void comm_destroy(Comm *c)
     if (c->h_mine) (void)hipHostFree(c->h_mine);
     if (c->h_all) (void)hipHostFree(c->h_all);
     if (c->counted) (void)hipEventDestroy(c->counted);
+    c->resolve_timers();
+    for (Comm::Timed &t : c->spare) { (void)hipEventDestroy(t.begin); (void)hipEventDestroy(t.end); }
     if (previous >= 0) (void)hipSetDevice(previous);
     delete c;
 }
@@ -160,6 +231,14 @@ void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, s
     DeviceGuard on_device(c->device);
     const Rccl &R = rccl();
     const size_t W = Comm::kWords;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    const Comm::Timed timer = c->take_timer();
+    hip_ok(hipEventRecord(timer.begin, stream), "event");
+    // (whatever happens below, the pair is closed and accounted for)
+    struct CloseTimer {
+        Comm *c; Comm::Timed t; hipStream_t s;
+        ~CloseTimer() { (void)hipEventRecord(t.end, s); c->in_flight.push_back(t); ++c->gathers; }
+    } close_timer{c, timer, stream};
     c->h_mine[0] = 0;
     c->h_mine[1] = static_cast<uint32_t>(std::min<size_t>(capacity, 0xffffffffu));
     c->h_mine[2] = static_cast<uint32_t>(static_cast<uint64_t>(gathered_capacity) & 0xffffffffu);
@@ -181,6 +260,8 @@ void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, s
         travels[r] = static_cast<size_t>(std::min<uint64_t>(stored, room - accepted));
         accepted += travels[r];
         total += stored;
+        if (r != root && c->rank == root) c->records_received += travels[r];
+        if (r == c->rank && c->rank != root) c->records_sent += travels[r];
     }
     constexpr size_t kRecord = sizeof(clsimhip_photon);
     if (c->world > 1) {

@@ -370,6 +370,7 @@ void Converter::setup_device_buffers()
     if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
     use_pool_ = true;
     pool_min_steps_ = kPooledKernelMinSteps;
+    pool_max_steps_ = pool_kernel_max_steps();
     if (const char *e = std::getenv("CLSIMHIP_KERNEL")) {          // pool / classic: that kernel for every bunch size
         use_pool_ = (std::strcmp(e, "pool") == 0);
         pool_min_steps_ = 0;
@@ -497,11 +498,27 @@ void Converter::finish(Slot &s, std::chrono::steady_clock::time_point &last_done
             r.pinned_capacity = buf.capacity;
             where = buf.p;
         } else {
+            // every pool buffer is with the caller (or the host refuses to page-lock more): the download goes into pageable memory,
+            // which is correct and slower -- said once, because nothing else shows it
+            static std::once_flag noted;
+            std::call_once(noted, [] {
+                std::fprintf(stderr, "clsimhip: every page-locked result buffer is in the caller's hands (release them with "
+                                     "clsimhip_release_result); photons are downloaded into pageable memory until one is free\n");
+            });
             photons.reset(new std::vector<clsimhip_photon>(hits));
             where = photons->data();
         }
-        hip_check(hipMemcpyAsync(where, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
-        hip_check(hipStreamSynchronize(copy_stream_), "download photons");
+        try {
+            hip_check(hipMemcpyAsync(where, s.d_photons, static_cast<size_t>(hits) * sizeof(DevPhoton), hipMemcpyDeviceToHost, copy_stream_), "download photons");
+            hip_check(hipStreamSynchronize(copy_stream_), "download photons");
+        } catch (...) {
+            // the pool buffer goes back to the pool (it stays counted in result_buffers_made_ and stays usable), not to hipHostFree
+            if (r.pinned) {
+                std::lock_guard<std::mutex> lk(result_pool_mutex_);
+                free_result_buffers_.push_back(PinnedBuffer{r.pinned.release(), r.pinned_capacity});
+            }
+            throw;
+        }
         if (!d_id_strings_) replace_indices(where, hits);      // OpenCL.cxx:1604-1619 does this on the caller thread
     }
     std::unique_ptr<std::vector<float>> histories;

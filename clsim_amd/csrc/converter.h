@@ -22,6 +22,7 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
 hipError_t launch_pool_kernel(const KParams &P, const KVariant &v, hipStream_t stream);
 hipError_t launch_pool_keep_kernel(const KParams &P, const KVariant &v, hipStream_t stream);     // prop_pool_keep_kernel.hip: without STOP_PHOTONS_ON_DETECTION
 bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings, int num_layers);
+size_t pool_kernel_max_steps();     // bunches beyond this many steps do not fit the pooled kernel's pending entries (23-bit step index)
 hipError_t launch_eval_math(int what, const float *xs, const float *ys, uint32_t n, float *out, hipStream_t stream);
 hipError_t launch_check_math(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap, hipStream_t stream);
 size_t prop_kernel_lds_bytes(uint32_t table_words);
@@ -45,6 +46,8 @@ struct Comm;
 void comm_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
 Comm *comm_create(int device, int rank, int world, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
 void comm_destroy(Comm *c);
+void comm_info(Comm *c, int *ranks, int *rank, int *device, char *pci_bus_id, size_t pci_bytes);
+void comm_statistics(Comm *c, uint64_t *gathers, double *gather_ms, uint64_t *records_sent, uint64_t *records_received, bool reset);
 void comm_gather_hits(Comm *c, const void *d_photons, const void *d_hit_count, size_t capacity, int root, void *d_gathered,
                       size_t gathered_capacity, uint64_t *counts_out, hipStream_t stream);
 
@@ -188,7 +191,11 @@ public:
     void set_device(int device);
     int device() const { return device_; }
     // the pooled kernel pays from ~3 steps per unit slot on: a launch that owns 1/k of the chip reaches that with 1/k of the steps
-    bool pooled_for(size_t n_steps) const { need_init(); return use_pool_ && n_steps * static_cast<size_t>(concurrent_launches_) >= pool_min_steps_; }
+    bool pooled_for(size_t n_steps) const
+    {
+        need_init();
+        return use_pool_ && n_steps <= pool_max_steps_ && n_steps * static_cast<size_t>(concurrent_launches_) >= pool_min_steps_;
+    }
     void set_concurrent_device_launches(int k);
     int concurrent_device_launches() const { return concurrent_launches_; }
     bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
@@ -295,6 +302,7 @@ private:
     int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)
     bool use_pool_ = false;                      // pooled kernel allowed (CLSIMHIP_KERNEL=pool|classic forces one)
     size_t pool_min_steps_ = 0;                  // ... for bunches of at least this many steps
+    size_t pool_max_steps_ = 0;                  // ... and at most this many (pool_kernel_max_steps(): the pending entries' 23-bit step index)
     hipError_t launch(const KParams &P, hipStream_t stream) const;
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
     hipStream_t copy_stream_ = nullptr;      // photon download

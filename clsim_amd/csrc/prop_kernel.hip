@@ -730,16 +730,21 @@ __global__ void __launch_bounds__(256) assemble_hits_kernel(const KParams Pvalue
         uint32_t *hw = reinterpret_cast<uint32_t *>(&h);
 #pragma unroll
         for (int w = 0; w < kStubWords; ++w) hw[w] = slot[w];
+        // A stub whose indices name no step / string / DOM (a corrupted record) is not expanded -- expanding it would read the step, the
+        // stream multiplier and the DOM tables out of range -- it stays as it is and is counted in queue[4]: the host path then fails
+        // the bunch like its own conversion would (converter.cpp: finish / replace_indices).  id_dom_start has one entry more than
+        // there are strings.
+        const uint32_t s_index = h.string_and_dom & 0xffffu, d_index = h.string_and_dom >> 16;
+        bool named = (h.step_index < P->n_steps) && (s_index < (uint32_t)P->num_strings);
+        if (named && P->id_strings) named = d_index < P->id_dom_start[s_index + 1u] - P->id_dom_start[s_index];
+        if (!named) {
+            atomicAdd(P->queue + 4, 1u);
+            continue;
+        }
         uint32_t rec[20];
         const float abs_lens_initial = make_hit_record<FLASHER>(P, h, rec);
-        if (P->id_strings) {                 // index -> ID (OpenCL.cxx:1565-1600), same for every record: wave-uniform branch
-            // (id_dom_start has one entry more than there are strings; a record whose indices do not name a DOM -- a corrupted stub -- keeps
-            // them and is counted in queue[4]: the host then fails the bunch like its own conversion would, converter.cpp: replace_indices)
-            const uint32_t s_index = rec[11] & 0xffffu, d_index = rec[11] >> 16;
-            const bool named = (s_index < (uint32_t)P->num_strings) && (d_index < P->id_dom_start[s_index + 1u] - P->id_dom_start[s_index]);
-            if (named) rec[11] = (uint32_t)(uint16_t)P->id_strings[s_index] | ((uint32_t)P->id_doms[P->id_dom_start[s_index] + d_index] << 16);
-            else atomicAdd(P->queue + 4, 1u);
-        }
+        if (P->id_strings)                   // index -> ID (OpenCL.cxx:1565-1600), same for every record: wave-uniform branch
+            rec[11] = (uint32_t)(uint16_t)P->id_strings[s_index] | ((uint32_t)P->id_doms[P->id_dom_start[s_index] + d_index] << 16);
 #pragma unroll
         for (int w = 0; w < 20; ++w) slot[w] = rec[w];
         // c.cl:836: the ring holds the absorption lengths LEFT at each scatter; the reference stores initial - left

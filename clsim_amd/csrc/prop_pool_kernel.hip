@@ -64,6 +64,11 @@ __host__ __device__ constexpr uint32_t pool_wave_words(uint32_t R, uint32_t extr
 // A pending unit: step index (below 2^23: a converter holds at most 6 139 850 streams), stream state, photons left in the slice (below 2^23: the
 // kernel's prologue caps the slice size), flags (slice number, last, waiting: 18 bits) -- 128 bits, one ds_read_b128 / ds_write_b128.  Every
 // word the ring does not need for the list is a ring entry more: 0.28 % per entry at 34 (profiles/r04/ab_ring_size.txt).
+// The index field is what bounds a bunch for this kernel: kPoolIndexBits + half of the 18 flag bits fill a word, so a bunch of 2^23 steps or
+// more never gets here (pool_kernel_max_steps(), Converter::pooled_for(), and the launcher below refuses it) -- the classic kernel runs it.
+constexpr uint32_t kPoolIndexBits = 23, kPoolFlagBits = 18, kPoolIndexMask = (1u << kPoolIndexBits) - 1u;
+static_assert(kPoolIndexBits + kPoolFlagBits / 2 == 32 && kPoolFlagBits % 2 == 0, "a pending entry's index (or count) and half of its flags share one word");
+static_assert((kFlagWaiting << 1) == (1u << kPoolFlagBits), "slice number + last + waiting are the 18 flag bits");
 typedef uint32_t pend_entry __attribute__((ext_vector_type(4)));
 DM void pend_store(uint32_t *list, uint32_t k, uint32_t sidx, uint64_t rx, uint32_t left, uint32_t flags)
 {
@@ -724,6 +729,7 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     if (P.history_n != 0 || v.tabulate || (v.keep_detected != CLSIMHIP_POOL_KEEP)) return hipErrorInvalidValue;
     if (P.num_layers >= (1 << 14)) return hipErrorInvalidValue;          // (a ring entry keeps the carried layer index in 14 bits: pool_kernel_fits() says so first)
+    if (P.n_steps > kPoolIndexMask) return hipErrorInvalidValue;          // (a pending entry keeps the step index in 23 bits: Converter::pooled_for() says so first)
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
     // CLSIMHIP_NO_FAST=1: the generic instantiation also where Compile() found every proof (tests compare the two)
     const char *no_fast = getenv("CLSIMHIP_NO_FAST");
@@ -743,6 +749,17 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
 }
 
 #ifndef CLSIMHIP_POOL_KEEP_UNIT
+// the largest bunch the pooled kernel's 23-bit step index can address (CLSIMHIP_POOL_INDEX_BITS lowers the GUARD for tests: bunches
+// beyond 2^bits - 1 steps then take the classic kernel, exactly what a bunch beyond 2^23 - 1 does)
+size_t pool_kernel_max_steps()
+{
+    uint32_t bits = kPoolIndexBits;
+    if (const char *e = getenv("CLSIMHIP_POOL_INDEX_BITS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < (int)kPoolIndexBits) bits = (uint32_t)v;
+    }
+    return (size_t{1} << bits) - 1;
+}
 // does the pooled kernel pay for this table image (its waves need at least kPoolWorthwhileReady ring entries)?  keep_strings: the
 // number of strings when the converter runs without STOP_PHOTONS_ON_DETECTION (the search's string masks share the pool's LDS), else 0
 bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings, int num_layers)

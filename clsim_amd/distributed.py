@@ -108,6 +108,23 @@ class HitGatherer:
             raise RuntimeError((self._lib.clsimhip_last_error(None) or b"").decode())
         return counts
 
+    def info(self):
+        """What the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), its HIP device and that device's PCI bus id."""
+        ranks, rank, device = C.c_int(0), C.c_int(-1), C.c_int(-1)
+        bus = C.create_string_buffer(32)
+        rc = self._lib.clsimhip_comm_info(self._h, C.byref(ranks), C.byref(rank), C.byref(device), bus, 32)
+        if rc != 0:
+            raise RuntimeError((self._lib.clsimhip_last_error(None) or b"").decode())
+        return {"rccl_ranks": ranks.value, "rccl_rank": rank.value, "device": device.value, "pci_bus_id": bus.value.decode()}
+
+    def statistics(self, reset=False):
+        """Gathers issued so far (waits for them): count, milliseconds on their stream, records sent / received."""
+        n, sent, received, ms = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        rc = self._lib.clsimhip_comm_statistics(self._h, C.byref(n), C.byref(ms), C.byref(sent), C.byref(received), 1 if reset else 0)
+        if rc != 0:
+            raise RuntimeError((self._lib.clsimhip_last_error(None) or b"").decode())
+        return {"gathers": n.value, "gather_ms": ms.value, "records_sent": sent.value, "records_received": received.value}
+
     def close(self):
         if self._h:
             self._lib.clsimhip_comm_destroy(self._h)

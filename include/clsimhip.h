@@ -314,6 +314,16 @@ int clsimhip_comm_get_unique_id(uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES]);
 /* ncclCommInitRank on HIP device `device_ordinal`; collective: every rank of the job calls it */
 int clsimhip_comm_create(int device_ordinal, int rank, int world_size, const uint8_t id[CLSIMHIP_UNIQUE_ID_BYTES], clsimhip_comm **out);
 void clsimhip_comm_destroy(clsimhip_comm *comm);
+/* What the communicator says about itself: ncclCommCount / ncclCommUserRank asked of the communicator after
+ * ncclCommInitRank (clsimhip_comm_create fails when they differ from what the caller passed), the HIP device it lives on
+ * and that device's PCI bus id (hipDeviceGetPCIBusId; "" if unknown).  A multi-GPU record quotes THESE numbers: N ranks
+ * with N distinct bus ids.  The reference reports per-device statistics from its server (I3CLSimServer.cxx:355-368).
+ * Any out pointer may be NULL. */
+int clsimhip_comm_info(clsimhip_comm *comm, int *rccl_ranks, int *rccl_rank, int *device_ordinal, char *pci_bus_id, size_t pci_bus_id_bytes);
+/* Gathers issued since creation (or the last reset): their number, the time they held the stream (HIP events around
+ * each clsimhip_gather_hits on its stream; the call waits for the gathers issued so far), the photon records this rank
+ * sent to a root / received as a root. */
+int clsimhip_comm_statistics(clsimhip_comm *comm, uint64_t *gathers, double *gather_ms, uint64_t *records_sent, uint64_t *records_received, int reset);
 /* Collective.  d_photons / d_hit_count: this rank's photon buffer (`capacity` records) and uint32 hit counter as
  * clsimhip_propagate_device left them.  On `root`, d_gathered (room for gathered_capacity records) receives rank 0's
  * photons, then rank 1's ...; counts_out[world_size] (host, every rank, may be NULL) receives the ranks' hit counters

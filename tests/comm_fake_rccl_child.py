@@ -33,12 +33,16 @@ def run_case(world, name, counters, capacity, root, gathered_capacity, salt, exp
     uid = HitGatherer.unique_id()
     errors = [None] * world
     results = [None] * world
+    stats = [None] * world
     barrier = threading.Barrier(world)
 
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
             g = HitGatherer(0, rank, world, uid)
+            info = g.info()
+            assert info["rccl_ranks"] == world and info["rccl_rank"] == rank and info["device"] == 0, info
+            assert len(info["pci_bus_id"]) >= 7 and info["pci_bus_id"].count(":") == 2, info          # "0000:75:00.0"
             stream = torch.cuda.Stream(device=dev)
             stored = min(counters[rank], capacity[rank])
             host = records(rank, capacity[rank], salt)
@@ -56,6 +60,10 @@ def run_case(world, name, counters, capacity, root, gathered_capacity, salt, exp
                     counts, raised = None, str(e)
                 stream.synchronize()
                 results[rank] = (counts, raised, gathered.cpu().numpy() if rank == root else None, host[:stored])
+            st = g.statistics()
+            assert st["gathers"] == rounds and st["gather_ms"] > 0.0, st
+            stats[rank] = st
+            assert g.statistics(reset=True)["gathers"] == rounds and g.statistics()["gathers"] == 0
             g.close()
         except BaseException as e:          # noqa: BLE001 -- reported by the main thread
             errors[rank] = e
@@ -79,6 +87,9 @@ def run_case(world, name, counters, capacity, root, gathered_capacity, salt, exp
     for r in range(world):
         travels.append(min(stored[r], room))
         room -= travels[-1]
+    for r in range(world):                  # the library's own account of what travelled
+        assert stats[r]["records_sent"] == (0 if r == root else travels[r] * rounds), (name, r, stats[r], travels)
+        assert stats[r]["records_received"] == ((sum(travels) - travels[root]) * rounds if r == root else 0), (name, r, stats[r], travels)
     expect = np.concatenate([results[r][3][:travels[r]] for r in range(world)]) if sum(travels) else np.zeros((0, 80), np.uint8)
     got = results[root][2]
     assert np.array_equal(got[:len(expect)], expect), "root buffer differs from the concatenation in case " + name
@@ -93,8 +104,33 @@ def run_case(world, name, counters, capacity, root, gathered_capacity, salt, exp
     print("case %s ok (world %d, %d records on the root)" % (name, world, len(expect)), flush=True)
 
 
+def lie_case(world):
+    """FAKE_RCCL_LIE_ABOUT_COUNT=1: every rank's communicator reports world - 1 ranks; clsimhip_comm_create must fail on all"""
+    uid = HitGatherer.unique_id()
+    seen = [None] * world
+
+    def rank_main(rank):
+        torch.cuda.set_device(0)
+        try:
+            HitGatherer(0, rank, world, uid)
+            seen[rank] = "created"
+        except RuntimeError as e:
+            seen[rank] = str(e)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive()
+    for r in range(world):
+        assert "reports rank %d of %d, asked for rank %d of %d" % (r, world - 1, r, world) in seen[r], seen
+    print("refused ok", flush=True)
+
+
 def main():
     world = int(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "lie":
+        return lie_case(world)
     rng = np.random.default_rng(100 + world)
     lib = C.CDLL(os.environ["CLSIMHIP_RCCL_LIBRARY"])
     cap = [4096] * world

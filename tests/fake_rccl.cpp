@@ -3,7 +3,7 @@
 // clsim_amd/csrc/comm.cpp loads RCCL by name at run time and honours CLSIMHIP_RCCL_LIBRARY; tests/test_comm_fake_rccl.py
 // points that variable at this library (in a child process) so that the multi-rank branch of clsimhip_gather_hits -- the
 // count all-gather, the grouped ncclSend / ncclRecv pairs, the overflow decision -- executes on the one GPU a test box
-// has.  It implements the nine entry points comm.cpp binds, with RCCL's calling rules checked rather than assumed:
+// has.  It implements the eleven entry points comm.cpp binds, with RCCL's calling rules checked rather than assumed:
 //   * ncclCommInitRank is collective (returns when all ranks of the id have joined),
 //   * ncclAllGather is collective, ordered after the work queued on the caller's stream,
 //   * ncclSend / ncclRecv must pair up (peer, byte count) -- a send nobody receives, a receive nobody sends, or a size
@@ -260,6 +260,22 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     if (shared_dir()) delete reinterpret_cast<FileComm *>(comm);
     else delete reinterpret_cast<FakeComm *>(comm);
+    return ncclSuccess;
+}
+
+// FAKE_RCCL_LIE_ABOUT_COUNT=1: the communicator reports one rank fewer than joined (the library must refuse it)
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = shared_dir() ? reinterpret_cast<const FileComm *>(comm)->n : reinterpret_cast<const FakeComm *>(comm)->world->n;
+    if (const char *e = std::getenv("FAKE_RCCL_LIE_ABOUT_COUNT")) if (e[0] == '1') --*count;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank)
+{
+    if (!comm || !rank) return ncclInvalidArgument;
+    *rank = shared_dir() ? reinterpret_cast<const FileComm *>(comm)->rank : reinterpret_cast<const FakeComm *>(comm)->rank;
     return ncclSuccess;
 }
 

@@ -31,7 +31,7 @@ def _run(world, workload, shard_steps, port, launcher="torchrun"):
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
             env.pop(k, None)
     cmd = front + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-                   "--workload", workload, "--verify-gather"] + (["--shard-steps", str(shard_steps)] if shard_steps else [])
+                   "--workload", workload] + (["--shard-steps", str(shard_steps)] if shard_steps else [])      # (gather verification: default at N>1)
     try:
         p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     finally:
@@ -57,7 +57,22 @@ def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port, launcher
     assert out["value"] is None and "REHEARSAL" in out["rehearsal"]
     cfg = out["config"]
     assert cfg["hit_gather"].startswith("clsimhip_gather_hits"), cfg["hit_gather"]          # not the torch.distributed fallback
-    assert cfg["gather_verified"] is True
+    assert cfg["gather_verified"] is True                    # without --verify-gather: it is the default at N > 1
+    # who took part, as the library's communicators and devices report it
+    assert cfg["rccl_ranks"] == world and cfg["control_group"]["world_size"] == world
+    assert len(cfg["rank_devices"]) == world and all(d and d.count(":") == 2 for d in cfg["rank_devices"])
+    assert cfg["distinct_devices"] == 1                      # the rehearsal's ranks time-share one GPU, and the line shows it
+    per = cfg["per_rank"]
+    for key in ("kernel_ms", "gather_ms", "seconds"):
+        assert per[key]["min"] > 0 and per[key]["max"] >= per[key]["min"] and 0 <= per[key]["argmax_rank"] < world, (key, per[key])
+    assert per["gathers"]["min"] == per["gathers"]["max"] == cfg["bunches_per_pass"]
+    assert len(set(per["pids"])) == world
+    assert sum(per["hits_stored_timed_region"]) == cfg["hits_gathered_per_pass"] and min(per["hits_stored_timed_region"]) > 0
+    assert per["records_sent"][0] == 0 and sum(per["records_sent"]) == per["records_received_by_root"] > 0
+    assert "multi_gpu_evidence" in out
+    rf = out["roofline"]
+    for key in ("valu_useful_frac", "valu_issue_slot_frac", "valu_lane_utilisation", "valu_overhead_ratio", "traffic_ratio", "pmc_is_stored"):
+        assert key in rf, key
     if shard is None:
         shard = 12500000
         assert cfg["bunches_per_pass"] == 3 and "C4 = BASELINE configs[3]" in cfg["workload"]

@@ -30,7 +30,7 @@ def test_fake_rccl_exports_what_comm_cpp_binds():
     lib = ctypes.CDLL(build_fake())
     src = open(os.path.join(ROOT, "clsim_amd", "csrc", "comm.cpp")).read()
     wanted = re.findall(r'sym\("(nccl\w+)"\)', src)
-    assert len(wanted) == 9
+    assert len(wanted) == 11 and "ncclCommCount" in wanted and "ncclCommUserRank" in wanted
     for name in wanted:
         assert hasattr(lib, name), name
 
@@ -43,3 +43,13 @@ def test_gather_hits_multi_rank_through_the_c_abi(world):
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     assert "all ok" in p.stdout
     assert p.stdout.count(" ok (world %d" % world) == 9
+
+
+@pytest.mark.gpu
+def test_a_communicator_that_counts_another_world_is_refused():
+    """clsimhip_comm_create asks the communicator itself (ncclCommCount / ncclCommUserRank): one that reports a world other
+    than the caller's never becomes a clsimhip_comm, so an N-rank record cannot be printed over it."""
+    env = dict(os.environ, CLSIMHIP_RCCL_LIBRARY=build_fake(), FAKE_RCCL_LIE_ABOUT_COUNT="1")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "comm_fake_rccl_child.py"), "2", "lie"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    assert "refused ok" in p.stdout

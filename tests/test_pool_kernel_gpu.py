@@ -114,3 +114,30 @@ def test_specialised_and_generic_instantiations_agree(pooled, name, n_steps, mon
         _, ph = conv.GetConversionResult()
         out.append((common.sort_photons(ph).tobytes(), conv.GetRNGState(len(steps)).tobytes()))
     assert out[0] == out[1]
+
+
+def test_bunch_beyond_the_pending_entries_step_index_takes_the_classic_kernel(pooled, monkeypatch):
+    """a pending entry of the pooled kernel keeps the step index in 23 bits; a converter may hold more streams than that
+    (user-supplied multipliers).  Converter::pooled_for() sends such bunches to the classic kernel and the pooled launcher refuses
+    them.  CLSIMHIP_POOL_INDEX_BITS lowers the guard (not the encoding), so the decision is testable with a small bunch: with 11
+    bits a bunch of 1 792 steps is pooled, one of 2 048 is not, and both give the oracle's photons."""
+    monkeypatch.setenv("CLSIMHIP_POOL_INDEX_BITS", "11")
+    cfg = common.config("mie")
+    T = common.oracle_tables(cfg)
+    x, a = common.streams(2048)
+    conv = common.product_converter(cfg, 2048)
+    assert conv.KernelForBunch(2047) == "pool" and conv.KernelForBunch(2048) == "classic"
+    xo = x
+    for n, expect in ((1792, "pool"), (2048, "classic")):
+        steps = common.steps_for(cfg, n, seed=41)
+        assert len(steps) == n and conv.KernelForBunch(n) == expect
+        ph_o, cnt_o, x_next, _ = capi.propagate(T, steps, xo[:n], a[:n], threads=8)
+        xo = np.concatenate([x_next, xo[n:]])
+        conv.EnqueueSteps(steps, 9)
+        _, ph_p = conv.GetConversionResult()
+        assert len(ph_p) == cnt_o and cnt_o > 10
+        assert common.sort_photons(capi.replace_indices_with_ids(ph_o, T.geo)).tobytes() == common.sort_photons(ph_p).tobytes()
+        assert np.array_equal(conv.GetRNGState(2048), xo)
+    monkeypatch.delenv("CLSIMHIP_POOL_INDEX_BITS")
+    conv = common.product_converter(cfg, 4096)
+    assert conv.KernelForBunch(4096) == "pool" and conv.KernelForBunch((1 << 23) - 1) == "pool" and conv.KernelForBunch(1 << 23) == "classic"

@@ -3,7 +3,16 @@ geometry bench.py measures (10 000 000 cascade steps x 200 photons on SPICE-Lea 
 from a point source at a DOM, 48 Mi-record photon buffer).  Pattern of test_baseline_size_properties: the whole bunch
 runs once on each of two converters (determinism: the multiset of all 80-byte records through an order-independent
 64-bit checksum computed on the device, and every final stream state), and the records of the first 2048 steps are
-pulled out of the big launch and compared bit for bit with the oracle run on those steps alone."""
+pulled out of the big launch and compared bit for bit with the oracle run on those steps alone.
+
+Round 5: a prefix never sees the end of the work queues, sub-queue exhaustion, unit retirement or the padded
+tail.  Steps are independent units with their own streams, so the oracle run on ANY subset of a bunch's steps, each with its own
+x[i], a[i], is exact: besides the prefix, 65 536 step indices drawn uniformly over the WHOLE bunch (the last 512 real steps and the
+first padding step always among them) are run through the oracle and compared, bit for bit, with the records of those identifiers
+inside the big launch and with those streams' final states -- both C3 bunches (the second from the first's final states at those
+indices), C5, and C2 without STOP_PHOTONS_ON_DETECTION on the pooled kernel."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,7 +55,29 @@ def prefix_records(records, m):
     return np.frombuffer(sub.tobytes(), dtype=PHOTON_DTYPE).copy()
 
 
-def check_at_size(cfg, bunches, capacity, hit_fraction_range, m=2048):
+SUBSET = 65536
+
+
+def whole_bunch_subset(steps, rng, size=SUBSET):
+    """sorted step indices spread over the whole bunch; always the last 512 real steps and, if the bunch is padded, the first
+    padding step and the very last step"""
+    n = len(steps)
+    real = int((steps["num"] > 0).sum()) if (steps["num"][-1] == 0) else n
+    forced = list(range(max(0, real - 512), real)) + ([real, n - 1] if real < n else [n - 1]) + [0]
+    drawn = rng.choice(n, size=min(size, n), replace=False)
+    return np.unique(np.concatenate([np.asarray(forced, dtype=np.int64), drawn.astype(np.int64)]))
+
+
+def subset_records(records, step_ids, n):
+    """records of the big launch (device tensor, n_hits x 80 bytes) whose identifier is in step_ids"""
+    wanted = torch.zeros(n, dtype=torch.bool, device=records.device)
+    wanted[torch.from_numpy(step_ids).to(records.device)] = True
+    ids = records.view(torch.int32)[:, 10].long()
+    sub = records[wanted[ids.clamp(0, n - 1)] & (ids >= 0) & (ids < n)].cpu().numpy()
+    return np.frombuffer(sub.tobytes(), dtype=PHOTON_DTYPE).copy()
+
+
+def check_at_size(cfg, bunches, capacity, hit_fraction_range, m=2048, stop_detected=True, expect_kernel="pool"):
     """bunches: step arrays of one size, run back to back on ONE converter (the RNG streams persist from bunch to bunch,
     propagation_kernel.c.cl:458-461, 911-912) -- and once more on a second converter."""
     if isinstance(bunches, np.ndarray):
@@ -55,16 +86,23 @@ def check_at_size(cfg, bunches, capacity, hit_fraction_range, m=2048):
     assert all(len(b) == n for b in bunches)
     dev = torch.device("cuda", 0)
     x, a = common.streams(n)
-    conv = common.product_converter(cfg, n)
-    conv_b = common.product_converter(cfg, n)
-    T = common.oracle_tables(cfg)
+    conv = common.product_converter(cfg, n, stop_detected=stop_detected)
+    conv_b = common.product_converter(cfg, n, stop_detected=stop_detected)
+    assert conv.KernelForBunch(n) == expect_kernel
+    T = common.oracle_tables(cfg, stop_detected=stop_detected)
     x_before, x_oracle, total = x, x[:m], 0
+    rng = np.random.default_rng(20260504)
+    threads = min(os.cpu_count() or 8, 256)
     for steps in bunches:
+        real = steps["num"] > 0                                          # a record's identifier IS its step's index (padding steps: no records)
+        assert np.array_equal(steps["id"][real], np.arange(n, dtype=steps["id"].dtype)[real])
         d_steps = torch.from_numpy(steps.view(np.uint8).reshape(n, 48).copy()).to(dev)
         rec1, cnt1 = big_run(conv, d_steps, n, capacity)
         x1 = conv.GetRNGState(n)
         sum1 = multiset_checksum(rec1)
         sub = prefix_records(rec1, m)
+        pick = whole_bunch_subset(steps, rng)
+        sub_pick = subset_records(rec1, pick, n)
         string_ok = bool((rec1.view(torch.int16)[:, 22] < 86).all()) and bool((rec1.view(torch.int16)[:, 22] >= 0).all())
         dom_ok = bool((rec1.view(torch.int16)[:, 23] < 60).all())
         del rec1
@@ -87,6 +125,12 @@ def check_at_size(cfg, bunches, capacity, hit_fraction_range, m=2048):
         assert len(sub) == cnt_o
         assert common.sort_photons(sub).tobytes() == common.sort_photons(ph_o).tobytes()
         assert np.array_equal(x1[:m], x_oracle)
+        # the same over the whole bunch: the drawn steps, each with ITS stream as the previous bunch left it
+        ph_s, cnt_s, x_s, _ = capi.propagate(T, steps[pick], x_before[pick], a[pick], threads=threads)
+        assert len(pick) >= min(SUBSET, n) and pick[-1] == n - 1 and cnt_s > 0.5 * len(pick) / n * cnt1
+        assert len(sub_pick) == cnt_s, (len(sub_pick), cnt_s)
+        assert common.sort_photons(sub_pick).tobytes() == common.sort_photons(ph_s).tobytes()
+        assert np.array_equal(x1[pick], x_s)
         x_before = x1
         total += cnt1
     return total
@@ -115,3 +159,14 @@ def test_c5_flasher_production_bunch():
     n = 2621440
     steps = S.flasher_steps(n, seed=1000, photons_per_step=400, position=(float(g["x"][k]), float(g["y"][k]), float(g["z"][k])))
     check_at_size(cfg, steps, capacity=48 << 20, hit_fraction_range=(5e-3, 5e-2))
+
+
+@pytest.mark.timeout(900)
+def test_c2_without_stop_on_detection_pooled_whole_bunch_subset():
+    """BASELINE configs[1] with the reference class's default detection mode (SetStopDetectedPhotons(false), OpenCL.cxx:86) on the
+    pooled kernel (prop_pool_keep_kernel.hip): 1 048 576 steps x 200 photons, a 65 536-step subset of the whole bunch and the
+    prefix against the oracle's restatement of that mode."""
+    cfg = common.config("mie")
+    n = 1 << 20
+    steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
+    check_at_size(cfg, steps, capacity=4 << 20, hit_fraction_range=(2e-4, 3e-3), stop_detected=False)
