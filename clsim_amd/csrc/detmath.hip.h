@@ -11,9 +11,16 @@
 // Polynomials: Cephes single precision (logf, expf, sinf, cosf), Horner form.
 // powr keeps log(x) as an unevaluated hi+lo pair so that |y*log x| ~ 10 (the
 // lambda^-kappa of the ice model) still rounds within ~1.2 ulp.
+//
+// Round 5: log, and sin / cos of arguments in [0, RN(2 pi)], are the table forms of oracle/oracle_math.h (om_log,
+// om_sincos_2pi) -- constants in math_tables.h (tools/make_math_tables.py writes the same text for both sides): 16 and
+// 17 vector instructions in place of 22 and 31.  The propagation kernels read the two tables from the front of their LDS
+// image (prop_device.hip.h: lds_log / lds_sincos_2pi; kMathTableWords), every other kernel from the global copies below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "math_tables.h"
 
 #define DM __device__ __forceinline__
 
@@ -118,6 +125,13 @@ DM float rsqrt_unit_(float x)
     return u2f((d < 0) ? below : above);
 }
 
+// the tables: words [0, 128) of an LDS image = 32 log rows {INV, H, L, 0}; words [128, 194) = 33 sincos rows {S, C}; padded to 196
+constexpr uint32_t kMathLogWords = 4u * MT_LOG_ROWS, kMathScWords = 2u * MT_SC_ROWS, kMathTableWords = (kMathLogWords + kMathScWords + 3u) & ~3u;
+static __device__ const float kLogTable[kMathLogWords] = MT_LOG_TABLE;
+static __device__ const float kScTable[kMathScWords] = MT_SC_TABLE;
+static const float kLogTableHost[kMathLogWords] = MT_LOG_TABLE;       // (what tables.cpp puts at the front of the LDS image)
+static const float kScTableHost[kMathScWords] = MT_SC_TABLE;
+
 constexpr float LN2_HI = 0.693359375f;
 constexpr float LN2_LO = -2.12194440e-4f;
 constexpr float LOG2E = 1.44269504088896341f;
@@ -145,18 +159,40 @@ DM float frexp_sqrt2(float x, int &e)
     return u2f(ix - ((uint32_t)e << 23));
 }
 
-DM float log_(float x)
+// A table in LDS is named by its BYTE ADDRESS (LdsTable{address}): the row load is then a ds_read whose address register holds
+// nothing but the row's offset -- through the symbol of the dynamic LDS array the compiler adds that symbol's address (0) with an
+// instruction of its own.  (In LDS address 0 is an ordinary address; the null pointer of that address space is all ones.)
+struct LdsTable { uint32_t address; };
+template <class Row> DM Row table_row_(const float *table, uint32_t byte_offset)
 {
-    int e;
-    const float m = frexp_sqrt2(x, e);
-    const float r = m - 1.0f;
-    const float fe = (float)e;
-    const float z = r * r;
-    float y = (r * z) * log_poly(r);
-    y = fma_(fe, LN2_LO, y);
-    y = fma_(-0.5f, z, y);
-    return fma_(fe, LN2_HI, r + y);
+    return *reinterpret_cast<const Row *>(reinterpret_cast<const char *>(table) + byte_offset);
 }
+template <class Row> DM Row table_row_(LdsTable table, uint32_t byte_offset)
+{
+    typedef const Row __attribute__((address_space(3))) *lds_row_ptr;
+    return *reinterpret_cast<lds_row_ptr>(static_cast<uintptr_t>(table.address + byte_offset));
+}
+
+// oracle_math.h: om_log.  `table`: the 32 rows, in LDS (a ds_read_b128 at an immediate offset) or in global memory.
+template <class Table>
+DM float log_with_(float x, Table table)
+{
+    typedef float row_t __attribute__((ext_vector_type(4)));
+    const uint32_t ix = f2u(x);
+    const float m = u2f((ix & 0x007fffffu) | 0x3f800000u);
+    const float fe = (float)__builtin_amdgcn_frexp_expf(x);             // e + 1 (x positive and normal)
+    const row_t row = table_row_<row_t>(table, (ix >> 14) & 0x1f0u);
+    const float r = fma_(m, row.x, -1.0f);
+    const float z = r * r;
+    float p = fma_(r, MT_LOG_P5, MT_LOG_P4);
+    p = fma_(r, p, MT_LOG_P3);
+    p = fma_(r, p, -0.5f);
+    const float t = fma_(z, p, r);
+    const float big = fma_(fe, MT_LN2_HI, row.y);
+    const float small = t + fma_(fe, MT_LN2_LO, row.z);
+    return big + small;
+}
+DM float log_(float x) { return log_with_<const float *>(x, kLogTable); }
 
 DM float exp_poly(float r)
 {
@@ -211,9 +247,9 @@ DM float powr_(float x, float y)
 // powr(x, y) for x in [0, 1], y > 0 with y |log x| <= 2 (oracle_math.h: om_powr_unit): single-word logarithm.  Without
 // branches: the argument of exp lies in [-2, 0], where exp_hl's range tests never fire, and x = 0 (whose logarithm is
 // finite garbage here) is put right by a select at the end.
-DM float powr_unit_(float x, float y)
+DM float powr_unit_from_log_(float x, float y, float log_x)
 {
-    const float hi = y * log_(x);
+    const float hi = y * log_x;
     const float k = rint_(hi * LOG2E);
     float r = fma_(-k, LN2_HI, hi);
     r = fma_(-k, LN2_LO, r);
@@ -224,6 +260,7 @@ DM float powr_unit_(float x, float y)
     const float v = u2f(f2u(p) + ((uint32_t)(int32_t)k << 23));
     return (x == 0.0f) ? 0.0f : v;
 }
+DM float powr_unit_(float x, float y) { return powr_unit_from_log_(x, y, log_(x)); }
 
 // cbrt and pow with a fractional exponent for the table maker's power axes (oracle_math.h: om_cbrt, om_pow_frac)
 DM float cbrt_(float x)
@@ -241,7 +278,29 @@ constexpr float PIO2_2 = -0x1.777a5cp-25f;
 constexpr float PIO2_3 = -0x1.ee59dap-50f;
 constexpr float TWO_O_PI = 0.636619772367581343f;
 
-DM void sincos_(float x, float &s, float &c)
+// oracle_math.h: om_sincos_2pi -- x in [0, RN(2 pi)].  `table`: the 33 rows {S, C}, in LDS or in global memory.
+constexpr float SINCOS_2PI_MAX = 6.2831855f;
+template <class Table>
+DM void sincos_2pi_with_(float x, float &s, float &c, Table table)
+{
+    typedef float row_t __attribute__((ext_vector_type(2)));
+    const float kf = fma_(x, MT_SC_16OPI, 12582912.0f);                 // 1.5 * 2^23 + rint(x * 16/pi): the integer is in the low bits
+    const float k = kf - 12582912.0f;
+    float r = fma_(-k, MT_SC_H1, x);
+    r = fma_(-k, MT_SC_H2, r);
+    const float z = r * r;
+    const float sp = fma_(z, MT_SIN_S1, MT_SIN_S0) * z;
+    const float sr = fma_(sp, r, r);
+    const float cm = fma_(z, MT_COS_C1, -0.5f) * z;
+    // the row's byte offset, 8 k: the pattern of kf is 0x4b400000 + k, and shifting it left by three drops the high bits mod 2^32
+    const row_t row = table_row_<row_t>(table, (f2u(kf) << 3) - (0x4b400000u << 3));
+    const float S = row.x, C = row.y;
+    s = S + fma_(S, cm, C * sr);
+    c = C + fma_(C, cm, -(S * sr));
+}
+DM void sincos_2pi_(float x, float &s, float &c) { sincos_2pi_with_<const float *>(x, s, c, kScTable); }
+
+DM void sincos_cephes_(float x, float &s, float &c)
 {
     const float k = rint_(x * TWO_O_PI);
     float r = fma_(-k, PIO2_1, x);
@@ -264,6 +323,14 @@ DM void sincos_(float x, float &s, float &c)
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
 }
+// oracle_math.h: om_sincos -- the table form on [0, RN(2 pi)], the Cephes form elsewhere
+template <class Table>
+DM void sincos_with_(float x, float &s, float &c, Table table)
+{
+    if (x >= 0.0f && x <= SINCOS_2PI_MAX) sincos_2pi_with_(x, s, c, table);
+    else sincos_cephes_(x, s, c);
+}
+DM void sincos_(float x, float &s, float &c) { sincos_with_<const float *>(x, s, c, kScTable); }
 
 // ---- once per recorded hit: binary64 (IEEE divide/sqrt/fma) ----
 DM double atan_small_d(double t)

@@ -71,6 +71,13 @@ enum CensusRegion { kCensusCrossing = 0, kCensusFilter = 1, kCensusLiu = 2, kCen
 #define CENSUS_REGION(P, region) ((void)0)
 #endif
 
+// The math tables of detmath.hip.h are the first dm::kMathTableWords words of every LDS image (tables.cpp puts them there): fixed
+// addresses, so the row loads are ds_read_b128 / ds_read_b64 with the table's offset as an immediate.
+// lds_words is the kernels' only LDS object and so sits at LDS address 0 (tests/test_codegen.py: no propagation kernel has a static
+// group segment): the tables are named by their byte addresses.
+DM float lds_log(float x) { return dm::log_with_(x, dm::LdsTable{0u}); }
+DM void lds_sincos_2pi(float x, float &s, float &c) { dm::sincos_2pi_with_(x, s, c, dm::LdsTable{4u * dm::kMathLogWords}); }
+
 DM float ldsf(uint32_t i) { return __builtin_bit_cast(float, lds_words[i]); }
 DM uint32_t ldsu(uint32_t i) { return lds_words[i]; }
 DM Rec4 lds_rec4(uint32_t i) { return *reinterpret_cast<const Rec4 *>(&lds_words[i]); }   // i % 4 == 0
@@ -243,7 +250,7 @@ DM float liu_cos(KP P, float u)
 {
     const float beta = P->liu_beta;
     // beta <= 0.09 (mean cosine >= 0.835, wave-uniform): beta |log u| <= 2 for u >= 2^-32, the single-word logarithm form
-    const float p = (FAST || beta <= 0.09f) ? dm::powr_unit_(u, beta) : dm::powr_(u, beta);
+    const float p = (FAST || beta <= 0.09f) ? dm::powr_unit_from_log_(u, beta, lds_log(u)) : dm::powr_(u, beta);
     return clampf_ordered(2.0f * p - 1.0f, -1.0f, 1.0f);
 }
 // Mixed.cxx:115-157, single random number form
@@ -400,9 +407,9 @@ DM void dom_position(KP P, uint32_t s, uint32_t d, float &x, float &y, float &z)
 // the special case only when a ballot says some lane needs it.
 DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
 {
-    const float b = 2.0f * kPi * u;
+    const float b = 2.0f * kPi * u;                                  // u in [0, 1): b in [0, RN(2 pi)]
     float sinb, cosb;
-    dm::sincos_(b, sinb, cosb);
+    lds_sincos_2pi(b, sinb, cosb);
     const float t = 1.0f - d.z * d.z;
     const float sinth = dm::sqrt_near_((t > 0.0f) ? t : 0.0f);     // 0 or >= 2^-24: |d.z| <= 1 is a float
     const float ox = d.x, oy = d.y, oz = d.z;
@@ -477,6 +484,7 @@ struct Birth {                  // propagation_kernel.c.cl:132-184 + :587: what 
 // c.cl:482-489: direction of a step from its (theta, phi); evaluated once when a lane takes the step
 DM Vec3 step_direction(const DevStep *step_ptr)
 {
+    // (the global-memory copy of the sincos table: scan_steps_kernel, one of the two callers, stages no LDS image; once per step)
     float sin_t, cos_t, sin_p, cos_p;
     dm::sincos_(step_ptr->theta, sin_t, cos_t);
     dm::sincos_(step_ptr->phi, sin_p, cos_p);
@@ -521,7 +529,7 @@ DM Birth photon_birth(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
         b.wlen = (source_type < (uint32_t)P->num_gen) ? generate_wavelength(P, (int)source_type, rx, ra) : 0.0f;
     }
     // c.cl:582-588: a fixed budget draws no random number
-    b.abs_lens_initial = P->has_fixed_abs ? P->fixed_abs : -dm::log_(rng_oc(rx, ra));
+    b.abs_lens_initial = P->has_fixed_abs ? P->fixed_abs : -lds_log(rng_oc(rx, ra));
     return b;
 }
 
@@ -570,7 +578,7 @@ DM float propagate_through_layers(KP P, Photon &ph, uint64_t &rx, uint32_t ra)
     if (ANISO) ph.abs_lens_left *= corr;
     const float lower = ((float)current_layer * thickness) + bottom;
     float boundary = (dz < 0.0f) ? lower : (lower + thickness);
-    const float sca_step_left = -dm::log_(rng_oc(rx, ra));
+    const float sca_step_left = -lds_log(rng_oc(rx, ra));
     float sca_len, abs_len, rcp_sca = 0.0f, rcp_abs = 0.0f;     // the current layer's lengths and, when `seeded`, RN(1 / length)
     const bool seeded = (MED == CLSIMHIP_LENGTHS_ICECUBE) && fast;
     layer_lengths<MED, FAST>(off_layers, len_table, ph.ice, current_layer, sca_len, abs_len, rcp_sca, rcp_abs, fast);

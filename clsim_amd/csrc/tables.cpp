@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "converter.h"
+#include "math_tables.h"
 
 namespace clsimhip {
 namespace {
@@ -83,6 +84,20 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     Image img;
     auto name = [&](const std::string &k, const std::vector<double> &v) { C.named[k] = v; };
     auto scalar = [&](const std::string &k, double v) { C.named[k] = std::vector<double>(1, v); };
+
+    // ---------------- the math tables of detmath.hip.h (round 5): ALWAYS the first words of the image, at fixed offsets --
+    // 32 log rows {INV, H, L, 0}, 33 sincos rows {S, C}, padded to a multiple of four words (prop_device.hip.h: lds_log, lds_sincos_2pi)
+    {
+        static const float log_rows[] = MT_LOG_TABLE;
+        static const float sc_rows[] = MT_SC_TABLE;
+        static_assert(sizeof(log_rows) == 4 * 4 * MT_LOG_ROWS && sizeof(sc_rows) == 4 * 2 * MT_SC_ROWS, "math table sizes");
+        const uint32_t at_log = img.add_floats(std::vector<float>(log_rows, log_rows + 4 * MT_LOG_ROWS));
+        const uint32_t at_sc = img.add_floats(std::vector<float>(sc_rows, sc_rows + 2 * MT_SC_ROWS));
+        img.align(4);
+        if (at_log != 0u || at_sc != 4u * MT_LOG_ROWS) throw Error(CLSIMHIP_ERR_CONFIG, "math tables are not at the front of the LDS image");
+        name("math_log_table", std::vector<double>(log_rows, log_rows + 4 * MT_LOG_ROWS));
+        name("math_sincos_table", std::vector<double>(sc_rows, sc_rows + 2 * MT_SC_ROWS));
+    }
 
     // ---------------- medium (MediumPropertiesSource.cxx:207-389) ----------------
     P.num_layers = m.num_layers;

@@ -21,9 +21,33 @@ static double ulp_err(float got, double want)
     } \
     printf("%-28s max %.3f ulp at x=%.9g\n", name, worst, wx); } while (0)
 
-int main(void)
+/* every float of a bit-pattern range (positive floats order like their patterns), against the x87 long double libm */
+static double ulp_err_l(float got, long double want)
+{
+    int e; frexpl(want, &e);
+    return (double)(fabsl((long double)got - want) / ldexpl(1.0L, e - 24));
+}
+#define SCAN_ALL(name, lo, hi, expr_got, expr_want) do { \
+    double worst = 0; float wx = 0; \
+    _Pragma("omp parallel") { double w = 0; float wi = 0; \
+        _Pragma("omp for schedule(static)") \
+        for (long long b = om_f2u(lo); b <= (long long)om_f2u(hi); ++b) { \
+            const float x = om_u2f((uint32_t)b); const double e = ulp_err_l(expr_got, expr_want); if (e > w) { w = e; wi = x; } } \
+        _Pragma("omp critical") if (w > worst) { worst = w; wx = wi; } } \
+    printf("%-28s max %.3f ulp at x=%a  (EVERY float of the range)\n", name, worst, wx); } while (0)
+
+static float sin_of(float x) { float s, c; om_sincos_2pi(x, &s, &c); return s; }
+static float cos_of(float x) { float s, c; om_sincos_2pi(x, &s, &c); return c; }
+
+int main(int argc, char **argv)
 {
     const long N = 20000000;
+    if (argc > 1 && argv[1][0] == 'e') {        /* `mathcheck exhaustive`: the round-5 table forms over their whole domains (a few core-minutes) */
+        SCAN_ALL("log [2^-40, 4)", 0x1p-40f, 0x1.fffffep+1f, om_log(x), logl((long double)x));
+        SCAN_ALL("sin [2^-60, RN(2pi)]", 0x1p-60f, OM_SINCOS_2PI_MAX, sin_of(x), sinl((long double)x));
+        SCAN_ALL("cos [2^-60, RN(2pi)]", 0x1p-60f, OM_SINCOS_2PI_MAX, cos_of(x), cosl((long double)x));
+        return 0;
+    }
     SCAN("log (0,1]", 5.9604645e-8, 1.0, N, om_log(x), log((double)x));
     SCAN("log [1,1000]", 1.0, 1000.0, N, om_log(x), log((double)x));
     SCAN("exp [-30,0]", -30.0, 0.0, N, om_exp(x), exp((double)x));

@@ -50,8 +50,10 @@ def test_float_literal_round_trip():
 
 
 @pytest.mark.parametrize("what,lo,hi,ref,ulps", [
-    (0, 6e-8, 1.0, np.log, 1.0), (1, -30.0, 0.0, np.exp, 1.2), (2, 0.0, 6.2831855, np.sin, 1.6),
-    (3, 0.0, 6.2831855, np.cos, 1.6), (5, -1.0, 1.0, np.arccos, 0.6), (8, 0.0, 100.0, np.sqrt, 0.5001),
+    # (round 5: log and sin / cos on [0, 2 pi] are the table forms -- oracle/mathcheck.c scans every float: 1.21 / 2.36 / 2.47 ulp;
+    # OpenCL allows 3 / 4 / 4.  Outside [0, 2 pi] sin and cos are the Cephes forms as before.)
+    (0, 6e-8, 1.0, np.log, 1.25), (0, 1.0, 1000.0, np.log, 1.0), (1, -30.0, 0.0, np.exp, 1.2), (2, 0.0, 6.2831855, np.sin, 2.4),
+    (3, 0.0, 6.2831855, np.cos, 2.5), (2, -100.0, 0.0, np.sin, 1.6), (3, 6.2832, 100.0, np.cos, 1.6), (5, -1.0, 1.0, np.arccos, 0.6), (8, 0.0, 100.0, np.sqrt, 0.5001),
     (10, -1.0, 1.0, np.arccos, 2.0)])
 def test_math_spec_accuracy(oracle_lib, what, lo, hi, ref, ulps):
     rng = np.random.Generator(np.random.PCG64(what))
@@ -211,3 +213,18 @@ def test_threaded_driver_without_stop_keeps_every_record():
         assert common.sort_photons(ph_n).tobytes() == common.sort_photons(ph_1).tobytes()
     per_step = np.bincount(ph_1["id"], minlength=1)
     assert per_step.max() > 4                                                  # some step recorded more hits than it has photons
+
+
+def test_product_and_oracle_math_tables_are_the_same_text():
+    """tools/make_math_tables.py writes the constants of the table-driven log / sincos twice -- the product may not include from
+    oracle/ -- and the two bodies must be identical (and regenerate identically)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def body(path):
+        t = open(os.path.join(root, path)).read()
+        return re.sub(r"^#ifndef \w+\n#define \w+\n", "", t)
+    a, b = body("clsim_amd/csrc/math_tables.h"), body("oracle/math_tables.h")
+    assert a == b and "MT_LOG_TABLE" in a and "MT_SC_TABLE" in a
+    before = open(os.path.join(root, "oracle", "math_tables.h")).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_math_tables.py")], stdout=subprocess.DEVNULL)
+    assert open(os.path.join(root, "oracle", "math_tables.h")).read() == before

@@ -7,7 +7,7 @@ restatement of the reference kernel with float operators that count themselves, 
 prices what was counted in vector instructions of gfx950, two ways:
 
   as_written   every operation the reference's expressions ask for, one by one, at the cost of the device's GENERIC sequence for
-               it (IEEE divide 11, square root 17, ..., the math library by name; profiles/r04/math_unit_costs.json) -- including the
+               it (IEEE divide 11, square root 17, ..., the math library by name; profiles/r05/math_unit_costs.json) -- including the
                DOM search's cell arithmetic, which the reference runs on every loop trip;
   transformed  the same photon histories with the bit-preserving transformations of DESIGN.md section 2 applied and every
                division / root at the cheapest form PROVEN exact for its site (price_transformed below): wavelength-only medium
@@ -16,7 +16,7 @@ prices what was counted in vector instructions of gfx950, two ways:
                remaining searches cost is the kernel's overhead, not the reference's arithmetic).  This is the floor the
                kernel's issued lane operations are compared with (roofline.valu.overhead_ratio).
 
-usage: tools/count_reference_ops.py [c2 c3 c5 ...] [--steps N] [--out profiles/r04/reference_ops.json]"""
+usage: tools/count_reference_ops.py [c2 c3 c5 ...] [--steps N] [--out profiles/r05/reference_ops.json]"""
 import argparse, hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,7 +33,7 @@ NAMED = {"div": "div", "sqrt": "sqrt", "rsqrt": "rsqrt", "log": "log", "exp": "e
 def unit_costs(cycles=False):
     """vector instructions per unit; cycles=True: full-rate issue slots (a quarter-rate instruction -- v_rcp_f32, v_sqrt_f32, the 32-bit integer
     multiplies -- holds the SIMD four times as long as an fma)"""
-    with open(os.path.join(ROOT, "profiles", "r04", "math_unit_costs.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05", "math_unit_costs.json")) as f:
         u = json.load(f)["units"]
     if cycles:
         u = {k: dict(v, valu=v["valu"] + 3 * v["of_them_quarter_rate"]) for k, v in u.items()}
@@ -133,7 +133,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workloads", nargs="*", default=["c2", "c3", "c5"])
     ap.add_argument("--steps", type=int, default=16384)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "reference_ops.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05", "reference_ops.json"))
     args = ap.parse_args()
     cost, proven = unit_costs()
     cost_c, proven_c = unit_costs(cycles=True)

@@ -600,7 +600,7 @@ def check_tabulate(case, write_fixtures):
         bins = np.zeros(tb["n_bins"], dtype=np.float64)
         np.add.at(bins, flat["index"], flat["weight"].astype(np.float64))
         nz = np.nonzero(bins)[0]
-        if len(nz) > 60000:             # (the five-dimensional table: the hash of the entry stream says it all; keep the fixture small)
+        if len(nz) > 100000:             # (the five-dimensional table: the hash of the entry stream says it all; keep the fixture small)
             nz = nz[:0]
         np.savez_compressed(out, num=num_v, left=left_v, rng_x=xs, entries_sha256=np.frombuffer(hashlib.sha256(flat.tobytes()).digest(), dtype=np.uint8),
                             bins_nonzero=nz.astype(np.uint32), bins_sum=bins[nz], n_bins=np.int64(tb["n_bins"]), entries_per_stream=np.int64(eps))
