@@ -150,6 +150,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
     // shader-clock cycles of the wave inside the service block, its publication of finished units, the unit take and the creation chunks
     unsigned long long t_service = 0, t_publish = 0, t_take = 0, t_create = 0;
+    // (round 5, profiles/r05/divergence_closing.txt) one ring hand-over, measured where the kernel does it: the five 16-byte words of a
+    // created photon stored (t_ring_store: the stores of one creation chunk, c_ring_stores chunks) and the hand-out block -- ballot, rank,
+    // five 16-byte loads, unpacking, the wave barrier (t_hand_out, c_hand_outs blocks)
+    unsigned long long t_ring_store = 0, c_ring_stores = 0, t_hand_out = 0, c_hand_outs = 0;
     const unsigned long long t_wave_start = __builtin_readcyclecounter();
 #endif
     // who holds what, as lane masks; taken at the end of a trip for the next one (and for the loop's exit, a plain backward branch)
@@ -345,6 +349,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     const uint64_t m_can = ballot(can);
                     const uint32_t slot = created + (uint32_t)__popcll(m_can & lanes_below);
                     const bool make = can && (slot < (R - n_ready));
+#ifdef CLSIMHIP_CENSUS
+                    unsigned long long t_q0 = 0;
+#endif
                     if (make) {
                         const WorkRecord *rec = work + e_sidx;
                         const uint32_t e_ra = rec->a;
@@ -352,6 +359,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         Photon born;
                         born.layer = 0;
                         create_photon<MED, TILT, FLASHER, false, FAST>(P, &rec->step, step_dir, e_rx, e_ra, born);
+#ifdef CLSIMHIP_CENSUS
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        t_q0 = __builtin_readcyclecounter();
+#endif
                         uint32_t pos = ready_head + n_ready + slot;
                         if (pos >= R) pos -= R;
                         if (pos >= R) pos -= R;
@@ -361,7 +372,13 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         q[2] = pend_entry{dm::f2u(born.abs_lens_left), dm::f2u(born.ice.sca_pow), dm::f2u(born.ice.abs_pow), dm::f2u(born.ice.abs_exp)};
                         q[3] = pend_entry{(uint32_t)born.rx_start, (uint32_t)(born.rx_start >> 32), e_sidx, e_ra};
                         q[4] = pend_entry{(uint32_t)e_rx, (uint32_t)(e_rx >> 32), e_left, e_flags | ((uint32_t)born.layer << 18)};       // (flags: 18 bits; layers < 2^14, checked by the launcher)
+#ifdef CLSIMHIP_CENSUS
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
                     }
+#ifdef CLSIMHIP_CENSUS
+                    if (t_q0 != 0) { t_ring_store += __builtin_readcyclecounter() - t_q0; ++c_ring_stores; }
+#endif
                     const bool keep = have && !make;
                     const uint64_t m_keep = ballot(keep);
                     // (every lane has read its entry above; the compacted entries land at or before the ones read)
@@ -386,6 +403,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 
             // ready photons for the lanes without one, oldest first
             if (n_ready != 0u) {
+#ifdef CLSIMHIP_CENSUS
+                const unsigned long long t_h0 = __builtin_readcyclecounter();
+#endif
                 const bool want = (st == kVacant);
                 const uint64_t m_want = ballot(want);
                 const uint32_t rank = (uint32_t)__popcll(m_want & lanes_below);
@@ -413,6 +433,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CLSIMHIP_CENSUS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (taken != 0u) { t_hand_out += __builtin_readcyclecounter() - t_h0; ++c_hand_outs; }
+#endif
             }
             // nothing runnable in this wave: every unit it holds waits for another wave's slice
             if (ballot(st != kVacant) == 0ull) __builtin_amdgcn_s_sleep(16);
@@ -583,6 +607,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         atomicAdd(d + 9, c_searches); atomicAdd(d + 10, c_chunks); atomicAdd(d + 11, c_empty_ring);
         atomicAdd(d + 12, t_service); atomicAdd(d + 13, t_publish); atomicAdd(d + 14, t_take); atomicAdd(d + 15, t_create);
         atomicAdd(d + 24600, (unsigned long long)__builtin_readcyclecounter() - t_wave_start);
+        atomicAdd(d + 24601, t_ring_store); atomicAdd(d + 24602, c_ring_stores); atomicAdd(d + 24603, t_hand_out); atomicAdd(d + 24604, c_hand_outs);
         const uint32_t w = blockIdx.x * (uint32_t)kPoolWavesPerBlock + wave_in_group;
         d[16 + 3 * w] = wall_clock64();
         d[16 + 3 * w + 1] = 0;

@@ -67,6 +67,11 @@ for spec in sys.argv[1:]:
               "first look at the work record) %.1f%%, creation chunks (polls, record reads, creation, compaction) %.1f%%, the rest (retire, hand-out) %.1f%%"
               % (100 * t_service / t_total, 100 * t_publish / t_total, 100 * t_take / t_total, 100 * t_create / t_total,
                  100 * (t_service - t_publish - t_take - t_create) / t_total), flush=True)
+        t_store, n_store, t_hand, n_hand = (float(v) for v in buf[24601:24605])
+        per_trip = t_total / trips
+        print("   one ring hand-over, shader clock: store of a creation chunk's photons (five 16-byte words per lane) %.0f cycles x %d chunks; hand-out block "
+              "(ballot, rank, five 16-byte loads, unpack, wave barrier) %.0f cycles x %d blocks; a wave trip takes %.0f cycles of wave time"
+              % (t_store / max(n_store, 1), int(n_store), t_hand / max(n_hand, 1), int(n_hand), per_trip), flush=True)
     # divergent regions (prop_device.hip.h: CENSUS_REGION): visits per wave trip and active lanes per visit
     names = ["layer crossing body", "search filter levels 2-3", "Liu branch", "HG branch", "full DOM search", "named DOM search", "photon creation",
              "service (free lanes)", "scattering (all)", "layer walk (all)", "aimed at the string?"]
