@@ -69,9 +69,12 @@ def parse():
                     help="N>1: gather the photons of launch k on a second stream while launch k+1 runs (two photon buffers). Default: "
                          "the gather runs between two launches on the launch stream -- the propagation kernel is a persistent grid "
                          "that fills every CU, a copy or RCCL kernel beside it gets slivers of the chip and slows it down (DESIGN.md 7)")
-    ap.add_argument("--consume-in-place", action="store_true",
-                    help="benchmark-host: the consumer reads the photons in the library's result buffer and releases it (a C/C++ "
-                         "consumer working on the records where they are) instead of copying them out first")
+    ap.add_argument("--copy-results", dest="consume_in_place", action="store_false",
+                    help="benchmark-host: the consumer copies every result (80 B per detected photon) into a buffer of its own before it counts "
+                         "them, like the C++ adapter's GetConversionResult() fills an I3CLSimPhotonSeries.  Default: the records are read in the "
+                         "library's page-locked result buffer, which is then released (GetConversionResultInPlace in both adapters) -- the "
+                         "reference's benchmark.py only counts the photons of a result")
+    ap.add_argument("--consume-in-place", dest="consume_in_place", action="store_true", default=True, help="(the default)")
     ap.add_argument("--shard-steps", type=int, default=0,
                     help="I3CLSimSteps per GPU and pass, cut into equal bunches of at most 6 139 850 (the converter's stream limit, "
                          "OpenCL.cxx:250).  Default: one --bunch at N=1; at N>1 the per-GPU shard of the configuration BASELINE names: "
@@ -228,10 +231,15 @@ def host_path_run(CV, args, steps_np, conv, bunches):
     producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(bunches)])
     producer.start()
     hits = 0
-    recycled = np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=PHOTON_DTYPE)        # the consumer's photon buffer, reused per bunch
+    recycled = None if args.consume_in_place else np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=PHOTON_DTYPE)     # (the copying consumer's buffer, reused per bunch)
     for _ in range(bunches):
-        _, ph = conv.GetConversionResult(out=recycled)
-        hits += len(ph)
+        if args.consume_in_place:               # the records where the library left them (benchmark.py only counts a result's photons)
+            _, ph, release = conv.GetConversionResultInPlace()
+            hits += len(ph)
+            release()
+        else:
+            _, ph = conv.GetConversionResult(out=recycled)
+            hits += len(ph)
     producer.join()
     elapsed = time.perf_counter() - t0
     st = conv.GetStatistics()
@@ -240,6 +248,8 @@ def host_path_run(CV, args, steps_np, conv, bunches):
     return {"value": photons / elapsed, "unit": "photons/s", "bunches": bunches, "steps_per_bunch": len(steps_np), "hits": hits,
             "seconds": elapsed, "device_utilization": device_ns * 1e-9 / elapsed,
             "device_ns_per_photon": device_ns / photons, "double_buffering": True,
+            "consumer": "reads the records in the library's page-locked result buffer, then releases it" if args.consume_in_place else
+                        "copies every result into a buffer of its own (--copy-results)",
             "definition": "sum(numPhotons) / wall clock from the first EnqueueSteps to the last GetConversionResult "
                           "(reference benchmark.py:335-340), outside the timed region of `value`"}
 

@@ -227,6 +227,31 @@ public:
         }
         return r;
     }
+    // Extension (no reference counterpart): the result where the library left it -- the page-locked buffer the device's records were
+    // downloaded into -- for a caller that consumes the records in place (a server that serialises them, a hit maker that walks
+    // them once): no I3CLSimPhotonSeries is allocated, nothing is copied.  `photons` stays valid while `hold` (or a copy of it) lives;
+    // the buffer goes back to the converter's pool when the last copy is dropped.  Photon histories, if recorded, are not part
+    // of the view: use GetConversionResult().  GetConversionResult() copies because its interface type owns a std::vector.
+    struct ConversionResultView {
+        uint32_t identifier = 0;
+        const I3CLSimPhoton *photons = nullptr;
+        std::size_t size = 0;
+        std::shared_ptr<const void> hold;
+        const I3CLSimPhoton *begin() const { return photons; }
+        const I3CLSimPhoton *end() const { return photons + size; }
+    };
+    ConversionResultView GetConversionResultInPlace()
+    {
+        ConversionResultView v;
+        const clsimhip_photon *p = nullptr;
+        check(clsimhip_get_conversion_result(handle_, &v.identifier, &p, &v.size));
+        v.photons = reinterpret_cast<const I3CLSimPhoton *>(p);
+        if (p) {
+            clsimhip_converter *h = handle_;
+            v.hold = std::shared_ptr<const void>(static_cast<const void *>(p), [h](const void *q) { (void)clsimhip_release_result(h, static_cast<const clsimhip_photon *>(q)); });
+        }
+        return v;
+    }
     std::map<std::string, double> GetStatistics() const override
     {
         double v[8];

@@ -83,5 +83,15 @@ int main(int argc, char **argv)
     std::printf("identifier %u photons %zu generated %.0f\n", r.identifier, r.photons->size(), st.at("TotalNumPhotonsGenerated"));
     for (const I3CLSimPhoton &p : *r.photons)
         if (p.string_id != 1 || p.om_id < 1 || p.om_id > 60) { std::printf("FAILED: bad IDs\n"); return 1; }
-    return (r.identifier == 42 && !r.photons->empty() && st.at("TotalNumPhotonsGenerated") == 200000.) ? 0 : 1;
+    // the same bunch once more through the in-place view: other streams states, so other photons -- checked for shape, IDs and the
+    // buffer's return to the pool (a second view after the first was dropped must succeed)
+    for (int k = 0; k < 2; ++k) {
+        conv.EnqueueSteps(steps, 43 + k);
+        I3CLSimStepToPhotonConverterHIP::ConversionResultView v = conv.GetConversionResultInPlace();
+        if (v.identifier != uint32_t(43 + k) || v.size == 0 || !v.hold) { std::printf("FAILED: in-place view\n"); return 1; }
+        for (const I3CLSimPhoton &p : v)
+            if (p.string_id != 1 || p.om_id < 1 || p.om_id > 60) { std::printf("FAILED: bad IDs in the view\n"); return 1; }
+        std::printf("view %d: identifier %u photons %zu\n", k, v.identifier, v.size);
+    }
+    return (r.identifier == 42 && !r.photons->empty() && conv.GetStatistics().at("TotalNumPhotonsGenerated") == 600000.) ? 0 : 1;
 }

@@ -26,3 +26,5 @@ def test_adapter_configures_and_compiles(tmp_path):
 def test_adapter_propagates_a_bunch(tmp_path):
     out = subprocess.check_output([build(tmp_path), "run"], text=True)
     assert "identifier 42" in out and "generated 200000" in out
+    # the in-place view (no I3CLSimPhotonSeries, the records where the library left them), twice: the buffer returns to the pool
+    assert "view 0: identifier 43" in out and "view 1: identifier 44" in out
