@@ -133,15 +133,23 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
     }
     // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
     const float c[5] = {c0, c1, c2, c3, c4};
-    index = 0;
+    uint32_t bin[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < ndim; ++k) {
         const int pw = P->tab_inverse[k];           // wave-uniform
         const float v = (pw <= 1) ? c[k] : (pw == 2) ? dm::sqrt_(c[k]) : (pw == 3) ? dm::cbrt_(c[k]) : dm::pow_frac_(c[k], P->tab_inv_exp[k]);
         const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
         int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-        b = clampi(b, -1, P->tab_nbins[k]) + 1;
-        index += P->tab_stride[k] * (uint32_t)b;
+        bin[k] = (uint32_t)(clampi(b, -1, P->tab_nbins[k]) + 1);
+    }
+    if (!ANGLE && P->tab_tiled) {
+        // the device's own order (kparams.h: tab_tiled): 2 x 2 x 2 bins of distance, polar angle and time in one 64-byte sector
+        index = (bin[0] >> 1) * P->tab_tile_stride[0] + bin[1] * P->tab_tile_stride[1] + (bin[2] >> 1) * P->tab_tile_stride[2] + ((bin[3] >> 1) << 3)
+                + (((bin[0] & 1u) << 2) | ((bin[2] & 1u) << 1) | (bin[3] & 1u));
+    } else {
+        index = 0;
+#pragma unroll
+        for (int k = 0; k < ndim; ++k) index += P->tab_stride[k] * bin[k];
     }
     return false;
 }

@@ -82,6 +82,20 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     for (size_t i = nd - 1; i-- > 0;) { shape_[i] = axes_[i].n_bins + 2; strides_[i] = strides_[i + 1] * shape_[i + 1]; }
     n_bins_ = strides_[0] * shape_[0];
     if (n_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
+    // The device's own bin order for four axes (round 5): 2 x 2 x 2 bins of axes 0, 2 and 3 -- distance, polar angle, time: the three
+    // a photon's path changes from sample to sample -- share one 64-byte sector; azimuth (axis 1) stays whole.  The table's sums are
+    // memory-side atomic requests of one sector each, and a path's consecutive samples then meet fewer sectors than with eight time
+    // bins to a sector.  bin_content_double() puts the sums into the reference's order (Axes.cxx:51-64).  CLSIMHIP_TAB_LAYOUT=linear
+    // keeps the reference's order on the device too (measurement; five-axis tables always).
+    tiled_ = (nd == 4);
+    if (const char *e = std::getenv("CLSIMHIP_TAB_LAYOUT")) tiled_ = tiled_ && (std::strcmp(e, "linear") != 0);
+    n_device_bins_ = n_bins_;
+    if (tiled_) {
+        const size_t h0 = (shape_[0] + 1) / 2, h2 = (shape_[2] + 1) / 2, h3 = (shape_[3] + 1) / 2;
+        tile_stride_[2] = h3 * 8; tile_stride_[1] = h2 * tile_stride_[2]; tile_stride_[0] = shape_[1] * tile_stride_[1];
+        n_device_bins_ = h0 * tile_stride_[0];
+        if (n_device_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
+    }
 
     {   // spectralBiasFactor_ (StepToTableConverter.cxx:142-152): photons of a bare Cherenkov spectrum between 300 and 600 nm per
         // photon drawn from the acceptance-weighted spectrum (ConverterUtils.cxx:44-105; lightsource.cpp)
@@ -114,6 +128,8 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         P.tab_nbins[k] = static_cast<int32_t>(ax.n_bins);
         P.tab_stride[k] = static_cast<uint32_t>(strides_[k]);
     }
+    P.tab_tiled = tiled_ ? 1u : 0u;
+    for (int k = 0; k < 3; ++k) P.tab_tile_stride[k] = tiled_ ? static_cast<uint32_t>(tile_stride_[k]) : 0u;
     P.tab_max0 = to_float_literal(axes_[0].max);
     P.tab_max3 = to_float_literal(axes_[3].max);
     const auto n_min = minimum_refractive_index(medium);
@@ -171,11 +187,11 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
     upload(reinterpret_cast<void **>(&d_rng_x_), x, streams * 8, "rng x");
     upload(reinterpret_cast<void **>(&d_rng_a_), a, streams * 4, "rng a");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&d_bins_), n_bins_ * sizeof(double)), "table bins");
-    hip_check(hipMemset(d_bins_, 0, n_bins_ * sizeof(double)), "table bins");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&d_bins_), n_device_bins_ * sizeof(double)), "table bins");
+    hip_check(hipMemset(d_bins_, 0, n_device_bins_ * sizeof(double)), "table bins");
     if (squared_) {
-        hip_check(hipMalloc(reinterpret_cast<void **>(&d_sq_bins_), n_bins_ * sizeof(double)), "squared weights");
-        hip_check(hipMemset(d_sq_bins_, 0, n_bins_ * sizeof(double)), "squared weights");
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_sq_bins_), n_device_bins_ * sizeof(double)), "squared weights");
+        hip_check(hipMemset(d_sq_bins_, 0, n_device_bins_ * sizeof(double)), "squared weights");
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_steps_), streams * sizeof(DevStep)), "steps");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), static_cast<size_t>(kQueueWords) * kQueueSlots * sizeof(uint32_t)), "step queue");
@@ -285,7 +301,20 @@ void Tabulator::bin_content_double(double *out, size_t n, bool squared)
     if (squared && !d_sq_bins_) throw Error(CLSIMHIP_ERR_STATE, "squared weights are not recorded");
     finish();
     std::lock_guard<std::mutex> lk(mutex_);
-    hip_check(hipMemcpy(out, squared ? d_sq_bins_ : d_bins_, n * sizeof(double), hipMemcpyDeviceToHost), "download table");
+    if (!tiled_) {
+        hip_check(hipMemcpy(out, squared ? d_sq_bins_ : d_bins_, n * sizeof(double), hipMemcpyDeviceToHost), "download table");
+        return;
+    }
+    // the device's tiled order -> the reference's (sample_bin in prop_kernel.hip forms the same index)
+    std::vector<double> device(n_device_bins_);
+    hip_check(hipMemcpy(device.data(), squared ? d_sq_bins_ : d_bins_, n_device_bins_ * sizeof(double), hipMemcpyDeviceToHost), "download table");
+    size_t at = 0;
+    for (size_t b0 = 0; b0 < shape_[0]; ++b0)
+        for (size_t b1 = 0; b1 < shape_[1]; ++b1)
+            for (size_t b2 = 0; b2 < shape_[2]; ++b2) {
+                const size_t base = (b0 >> 1) * tile_stride_[0] + b1 * tile_stride_[1] + (b2 >> 1) * tile_stride_[2] + ((b0 & 1) << 2) + ((b2 & 1) << 1);
+                for (size_t b3 = 0; b3 < shape_[3]; ++b3) out[at++] = device[base + ((b3 >> 1) << 3) + (b3 & 1)];
+            }
 }
 
 void Tabulator::bin_content(float *out, size_t n, bool squared, bool normalized)

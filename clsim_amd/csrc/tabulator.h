@@ -58,6 +58,8 @@ private:
     std::vector<AxisData> axes_;
     std::vector<size_t> shape_, strides_;
     size_t n_bins_ = 0;
+    bool tiled_ = false;                     // the device keeps the bins in 2 x 2 x 2 tiles of axes 0, 2, 3 (tabulator.cpp)
+    size_t n_device_bins_ = 0, tile_stride_[3] = {0, 0, 0};
     bool squared_;
     double reference_area_, step_length_;
     double n_group_ = 0, n_phase_ = 0;
