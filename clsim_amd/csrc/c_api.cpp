@@ -815,7 +815,7 @@ int clsimhip_step_store_insert(clsimhip_step_store *s, const clsimhip_step *step
 {
     return guarded(nullptr, [&] {
         need(s, "store"); if (n) need(steps, "steps");
-        for (size_t i = 0; i < n; ++i) s->impl.insert(steps[i]);
+        s->impl.insert_many(steps, n);
     });
 }
 int clsimhip_step_store_size(const clsimhip_step_store *s, size_t *out)

@@ -54,6 +54,7 @@ Converter::~Converter()
     if (in_queue_) in_queue_->close();
     if (out_queue_) out_queue_->close();
     if (worker_.joinable()) worker_.join();
+    in_queue_.reset();              // jobs nobody took give their page-locked step buffers back to the pool, which release_device() frees
     release_device();
 }
 
@@ -81,9 +82,12 @@ void Converter::release_device()
         (void)hipFree(sl.d_steps); (void)hipFree(sl.d_photons); (void)hipFree(sl.d_hit_count); (void)hipFree(sl.d_hist_out);
         if (sl.h_hist) (void)hipHostFree(sl.h_hist);
         if (sl.h_steps) (void)hipHostFree(sl.h_steps);
+        if (sl.step_buffer.p) (void)hipHostFree(sl.step_buffer.p);
         if (sl.h_hit_count) (void)hipHostFree(sl.h_hit_count);
         sl = Slot();
     }
+    for (const StepBuffer &b : free_step_buffers_) (void)hipHostFree(b.p);
+    free_step_buffers_.clear(); step_buffers_made_ = 0; step_pool_bytes_ = 0; step_pinning_refused_ = false;
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_); (void)hipFree(d_id_strings_); (void)hipFree(d_id_doms_); (void)hipFree(d_id_dom_start_);
     for (const PinnedBuffer &b : free_result_buffers_) (void)hipHostFree(b.p);
     free_result_buffers_.clear(); result_buffers_made_ = 0; pinning_refused_ = false;
@@ -439,20 +443,73 @@ void Converter::enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t ide
     if (n % workgroup_size_ != 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "The number of steps is not a multiple of the workgroup size!");
     Job job;
     job.id = identifier;
-    job.steps.assign(steps, steps + n);
+    job.n = n;
+    for (size_t i = 0; i < n; ++i) job.generated += steps[i].num_photons;
+    job.pinned = StepLease(this, take_step_buffer(n));
+    if (job.pinned.b.p) std::memcpy(job.pinned.b.p, steps, n * sizeof(clsimhip_step));
+    else job.steps.assign(steps, steps + n);
     in_queue_->put(std::move(job));
 }
 
-// OpenCL.cxx:824-934: upload, launch; everything is queued on the compute stream, nothing waits
-void Converter::submit(Slot &s, const Job &job)
+Converter::StepBuffer Converter::take_step_buffer(size_t steps)
 {
-    const size_t n = job.steps.size();
+    {
+        std::lock_guard<std::mutex> lk(step_pool_mutex_);
+        size_t best = free_step_buffers_.size();
+        for (size_t i = 0; i < free_step_buffers_.size(); ++i)
+            if (free_step_buffers_[i].capacity >= steps && (best == free_step_buffers_.size() || free_step_buffers_[i].capacity < free_step_buffers_[best].capacity)) best = i;
+        if (best != free_step_buffers_.size()) {
+            const StepBuffer b = free_step_buffers_[best];
+            free_step_buffers_.erase(free_step_buffers_.begin() + static_cast<std::ptrdiff_t>(best));
+            return b;
+        }
+        if (step_pinning_refused_ || step_buffers_made_ >= kStepBuffers) return StepBuffer();
+    }
+    StepBuffer b;
+    b.capacity = std::min(max_workitems_, steps + steps / 4);
+    if (b.capacity < steps) b.capacity = steps;
+    const size_t bytes = b.capacity * sizeof(clsimhip_step);
+    {
+        std::lock_guard<std::mutex> lk(step_pool_mutex_);
+        if (step_pool_bytes_ + bytes > kStepPoolBytes && step_buffers_made_ >= 3) return StepBuffer();
+        ++step_buffers_made_;
+        step_pool_bytes_ += bytes;
+    }
+    DeviceGuard on_device(device_);
+    if (hipHostMalloc(reinterpret_cast<void **>(&b.p), bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(step_pool_mutex_);
+        --step_buffers_made_;
+        step_pool_bytes_ -= bytes;
+        step_pinning_refused_ = true;
+        return StepBuffer();
+    }
+    return b;
+}
+
+void Converter::give_step_buffer(StepBuffer b)
+{
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(step_pool_mutex_);
+    free_step_buffers_.push_back(b);
+}
+
+// OpenCL.cxx:824-934: upload, launch; everything is queued on the compute stream, nothing waits
+void Converter::submit(Slot &s, Job &job)
+{
+    const size_t n = job.n;
     s.id = job.id;
-    s.generated = 0;
-    for (const clsimhip_step &st : job.steps) s.generated += st.num_photons;
-    std::memcpy(s.h_steps, job.steps.data(), n * sizeof(clsimhip_step));
+    s.generated = job.generated;
+    // (the slot's previous upload finished long ago: its kernel has, or the slot would not be free)
+    give_step_buffer(s.step_buffer);
+    s.step_buffer = job.pinned.release();
+    const clsimhip_step *source = s.step_buffer.p;
+    if (!source) {
+        std::memcpy(s.h_steps, job.steps.data(), n * sizeof(clsimhip_step));
+        source = s.h_steps;
+    }
     // the upload has a stream of its own: with double buffering it runs while the previous bunch's kernel does
-    hip_check(hipMemcpyAsync(s.d_steps, s.h_steps, n * sizeof(DevStep), hipMemcpyHostToDevice, upload_stream_), "upload steps");
+    hip_check(hipMemcpyAsync(s.d_steps, source, n * sizeof(DevStep), hipMemcpyHostToDevice, upload_stream_), "upload steps");
     hip_check(hipEventRecord(s.uploaded, upload_stream_), "event");
     hip_check(hipStreamWaitEvent(stream_, s.uploaded, 0), "wait for the upload");
     hip_check(hipMemsetAsync(s.d_hit_count, 0, 4, stream_), "reset hit counter");

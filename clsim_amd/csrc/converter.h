@@ -201,7 +201,26 @@ public:
     bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
 
 private:
-    struct Job { uint32_t id; std::vector<clsimhip_step> steps; };
+    // A bunch on its way to the worker: the caller's steps are copied ONCE, in the caller's thread, into a page-locked buffer of the
+    // step pool, which the worker uploads from (round 5; before, a vector here and a second copy into the slot's staging buffer on
+    // the worker thread -- 8 ms per million steps in front of the first kernel of a run).  With every pool buffer in flight the
+    // steps travel in a vector as before.
+    struct StepBuffer { clsimhip_step *p = nullptr; size_t capacity = 0; };
+    // (a pool buffer on loan: whoever drops it -- a job the closed queue refused, a queue destroyed with jobs inside -- returns it)
+    struct StepLease {
+        Converter *owner = nullptr;
+        StepBuffer b;
+        StepLease() = default;
+        StepLease(Converter *o, StepBuffer buf) : owner(o), b(buf) {}
+        StepLease(StepLease &&o) noexcept : owner(o.owner), b(o.b) { o.b = StepBuffer(); }
+        StepLease &operator=(StepLease &&o) noexcept { if (this != &o) { drop(); owner = o.owner; b = o.b; o.b = StepBuffer(); } return *this; }
+        StepLease(const StepLease &) = delete;
+        StepLease &operator=(const StepLease &) = delete;
+        ~StepLease() { drop(); }
+        StepBuffer release() { const StepBuffer r = b; b = StepBuffer(); return r; }
+        void drop() { if (owner && b.p) owner->give_step_buffer(b); b = StepBuffer(); }
+    };
+    struct Job { uint32_t id = 0; size_t n = 0; uint64_t generated = 0; StepLease pinned; std::vector<clsimhip_step> steps; };
     // The photons of a result live in a page-locked buffer of the converter's pool (the download lands there and the
     // caller reads them there until ReleaseResult: no host copy in between), or -- when the pool is exhausted because the
     // caller holds more results than it has buffers -- in a vector of their own.
@@ -261,7 +280,8 @@ private:
         uint32_t *d_hit_count = nullptr;
         float *d_hist_out = nullptr;            // photon histories of the slot's hits (history_entries_ float4 each)
         float *h_hist = nullptr;
-        clsimhip_step *h_steps = nullptr;       // pinned staging
+        clsimhip_step *h_steps = nullptr;       // pinned staging (for a job that came without a pool buffer)
+        StepBuffer step_buffer;                 // the pool buffer the slot's upload reads; goes back to the pool when the slot is used again
         uint32_t *h_hit_count = nullptr;
         hipEvent_t start = nullptr, stop = nullptr, counted = nullptr, uploaded = nullptr;
         uint32_t id = 0;
@@ -281,11 +301,22 @@ private:
     bool pinning_refused_ = false;                      // the host would not page-lock more: results are copied out from then on
     std::mutex result_pool_mutex_;
     PinnedBuffer take_result_buffer(size_t records);    // {nullptr, 0} when every buffer is with the caller (or the host refuses)
+    // Page-locked step buffers (see Job): input queue depth + one per slot + the one being filled, each sized by the bunch it first
+    // carried (a quarter more), at most kStepPoolBytes in all
+    static constexpr int kStepBuffers = 8;
+    static constexpr size_t kStepPoolBytes = size_t{1} << 30;
+    std::vector<StepBuffer> free_step_buffers_;
+    int step_buffers_made_ = 0;
+    size_t step_pool_bytes_ = 0;
+    bool step_pinning_refused_ = false;
+    std::mutex step_pool_mutex_;
+    StepBuffer take_step_buffer(size_t steps);
+    void give_step_buffer(StepBuffer b);
     // index -> ID tables on the device (host path: converted by assemble_hits_kernel); null when an ID does not fit the record
     int16_t *d_id_strings_ = nullptr;
     uint16_t *d_id_doms_ = nullptr;
     uint32_t *d_id_dom_start_ = nullptr;
-    void submit(Slot &s, const Job &job);
+    void submit(Slot &s, Job &job);
     void finish(Slot &s, std::chrono::steady_clock::time_point &last_done, bool &first);
     WorkRecord *d_work_ = nullptr;           // per step: work record (kparams.h), rebuilt by every launch
     uint32_t *d_queue_ = nullptr;            // ring of step-queue heads, one per launch in flight

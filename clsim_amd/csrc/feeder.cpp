@@ -10,7 +10,10 @@
 // light source are born on the GPU in one launch (steps_kernel.hip) and enter the store in the same order and chunks.
 #include "feeder.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 extern "C" int clsimhip_generate_steps(int device, const clsimhip_step_request *requests, size_t n, uint64_t seed, size_t granularity,
@@ -41,6 +44,49 @@ StepProducer::~StepProducer()
     if (previous >= 0) (void)hipSetDevice(previous);
 }
 
+// stream and buffers (the caller has selected the device)
+void StepProducer::ensure(size_t steps, size_t requests)
+{
+    if (!stream_) {
+        int least = 0, greatest = 0;
+        hip_must(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priorities");
+        hip_must(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "step producer stream");
+    }
+    if (steps > cap_steps_) {
+        const size_t cap = steps + steps / 4;
+        (void)hipFree(d_steps_); d_steps_ = nullptr;
+        if (h_steps_) { (void)hipHostFree(h_steps_); h_steps_ = nullptr; }
+        cap_steps_ = 0;
+        hip_must(hipMalloc(&d_steps_, cap * sizeof(clsimhip_step)), "step buffer");
+        hip_must(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), cap * sizeof(clsimhip_step), hipHostMallocDefault), "pinned step buffer");
+        cap_steps_ = cap;
+    }
+    if (requests > cap_req_) {
+        const size_t cap = 2 * requests;
+        (void)hipFree(d_req_); (void)hipFree(d_first_); d_req_ = d_first_ = nullptr;
+        if (h_req_) { (void)hipHostFree(h_req_); h_req_ = nullptr; }
+        if (h_first_) { (void)hipHostFree(h_first_); h_first_ = nullptr; }
+        cap_req_ = 0;
+        hip_must(hipMalloc(&d_req_, cap * sizeof(clsimhip_step_request)), "request buffer");
+        hip_must(hipMalloc(&d_first_, cap * sizeof(uint64_t)), "offset buffer");
+        hip_must(hipHostMalloc(&h_req_, cap * sizeof(clsimhip_step_request), hipHostMallocDefault), "pinned request buffer");
+        hip_must(hipHostMalloc(&h_first_, cap * sizeof(uint64_t), hipHostMallocDefault), "pinned offset buffer");
+        cap_req_ = cap;
+    }
+}
+
+void StepProducer::reserve(size_t steps, size_t requests) noexcept
+{
+    try {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device_ < 0 || device_ >= count) { (void)hipGetLastError(); return; }
+        DeviceGuard on_device(device_);
+        ensure(steps, requests);
+    } catch (...) {
+        (void)hipGetLastError();
+    }
+}
+
 const clsimhip_step *StepProducer::generate(const std::vector<clsimhip_step_request> &requests, uint64_t seed, size_t granularity, size_t &real, size_t &padded)
 {
     // the plan of clsimhip_generate_steps (c_api.cpp: plan_steps), with its checks
@@ -61,32 +107,7 @@ const clsimhip_step *StepProducer::generate(const std::vector<clsimhip_step_requ
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available (the step producer has no CPU fallback)");
     if (device_ < 0 || device_ >= count) throw Error(CLSIMHIP_ERR_DEVICE, "device ordinal out of range");
     DeviceGuard on_device(device_);
-    if (!stream_) {
-        int least = 0, greatest = 0;
-        hip_must(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priorities");
-        hip_must(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "step producer stream");
-    }
-    if (padded > cap_steps_) {
-        const size_t cap = padded + padded / 4;
-        (void)hipFree(d_steps_); d_steps_ = nullptr;
-        if (h_steps_) { (void)hipHostFree(h_steps_); h_steps_ = nullptr; }
-        cap_steps_ = 0;
-        hip_must(hipMalloc(&d_steps_, cap * sizeof(clsimhip_step)), "step buffer");
-        hip_must(hipHostMalloc(reinterpret_cast<void **>(&h_steps_), cap * sizeof(clsimhip_step), hipHostMallocDefault), "pinned step buffer");
-        cap_steps_ = cap;
-    }
-    if (n + 1 > cap_req_) {
-        const size_t cap = 2 * (n + 1);
-        (void)hipFree(d_req_); (void)hipFree(d_first_); d_req_ = d_first_ = nullptr;
-        if (h_req_) { (void)hipHostFree(h_req_); h_req_ = nullptr; }
-        if (h_first_) { (void)hipHostFree(h_first_); h_first_ = nullptr; }
-        cap_req_ = 0;
-        hip_must(hipMalloc(&d_req_, cap * sizeof(clsimhip_step_request)), "request buffer");
-        hip_must(hipMalloc(&d_first_, cap * sizeof(uint64_t)), "offset buffer");
-        hip_must(hipHostMalloc(&h_req_, cap * sizeof(clsimhip_step_request), hipHostMallocDefault), "pinned request buffer");
-        hip_must(hipHostMalloc(&h_first_, cap * sizeof(uint64_t), hipHostMallocDefault), "pinned offset buffer");
-        cap_req_ = cap;
-    }
+    ensure(padded, n + 1);
     if (n) std::memcpy(h_req_, requests.data(), n * sizeof(clsimhip_step_request));
     std::memcpy(h_first_, first.data(), (n + 1) * sizeof(uint64_t));
     if (n) hip_must(hipMemcpyAsync(d_req_, h_req_, n * sizeof(clsimhip_step_request), hipMemcpyHostToDevice, stream_), "upload requests");
@@ -106,6 +127,12 @@ Feeder::Feeder(const PPCConverter *ppc, int device, uint64_t seed, size_t max_bu
     if (max_bunch_ % granularity_ != 0) throw Error(CLSIMHIP_ERR_ARGUMENT, "MaxBunchSize is not a multiple of BunchSizeGranularity!");   // :83-84
     in_.reset(new BoundedQueue<Item>(queue_depth ? queue_depth : 10));       // queueToGeant4_, queueFromGeant4_ (:64-65: depth 10 by default)
     out_.reset(new BoundedQueue<Result>(queue_depth ? queue_depth : 10));
+    if (ppc_) {
+        // the step producer's stream and buffers now (Initialize() of the Python / C++ classes), sized for a light source of three
+        // bunches (a 40 TeV cascade is 2.4 bunches of a million steps); a larger one grows them when it comes
+        producer_.reset(new StepProducer(device_));
+        producer_->reserve(3 * max_bunch_, 4096);
+    }
     thread_ = std::thread([this] { worker(); });
 }
 
@@ -217,7 +244,7 @@ void Feeder::insert_and_flush(const clsimhip_step *steps, size_t n)
 {
     for (size_t lo = 0; lo < n; lo += max_bunch_) {
         const size_t hi = std::min(n, lo + max_bunch_);
-        for (size_t i = lo; i < hi; ++i) store_.insert(steps[i]);
+        store_.insert_many(steps + lo, hi - lo);
         flush(false);
     }
 }
@@ -231,15 +258,24 @@ void Feeder::worker()
             flush(it.barrier);                              // :355-361
             if (it.barrier) continue;
             if (it.has_particle) {
+                static const bool trace = std::getenv("CLSIMHIP_FEEDER_TRACE") != nullptr;      // analysis: where a light source's time goes
+                const auto t_a = std::chrono::steady_clock::now();
                 std::vector<clsimhip_step_request> requests;
                 ppc_->enqueue(it.particle, requests);
+                const auto t_b = std::chrono::steady_clock::now();
                 // one random stream set per light source: results do not depend on what else is in the queue
                 // (and an identifier that comes back gets streams of its own: OccurrenceCounter, lightsource.h)
                 const uint64_t seed = seed_ ^ (0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(it.identifier) + 1ull)) ^ occurrences_.mix(it.identifier);
                 if (!producer_) producer_.reset(new StepProducer(device_));
                 size_t real = 0, padded = 0;
                 const clsimhip_step *steps = producer_->generate(requests, seed, 1, real, padded);
+                const auto t_c = std::chrono::steady_clock::now();
                 if (real) insert_and_flush(steps, real);
+                if (trace) {
+                    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                    std::fprintf(stderr, "feeder: light source %u: %zu requests in %.1f ms, %zu steps born and downloaded in %.1f ms, store + bunches %.1f ms\n",
+                                 it.identifier, requests.size(), ms(t_a, t_b), real, ms(t_b, t_c), ms(t_c, std::chrono::steady_clock::now()));
+                }
             } else {
                 insert_and_flush(it.steps.data(), it.steps.size());
             }

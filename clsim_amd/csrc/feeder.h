@@ -24,8 +24,13 @@ public:
     StepProducer &operator=(const StepProducer &) = delete;
     // the steps of `requests` (padded to `granularity`); the pointer stays valid until the next call
     const clsimhip_step *generate(const std::vector<clsimhip_step_request> &requests, uint64_t seed, size_t granularity, size_t &real, size_t &padded);
+    // stream and buffers for `steps` steps and `requests` requests now, not inside the first light source's conversion (page-locking
+    // 150 MB takes tens of milliseconds: the reference's benchmark flow waited for them in front of its first bunch).  Never throws:
+    // without a device, or without the memory, the first generate() reports it.
+    void reserve(size_t steps, size_t requests) noexcept;
 
 private:
+    void ensure(size_t steps, size_t requests);
     int device_;
     hipStream_t stream_ = nullptr;
     void *d_steps_ = nullptr, *d_req_ = nullptr, *d_first_ = nullptr;

@@ -18,6 +18,7 @@ public:
 
     // insert_copy(step.GetNumPhotons(), step): one FIFO per photon count, identifiers counted (StepStore.h:266-283)
     void insert(const clsimhip_step &step);
+    void insert_many(const clsimhip_step *steps, size_t n);        // insert() for each of them, in order
     size_t size() const { return size_; }
     bool empty() const { return size_ == 0; }
     // steps of this identifier still in the store (StepStore.h:308-312)

@@ -84,3 +84,30 @@ def test_padding_quirk_of_the_reference():
     assert store.size_with_dummy_fill(64) == 192 and store.size_with_dummy_fill(1) == 128 and store.size_with_dummy_fill(100) == 200
     with pytest.raises(I3CLSimStepToPhotonConverter_exception):
         SS.StepBuncher(100, 64)
+
+
+def test_bulk_insertion_and_run_wise_popping_equal_the_step_by_step_model():
+    """round 5: the feeder inserts a light source's steps run by run (equal photon count and identifier: one range insertion, one
+    count) and bunches leave a FIFO in one copy; the store must stay the reference's (I3CLSimStepStore.h:163-198, 266-296) whatever the
+    run structure: long runs (a cascade: all steps but the last carry 200 photons), single steps, interleaved identifiers, partial
+    pops that cut runs and identifiers in two."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    store, model = SS.I3CLSimStepStore(4), B.StepStoreModel()
+    for round_ in range(6):
+        parts = []
+        for identifier in (5, 6, 5, 9):
+            run = random_steps(rng, int(rng.integers(1, 300)), identifier, max_photons=3)
+            if rng.random() < 0.5:
+                run["num"] = 200                    # one long run
+            parts.append(run)
+        steps = np.concatenate(parts)
+        store.insert_copy(steps)                     # a whole array: one call into clsimhip_step_store_insert
+        for s in steps:
+            model.insert_copy(s)
+        assert store.size() == model.size()
+        assert [store.count(i) for i in (5, 6, 9, 1)] == [model.count(i) for i in (5, 6, 9, 1)]
+        k = int(rng.integers(1, store.size()))
+        assert same(store.pop_bunch_to_vector(k), model.pop_bunch_to_vector(k))
+        assert [store.count(i) for i in (5, 6, 9)] == [model.count(i) for i in (5, 6, 9)]
+    n = store.size()
+    assert same(store.pop_bunch_to_vector(n + 7), model.pop_bunch_to_vector(n + 7)) and store.empty()
