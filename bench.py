@@ -506,6 +506,30 @@ def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, ke
 WORKLOAD_NAMES = {"c2": "C2 = BASELINE configs[1]", "c3": "C3 (the ice and detector of BASELINE configs[2])", "c5": "C5 = BASELINE configs[4] (flasher half)"}
 
 
+def check_world(everyone, world, library_communicator):
+    """Did `world` ranks on `world` DIFFERENT devices take part?  `everyone`: one record per rank as the ranks reported themselves
+    (pci_bus_id: hipDeviceGetPCIBusId of the device the rank's communicator lives on; rccl_ranks / rccl_rank: ncclCommCount /
+    ncclCommUserRank of that communicator).  Returns (ok, reason).  Pure: tests/test_bench_multi_rank_rehearsal.py calls it on the CPU."""
+    if len(everyone) != world:
+        return False, "%d ranks reported, %d expected" % (len(everyone), world)
+    buses = [e.get("pci_bus_id") for e in everyone]
+    if any(not b for b in buses):
+        return False, "a rank could not name its device: %s" % buses
+    if len(set(buses)) != world:
+        return False, "the ranks sit on %d distinct devices %s" % (len(set(buses)), buses)
+    if sorted(e.get("rank") for e in everyone) != list(range(world)):
+        return False, "the ranks are not 0..%d: %s" % (world - 1, [e.get("rank") for e in everyone])
+    if library_communicator:
+        counted = [e.get("rccl_ranks") for e in everyone]
+        if any(c != world for c in counted):
+            return False, "the RCCL communicators count %s ranks" % counted
+        if sorted(e.get("rccl_rank") for e in everyone) != list(range(world)):
+            return False, "the RCCL communicators' ranks are %s" % [e.get("rccl_rank") for e in everyone]
+        if any(e.get("rccl_rank") != e.get("rank") for e in everyone):
+            return False, "a communicator's rank differs from its process's"
+    return True, ""
+
+
 def emit(line):
     """The one JSON line goes to the process's ORIGINAL stdout (see main)."""
     os.write(JSON_FD, (line + "\n").encode())
@@ -854,12 +878,10 @@ def main():
             everyone = [mine]
         buses = [e["pci_bus_id"] for e in everyone]
         counted = [e["rccl_ranks"] for e in everyone]
-        distinct = len(set(buses)) == world and None not in buses
-        agree = gatherer is None or (all(c == world for c in counted) and sorted(e["rccl_rank"] for e in everyone) == list(range(world)))
-        if world > 1 and not rehearsal and not (distinct and agree):
+        ok_world, why = check_world(everyone, world, gatherer is not None)
+        if world > 1 and not rehearsal and not ok_world:
             if rank == 0:
-                sys.stderr.write("bench.py: --gpus %d but the ranks sit on devices %s and their communicators count %s ranks: not an "
-                                 "N-GPU run, no line printed\n" % (world, buses, counted))
+                sys.stderr.write("bench.py: --gpus %d: %s: not an N-GPU run, no line printed\n" % (world, why))
             if gatherer is not None:
                 gatherer.close()
             dist.barrier()
@@ -876,6 +898,7 @@ def main():
                                          "none: the torch.distributed fallback ran",
                     "control_group": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1)},
                     "rank_devices": buses, "distinct_devices": len(set(buses)),
+                    "n_ranks_on_n_devices": ok_world, "n_ranks_on_n_devices_why_not": (why or None),
                     "rank_device_names": sorted(set(e["device_name"] for e in everyone)),
                     "per_rank": {"kernel_ms": spread("kernel_ms"), "gather_ms": spread("gather_ms"), "seconds": spread("seconds"),
                                  "launches": spread("launches"), "gathers": spread("gathers"),

@@ -62,6 +62,7 @@ def test_bench_multi_rank_path_on_one_gpu(world, workload, shard, port, launcher
     assert cfg["rccl_ranks"] == world and cfg["control_group"]["world_size"] == world
     assert len(cfg["rank_devices"]) == world and all(d and d.count(":") == 2 for d in cfg["rank_devices"])
     assert cfg["distinct_devices"] == 1                      # the rehearsal's ranks time-share one GPU, and the line shows it
+    assert cfg["n_ranks_on_n_devices"] is False and "1 distinct devices" in cfg["n_ranks_on_n_devices_why_not"]
     per = cfg["per_rank"]
     for key in ("kernel_ms", "gather_ms", "seconds"):
         assert per[key]["min"] > 0 and per[key]["max"] >= per[key]["min"] and 0 <= per[key]["argmax_rank"] < world, (key, per[key])
@@ -111,3 +112,32 @@ def test_plain_gpus_n_starts_n_ranks_of_its_own():
         assert "bench.py: rank %d of 3" % r in p.stderr, p.stderr[-2000:]
         assert "bench.py: rank %d exited with" % r in p.stderr
     assert p.stderr.count("needs a GPU") == 3
+
+
+def test_an_n_gpu_line_needs_n_ranks_on_n_devices():
+    """bench.py: check_world() -- what the ranks reported about themselves decides whether an N > 1 line is printed at all (exit code 4
+    otherwise): N records, N distinct PCI bus ids, ranks 0..N-1, and every communicator counting N ranks with the process's own rank."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    def world(n, **change):
+        recs = [dict(rank=r, pci_bus_id="0000:%02x:00.0" % (0x10 + r), rccl_ranks=n, rccl_rank=r) for r in range(n)]
+        for r, fields in change.items():
+            recs[int(r[1:])].update(fields)
+        return recs
+    assert bench.check_world(world(8), 8, True) == (True, "")
+    assert bench.check_world(world(2), 2, False) == (True, "")
+    ok, why = bench.check_world(world(4, r3=dict(pci_bus_id="0000:10:00.0")), 4, True)        # two ranks on one GPU
+    assert not ok and "3 distinct devices" in why
+    ok, why = bench.check_world(world(4, r2=dict(pci_bus_id=None)), 4, True)
+    assert not ok and "could not name its device" in why
+    ok, why = bench.check_world(world(4, r1=dict(rccl_ranks=1)), 4, True)                      # a communicator of its own
+    assert not ok and "count" in why
+    assert bench.check_world(world(4, r1=dict(rccl_ranks=1)), 4, False)[0]                     # (the torch.distributed fallback has no library communicator)
+    ok, why = bench.check_world(world(4, r1=dict(rccl_rank=2), r2=dict(rccl_rank=1)), 4, True)
+    assert not ok and "differs" in why
+    ok, why = bench.check_world(world(4)[:3], 4, True)
+    assert not ok and "3 ranks reported" in why
+    ok, why = bench.check_world(world(2, r1=dict(rank=0)), 2, False)
+    assert not ok and "not 0..1" in why

@@ -170,3 +170,29 @@ def test_c2_without_stop_on_detection_pooled_whole_bunch_subset():
     n = 1 << 20
     steps = S.cascade_steps(n, seed=1000, photons_per_step=200)
     check_at_size(cfg, steps, capacity=4 << 20, hit_fraction_range=(2e-4, 3e-3), stop_detected=False)
+
+
+@pytest.mark.timeout(900)
+def test_c4_one_gpu_shard_three_bunches():
+    """BASELINE configs[3] = 100M steps over 8 GPUs: ONE GPU's shard as bench.py --gpus 8 runs it (rank 0) -- 12 500 000 cascade steps
+    on SPICE-Mie in 3 bunches of 4 166 912 on one converter (the last one padded), streams carried from bunch to bunch.  No second GPU
+    is needed to check a shard: steps are independent units and a rank's streams are its own.  Prefix and whole-bunch subset of every
+    bunch against the oracle, determinism on a second converter."""
+    cfg = common.config("mie")
+    shard, n = 12500000, 4166912
+    bunches = [S.cascade_steps(min(n, shard - b * n), seed=1000 + 7919 * b, photons_per_step=200, pad_to=n) for b in range(3)]
+    assert sum(int((b["num"] > 0).sum()) for b in bunches) == shard and int((bunches[2]["num"] == 0).sum()) == 3 * n - shard
+    check_at_size(cfg, bunches, capacity=4 << 20, hit_fraction_range=(2e-4, 3e-3))
+
+
+@pytest.mark.timeout(600)
+def test_c5_eight_gpu_split_shard_on_the_classic_kernel():
+    """BASELINE configs[4] split over 8 GPUs: 10^9 photons / 8 / 400 = 312 500 flasher steps per GPU, padded to 312 832 -- fewer than the
+    pooled kernel's threshold, so the classic kernel runs them (bench.py: stream_count_note).  The whole shard's subset and prefix
+    against the oracle."""
+    cfg = common.config("flasher")
+    g = cfg["geom"]
+    k = int(np.argmin(np.abs(g["x"]) + np.abs(g["y"]) + np.abs(g["z"] + 100.0)))
+    steps = S.flasher_steps(312500, seed=1000, photons_per_step=400, position=(float(g["x"][k]), float(g["y"][k]), float(g["z"][k])), pad_to=512)
+    assert len(steps) == 312832
+    check_at_size(cfg, steps, capacity=8 << 20, hit_fraction_range=(5e-3, 5e-2), expect_kernel="classic")
