@@ -310,7 +310,17 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
     upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
     upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size() * sizeof(uint32_t), "string proximity map");
-    upload(reinterpret_cast<void **>(&d_dom_prox_), tables_.dom_prox.data(), tables_.dom_prox.size() * 4, "DOM proximity map");
+    {   // the DOM proximity map as the kernels read it: every cell with the centre of the DOM it names (kparams.h: dom_cells)
+        const size_t cells = tables_.dom_prox.size();
+        std::vector<uint32_t> fused(4 * cells, 0u);
+        for (size_t c = 0; c < cells; ++c) {
+            const uint32_t w = tables_.dom_prox[c], id = w & 0xffffu;
+            fused[4 * c] = w;
+            if (id != 0xffffu && 4 * static_cast<size_t>(id) + 2 < tables_.dom_centres.size())
+                std::memcpy(&fused[4 * c + 1], &tables_.dom_centres[4 * static_cast<size_t>(id)], 12);
+        }
+        upload(reinterpret_cast<void **>(&d_dom_prox_), fused.data(), fused.size() * 4, "DOM proximity map");
+    }
     upload(reinterpret_cast<void **>(&d_dom_centres_), tables_.dom_centres.data(), tables_.dom_centres.size() * 4, "DOM centres");
     upload(reinterpret_cast<void **>(&d_dom_named_), tables_.dom_named.data(), tables_.dom_named.size() * 4, "named-DOM records");
     upload(reinterpret_cast<void **>(&d_dom_tx_), G.dom_tx.data(), G.dom_tx.size() * 2, "dom_tx");
@@ -421,7 +431,7 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
     P.work = d_work_ + rng_offset;       // work records live with the stream slots: launches on disjoint slots may overlap
     P.len_table = d_len_table_;
     P.prox_map = d_prox_map_;
-    P.dom_prox = d_dom_prox_;
+    P.dom_cells = reinterpret_cast<const uint4 *>(d_dom_prox_);
     P.dom_centres = reinterpret_cast<const float4 *>(d_dom_centres_);
     P.dom_named = reinterpret_cast<const uint4 *>(d_dom_named_);
     P.hist_ring = d_hist_ring_;

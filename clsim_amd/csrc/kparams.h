@@ -103,7 +103,9 @@ struct KParams {
     // so only if the segment comes within its radius (prop_device.hip.h: dom_search_needed).  Consulted only by lanes whose step reaches a
     // string cylinder: most of them pass between two DOMs of the string (17 m apart, 0.8 m radius), and photons born
     // at a DOM (flashers) spend their lives within metres of it.  <= 64 MB in HBM, the words in use L2 / MALL resident.
-    const uint32_t *dom_prox;
+    // (round 5) On the device a cell is 16 bytes: {that word, x, y, z of the named DOM's centre} -- one load where rounds 2-4 made two
+    // dependent ones (the word, then dom_centres[id]); 4 x the bytes, of which the columns around the strings (a few MB) are ever read.
+    const uint4 *dom_cells;
     const float4 *dom_centres;          // x, y, z of every DOM as dom_position() reconstructs it, w = 0
     // Where the reference's search would meet that DOM (prop_device.hip.h: find_collision_named): x = string index | DOM number
     // in the string << 16; y = first cell column | first cell row << 12 | subdetector << 24 and w = last column | last row << 12 of

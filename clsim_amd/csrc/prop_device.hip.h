@@ -768,13 +768,14 @@ DM uint32_t dom_search_needed(KP P, const Photon &ph, float len)
     const int ix = clamp_index((int)((ph.px - P->dprox_x0) * inv), P->dprox_nx - 1);
     const int iy = clamp_index((int)((ph.py - P->dprox_y0) * inv), ny - 1);
     const int iz = clamp_index((int)((ph.pz - P->dprox_z0) * inv), nz - 1);
-    const uint32_t w = P->dom_prox[((uint32_t)ix * (uint32_t)ny + (uint32_t)iy) * (uint32_t)nz + (uint32_t)iz];      // z runs fastest; at most 2^24 cells
+    // the cell: {word, centre of the DOM it names} in one 16-byte load (z runs fastest; at most 2^24 cells)
+    const uint4 cell = P->dom_cells[((uint32_t)ix * (uint32_t)ny + (uint32_t)iy) * (uint32_t)nz + (uint32_t)iz];
+    const uint32_t w = cell.x;
     const float others = (float)((w >> 16) & 0xffu) * 0.25f;
     if (!(len < others)) return kSearchFull;
     const uint32_t id = w & 0xffffu;
     if (id == 0xffffu) return kSearchNone;
-    const float4 c = P->dom_centres[id];
-    const float wx = c.x - ph.px, wy = c.y - ph.py, wz = c.z - ph.pz;
+    const float wx = dm::u2f(cell.y) - ph.px, wy = dm::u2f(cell.z) - ph.py, wz = dm::u2f(cell.w) - ph.pz;        // (== dom_centres[id])
     // The reference's own sphere test for this DOM (c.cl:133-163) begins with urdot = (centre - photon) . direction -- these
     // operands, this order -- and discards the DOM when smin1 = urdot - discr < 0 with some discr >= 0: "starting inside the
     // DOM", which lets a flasher's photons leave the sphere they are born in (:157-159).
