@@ -174,8 +174,8 @@ def tabulator_bench(args, torch, device):
     # The bound this kernel has: its table sums are fp64 atomic adds that execute at the memory side (MI355X_MICROARCH.md, Global float
     # atomics: 1.3 TB/s of added bytes for 256-byte contiguous wave instructions, 0.08 TB/s = 2e10 lane-adds/s when every lane adds to a row
     # of its own -- which is what a path sample's bin is).  Added bytes per pass come from a stored rocprofv3 --pmc WRITE_SIZE pass of this
-    # command (profiles/r04/tab_pmc.json, "WRITE_SIZE reads the bytes exactly for float atomics"); the kernel time is live.
-    ppath = os.path.join(ROOT, "profiles", "r04", "tab_pmc.json")
+    # command (profiles/r05/tab_pmc.json, "WRITE_SIZE reads the bytes exactly for float atomics"); the kernel time is live.
+    ppath = os.path.join(ROOT, "profiles", "r05", "tab_pmc.json")
     if os.path.exists(ppath) and args.workload == "tab" and args.photons_per_step == 200 and n == 262144:
         with open(ppath) as f:
             prof = json.load(f)
@@ -189,7 +189,7 @@ def tabulator_bench(args, torch, device):
                            "peaks": "MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes for contiguous 256-byte wave instructions; 64 lanes in 64 "
                                     "different rows 17x slower, 0.08 TB/s = 2e10 adds/s -- a path sample's bin is a row of its own, so the second is this kernel's bound",
                            "traffic": prof.get("fabric_bytes_per_launch"), "atomic_requests_per_launch": requests,
-                           "traffic_source": {"file": "profiles/r04/tab_pmc.json", "git_revision": prof.get("git_revision"), "kernel": prof.get("kernel"),
+                           "traffic_source": {"file": "profiles/r05/tab_pmc.json", "git_revision": prof.get("git_revision"), "kernel": prof.get("kernel"),
                                               "profiled_kernel_ms": prof.get("kernel_ms")},
                            "avg_kernel_ms": kernel_ms}
     if not args.no_cpu_baseline:

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""The "current numbers" table of DESIGN.md section 6, generated from the kept measurement files of the round (profiles/r04/final_*:
+"""The "current numbers" table of DESIGN.md section 6, generated from the kept measurement files of the round (profiles/r05/final_*:
 bench.py lines and rocprofv3 summaries taken at the shipped revision).  `--write` replaces the block between the numbers markers in
 DESIGN.md; tests/test_design_numbers.py fails when DESIGN.md and the files disagree."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r04")
+R = os.path.join(ROOT, "profiles", "r05")
 ROWS = [("C2 = configs[1] (the headline; `python bench.py`)", "final_bench_default_line.json", "final_c2_pmc_summary.json"),
         ("C3 = configs[2], 10 M steps in two bunches (`--workload c3`)", "final_bench_c3.json", "final_c3_pmc_summary.json"),
         ("C5 = configs[4], flasher half (`--workload c5`)", "final_bench_c5.json", "final_c5_pmc_summary.json"),

@@ -14,7 +14,8 @@ $B > $OUT/final_bench_default_line.json 2> $OUT/default.err; echo default rc=$?
 $B --workload c3 --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c3.json 2> $OUT/c3.err; echo c3 rc=$?
 $B --workload c5 --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c5.json 2> $OUT/c5.err; echo c5 rc=$?
 $B --workload benchmark --steps 5 --warmup 1 > $OUT/final_bench_benchmark.json 2> $OUT/benchmark.err; echo benchmark rc=$?
-$B --workload benchmark-host --steps 4 > $OUT/final_bench_benchmark_host.json 2> $OUT/benchmark_host.err; echo benchmark-host rc=$?
+$B --workload benchmark-host --steps 12 > $OUT/final_bench_benchmark_host.json 2> $OUT/benchmark_host.err; echo benchmark-host rc=$?
+$B --workload benchmark-host --steps 4 > $OUT/final_bench_benchmark_host_8_events.json 2> $OUT/benchmark_host8.err; echo benchmark-host-8 rc=$?
 $B --keep-detected --no-cpu-baseline --no-host-path --steps 10 --warmup 2 > $OUT/final_bench_c2_keep.json 2> $OUT/c2_keep.err; echo c2keep rc=$?
 $B --workload c3 --keep-detected --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c3_keep.json 2> $OUT/c3_keep.err; echo c3keep rc=$?
 $B --workload c5 --keep-detected --no-cpu-baseline --no-host-path --steps 5 --warmup 1 > $OUT/final_bench_c5_keep.json 2> $OUT/c5_keep.err; echo c5keep rc=$?
