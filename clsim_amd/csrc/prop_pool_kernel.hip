@@ -40,6 +40,9 @@ namespace clsimhip {
 #define CLSIMHIP_POOL_BLOCK 768                 // 12 waves per workgroup, 2 workgroups per CU
 #define CLSIMHIP_POOL_WAVES 6                   // waves per SIMD the register allocation aims at (<= 80 VGPRs)
 #endif
+#ifndef CLSIMHIP_POOL_GROUPS
+#define CLSIMHIP_POOL_GROUPS 2                  // workgroups per CU the LDS is shared between (experiments: 4 groups of 7 waves, profiles/r05/ab_seven_waves.txt)
+#endif
 #ifndef CLSIMHIP_NAMED_POLICY
 #define CLSIMHIP_NAMED_POLICY 4                 // which parked lanes take the search confined to one DOM (see the search block)
 #endif
@@ -620,7 +623,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
 // workgroup, the rest goes to the waves' pools); keep_strings: the detector's strings without STOP_PHOTONS_ON_DETECTION, else 0
 static int pool_ring_that_fits(uint32_t table_words, uint32_t keep_strings)
 {
-    const int budget_words = (160 * 1024 / 2 - 2048) / 4 - (int)((table_words + 3u) & ~3u);         // per workgroup
+    const int budget_words = (160 * 1024 / CLSIMHIP_POOL_GROUPS - 4096 / CLSIMHIP_POOL_GROUPS) / 4 - (int)((table_words + 3u) & ~3u);         // per workgroup
     const int per_wave = (budget_words / kPoolWavesPerBlock) & ~3;                      // (a wave's region is a multiple of 16 bytes)
     return (per_wave - (int)kPoolFixedWords - (int)pool_keep_extra_words(keep_strings) - (int)kPendWords * 64) / (int)(kReadyWords + kPendWords);
 }
