@@ -652,6 +652,12 @@ def main():
     rehearsal = os.environ.get("CLSIMHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    # A launcher that gives every rank a device mask of its own (HIP_VISIBLE_DEVICES=r: one visible device, ordinal 0) is as good as
+    # one that shows every rank all of them: the rank takes what it sees.  Fewer visible devices than ranks any other way maps several
+    # ranks onto one GPU -- which check_world() below then refuses to report as an N-GPU run.
+    visible = torch.cuda.device_count()
+    if visible >= 1 and local_rank >= visible:
+        local_rank = 0 if visible == 1 else local_rank % visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctl = torch.device("cpu") if rehearsal else dev     # where the control tensors of torch.distributed live
