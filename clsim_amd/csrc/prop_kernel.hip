@@ -282,7 +282,11 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
                 if ((lane >= (uint32_t)off) && !flag) { sum += up; sum_sq += up_sq; flag = up_flag; }
             }
             if (commit && ((lane == 63u) || (next_key != key))) {
+#ifdef CLSIMHIP_EXP_TAB_F32      // experiment (profiles/r05/ab_tab_f32.txt): what binary32 atomics would buy; the table's contents are meaningless in this build
+                unsafeAtomicAdd(reinterpret_cast<float *>(P->tab_bins) + index, (float)sum);
+#else
                 unsafeAtomicAdd(P->tab_bins + index, sum);
+#endif
                 if (squares) unsafeAtomicAdd(P->tab_sq_bins + index, sum_sq);
             }
         }
