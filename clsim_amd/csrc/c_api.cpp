@@ -619,8 +619,8 @@ int clsimhip_check_math_exhaustive(int device_ordinal, int what, int exp_lo, int
 {
     return guarded(nullptr, [&] {
         need(result, "result");
-        if (!((what >= 11 && what <= 13) || (what >= 16 && what <= 18)) || exp_lo < -126 || exp_hi > 127 || exp_lo > exp_hi || result_cap < 1 || result_cap > 4096)
-            throw Error(CLSIMHIP_ERR_CONFIG, "clsimhip_check_math_exhaustive: what in 11..13 or 16..18, -126 <= exp_lo <= exp_hi <= 127, 1 <= result_cap <= 4096");
+        if (!((what >= 11 && what <= 13) || (what >= 16 && what <= 19)) || exp_lo < -126 || exp_hi > 127 || exp_lo > exp_hi || result_cap < 1 || result_cap > 4096)
+            throw Error(CLSIMHIP_ERR_CONFIG, "clsimhip_check_math_exhaustive: what in 11..13 or 16..19, -126 <= exp_lo <= exp_hi <= 127, 1 <= result_cap <= 4096");
         auto chk = [](hipError_t e, const char *w) { if (e != hipSuccess) throw Error(CLSIMHIP_ERR_DEVICE, std::string(w) + ": " + hipGetErrorString(e)); };
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw Error(CLSIMHIP_ERR_DEVICE, "no HIP device available");

@@ -391,7 +391,7 @@ DM float acos_f(float x)
     if (!(ax <= 1.0f)) return u2f(0x7fc00000u);
     const bool big = ax > 0.5f;
     const float z = big ? 0.5f * (1.0f - ax) : ax * ax;
-    const float s = big ? sqrt_(z) : ax;
+    const float s = big ? sqrt_near_(z) : ax;                 // (big: z is 0 or in [2^-26, 1/4], where sqrt_near_ is the IEEE root; else unused)
     const float p = (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f;
     const float a = s + (s * z) * p;                         // asin(s)
     if (big) return (x < 0.0f) ? (3.14159265358979f - 2.0f * a) : (2.0f * a);

@@ -49,17 +49,6 @@
 namespace clsimhip {
 
 // ---------------- TABULATE (c.cl:228-303) ----------------
-// Polynomial.cxx:96-153
-DM float angular_acceptance(KP P, float x)
-{
-    if (P->ang_has_min && x < P->ang_min) return P->ang_underflow;
-    if (P->ang_has_max && x > P->ang_max) return P->ang_overflow;
-    const int n = P->ang_n;
-    if (n == 0) return 0.0f;
-    float r = ldsf(P->off_ang + (uint32_t)(n - 1));
-    for (int i = n - 2; i >= 0; --i) r = ldsf(P->off_ang + (uint32_t)i) + x * r;
-    return r;
-}
 DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float bz, float bw)
 {
     return ((ax * bx + ay * by) + az * bz) + aw * bw;
@@ -74,14 +63,88 @@ DM float dot4(float ax, float ay, float az, float aw, float bx, float by, float 
 // LDS record at off_tab (tabulator.cpp): [0..4] scale, [5..9] offset, [10..14] bins, [15..19] stride, [20..24] sqrt axis,
 // [25] max of axis 0, [26] max of axis 3, [27] min_invGroupVel, [28] tan_thetaC, [29] VOLUME_MODE_STEP, [30] dimensions
 struct Segment { float px, py, pz, pt, dx, dy, dz, igv, wlen; };
-// (x, a): the photon's stream before the two draws of this sample (ANGLE = TABULATE_IMPACT_ANGLE only)
+// The wave-uniform constants of a path sample, read ONCE per savePath call into scalar registers (round 5, second half: the
+// sample loop used to read each where it needed it -- some twenty scalar loads per 64 samples, every one followed by its own
+// s_waitcnt: the loop was waiting for the scalar cache, not for its atomics; profiles/r05/ab_tab_bound.txt).
+struct TabK {
+    float ref[12];
+    int32_t kind, full_azimuth;
+    float scale[5], offset[5], inv_exp[5];
+    int32_t inverse[5], nbins[5];
+    uint32_t stride[5];
+    uint32_t tiled, tile_stride[3];
+    float max0, max3, min_inv_groupvel, tan_thetac;
+};
 template <bool ANGLE>
-DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uint64_t x, uint32_t a, uint32_t &index)
+DM TabK tab_constants(KP P)
 {
-    const uint32_t T = P->off_tab;
-    (void)ref_lds; (void)T;
-    // wave-uniform constants: scalar loads from the parameter block (they used to be ~36 LDS reads per sample batch)
-    auto R = [&](int k) { return P->tab_ref[k]; };
+    TabK K;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) K.ref[k] = P->tab_ref[k];
+    K.kind = P->tab_axes_kind;
+    K.full_azimuth = P->tab_full_azimuth;
+    constexpr int ndim = ANGLE ? 5 : 4;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const bool used = k < ndim;
+        K.scale[k] = used ? P->tab_scale[k] : 0.0f;
+        K.offset[k] = used ? P->tab_offset[k] : 0.0f;
+        K.inv_exp[k] = used ? P->tab_inv_exp[k] : 0.0f;
+        K.inverse[k] = used ? P->tab_inverse[k] : 0;
+        K.nbins[k] = used ? P->tab_nbins[k] : 0;
+        K.stride[k] = used ? P->tab_stride[k] : 0u;
+    }
+    K.tiled = ANGLE ? 0u : P->tab_tiled;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) K.tile_stride[k] = ANGLE ? 0u : P->tab_tile_stride[k];
+    K.max0 = P->tab_max0;
+    K.max3 = P->tab_max3;
+    K.min_inv_groupvel = P->tab_min_inv_groupvel;
+    K.tan_thetac = P->tab_tan_thetac;
+    return K;
+}
+// Axis::GetIndexCode (Axes.cxx:69-90, Axis.cxx:45-60): clamp(convert_int_sat_rtn(t), -1, n) + 1 for t = scale * inverse(x) - offset.
+// axis_bin_generic_ spells the saturating floor conversion out (NaN -> 0, beyond the int range -> its ends); axis_bin_ is the same
+// function in four instructions -- v_cvt_flr_i32_f32 floors and saturates by itself -- which
+// clsimhip_check_math_exhaustive(19) compares on ALL 2^32 bit patterns on the device (tests/test_detmath_gpu.py).
+DM uint32_t axis_bin_generic_(float t, int nbins)
+{
+    const float f = __builtin_floorf(t);
+    const int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
+    return (uint32_t)(clampi(b, -1, nbins) + 1);
+}
+DM uint32_t axis_bin_(float t, int nbins)
+{
+    int b, r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(t));
+    b = (t != t) ? 0 : b;                                               // (the instruction does not send NaN to 0: measured)
+    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(b), "s"(nbins));
+    return (uint32_t)(r + 1);
+}
+// FASTMATH (round 5): the sample's square roots and quotients through the range-restricted exact forms of detmath.hip.h (sqrt_near_: 8
+// instructions for the IEEE sequence's 17; div_near_: 8 for 11, and no VCC), which return the IEEE results on their admitted ranges;
+// `ok` comes back false for a lane with an operand outside them (a sample exactly on the table's axis or in its plane, a negative delay
+// time), and the caller then runs the IEEE flavour for the whole wave (a wave-uniform decision: one batch in a few hundred).
+DM bool sqrt_near_ok_(float x)      // +0, or 2^-96 ... 2^100
+{
+    const uint32_t u = dm::f2u(x);
+    return (u == 0u) || ((u - 0x0f800000u) <= (0x71800000u - 0x0f800000u));
+}
+template <bool FASTMATH> DM float tab_sqrt_(float x, bool &ok)
+{
+    if (FASTMATH) { ok = ok && sqrt_near_ok_(x); return dm::sqrt_near_(x); }
+    return dm::sqrt_(x);
+}
+template <bool FASTMATH> DM float tab_div_(float a, float b, bool &ok)       // (|b| within 2^-50 ... 2^50 wherever ok stays true)
+{
+    if (FASTMATH) { ok = ok && dm::div_near_ok_(a) && (__builtin_fabsf(a) <= 1.152921504606847e18f); return dm::div_near_(a, b); }
+    return a / b;
+}
+// (x, a): the photon's stream before the two draws of this sample (ANGLE = TABULATE_IMPACT_ANGLE only)
+template <bool ANGLE, bool FASTMATH>
+DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_t a, uint32_t &index, bool &ok)
+{
+    auto R = [&](int k) { return K.ref[k]; };
     // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
     const float ax = g.px + d * g.dx, ay = g.py + d * g.dy, az = g.pz + d * g.dz, aw = g.pt + d * g.igv;
     const float px = ax - R(0), py = ay - R(1), pz = az - R(2);
@@ -89,74 +152,100 @@ DM bool sample_bin(KP P, const uint32_t *ref_lds, const Segment &g, float d, uin
     const float ux = R(4), uy = R(5), uz = R(6), uw = R(7), qx = R(8), qy = R(9), qz = R(10), qw = R(11);
     const float l = dot4(px, py, pz, pw, ux, uy, uz, uw);
     const float rx_ = px - l * ux, ry_ = py - l * uy, rz_ = pz - l * uz, rw_ = pw - l * uw;
-    const float n_rho = dm::sqrt_(rx_ * rx_ + ry_ * ry_ + rz_ * rz_);
+    const float n_rho = tab_sqrt_<FASTMATH>(rx_ * rx_ + ry_ * ry_ + rz_ * rz_, ok);
     constexpr int ndim = ANGLE ? 5 : 4;
+    constexpr float kDegree = kPi / 180;
     float c0, c1, c2, c3, c4 = 0.0f;
-    if (P->tab_axes_kind == 0) {
-        c0 = dm::sqrt_(px * px + py * py + pz * pz);
-        const float azimuth = (n_rho > 0.0f) ? dm::acos_f(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / n_rho) / (kPi / 180) : 0.0f;
-        if (P->tab_full_azimuth) {
+    if (K.kind == 0) {
+        c0 = tab_sqrt_<FASTMATH>(px * px + py * py + pz * pz, ok);
+        float azimuth = 0.0f;
+        if (n_rho > 0.0f) {
+            const float angle = dm::acos_f(tab_div_<FASTMATH>(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw), n_rho, ok));
+            if (FASTMATH) { ok = ok && dm::div_near_ok_(angle); azimuth = dm::div_near_with_(angle, kDegree, 1.0f / kDegree); }
+            else azimuth = angle / kDegree;
+        }
+        if (K.full_azimuth) {
             const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
             const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
             c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
         } else {
             c1 = azimuth;
         }
-        c2 = (c0 > 0.0f) ? (l / c0) : 0.0f;
-        c3 = pw - c0 * P->tab_min_inv_groupvel;
+        c2 = (c0 > 0.0f) ? tab_div_<FASTMATH>(l, c0, ok) : 0.0f;
+        c3 = pw - c0 * K.min_inv_groupvel;
     } else {
         c0 = n_rho;
-        c1 = (c0 > 0.0f) ? dm::acos_f(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw) / c0) : 0.0f;
+        c1 = (c0 > 0.0f) ? dm::acos_f(tab_div_<FASTMATH>(dot4(rx_, ry_, rz_, rw_, qx, qy, qz, qw), c0, ok)) : 0.0f;
         c2 = R(2) + l * uz;
-        c3 = pw - (l + c0 * P->tab_tan_thetac) * 3.33564095f;
+        c3 = pw - (l + c0 * K.tan_thetac) * 3.33564095f;
     }
     if (ANGLE) {
         // TABULATE_IMPACT_ANGLE (spherical :67-79, cylindrical :61-76): drawn before the bounds check, like the reference
         const float sina = dm::sqrt_(rng_co(x, a));
         Vec3 dd = {g.dx, g.dy, g.dz};
         scatter_direction(dm::sqrt_(1.0f - sina * sina), sina, dd, rng_co(x, a));
-        if (P->tab_axes_kind == 0) {
-            c4 = (c0 > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, px, py, pz, pw) / c0) : 1.0f;
+        if (K.kind == 0) {
+            c4 = (c0 > 0.0f) ? tab_div_<FASTMATH>(dot4(dd.x, dd.y, dd.z, g.wlen, px, py, pz, pw), c0, ok) : 1.0f;
         } else {
             // (l - rho*recip(tan_thetaC))*dir, component by component as OpenCL evaluates it
-            const float rt = 1.0f / P->tab_tan_thetac;
+            const float rt = 1.0f / K.tan_thetac;
             const float kx = ax - (R(0) + (l - rx_ * rt) * ux), ky = ay - (R(1) + (l - ry_ * rt) * uy);
             const float kz = az - (R(2) + (l - rz_ * rt) * uz), kw = aw - (R(3) + (l - rw_ * rt) * uw);
             const float cdist = dm::sqrt_(kx * kx + ky * ky + kz * kz);
             c4 = (cdist > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, kx, ky, kz, kw) / cdist) : 1.0f;
         }
     }
-    if (P->tab_axes_kind == 0) {
-        if ((c3 > P->tab_max3) || (c0 > P->tab_max0)) return true;
+    if (K.kind == 0) {
+        if ((c3 > K.max3) || (c0 > K.max0)) return true;
     } else {
-        if (c3 > P->tab_max3) return true;
+        if (c3 > K.max3) return true;
     }
-    // Axes.cxx:69-90, Axis.cxx:45-60: clamp(convert_int_sat_rtn(scale * inverse(x) - offset), -1, n) + 1
     const float c[5] = {c0, c1, c2, c3, c4};
     uint32_t bin[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < ndim; ++k) {
-        const int pw = P->tab_inverse[k];           // wave-uniform
-        const float v = (pw <= 1) ? c[k] : (pw == 2) ? dm::sqrt_(c[k]) : (pw == 3) ? dm::cbrt_(c[k]) : dm::pow_frac_(c[k], P->tab_inv_exp[k]);
-        const float f = __builtin_floorf(P->tab_scale[k] * v - P->tab_offset[k]);
-        int b = (f != f) ? 0 : ((f >= 2147483648.0f) ? 2147483647 : ((f < -2147483648.0f) ? (-2147483647 - 1) : (int)f));
-        bin[k] = (uint32_t)(clampi(b, -1, P->tab_nbins[k]) + 1);
+        const int pw = K.inverse[k];                // wave-uniform
+        const float v = (pw <= 1) ? c[k] : (pw == 2) ? tab_sqrt_<FASTMATH>(c[k], ok) : (pw == 3) ? dm::cbrt_(c[k]) : dm::pow_frac_(c[k], K.inv_exp[k]);
+        bin[k] = axis_bin_(K.scale[k] * v - K.offset[k], K.nbins[k]);
     }
-    if (!ANGLE && P->tab_tiled) {
+    if (!ANGLE && K.tiled) {
         // the device's own order (kparams.h: tab_tiled): 2 x 2 x 2 bins of distance, polar angle and time in one 64-byte sector
-        index = (bin[0] >> 1) * P->tab_tile_stride[0] + bin[1] * P->tab_tile_stride[1] + (bin[2] >> 1) * P->tab_tile_stride[2] + ((bin[3] >> 1) << 3)
+        index = (bin[0] >> 1) * K.tile_stride[0] + bin[1] * K.tile_stride[1] + (bin[2] >> 1) * K.tile_stride[2] + ((bin[3] >> 1) << 3)
                 + (((bin[0] & 1u) << 2) | ((bin[2] & 1u) << 1) | (bin[3] & 1u));
     } else {
         index = 0;
 #pragma unroll
-        for (int k = 0; k < ndim; ++k) index += P->tab_stride[k] * bin[k];
+        for (int k = 0; k < ndim; ++k) index += K.stride[k] * bin[k];
     }
     return false;
 }
-DM void add_to_bin(KP P, uint32_t index, float w)
+// Lane shifts of the sample loop's segmented sum as DPP moves (row_shr 1, 2, 4, 8, then the row broadcasts 15 and 31; lanes without
+// a source read zero): a step is three register moves where __shfl_up is three trips through the LDS crossbar, and the six steps are
+// one dependent chain.
+template <int CTRL, int ROW_MASK>
+DM uint32_t dpp_zero_(uint32_t v)
 {
-    unsafeAtomicAdd(P->tab_bins + index, (double)w);
-    if (P->tab_sq_bins) unsafeAtomicAdd(P->tab_sq_bins + index, (double)w * (double)w);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK>
+DM void segmented_step_(double &sum, double &sum_sq, int &flag, bool squares)
+{
+    const uint64_t bits = __builtin_bit_cast(uint64_t, sum);
+    const uint32_t lo = dpp_zero_<CTRL, ROW_MASK>((uint32_t)bits), hi = dpp_zero_<CTRL, ROW_MASK>((uint32_t)(bits >> 32));
+    const int up_flag = (int)dpp_zero_<CTRL, ROW_MASK>((uint32_t)flag);
+    const double up = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+    double up_sq = 0.0;
+    if (squares) {
+        const uint64_t sb = __builtin_bit_cast(uint64_t, sum_sq);
+        const uint32_t slo = dpp_zero_<CTRL, ROW_MASK>((uint32_t)sb), shi = dpp_zero_<CTRL, ROW_MASK>((uint32_t)(sb >> 32));
+        up_sq = __builtin_bit_cast(double, (uint64_t)slo | ((uint64_t)shi << 32));
+    }
+    if (!flag) { sum += up; sum_sq += up_sq; flag = up_flag; }
+}
+DM void add_to_bin(double *bins, double *sq_bins, uint32_t index, float w)
+{
+    unsafeAtomicAdd(bins + index, (double)w);
+    if (sq_bins) unsafeAtomicAdd(sq_bins + index, (double)w * (double)w);
 }
 
 // savePath for a whole wave (called by all 64 lanes; `active` lanes bring one path segment each).
@@ -167,30 +256,59 @@ DM void add_to_bin(KP P, uint32_t index, float w)
 // samples are evaluated 64 at a time by whichever lanes, and a sample is added to the table unless its segment
 // went out of bounds at an earlier sample.  Bins and weights are those of the per-lane walk, bit for bit.
 // Returns true for lanes whose photon left the table.
+// Keeps a wave-uniform value where it is (a scalar register, loaded here): without it the compiler sinks each parameter load to its
+// first use, and the prologue below becomes a chain of scalar loads that each wait for the scalar cache.
+template <typename T>
+DM T here_(T v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
 template <bool ANGLE>
-DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool active, const Photon &ph, float weight,
-                       float length, float &remainder, float depth, float this_depth, uint64_t &rx, uint32_t ra)
+DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight,
+                       float length, float &remainder, float depth, float this_depth, uint64_t &rx, uint32_t ra
+#ifdef CLSIMHIP_TAB_TIMERS
+                       , uint64_t &t_list, uint64_t &t_last
+#endif
+                       )
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const float vstep = ldsf(P->off_tab + 29u);
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const float vstep = here_(P->tab_volume_step);
     // ANGLE = TABULATE_IMPACT_ANGLE: every sample draws two numbers from the photon's stream (its impact point on the
     // DOM), the angular acceptance is a table axis instead of a weight (c.cl:246-251)
     constexpr bool angle_axis = ANGLE;
-    const float impact = active ? (angle_axis ? weight : weight * angular_acceptance(P, ph.d.z)) : 0.0f;
+    float impact = active ? weight : 0.0f;
+    if (!angle_axis) {
+        // getAngularAcceptance (Polynomial.cxx:96-153), its parameters read in one go
+        const int has_min = here_(P->ang_has_min), has_max = here_(P->ang_has_max), n_coeff = here_(P->ang_n);
+        const float a_min = here_(P->ang_min), a_max = here_(P->ang_max), a_under = here_(P->ang_underflow), a_over = here_(P->ang_overflow);
+        const uint32_t off = here_(P->off_ang);
+        const float x = ph.d.z;
+        float r = 0.0f;
+        if (n_coeff > 0) {
+            r = ldsf(off + (uint32_t)(n_coeff - 1));
+            for (int i = n_coeff - 2; i >= 0; --i) r = ldsf(off + (uint32_t)i) + x * r;
+        }
+        if (has_max && x > a_max) r = a_over;
+        if (has_min && x < a_min) r = a_under;
+        impact = active ? weight * r : 0.0f;
+    }
     // number of samples and the value d ends with
     uint32_t n = 0;
     float d_end = remainder;
     // (the cap only guards the GPU against a walk that cannot advance, d + step == d; the reference's own walk ends
     // after TABLE_ENTRIES_PER_STREAM = 5000 samples of the whole step)
     if (active) for (; (d_end < length) && (n < (1u << 16)); d_end += vstep) ++n;
-    // exclusive prefix sum over the wave
+    // inclusive prefix sum over the wave, as DPP moves (row shifts 1, 2, 4, 8, then the row broadcasts)
     uint32_t incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= (uint32_t)off) incl += up;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    incl += dpp_zero_<0x111, 0xf>(incl);
+    incl += dpp_zero_<0x112, 0xf>(incl);
+    incl += dpp_zero_<0x114, 0xf>(incl);
+    incl += dpp_zero_<0x118, 0xf>(incl);
+    incl += dpp_zero_<0x142, 0xa>(incl);
+    incl += dpp_zero_<0x143, 0xc>(incl);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint32_t first = incl - n;
     // pool layout: d and owner per sample, plus the stream state before the sample's draws when there is an angle axis
     // (then the pool holds half as many samples)
@@ -199,7 +317,21 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
     bool stop = false;
     if (total == 0u) {
         // nothing to record
+#ifdef CLSIMHIP_EXP_TAB_NOSAMPLES   // experiment (profiles/r05/ab_tab_bound.txt): propagation alone; a segment's last sample is still looked at, so that photons leave the table where they do
+    } else if (true) {
+        const TabK K = tab_constants<ANGLE>(P);
+        double *const bins = P->tab_bins;
+        if (active && n > 0u) {
+            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, ph.tab_wlen};
+            uint32_t index;
+            bool ok_ = true;
+            if (sample_bin<ANGLE, false>(K, g, d_end - vstep, rx, ra, index, ok_)) stop = true;
+            if (index == 0xfffffff0u) unsafeAtomicAdd(bins + index, 1.0);
+        }
+#endif
     } else if (total > slots) {
+        const TabK K = tab_constants<ANGLE>(P);
+        double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
         // (rare) more samples than the pool holds: every lane walks its own segment
         if (active) {
             const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, ph.tab_wlen};
@@ -208,15 +340,17 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
                 uint32_t index;
                 const uint64_t x_sample = rx;
                 if (angle_axis) { (void)rng_co(rx, ra); (void)rng_co(rx, ra); }
-                if (sample_bin<ANGLE>(P, ref_lds, g, d, x_sample, ra, index)) { stop = true; break; }
-                add_to_bin(P, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
+                bool ok_ = true;
+                if (sample_bin<ANGLE, false>(K, g, d, x_sample, ra, index, ok_)) { stop = true; break; }
+                add_to_bin(bins, sq_bins, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
             }
             d_end = d;
         }
     } else {
+        const TabK K = tab_constants<ANGLE>(P);
+        double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
+        const bool squares = (sq_bins != nullptr);
         uint32_t *slot_d = wave_lds, *slot_owner = wave_lds + slots, *slot_xlo = wave_lds + 2u * slots, *slot_xhi = wave_lds + 3u * slots;
-        int *first_oob = reinterpret_cast<int *>(wave_lds + 2 * kTabSlots);
-        first_oob[lane] = 0x7fffffff;
         if (active) {
             float d = remainder;
             for (uint32_t j = 0; j < n; ++j, d += vstep) {
@@ -233,13 +367,29 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CLSIMHIP_TAB_TIMERS
+        { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; }
+#endif
+        // Out of bounds (isOutOfBounds ends the walk: c.cl:781-784) is rare -- once in a photon's life -- and is kept in
+        // registers: `dead`, the wave-uniform mask of lanes whose segment has left the table at an earlier sample, and per
+        // lane the index of its own segment's first such sample.
+        uint64_t dead = 0ull;
+        int my_first_oob = 0x7fffffff;
+        // (the next 64 samples' slots are read while these 64 are worked on)
+        uint32_t tag_next = (lane < total) ? slot_owner[lane] : 0u;
+        uint32_t d_next = (lane < total) ? slot_d[lane] : 0u;
         for (uint32_t base = 0; base < total; base += 64u) {
             const uint32_t slot = base + lane;
             const bool have = slot < total;
-            const uint32_t tag = have ? slot_owner[slot] : 0u;
+            const uint32_t tag = tag_next;
+            const float d = __builtin_bit_cast(float, d_next);
+            if (base + 64u < total) {
+                const bool more = slot + 64u < total;
+                tag_next = more ? slot_owner[slot + 64u] : 0u;
+                d_next = more ? slot_d[slot + 64u] : 0u;
+            }
             const int owner = (int)(tag & 0xffu);
             const int j = (int)(tag >> 8);
-            const float d = have ? __builtin_bit_cast(float, slot_d[slot]) : 0.0f;
             // the owner's segment
             Segment g;
             g.px = __shfl(ph.px, owner); g.py = __shfl(ph.py, owner); g.pz = __shfl(ph.pz, owner); g.pt = __shfl(ph.pt, owner);
@@ -257,55 +407,77 @@ DM bool save_path_wave(KP P, const uint32_t *ref_lds, uint32_t *wave_lds, bool a
             const float o_impact = __shfl(impact, owner);
             uint32_t index = 0;
             bool oob = false;
+            // the weight's quotient with the sample's (c.cl:270-272)
+            bool ok = true;
+            float along = 0.0f;
             if (have) {
-                oob = sample_bin<ANGLE>(P, ref_lds, g, d, x_sample, a_sample, index);
-                if (oob) atomicMin(&first_oob[owner], j);
+                oob = sample_bin<ANGLE, true>(K, g, d, x_sample, a_sample, index, ok);
+                along = tab_div_<true>(d, o_length, ok);
+                ok = ok && (o_length <= 1.125899906842624e15f);       // (2^50; a segment is longer than its samples' d)
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (__builtin_expect(ballot(!ok) != 0ull, 0)) {
+                // some lane's operand lies outside the exact forms' ranges: the IEEE sequences for the whole wave
+                if (have) {
+                    oob = sample_bin<ANGLE, false>(K, g, d, x_sample, a_sample, index, ok);
+                    along = d / o_length;
+                }
+            }
+            bool commit = have && !oob;
+            const uint64_t m_oob = ballot(oob);
+            if (__builtin_expect((m_oob | dead) != 0ull, 0)) {
+                // a segment's samples sit on neighbouring lanes in walking order: the lanes of my segment before me are
+                // [lane - j, lane) as far as they belong to this batch
+                const uint32_t start = (lane > (uint32_t)j) ? lane - (uint32_t)j : 0u;
+                const uint64_t mine_before = lanes_below & ~((1ull << start) - 1ull);
+                commit = commit && ((m_oob & mine_before) == 0ull) && (((dead >> owner) & 1ull) == 0ull);
+                for (uint64_t m = m_oob; m != 0ull; m &= m - 1ull) {
+                    const int l = __builtin_ctzll(m);
+                    const int o = __builtin_amdgcn_readlane(owner, l);
+                    if (((dead >> o) & 1ull) == 0ull) {          // this segment's first sample out of bounds
+                        dead |= 1ull << o;
+                        const int jj = __builtin_amdgcn_readlane(j, l);
+                        if ((int)lane == o) my_first_oob = jj;
+                    }
+                }
+            }
             // Consecutive samples of a segment fall into the same bin 60 % of the time: equal-bin neighbours are summed
             // in the wave first (segmented scan over the lanes, in double: sums of a few floats are exact there) and
             // the last lane of each run issues the atomic.  2.5x fewer read-modify-writes on the 670 MB table.
-            const bool commit = have && !oob && (j < first_oob[owner]);
-            const float w = commit ? o_impact * dm::exp_(-(o_depth + (d / o_length) * o_this)) : 0.0f;
+            const float w = commit ? o_impact * dm::exp_(-(o_depth + along * o_this)) : 0.0f;
             const uint32_t key = commit ? index : 0xffffffffu;
-            const uint32_t prev_key = (uint32_t)__shfl_up((int)key, 1), next_key = (uint32_t)__shfl_down((int)key, 1);
-            int flag = ((lane == 0u) || (prev_key != key) || !commit) ? 1 : 0;     // first lane of its run
+            // (wave_shr:1 / wave_shl:1; the lane without a neighbour keeps a key that is not its own)
+            const uint32_t prev_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138, 0xf, 0xf, false);
+            const uint32_t next_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x130, 0xf, 0xf, false);
+            int flag = ((prev_key != key) || !commit) ? 1 : 0;     // first lane of its run
             double sum = (double)w, sum_sq = (double)w * (double)w;
-            const bool squares = (P->tab_sq_bins != nullptr);
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const double up = __shfl_up(sum, off);
-                const double up_sq = squares ? __shfl_up(sum_sq, off) : 0.0;
-                const int up_flag = __shfl_up(flag, off);
-                if ((lane >= (uint32_t)off) && !flag) { sum += up; sum_sq += up_sq; flag = up_flag; }
-            }
-            if (commit && ((lane == 63u) || (next_key != key))) {
-#ifdef CLSIMHIP_EXP_TAB_F32      // experiment (profiles/r05/ab_tab_f32.txt): what binary32 atomics would buy; the table's contents are meaningless in this build
-                unsafeAtomicAdd(reinterpret_cast<float *>(P->tab_bins) + index, (float)sum);
+            segmented_step_<0x111, 0xf>(sum, sum_sq, flag, squares);
+            segmented_step_<0x112, 0xf>(sum, sum_sq, flag, squares);
+            segmented_step_<0x114, 0xf>(sum, sum_sq, flag, squares);
+            segmented_step_<0x118, 0xf>(sum, sum_sq, flag, squares);
+            segmented_step_<0x142, 0xa>(sum, sum_sq, flag, squares);
+            segmented_step_<0x143, 0xc>(sum, sum_sq, flag, squares);
+#ifdef CLSIMHIP_EXP_TAB_NOATOMIC // experiment (profiles/r05/ab_tab_bound.txt): the kernel's arithmetic alone; a condition no sample meets keeps it alive
+            if (commit && (next_key != key) && (sum < -1.0e300)) {
 #else
-                unsafeAtomicAdd(P->tab_bins + index, sum);
+            if (commit && (next_key != key)) {
 #endif
-                if (squares) unsafeAtomicAdd(P->tab_sq_bins + index, sum_sq);
+                unsafeAtomicAdd(bins + index, sum);
+                if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
             }
         }
+        if (active && (my_first_oob != 0x7fffffff)) {
+            stop = true;
+            d_end = __builtin_bit_cast(float, slot_d[first + (uint32_t)my_first_oob]);
+            if (angle_axis) {
+                // the walk ended at sample my_first_oob, whose two draws were made: the stream stands behind them
+                rx = rx_before;
+                for (int k = 0; k <= my_first_oob; ++k) { (void)rng_co(rx, ra); (void)rng_co(rx, ra); }
+            }
+        }
+        // (the lists are this wave's own and the next trip writes them again: its reads above have to be done first)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
-            const int s_ = first_oob[lane];
-            if (s_ != 0x7fffffff) {
-                stop = true;
-                d_end = __builtin_bit_cast(float, slot_d[first + (uint32_t)s_]);
-                if (angle_axis) {
-                    // the walk ended at sample s_, whose two draws were made: the stream stands behind them
-                    rx = rx_before;
-                    for (int k = 0; k <= s_; ++k) { (void)rng_co(rx, ra); (void)rng_co(rx, ra); }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     if (active) remainder = d_end - length;
     return stop;
@@ -380,6 +552,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     bool last_slice = false;   // the unit ends its step
     bool alive = true;
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
+    float unit_weight = 0.0f;   // TABULATE: the step's weight (c.cl:246-251), read when the lane takes the unit
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.layer = 0;
@@ -398,6 +571,12 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     // plain backward branch)
     bool need_next = true;
     uint64_t m_need = ~0ull, m_ready = 0ull;
+#ifdef CLSIMHIP_TAB_TIMERS      // analysis build of the table maker (tools/exp_tab_timers.py): shader-clock time per phase of a trip, summed per wave
+    uint64_t t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+#define TAB_STAMP(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_acc[k] += now_ - t_last; t_last = now_; }
+#else
+#define TAB_STAMP(k)
+#endif
     for (uint32_t trip = 0;; ++trip) {
         if (!TAB && ((trip & ((1u << kPrioShift) - 1u)) == 0u)) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -492,6 +671,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ra = rec->a;
                     step_dir = work_direction(&rec->step);
+                    if (TABULATE) unit_weight = P->steps[sidx].weight;      // (the work record carries the direction there)
                     waiting = false;
                 }
             }
@@ -512,6 +692,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             }
         }
 
+        TAB_STAMP(0)        // units and creation
         // ---- one reference loop iteration for the lanes that hold a photon ----
         // A lane runs the layer walk; if its step could reach a string (2 % of the lanes) it parks with the step
         // length until `k_search` lanes of the wave are parked (or nothing else can advance), and the DOM search runs
@@ -583,19 +764,25 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
         }
+        TAB_STAMP(1)        // layer walk
         if (TABULATE) {
             // c.cl:755-785; the absorption budget is the fixed PROPAGATE_FOR_FIXED_NUMBER_OF_ABSORPTION_LENGTHS
             const KP P = fresh_params(P0);
             const float travelled = P->fixed_abs - ph.abs_lens_left;
-            const float weight = run ? P->steps[sidx].weight : 0.0f;          // (the work record carries the direction there)
+            const float weight = run ? unit_weight : 0.0f;
             uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
-            const bool left_table = save_path_wave<TAB == 2>(P, lds_words + P->table_words, wave_lds, run, ph, weight, distance,
-                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra);
+            const bool left_table = save_path_wave<TAB == 2>(P, wave_lds, run, ph, weight, distance,
+                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra
+#ifdef CLSIMHIP_TAB_TIMERS
+                                                             , t_acc[6], t_last
+#endif
+                                                             );
             if (run) {
                 if (left_table) ph.abs_lens_left = 0.0f;
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
             }
         }
+        TAB_STAMP(2)        // savePath
         // ---- hit write-out (c.cl:329-385, collision c.cl:557-578) ----
         // The stubs collect in the wave's staging area across trips and leave kStageRecords at a time (and at the end of the
         // kernel): one atomic on the chip-wide hit counter per eight hits (prop_pool_kernel.hip).  A photon history is
@@ -663,8 +850,20 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         need_next = alive && !parked && (ph.abs_lens_left < kEpsilon);
         m_need = ballot(need_next);
         m_ready = ballot(alive && !need_next);
+        TAB_STAMP(3)        // advance, scattering
+#ifdef CLSIMHIP_TAB_TIMERS
+        t_acc[4] += 1;      // trips
+        t_acc[5] += (uint64_t)__popcll(ballot(run));
+#endif
         if ((m_need | m_ready) == 0ull) break;
     }
+#ifdef CLSIMHIP_TAB_TIMERS
+    if (TABULATE && lane == 0) {
+        // (the table's first words take the sums: its contents are meaningless in this build)
+        double *out = fresh_params(P0)->tab_bins;
+        for (int k = 0; k < 7; ++k) unsafeAtomicAdd(out + k, (double)t_acc[k]);
+    }
+#endif
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
 #ifdef CLSIMHIP_CENSUS
     if (lane == 0 && !TAB) {
@@ -800,12 +999,28 @@ __global__ void eval_math_kernel(int what, const float *xs, const float *ys, uin
 
 // Exhaustive proof runs for the range-restricted operations of detmath.hip.h: every significand (2^23) x every binary
 // exponent in [exp_lo, exp_hi], both signs for the reciprocal, against the IEEE operation.  what: 11 rcp_, 12 sqrt_near_,
-// 13 rsqrt_near_; 16 div_near_ (two-argument: see the kernel); 17 rcp_of_rcp_(rcp_(x), x) against 1/(1/x); 18 rsqrt_unit_ on its window.
+// 13 rsqrt_near_; 16 div_near_ (two-argument: see the kernel); 17 rcp_of_rcp_(rcp_(x), x) against 1/(1/x); 18 rsqrt_unit_ on its window;
+// 19 the table maker's axis_bin_ on every bit pattern (exponents do not apply).
 // result[0] = mismatches, result[1..] = bit patterns of the first few mismatching arguments.
 __global__ void check_math_kernel(int what, int exp_lo, int exp_hi, uint32_t *result, uint32_t result_cap)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;        // significand bits
     if (m >= (1u << 23)) return;
+    if (what == 19) {
+        // axis_bin_ against axis_bin_generic_: every one of the 2^32 bit patterns (512 per thread) x five bin counts
+        for (uint32_t k = 0; k < 512u; ++k) {
+            const float t = dm::u2f((m << 9) | k);
+            const int counts[5] = {1, 36, 105, 200, 65534};
+            for (int c = 0; c < 5; ++c) {
+                const int nb = __builtin_amdgcn_readfirstlane(counts[c]);
+                if (axis_bin_(t, nb) != axis_bin_generic_(t, nb)) {
+                    const uint32_t k2 = atomicAdd(result, 1u);
+                    if (k2 + 1u < result_cap) result[k2 + 1u] = dm::f2u(t);
+                }
+            }
+        }
+        return;
+    }
     if (what == 16) {
         // div_near_: every divisor significand x the divisor exponents [exp_lo, exp_hi] x both divisor signs x 40 numerators:
         // 32 pseudo-random ones over the whole admissible range and both signs, and 8 built from the divisor (exact and

@@ -119,6 +119,14 @@ def test_range_restricted_operations_equal_the_ieee_ones_on_every_input(what, ex
     assert bad == 0, "%d mismatches, first arguments %s" % (bad, [float.hex(float(v)) for v in first[:8]])
 
 
+def test_axis_bin_conversion_equals_the_spelled_out_one_on_every_bit_pattern():
+    """The table maker's axis_bin_ (prop_kernel.hip: v_cvt_flr_i32_f32 + v_med3_i32) against the generic saturating floor
+    conversion and clamp of Axis::GetIndexCode (Axis.cxx:45-60): all 2^32 bit patterns -- NaNs, infinities, denormals,
+    both signs -- x five bin counts."""
+    bad, first = check_exhaustive(19, 0, 0)
+    assert bad == 0, "%d mismatches, first arguments %s" % (bad, [float.hex(float(v)) for v in first[:8]])
+
+
 def test_square_root_of_zero_stays_zero():
     x = np.array([0.0, 1.0, 4.0, 2.0, 5.9604645e-8], dtype=np.float32)
     assert np.array_equal(bits(device_eval(12, x)), bits(np.sqrt(x)))
