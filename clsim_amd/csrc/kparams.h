@@ -185,10 +185,11 @@ struct KParams {
     int32_t tab_inverse[5], tab_nbins[5];       // tab_inverse: the axis' power (0, 1: identity, 2: sqrt, 3: cbrt, above: pow(x, tab_inv_exp))
     float tab_inv_exp[5];                       // ToFloatString(1./power), Axis.cxx:168
     uint32_t tab_stride[5];
-    // round 5: four-axis tables are kept TILED on the device -- 2 x 2 x 2 bins of axes 0, 2, 3 (distance, polar angle, time) share one
+    // round 5: four-axis tables are kept TILED on the device -- eight bins (tab_tile_bits) of axes 0, 2, 3 (distance, polar angle, time) share one
     // 64-byte sector, so that a photon path's consecutive samples meet fewer sectors (tabulator.cpp: tiled_; sample_bin) -- and put into
     // the reference's order when the table is read.  tab_tiled = 0: the reference's order (five axes; CLSIMHIP_TAB_LAYOUT=linear).
-    uint32_t tab_tiled, tab_tile_stride[3];     // strides of b0 >> 1, b1, b2 >> 1 (b3 >> 1 has stride 8)
+    uint32_t tab_tiled, tab_tile_stride[3];     // strides of b0 >> e0, b1, b2 >> e2 (b3 >> e3 has stride 8)
+    uint32_t tab_tile_bits[3];                  // e0, e2, e3: a sector holds 2^e0 x 2^e2 x 2^e3 bins of axes 0, 2, 3 (e0 + e2 + e3 = 3)
     float tab_max0, tab_max3, tab_min_inv_groupvel, tab_tan_thetac, tab_volume_step;
     int32_t ang_n;                      // getAngularAcceptance polynomial (coefficients in the LDS image)
     uint32_t off_ang;

@@ -72,7 +72,7 @@ struct TabK {
     float scale[5], offset[5], inv_exp[5];
     int32_t inverse[5], nbins[5];
     uint32_t stride[5];
-    uint32_t tiled, tile_stride[3];
+    uint32_t tiled, tile_stride[3], tile_bits[3];
     float max0, max3, min_inv_groupvel, tan_thetac;
 };
 template <bool ANGLE>
@@ -96,7 +96,7 @@ DM TabK tab_constants(KP P)
     }
     K.tiled = ANGLE ? 0u : P->tab_tiled;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) K.tile_stride[k] = ANGLE ? 0u : P->tab_tile_stride[k];
+    for (int k = 0; k < 3; ++k) { K.tile_stride[k] = ANGLE ? 0u : P->tab_tile_stride[k]; K.tile_bits[k] = ANGLE ? 0u : P->tab_tile_bits[k]; }
     K.max0 = P->tab_max0;
     K.max3 = P->tab_max3;
     K.min_inv_groupvel = P->tab_min_inv_groupvel;
@@ -209,9 +209,11 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
         bin[k] = axis_bin_(K.scale[k] * v - K.offset[k], K.nbins[k]);
     }
     if (!ANGLE && K.tiled) {
-        // the device's own order (kparams.h: tab_tiled): 2 x 2 x 2 bins of distance, polar angle and time in one 64-byte sector
-        index = (bin[0] >> 1) * K.tile_stride[0] + bin[1] * K.tile_stride[1] + (bin[2] >> 1) * K.tile_stride[2] + ((bin[3] >> 1) << 3)
-                + (((bin[0] & 1u) << 2) | ((bin[2] & 1u) << 1) | (bin[3] & 1u));
+        // the device's own order (kparams.h: tab_tiled): 2^e0 x 2^e2 x 2^e3 = 8 bins of distance, polar angle and time in one 64-byte sector
+        const uint32_t e0 = K.tile_bits[0], e2 = K.tile_bits[1], e3 = K.tile_bits[2];
+        const uint32_t h0 = bin[0] >> e0, h2 = bin[2] >> e2, h3 = bin[3] >> e3;
+        index = h0 * K.tile_stride[0] + bin[1] * K.tile_stride[1] + h2 * K.tile_stride[2] + (h3 << 3)
+                + (((bin[0] - (h0 << e0)) << (e2 + e3)) | ((bin[2] - (h2 << e2)) << e3) | (bin[3] - (h3 << e3)));
     } else {
         index = 0;
 #pragma unroll
@@ -483,6 +485,230 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
     return stop;
 }
 
+// savePath for a whole wave, four-axis tables (round 5, second half).  As above, but the pool outlives the loop trip: a trip works its
+// samples off in FULL batches of 64 and carries the remainder (fewer than 64) into the next trip, where they are the front of the pool
+// -- a trip brings 117 samples on average, and two or three batches of which the last one is half empty were 24 % of this loop's
+// issue slots.  What makes that possible:
+//   * a sample names its segment by a record in LDS (two generations of 64 records, alternating per trip) instead of by its owner's
+//     registers, which have moved on by the next trip;
+//   * leaving the table must be known in the trip it happens (the photon is dropped and its stream is not drawn from again,
+//     c.cl:781-784), so a trip may only carry samples when every one of its segments is CERTAINLY inside the table: the far end of
+//     the segment stays below the distance axis' end and its latest delay time below the time axis' end, each with a margin four
+//     orders of magnitude above the rounding of the sample's own arithmetic (conservative in one direction: a trip with a segment
+//     that fails the test -- the last trip or two of a photon's life, every trip of a cylindrical table -- works off everything it
+//     has, as before).  A carried sample is therefore never out of bounds;
+//   * samples carried once are in the next trip's first batch, or that trip works off everything (fewer than 64 in all), so a record
+//     is read in its own trip and the next one only.
+// `carry`, `parity`: wave-uniform state across trips; flush: work off everything (after the wave's last trip).
+DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight, float length, float &remainder,
+                             float depth, float this_depth, uint32_t &carry, uint32_t &parity, bool flush
+#ifdef CLSIMHIP_TAB_TIMERS
+                             , uint64_t &t_list, uint64_t &t_last
+#endif
+                             )
+{
+    typedef float row_t __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const float vstep = here_(P->tab_volume_step);
+    float impact = active ? weight : 0.0f;
+    {
+        // getAngularAcceptance (Polynomial.cxx:96-153), its parameters read in one go
+        const int has_min = here_(P->ang_has_min), has_max = here_(P->ang_has_max), n_coeff = here_(P->ang_n);
+        const float a_min = here_(P->ang_min), a_max = here_(P->ang_max), a_under = here_(P->ang_underflow), a_over = here_(P->ang_overflow);
+        const uint32_t off = here_(P->off_ang);
+        const float x = ph.d.z;
+        float r = 0.0f;
+        if (n_coeff > 0) {
+            r = ldsf(off + (uint32_t)(n_coeff - 1));
+            for (int i = n_coeff - 2; i >= 0; --i) r = ldsf(off + (uint32_t)i) + x * r;
+        }
+        if (has_max && x > a_max) r = a_over;
+        if (has_min && x < a_min) r = a_under;
+        impact = active ? weight * r : 0.0f;
+    }
+    uint32_t n = 0;
+    float d_end = remainder;
+    if (active) for (; (d_end < length) && (n < (1u << 16)); d_end += vstep) ++n;
+    uint32_t incl = n;
+    incl += dpp_zero_<0x111, 0xf>(incl);
+    incl += dpp_zero_<0x112, 0xf>(incl);
+    incl += dpp_zero_<0x114, 0xf>(incl);
+    incl += dpp_zero_<0x118, 0xf>(incl);
+    incl += dpp_zero_<0x142, 0xa>(incl);
+    incl += dpp_zero_<0x143, 0xc>(incl);
+    const uint32_t fresh = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t first = carry + (incl - n);
+    const uint32_t total = carry + fresh;
+    bool stop = false;
+    if (total == 0u) {
+        if (active) remainder = d_end - length;      // (no lane's segment holds a sample)
+        return false;
+    }
+    const TabK K = tab_constants<false>(P);
+    double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
+    const bool squares = (sq_bins != nullptr);
+    uint32_t *pool_d = wave_lds, *pool_tag = wave_lds + kTabPool;
+    uint32_t *records = wave_lds + 2 * kTabPool;
+    const uint32_t my_record = (parity << 6) | lane;
+    bool everything = flush || (total < 64u);
+    if (__builtin_expect(total > (uint32_t)kTabPool, 0)) {
+        // (rare) more samples than the pool holds: this trip's segments are walked by their own lanes, after the carried samples
+        everything = true;
+    } else if (active && (n != 0u)) {
+        row_t *rec = reinterpret_cast<row_t *>(records + my_record * (uint32_t)kTabSegWords);
+        rec[0] = row_t{ph.px, ph.py, ph.pz, ph.pt};
+        rec[1] = row_t{ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
+        rec[2] = row_t{length, depth, this_depth, impact};
+        float d = remainder;
+        for (uint32_t j = 0; j < n; ++j, d += vstep) {
+            pool_d[first + j] = __builtin_bit_cast(uint32_t, d);
+            pool_tag[first + j] = my_record | (j << 8);
+        }
+    }
+    const bool walk_alone = total > (uint32_t)kTabPool;
+    // is every segment of this trip certainly inside the table?  (spherical axes; see above)
+    if (!everything) {
+        bool inside = false;
+        if (K.kind == 0) {
+            const float qx = ph.px - K.ref[0], qy = ph.py - K.ref[1], qz = ph.pz - K.ref[2];
+            const float r0 = __builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz);
+            const float far = (r0 + length) * 1.0001f + 0.01f;
+            const float near = __builtin_fmaxf((r0 - length) * 0.9999f - 0.01f, 0.0f);
+            const float t_end = (ph.pt - K.ref[3]) + length * ph.inv_groupvel;
+            const float latest = (t_end + 1.0e-4f * __builtin_fabsf(t_end) + 0.01f) - near * K.min_inv_groupvel * 0.9999f;
+            inside = (far < K.max0) && (latest < K.max3 - 1.0e-4f * __builtin_fabsf(K.max3) - 0.01f);
+        }
+        everything = ballot(active && (n != 0u) && !inside) != 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CLSIMHIP_TAB_TIMERS
+    { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; }
+#endif
+    const uint32_t pooled = walk_alone ? carry : total;                             // samples in the pool
+    const uint32_t work = everything ? pooled : (pooled & ~63u);                    // ... and how many of them this trip works off
+    uint64_t dead = 0ull;
+    int my_first_oob = 0x7fffffff;
+    uint32_t tag_next = (lane < work) ? pool_tag[lane] : 0u;
+    uint32_t d_next = (lane < work) ? pool_d[lane] : 0u;
+    for (uint32_t base = 0; base < work; base += 64u) {
+        const uint32_t slot = base + lane;
+        const bool have = slot < work;
+        const uint32_t tag = tag_next;
+        const float d = __builtin_bit_cast(float, d_next);
+        if (base + 64u < work) {
+            const bool more = slot + 64u < work;
+            tag_next = more ? pool_tag[slot + 64u] : 0u;
+            d_next = more ? pool_d[slot + 64u] : 0u;
+        }
+        const uint32_t record = tag & 0x7fu;
+        const int j = (int)(tag >> 8);
+        const row_t *rec = reinterpret_cast<const row_t *>(records + record * (uint32_t)kTabSegWords);
+        const row_t r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const Segment g = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, 0.0f};
+        const float o_length = r2.x, o_depth = r2.y, o_this = r2.z, o_impact = r2.w;
+        uint32_t index = 0;
+        bool oob = false;
+        bool ok = true;
+        float along = 0.0f;
+        if (have) {
+            oob = sample_bin<false, true>(K, g, d, 0ull, 0u, index, ok);
+            along = tab_div_<true>(d, o_length, ok);
+            ok = ok && (o_length <= 1.125899906842624e15f);       // (2^50; a segment is longer than its samples' d)
+        }
+        if (__builtin_expect(ballot(!ok) != 0ull, 0)) {
+            // some lane's operand lies outside the exact forms' ranges: the IEEE sequences for the whole wave
+            if (have) {
+                oob = sample_bin<false, false>(K, g, d, 0ull, 0u, index, ok);
+                along = d / o_length;
+            }
+        }
+        bool commit = have && !oob;
+        const uint64_t m_oob = ballot(oob);
+        if (__builtin_expect((m_oob | dead) != 0ull, 0)) {
+            // (only this trip's segments can leave the table; a segment's samples sit on neighbouring lanes in walking order)
+            const bool mine = (record >> 6) == parity;
+            const int owner = (int)(record & 63u);
+            const uint32_t start = (lane > (uint32_t)j) ? lane - (uint32_t)j : 0u;
+            const uint64_t mine_before = lanes_below & ~((1ull << start) - 1ull);
+            commit = commit && !(mine && (((m_oob & mine_before) != 0ull) || (((dead >> owner) & 1ull) != 0ull)));
+            for (uint64_t m = m_oob; m != 0ull; m &= m - 1ull) {
+                const int l = __builtin_ctzll(m);
+                const int o = __builtin_amdgcn_readlane(owner, l);
+                if (((dead >> o) & 1ull) == 0ull) {          // this segment's first sample out of bounds
+                    dead |= 1ull << o;
+                    const int jj = __builtin_amdgcn_readlane(j, l);
+                    if ((int)lane == o) my_first_oob = jj;
+                }
+            }
+        }
+        const float w = commit ? o_impact * dm::exp_(-(o_depth + along * o_this)) : 0.0f;
+        const uint32_t key = commit ? index : 0xffffffffu;
+        // equal-bin neighbours are summed within rows of 16 lanes (row_shr / row_shl 1: the lane at a row's end keeps a key that is
+        // not its own, so a run ends there; four DPP steps instead of six, and what a run loses at a row's end -- a second atomic into
+        // the same sector from the same instruction -- the memory side merges)
+#ifdef CLSIMHIP_EXP_TAB_SCAN_ROWS
+        const uint32_t prev_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xf, 0xf, false);
+        const uint32_t next_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x101, 0xf, 0xf, false);
+#else
+        const uint32_t prev_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138, 0xf, 0xf, false);
+        const uint32_t next_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x130, 0xf, 0xf, false);
+#endif
+        int flag = ((prev_key != key) || !commit) ? 1 : 0;     // first lane of its run
+        double sum = (double)w, sum_sq = (double)w * (double)w;
+        segmented_step_<0x111, 0xf>(sum, sum_sq, flag, squares);
+        segmented_step_<0x112, 0xf>(sum, sum_sq, flag, squares);
+        segmented_step_<0x114, 0xf>(sum, sum_sq, flag, squares);
+        segmented_step_<0x118, 0xf>(sum, sum_sq, flag, squares);
+#ifndef CLSIMHIP_EXP_TAB_SCAN_ROWS
+        segmented_step_<0x142, 0xa>(sum, sum_sq, flag, squares);
+        segmented_step_<0x143, 0xc>(sum, sum_sq, flag, squares);
+#endif
+#ifdef CLSIMHIP_EXP_TAB_NOATOMIC
+        if (commit && (next_key != key) && (sum < -1.0e300)) {
+#else
+        if (commit && (next_key != key)) {
+#endif
+            unsafeAtomicAdd(bins + index, sum);
+            if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
+        }
+    }
+    if (walk_alone) {
+        if (active) {
+            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, 0.0f};
+            float d = remainder;
+            for (uint32_t taken = 0; (d < length) && (taken < n); d += vstep, ++taken) {
+                uint32_t index;
+                bool ok_ = true;
+                if (sample_bin<false, false>(K, g, d, 0ull, 0u, index, ok_)) { stop = true; break; }
+                add_to_bin(bins, sq_bins, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
+            }
+            d_end = d;
+        }
+        carry = 0u;
+    } else {
+        if (active && (my_first_oob != 0x7fffffff)) {
+            stop = true;
+            d_end = __builtin_bit_cast(float, pool_d[first + (uint32_t)my_first_oob]);
+        }
+        const uint32_t rest = pooled - work;
+        if (rest != 0u) {
+            // the remainder moves to the front of the pool (work is a multiple of 64 and at least 64 here)
+            const uint32_t t_ = (lane < rest) ? pool_tag[work + lane] : 0u, d_ = (lane < rest) ? pool_d[work + lane] : 0u;
+            if (lane < rest) { pool_tag[lane] = t_; pool_d[lane] = d_; }
+        }
+        carry = rest;
+        parity ^= 1u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) remainder = d_end - length;
+    return stop;
+}
+
 // TAB: 0 = photon propagation, 1 = TABULATE, 2 = TABULATE + TABULATE_IMPACT_ANGLE (a kernel of its own, so that the
 // four-dimensional table maker keeps its register allocation).  4 waves per SIMD: 86-110 VGPRs, nothing spilled, since
 // the sampling constants are scalar loads from the parameter block.
@@ -553,6 +779,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     bool alive = true;
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     float unit_weight = 0.0f;   // TABULATE: the step's weight (c.cl:246-251), read when the lane takes the unit
+    uint32_t tab_carry = 0u, tab_parity = 0u;      // TABULATE, four axes: samples carried into the next trip, generation of the segment records (save_path_wave_carry)
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.layer = 0;
@@ -770,13 +997,20 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             const KP P = fresh_params(P0);
             const float travelled = P->fixed_abs - ph.abs_lens_left;
             const float weight = run ? unit_weight : 0.0f;
-            uint32_t *wave_lds = lds_words + P->table_words + 16u + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
-            const bool left_table = save_path_wave<TAB == 2>(P, wave_lds, run, ph, weight, distance,
-                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra
+            uint32_t *wave_lds = lds_words + ((P->table_words + 16u + 3u) & ~3u) + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;     // (16-byte rows)
+            bool left_table;
+            if (TAB == 2) left_table = save_path_wave<true>(P, wave_lds, run, ph, weight, distance,
+                                                            ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra
 #ifdef CLSIMHIP_TAB_TIMERS
-                                                             , t_acc[6], t_last
+                                                            , t_acc[6], t_last
 #endif
-                                                             );
+                                                            );
+            else left_table = save_path_wave_carry(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
+                                                   tab_carry, tab_parity, false
+#ifdef CLSIMHIP_TAB_TIMERS
+                                                   , t_acc[6], t_last
+#endif
+                                                   );
             if (run) {
                 if (left_table) ph.abs_lens_left = 0.0f;
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
@@ -856,6 +1090,17 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         t_acc[5] += (uint64_t)__popcll(ballot(run));
 #endif
         if ((m_need | m_ready) == 0ull) break;
+    }
+    if ((TAB == 1) && (tab_carry != 0u)) {
+        // the samples the last trip carried
+        const KP P = fresh_params(P0);
+        uint32_t *wave_lds = lds_words + ((P->table_words + 16u + 3u) & ~3u) + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
+        float no_remainder = 0.0f;
+        (void)save_path_wave_carry(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true
+#ifdef CLSIMHIP_TAB_TIMERS
+                                   , t_acc[6], t_last
+#endif
+                                   );
     }
 #ifdef CLSIMHIP_TAB_TIMERS
     if (TABULATE && lane == 0) {
@@ -1130,7 +1375,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
     KParams P = Pin;
     constexpr bool TABULATE = (TAB == 1) || (TAB == 2);
     // (without STOP_PHOTONS_ON_DETECTION: one more word per lane and 64 strings, find_collisions_keep's string mask)
-    const size_t lds_bytes = TABULATE ? (size_t)(P.table_words + 16 + kWavesPerBlock * kTabWaveWords) * 4
+    const size_t lds_bytes = TABULATE ? (size_t)(((P.table_words + 16 + 3) & ~3u) + kWavesPerBlock * kTabWaveWords) * 4
                                       : (size_t)(P.table_words + kWavesPerBlock * kStageRecords * kStubWords + kBlock
                                                  + ((TAB == 3) ? kBlock * (((size_t)P.num_strings + 63u) >> 6) : 0u)) * 4;
     if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;

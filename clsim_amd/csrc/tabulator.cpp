@@ -82,16 +82,23 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     for (size_t i = nd - 1; i-- > 0;) { shape_[i] = axes_[i].n_bins + 2; strides_[i] = strides_[i + 1] * shape_[i + 1]; }
     n_bins_ = strides_[0] * shape_[0];
     if (n_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
-    // The device's own bin order for four axes (round 5): 2 x 2 x 2 bins of axes 0, 2 and 3 -- distance, polar angle, time: the three
-    // a photon's path changes from sample to sample -- share one 64-byte sector; azimuth (axis 1) stays whole.  The table's sums are
-    // memory-side atomic requests of one sector each, and a path's consecutive samples then meet fewer sectors than with eight time
-    // bins to a sector.  bin_content_double() puts the sums into the reference's order (Axes.cxx:51-64).  CLSIMHIP_TAB_LAYOUT=linear
-    // keeps the reference's order on the device too (measurement; five-axis tables always).
+    // The device's own bin order for four axes (round 5): 4 x 2 x 1 bins of axes 0, 2 and 3 -- distance, polar angle, time -- share one
+    // 64-byte sector; azimuth (axis 1) stays whole.  The table's sums are memory-side atomic requests of one sector each, and a path's
+    // consecutive samples then meet fewer sectors than with eight time bins to a sector: the distance and polar-angle bins are the
+    // ones a path crosses (profiles/r05/tab_tile_scan.txt: 2 x 2 x 2 1.5 % behind, eight time bins 14 %).  bin_content_double() puts the
+    // sums into the reference's order (Axes.cxx:51-64).  CLSIMHIP_TAB_LAYOUT=linear keeps the reference's order on the device too
+    // (measurement; five-axis tables always).
     tiled_ = (nd == 4);
     if (const char *e = std::getenv("CLSIMHIP_TAB_LAYOUT")) tiled_ = tiled_ && (std::strcmp(e, "linear") != 0);
     n_device_bins_ = n_bins_;
+    if (const char *e = std::getenv("CLSIMHIP_TAB_TILE")) {
+        // (measurement: the tile's shape as three digits e0 e2 e3 with e0 + e2 + e3 = 3, e.g. 210 = 4 x 2 x 1 bins of distance, polar angle, time)
+        if (std::strlen(e) == 3 && e[0] >= '0' && e[1] >= '0' && e[2] >= '0' && (e[0] - '0') + (e[1] - '0') + (e[2] - '0') == 3)
+            for (int k = 0; k < 3; ++k) tile_bits_[k] = static_cast<unsigned>(e[k] - '0');
+    }
     if (tiled_) {
-        const size_t h0 = (shape_[0] + 1) / 2, h2 = (shape_[2] + 1) / 2, h3 = (shape_[3] + 1) / 2;
+        const size_t t0 = size_t(1) << tile_bits_[0], t2 = size_t(1) << tile_bits_[1], t3 = size_t(1) << tile_bits_[2];
+        const size_t h0 = (shape_[0] + t0 - 1) / t0, h2 = (shape_[2] + t2 - 1) / t2, h3 = (shape_[3] + t3 - 1) / t3;
         tile_stride_[2] = h3 * 8; tile_stride_[1] = h2 * tile_stride_[2]; tile_stride_[0] = shape_[1] * tile_stride_[1];
         n_device_bins_ = h0 * tile_stride_[0];
         if (n_device_bins_ >= 0xffffffffull) throw Error(CLSIMHIP_ERR_CONFIG, "table has more than 2^32 bins");
@@ -130,6 +137,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     }
     P.tab_tiled = tiled_ ? 1u : 0u;
     for (int k = 0; k < 3; ++k) P.tab_tile_stride[k] = tiled_ ? static_cast<uint32_t>(tile_stride_[k]) : 0u;
+    for (int k = 0; k < 3; ++k) P.tab_tile_bits[k] = tile_bits_[k];
     P.tab_max0 = to_float_literal(axes_[0].max);
     P.tab_max3 = to_float_literal(axes_[3].max);
     const auto n_min = minimum_refractive_index(medium);
@@ -312,8 +320,10 @@ void Tabulator::bin_content_double(double *out, size_t n, bool squared)
     for (size_t b0 = 0; b0 < shape_[0]; ++b0)
         for (size_t b1 = 0; b1 < shape_[1]; ++b1)
             for (size_t b2 = 0; b2 < shape_[2]; ++b2) {
-                const size_t base = (b0 >> 1) * tile_stride_[0] + b1 * tile_stride_[1] + (b2 >> 1) * tile_stride_[2] + ((b0 & 1) << 2) + ((b2 & 1) << 1);
-                for (size_t b3 = 0; b3 < shape_[3]; ++b3) out[at++] = device[base + ((b3 >> 1) << 3) + (b3 & 1)];
+                const unsigned e0 = tile_bits_[0], e2 = tile_bits_[1], e3 = tile_bits_[2];
+                const size_t base = (b0 >> e0) * tile_stride_[0] + b1 * tile_stride_[1] + (b2 >> e2) * tile_stride_[2]
+                                    + ((b0 & ((size_t(1) << e0) - 1)) << (e2 + e3)) + ((b2 & ((size_t(1) << e2) - 1)) << e3);
+                for (size_t b3 = 0; b3 < shape_[3]; ++b3) out[at++] = device[base + ((b3 >> e3) << 3) + (b3 & ((size_t(1) << e3) - 1))];
             }
 }
 

@@ -58,8 +58,9 @@ private:
     std::vector<AxisData> axes_;
     std::vector<size_t> shape_, strides_;
     size_t n_bins_ = 0;
-    bool tiled_ = false;                     // the device keeps the bins in 2 x 2 x 2 tiles of axes 0, 2, 3 (tabulator.cpp)
+    bool tiled_ = false;                     // the device keeps the bins in tiles of eight of axes 0, 2, 3 (tabulator.cpp)
     size_t n_device_bins_ = 0, tile_stride_[3] = {0, 0, 0};
+    unsigned tile_bits_[3] = {2, 1, 0};      // bins per sector along axes 0, 2, 3 as powers of two (sum 3): 4 x 2 x 1 (tabulator.cpp)
     bool squared_;
     double reference_area_, step_length_;
     double n_group_ = 0, n_phase_ = 0;
