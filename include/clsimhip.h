@@ -380,7 +380,9 @@ int clsimhip_eval_device_random(clsimhip_converter *c, int what, int generator, 
  * exponent in [exp_lo, exp_hi].  result[0] = number of mismatches, result[1..cap) = bit patterns of the first ones.
  * what = 16: the range-restricted divide, all 2^23 divisor significands x the divisor exponents [exp_lo, exp_hi] x both
  * divisor signs x 40 numerators each (random and adversarial, exponents -40 ... 60); result[1..] = (numerator, divisor)
- * pairs of the first mismatches. */
+ * pairs of the first mismatches.  what = 17 / 18: the reciprocal of a reciprocal, the reciprocal root next to one (detmath.hip.h).
+ * what = 19: the table maker's axis bin (floor, saturating conversion, clamp: Axis.cxx:45-60) as the kernel forms it against the
+ * spelled-out conversion on ALL 2^32 bit patterns x five bin counts (exp_lo / exp_hi do not apply). */
 int clsimhip_check_math_exhaustive(int device_ordinal, int what, int exp_lo, int exp_hi, uint32_t *result, size_t result_cap);
 
 const char *clsimhip_version(void);
