@@ -671,7 +671,11 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
 #else
         if (commit && (next_key != key)) {
 #endif
+#ifdef CLSIMHIP_EXP_TAB_F32      // experiment (profiles/r05/ab_tab_bound.txt): binary32 atomics into the same sectors; the table's contents are meaningless in this build
+            unsafeAtomicAdd(reinterpret_cast<float *>(bins + index), (float)sum);
+#else
             unsafeAtomicAdd(bins + index, sum);
+#endif
             if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
         }
     }

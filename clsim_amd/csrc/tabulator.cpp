@@ -172,6 +172,7 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
         tables_.named["getAngularAcceptance"] = angular.coefficients;
     }
     tables_.named["TABULATOR"] = {n_group_, n_phase_, P.tab_min_inv_groupvel, P.tab_tan_thetac, double(n_bins_)};
+    tables_.named["LDS_IMAGE_WORDS"] = {double(P.table_words)};          // (what a workgroup stages; the waves' sample pools come on top)
     tables_.named["TABULATOR_SCALE"] = std::vector<double>(P.tab_scale, P.tab_scale + nd);
     tables_.named["TABULATOR_OFFSET"] = std::vector<double>(P.tab_offset, P.tab_offset + nd);
 
