@@ -171,12 +171,12 @@ def tabulator_bench(args, torch, device):
            "config": {"workload": "%d steps x %d photons at the origin, spherical axes %s, spice_mie, 42 absorption lengths, "
                                   "1 m sampling; BASELINE.json configs[4] (tablemaker half)"
                                   % (n, args.photons_per_step, "x".join(str(v - 2) for v in tab.shape))}}
-    # The bound this kernel has SINCE the second half of round 5 (measured, profiles/r05/ab_tab_bound.txt: with its atomics compiled out a
-    # pass takes 1.77 s instead of 1.97; before that the kernel was issue bound and the atomics cost 1.6 %): its table sums are fp64 atomic
-    # adds that execute at the memory side (MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes for 256-byte contiguous wave
-    # instructions, 0.08 TB/s = 2e10 lane-adds/s when every lane adds to a row of its own -- which is what a path sample's bin is).  Added
-    # bytes per pass come from a stored rocprofv3 --pmc WRITE_SIZE pass of this command (profiles/r05/tab_pmc.json, "WRITE_SIZE reads the
-    # bytes exactly for float atomics"); the kernel time is live.
+    # The table sums are fp64 atomic adds that execute at the memory side (MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes
+    # for 256-byte contiguous wave instructions = 2e10 sector requests per second; measured here for this kernel's shape, tools/micro/atomic_rate.hip:
+    # 2.2e10 fp64 sector requests per second whatever the lanes per sector).  What the atomics cost the kernel is measured too
+    # (profiles/r05/ab_tab_bound.txt): compiled out, a pass takes 1.77 s instead of 1.97 -- 11 %, at 0.53 of their rate; the arithmetic is the
+    # rest.  Added bytes per pass come from a stored rocprofv3 --pmc WRITE_SIZE pass of this command (profiles/r05/tab_pmc.json, "WRITE_SIZE
+    # reads the bytes exactly for float atomics"); the kernel time is live.
     ppath = os.path.join(ROOT, "profiles", "r05", "tab_pmc.json")
     if os.path.exists(ppath) and args.workload == "tab" and args.photons_per_step == 200 and n == 262144:
         with open(ppath) as f:
@@ -184,13 +184,14 @@ def tabulator_bench(args, torch, device):
         requests = prof["write_bytes_per_launch"] / 64.0           # a lane's add to a bin of its own leaves the L2 as one 64-byte atomic request
         added = requests * 8.0
         seconds = kernel_ms * 1e-3
-        out["roofline"] = {"bound": "hbm", "what": "memory-side fp64 atomic adds of the table sums: one 64-byte request per sector and wave instruction (measured bound: "
-                                                   "profiles/r05/ab_tab_bound.txt; the arithmetic alone takes 0.9 of the pass)",
+        out["roofline"] = {"bound": "hbm", "what": "memory-side fp64 atomic adds of the table sums: one 64-byte request per sector and wave instruction (they cost 11 % of a "
+                                                   "pass, measured by compiling them out; the arithmetic is the rest: profiles/r05/ab_tab_bound.txt)",
                            "achieved": added / seconds / 1e9, "peak": 1300.0, "unit": "GB/s of added bytes", "frac": added / seconds / 1e9 / 1300.0,
-                           "atomic_requests_per_s": requests / seconds, "scattered_atomic_peak_per_s": 2.0e10,
-                           "frac_of_scattered_rate": requests / seconds / 2.0e10,
-                           "peaks": "MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes for contiguous 256-byte wave instructions; 64 lanes in 64 "
-                                    "different rows 17x slower, 0.08 TB/s = 2e10 adds/s -- a path sample's bin is a row of its own, so the second is this kernel's bound",
+                           "atomic_requests_per_s": requests / seconds, "scattered_atomic_peak_per_s": 2.2e10,
+                           "frac_of_scattered_rate": requests / seconds / 2.2e10,
+                           "peaks": "MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes for contiguous 256-byte wave instructions (= 2e10 sector requests/s); "
+                                    "tools/micro/atomic_rate.hip on this chip: 2.2e10 fp64 sector requests/s for 8 ... 64 lanes into 8 ... 64 random sectors per instruction "
+                                    "(profiles/r05/atomic_rate_microbench.txt) -- the second is the rate this kernel's requests are priced against",
                            "traffic": prof.get("fabric_bytes_per_launch"), "atomic_requests_per_launch": requests,
                            "traffic_source": {"file": "profiles/r05/tab_pmc.json", "git_revision": prof.get("git_revision"), "kernel": prof.get("kernel"),
                                               "profiled_kernel_ms": prof.get("kernel_ms")},
