@@ -503,7 +503,7 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
 DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight, float length, float &remainder,
                              float depth, float this_depth, uint32_t &carry, uint32_t &parity, bool flush
 #ifdef CLSIMHIP_TAB_TIMERS
-                             , uint64_t &t_list, uint64_t &t_last
+                             , uint64_t &t_list, uint64_t &t_last, uint64_t &t_add
 #endif
                              )
 {
@@ -666,6 +666,9 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
         segmented_step_<0x142, 0xa>(sum, sum_sq, flag, squares);
         segmented_step_<0x143, 0xc>(sum, sum_sq, flag, squares);
 #endif
+#ifdef CLSIMHIP_TAB_TIMERS
+        const uint64_t t_before_add = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef CLSIMHIP_EXP_TAB_NOATOMIC
         if (commit && (next_key != key) && (sum < -1.0e300)) {
 #else
@@ -678,6 +681,9 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
 #endif
             if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
         }
+#ifdef CLSIMHIP_TAB_TIMERS
+        t_add += __builtin_amdgcn_s_memtime() - t_before_add;
+#endif
     }
     if (walk_alone) {
         if (active) {
@@ -803,7 +809,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     bool need_next = true;
     uint64_t m_need = ~0ull, m_ready = 0ull;
 #ifdef CLSIMHIP_TAB_TIMERS      // analysis build of the table maker (tools/exp_tab_timers.py): shader-clock time per phase of a trip, summed per wave
-    uint64_t t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
 #define TAB_STAMP(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_acc[k] += now_ - t_last; t_last = now_; }
 #else
 #define TAB_STAMP(k)
@@ -914,6 +920,9 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 create_photon<MED, TILT, FLASHER, TABULATE, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
+#ifdef CLSIMHIP_EXP_TAB_LOADS_IN_BLOCK
+            if (TABULATE) asm volatile("" :: "v"(rx), "v"(ra), "v"(step_dir.x), "v"(step_dir.y), "v"(step_dir.z), "v"(unit_weight), "v"(photons_left), "v"(sidx), "v"(slice));
+#endif
             // nothing runnable in this wave: every lane waits for another wave's slice
             if ((m_ready == 0ull) && (ballot(alive && !need) == 0ull)) {
 #ifdef CLSIMHIP_DEBUG_COUNTERS
@@ -1012,7 +1021,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             else left_table = save_path_wave_carry(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
                                                    tab_carry, tab_parity, false
 #ifdef CLSIMHIP_TAB_TIMERS
-                                                   , t_acc[6], t_last
+                                                   , t_acc[6], t_last, t_acc[7]
 #endif
                                                    );
             if (run) {
@@ -1061,6 +1070,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                 }
             }
         }
+        TAB_STAMP(8)        // (analysis build: up to the advance)
         if (advance) {
             if (hit) ph.abs_lens_left = 0.0f;                                   // c.cl:741-744
             ph.px += ph.d.x * distance;
@@ -1078,7 +1088,9 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     ring[ph.num_scatters % hn] = make_float4(ph.px, ph.py, ph.pz, ph.abs_lens_left);
                 }
                 if (ANISO && P->has_pre) apply_matrix(P->pre, P->pre_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
+                TAB_STAMP(9)        // (position update, history)
                 const float cos_s = scattering_cos<FAST>(P, rx, ra);
+                TAB_STAMP(10)       // (scattering angle)
                 const float sin_s = dm::sqrt_near_(1.0f - sqr(cos_s));       // |cos_s| <= 1: 0 or >= 2^-24
                 scatter_direction(cos_s, sin_s, ph.d, rng_co(rx, ra));
                 if (ANISO && P->has_post) apply_matrix(P->post, P->post_renorm, ph.d, FAST || (P->div_ok & kFastMatrices) != 0u);
@@ -1102,7 +1114,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         float no_remainder = 0.0f;
         (void)save_path_wave_carry(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true
 #ifdef CLSIMHIP_TAB_TIMERS
-                                   , t_acc[6], t_last
+                                   , t_acc[6], t_last, t_acc[7]
 #endif
                                    );
     }
@@ -1110,7 +1122,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     if (TABULATE && lane == 0) {
         // (the table's first words take the sums: its contents are meaningless in this build)
         double *out = fresh_params(P0)->tab_bins;
-        for (int k = 0; k < 7; ++k) unsafeAtomicAdd(out + k, (double)t_acc[k]);
+        for (int k = 0; k < 12; ++k) unsafeAtomicAdd(out + k, (double)t_acc[k]);
     }
 #endif
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);

@@ -24,10 +24,12 @@ steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=2
 tab.EnqueueSteps(steps, (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0))
 tab.Finish()
 ms = tab.GetStatistics()["KernelTimeMs"]
-t = tab.GetBinSums().ravel()[:7].astype(np.float64)
+t = tab.GetBinSums().ravel()[:12].astype(np.float64)
 names = ["units + creation", "layer walk", "savePath: sample loop", "advance + scattering", "trips", "lanes running", "savePath: counting, prefix sum, lists"]
-cyc = t[[0, 1, 6, 2, 3]]
+cyc = np.array([t[0], t[1], t[6], t[2], t[3] + t[8] + t[9] + t[10]])
 print("kernel %.1f ms, %d steps x 200 photons; wave trips %.4g, lanes with a photon per trip %.1f" % (ms, n, t[4], t[5] / t[4]))
 print("shader-clock cycles per wave trip (sum over the phases %.0f):" % (cyc.sum() / t[4]))
 for k in (0, 1, 6, 2, 3):
     print("  %-40s %8.0f  %5.1f %%" % (names[k], t[k] / t[4], 100 * t[k] / cyc.sum()))
+print("  of advance + scattering: up to the advance %.0f, position update %.0f, scattering angle %.0f, the rest (rotation, loop end) %.0f" % (t[8] / t[4], t[9] / t[4], t[10] / t[4], t[3] / t[4]))
+print("  of the sample loop, around the atomic instruction (between two s_memtime): %.0f cycles per trip" % (t[7] / t[4]))

@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) adds(double *table, uint64_t n_sectors, i
 
 // the same adds behind `filler` dependent fused multiply-adds per instruction (the table maker's shape: ~3 300 cycles of arithmetic per 64 samples
 // and wave, three waves per SIMD): what do the atomics cost a kernel that is far from their rate?
+template <bool SETREG>
 __global__ void __launch_bounds__(256) adds_beside_arithmetic(double *table, uint64_t n_sectors, int iterations, int lanes, int sectors, int filler, int with_adds, float *sink)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -41,6 +42,11 @@ __global__ void __launch_bounds__(256) adds_beside_arithmetic(double *table, uin
     const uint32_t bin = (lane / (uint32_t)sectors) & 7u;
     float acc = (float)lane * 1.0e-3f;
     for (int it = 0; it < iterations; ++it) {
+        if (SETREG) {
+            // the propagation kernels' random numbers convert with round-toward-zero through the MODE register (prop_device.hip.h: rng_co):
+            // does s_setreg wait for the wave's outstanding vector memory operations?
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\tv_cvt_f32_u32_e32 %0, %0\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(acc));
+        }
         for (int k = 0; k < filler; ++k) acc = __builtin_fmaf(acc, 0.999f, 1.0e-3f);
         const uint32_t h = mix(mix(wave * 0x9e3779b9u + (uint32_t)it) + group * 0x85ebca6bu);
         const uint64_t sector = ((uint64_t)h * n_sectors) >> 32;
@@ -89,18 +95,22 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&sink, 64));
     printf("\nadds beside arithmetic (24 lanes into 16 sectors per instruction, f64), %d waves per SIMD:\n", waves_per_simd);
     printf("%8s %14s %14s %10s %14s\n", "filler", "ms without", "ms with adds", "ratio", "requests/s");
-    for (int filler : {0, 100, 200, 400, 800, 1600}) {
-        const int iterations = filler >= 800 ? 3000 : 10000;
-        float ms2[2] = {0, 0};
-        for (int with_adds = 0; with_adds < 2; ++with_adds)
-            for (int rep = 0; rep < 2; ++rep) {
-                CHECK(hipEventRecord(e0));
-                hipLaunchKernelGGL(adds_beside_arithmetic, dim3(grid), dim3(256), 0, 0, table, n_sectors, iterations, 24, 16, filler, with_adds, sink);
-                CHECK(hipEventRecord(e1));
-                CHECK(hipEventSynchronize(e1));
-                CHECK(hipEventElapsedTime(&ms2[with_adds], e0, e1));
-            }
-        printf("%8d %14.2f %14.2f %10.3f %14.4g\n", filler, ms2[0], ms2[1], ms2[1] / ms2[0], (double)grid * 4 * iterations * 16 / (ms2[1] * 1e-3));
+    for (int setreg = 0; setreg < 2; ++setreg) {
+        if (setreg) printf("... with an s_setreg MODE pair (round toward zero and back) behind every add instruction:\n");
+        for (int filler : {0, 100, 200, 400, 800, 1600}) {
+            const int iterations = filler >= 800 ? 3000 : 10000;
+            float ms2[2] = {0, 0};
+            for (int with_adds = 0; with_adds < 2; ++with_adds)
+                for (int rep = 0; rep < 2; ++rep) {
+                    CHECK(hipEventRecord(e0));
+                    if (setreg) hipLaunchKernelGGL(adds_beside_arithmetic<true>, dim3(grid), dim3(256), 0, 0, table, n_sectors, iterations, 24, 16, filler, with_adds, sink);
+                    else hipLaunchKernelGGL(adds_beside_arithmetic<false>, dim3(grid), dim3(256), 0, 0, table, n_sectors, iterations, 24, 16, filler, with_adds, sink);
+                    CHECK(hipEventRecord(e1));
+                    CHECK(hipEventSynchronize(e1));
+                    CHECK(hipEventElapsedTime(&ms2[with_adds], e0, e1));
+                }
+            printf("%8d %14.2f %14.2f %10.3f %14.4g\n", filler, ms2[0], ms2[1], ms2[1] / ms2[0], (double)grid * 4 * iterations * 16 / (ms2[1] * 1e-3));
+        }
     }
     return 0;
 }
