@@ -13,7 +13,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t h) { h ^= h >> 16; h *= 0x7feb3
 
 // `f32`: binary32 adds into the same sectors' first words instead
 template <bool F32>
-__global__ void __launch_bounds__(256) adds(double *table, uint64_t n_sectors, int iterations, int lanes, int sectors)
+__global__ void __launch_bounds__(256) adds(double *table, uint64_t n_sectors, int iterations, int lanes, int sectors, int repeat = 1)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) adds(double *table, uint64_t n_sectors, i
     const uint32_t group = lane % (uint32_t)sectors;            // which of the instruction's sectors
     const uint32_t bin = (lane / (uint32_t)sectors) & 7u;       // which bin of it
     for (int it = 0; it < iterations; ++it) {
-        const uint32_t h = mix(mix(wave * 0x9e3779b9u + (uint32_t)it) + group * 0x85ebca6bu);
+        const uint32_t h = mix(mix(wave * 0x9e3779b9u + (uint32_t)(it / repeat)) + group * 0x85ebca6bu);       // (the same sectors `repeat` instructions in a row)
         const uint64_t sector = ((uint64_t)h * n_sectors) >> 32;
         if (active) {
             if (F32) unsafeAtomicAdd(reinterpret_cast<float *>(table + sector * 8u + bin), 1.0f);
@@ -90,6 +90,21 @@ int main(int argc, char **argv)
                 }
             }
         }
+    // the same sectors again: a photon's next segment often lands in the sector its last one ended in
+    printf("\na wave adds into the same 16 sectors R instructions in a row (24 lanes, f64):\n%6s %14s %14s\n", "R", "instr/s", "requests/s");
+    for (int repeat : {1, 2, 4, 8, 64}) {
+        const int iterations = 20000;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(adds<false>, dim3(grid), dim3(256), 0, 0, table, n_sectors, iterations, 24, 16, repeat);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        const double instr = (double)grid * 4 * iterations / (ms * 1e-3);
+        printf("%6d %14.4g %14.4g\n", repeat, instr, instr * 16);
+    }
     // arithmetic beside the adds
     float *sink = nullptr;
     CHECK(hipMalloc(&sink, 64));
