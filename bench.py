@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the host_path object (profile passes: counters then cover the timed launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-table-maker", action="store_true", help="skip the table_maker object of the default line")
     ap.add_argument("--gather-overlap", action="store_true",
                     help="N>1: gather the photons of launch k on a second stream while launch k+1 runs (two photon buffers). Default: "
                          "the gather runs between two launches on the launch stream -- the propagation kernel is a persistent grid "
@@ -126,19 +127,19 @@ def cpu_baseline(args, steps_np, seconds):
                       (n, args.photons_per_step, photons, hits, dt, cores)}
 
 
-def tabulator_bench(args, torch, device):
+def tabulator_measure(args, device, workload, passes, warmup, cpu_seconds, photons_per_step=200, bunch=262144):
     """Table maker (python/tablemaker/tabulator.py defaults): cascade-like steps at the origin,
     spherical table 200 x 36 x 100 x 105 bins (+ under/overflow), SPICE-Mie, 42 absorption lengths per photon, one
-    path sample per metre.  Not the headline metric: prints photons/s and path samples/s of the TABULATE kernel and the
-    oracle's rate on the host cores (the reference runs this kernel as a single CPU work item)."""
+    path sample per metre.  Not the headline metric: photons/s and path samples/s of the TABULATE kernel and the
+    oracle's rate on the host cores (the reference runs this kernel as a single CPU work item).  Returns the record."""
     import math
     from clsim_amd import converter as CV
     from clsim_amd import synthetic as S
     from clsim_amd import tabulator as TB
-    n = ((262144 if args.bunch == (1 << 20) else min(args.bunch, 1 << 19)) // 256) * 256     # >= 4 workgroups per CU
+    n = (bunch // 256) * 256                                     # 262 144: >= 4 workgroups per CU
     medium = CV.MakeIceCubeMediumProperties(iceDataDirectory=os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
     axis_list = [TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)]
-    if args.workload == "tab5":             # fifth axis = cosine of the impact angle (TABULATE_IMPACT_ANGLE), coarser in azimuth
+    if workload == "tab5":             # fifth axis = cosine of the impact angle (TABULATE_IMPACT_ANGLE), coarser in azimuth
         axis_list = [TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 12), TB.LinearAxis(-1, 1, 50), TB.PowerAxis(0, 7e3, 105, 2),
                      TB.LinearAxis(-1, 1, 10)]
     axes = TB.SphericalAxes(axis_list)
@@ -147,45 +148,51 @@ def tabulator_bench(args, torch, device):
     x = CV.seed_streams(a)
     tab = TB.I3CLSimStepToTableConverterHIP(device, axes, False, medium, math.pi * 0.16510 ** 2, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ang), (x, a))
-    steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=args.photons_per_step)
+    steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=photons_per_step)
     ref = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tab.EnqueueSteps(steps, ref)
     tab.Finish()
-    before = float(tab.GetBinSums().sum()) if args.warmup else 0.0
+    before = float(tab.GetBinSums().sum()) if warmup else 0.0
     k0 = tab.GetStatistics()["KernelTimeMs"]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(passes):
         tab.EnqueueSteps(steps, ref)
     tab.Finish()
     elapsed = time.perf_counter() - t0
     st = tab.GetStatistics()
-    kernel_ms = (st["KernelTimeMs"] - k0) / args.steps
+    kernel_ms = (st["KernelTimeMs"] - k0) / passes
     photons = int(steps["num"].sum())
     sums = tab.GetBinSums()
     occupied = int((sums > 0).sum())
-    out = {"metric": "tabulated photons/sec (TABULATE kernel, 1 GPU)", "value": photons * args.steps / elapsed, "unit": "photons/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-           "kernel_ms_per_pass": kernel_ms, "photons_per_pass": photons, "table_bins": tab.n_bins, "occupied_bins": occupied,
-           "sum_of_weights_per_pass": (float(sums.sum()) - before) / args.steps,
+    total = float(sums.sum())
+    del sums, tab
+    out = {"metric": "tabulated photons/sec (TABULATE kernel, 1 GPU)", "value": photons * passes / elapsed, "unit": "photons/s",
+           "n_gpus": 1, "steps": passes, "warmup": warmup, "ms_per_step": 1e3 * elapsed / passes,
+           "kernel_ms_per_pass": kernel_ms, "photons_per_pass": photons, "table_bins": int(st["NumBins"]), "occupied_bins": occupied,
+           "sum_of_weights_per_pass": (total - before) / passes,
            "config": {"workload": "%d steps x %d photons at the origin, spherical axes %s, spice_mie, 42 absorption lengths, "
                                   "1 m sampling; BASELINE.json configs[4] (tablemaker half)"
-                                  % (n, args.photons_per_step, "x".join(str(v - 2) for v in tab.shape))}}
+                                  % (n, photons_per_step, "x".join(str(ax.n_bins) for ax in axis_list))}}
     # The table sums are fp64 atomic adds that execute at the memory side (MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes
     # for 256-byte contiguous wave instructions = 2e10 sector requests per second; measured here for this kernel's shape, tools/micro/atomic_rate.hip:
     # 2.2e10 fp64 sector requests per second whatever the lanes per sector).  What the atomics cost the kernel is measured too
     # (profiles/r05/ab_tab_bound.txt): compiled out, a pass takes 1.77 s instead of 1.97 -- 11 %, at 0.53 of their rate; the arithmetic is the
-    # rest.  Added bytes per pass come from a stored rocprofv3 --pmc WRITE_SIZE pass of this command (profiles/r05/tab_pmc.json, "WRITE_SIZE
-    # reads the bytes exactly for float atomics"); the kernel time is live.
-    ppath = os.path.join(ROOT, "profiles", "r05", "tab_pmc.json")
-    if os.path.exists(ppath) and args.workload == "tab" and args.photons_per_step == 200 and n == 262144:
+    # rest, so the kernel is bound by vector issue like the propagator and the atomic-rate fraction is the secondary figure.  Atomic requests per
+    # pass come from a stored rocprofv3 --pmc WRITE_SIZE pass of this command ("WRITE_SIZE reads the bytes exactly for float atomics"); the
+    # kernel time is live.
+    ppath = next((q for q in (os.path.join(ROOT, "profiles", r, "tab_pmc.json") for r in ("r06", "r05")) if os.path.exists(q)), None)
+    if ppath and workload == "tab" and photons_per_step == 200 and n == 262144:
         with open(ppath) as f:
             prof = json.load(f)
         requests = prof["write_bytes_per_launch"] / 64.0           # a lane's add to a bin of its own leaves the L2 as one 64-byte atomic request
         added = requests * 8.0
         seconds = kernel_ms * 1e-3
-        out["roofline"] = {"bound": "hbm", "what": "memory-side fp64 atomic adds of the table sums: one 64-byte request per sector and wave instruction (they cost 11 % of a "
-                                                   "pass, measured by compiling them out; the arithmetic is the rest: profiles/r05/ab_tab_bound.txt)",
+        out["roofline"] = {"bound": "valu-issue",
+                           "what": "the sample loop's arithmetic is the bound (a pass with the atomics compiled out takes 0.90 of the time: "
+                                   "profiles/r05/ab_tab_bound.txt); secondary: the memory-side fp64 atomic adds of the table sums, one 64-byte request "
+                                   "per sector and wave instruction, priced against the measured scattered-atomic rate (`frac_of_scattered_rate`) and, "
+                                   "as `achieved`/`peak`/`frac`, against the guide's contiguous-add figure",
                            "achieved": added / seconds / 1e9, "peak": 1300.0, "unit": "GB/s of added bytes", "frac": added / seconds / 1e9 / 1300.0,
                            "atomic_requests_per_s": requests / seconds, "scattered_atomic_peak_per_s": 2.2e10,
                            "frac_of_scattered_rate": requests / seconds / 2.2e10,
@@ -193,57 +200,66 @@ def tabulator_bench(args, torch, device):
                                     "tools/micro/atomic_rate.hip on this chip: 2.2e10 fp64 sector requests/s for 8 ... 64 lanes into 8 ... 64 random sectors per instruction "
                                     "(profiles/r05/atomic_rate_microbench.txt) -- the second is the rate this kernel's requests are priced against",
                            "traffic": prof.get("fabric_bytes_per_launch"), "atomic_requests_per_launch": requests,
-                           "traffic_source": {"file": "profiles/r05/tab_pmc.json", "git_revision": prof.get("git_revision"), "kernel": prof.get("kernel"),
+                           "traffic_source": {"file": os.path.relpath(ppath, ROOT), "git_revision": prof.get("git_revision"), "kernel": prof.get("kernel"),
                                               "profiled_kernel_ms": prof.get("kernel_ms")},
                            "avg_kernel_ms": kernel_ms}
-    if not args.no_cpu_baseline:
-        # path samples are counted by the oracle on a small sample of the same steps (they are the same on both sides)
+    if cpu_seconds > 0:
+        # the oracle with the reference's host loop around the kernel (oracle_tabulate_accumulate: every step in calls of 16 photons, entries
+        # added up and dropped) on steps of the SAME bunch at their real 200 photons, all host cores, for about `cpu_seconds`
         from oracle import builders as B
         from oracle import capi
         cores = os.cpu_count() or 1
         med = B.load_ppc_ice(os.path.join(ROOT, "clsim_amd", "data", "ice", "spice_mie"))
         o_axes = [B.power_axis(0, 580, 200, 2), B.linear_axis(0, 180, 36), B.linear_axis(-1, 1, 100), B.power_axis(0, 7e3, 105, 2)]
-        m = max(cores, 256)
-        small = steps[:m].copy()
-        small["num"] = 8
-        tb = B.tabulator_config("spherical", o_axes, med, ang, entries_per_stream=40000)
+        if workload == "tab5":
+            o_axes = [B.power_axis(0, 580, 200, 2), B.linear_axis(0, 180, 12), B.linear_axis(-1, 1, 50), B.power_axis(0, 7e3, 105, 2), B.linear_axis(-1, 1, 10)]
+        tb = B.tabulator_config("spherical", o_axes, med, ang, entries_per_stream=65536)
         bias = B.icecube_dom_acceptance()
         g = S.single_string_geometry()
         geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
         T = capi.make_tables(med, geo, [B.cherenkov_wlen_generator(bias, med)], bias, pancake=1.0, tabulator=tb)
-        # a bounded sample: the same steps again and again from the streams as they stand, for about ten seconds of oracle time
         ref_o = B.reference_particle(ref[:3], ref[3], ref[4:])
-        xs, done, samples, passes, dt = x[:m], 0, 0, 0, 0.0
-        while dt < 10.0 and passes < 400:
-            t1 = time.time()
-            ent, num, left, xs = capi.tabulate(T, small, xs, a[:m], ref_o, threads=cores)
-            dt += time.time() - t1
-            done += int(small["num"].sum() - left.sum())
-            samples += int(num.sum())
-            passes += 1
+        probe = min(n, 2 * cores)
+        t1 = time.time()
+        capi.tabulate_accumulate(T, steps[:probe], x[:probe], a[:probe], ref_o, photons_per_call=16, threads=cores)
+        pace = max(time.time() - t1, 1e-3) / probe
+        m = int(min(n, max(probe, (cpu_seconds / pace) // cores * cores)))
+        t1 = time.time()
+        _, counts, _ = capi.tabulate_accumulate(T, steps[:m], x[:m], a[:m], ref_o, photons_per_call=16, threads=cores)
+        dt = time.time() - t1
+        done, samples = int(steps["num"][:m].sum()), int(counts.sum())
         out["samples_per_photon"] = float(samples) / max(done, 1)
         out["path_samples_per_sec"] = out["samples_per_photon"] * out["value"]
         out["cpu_baseline"] = {"value": done / dt, "unit": "photons/s", "cores": cores, "kind": "port",
-                               "sample": "%d passes of %d steps x 8 photons (%d path samples) in %.1f s, %d threads; the reference runs this kernel "
-                                         "as ONE work item (StepToTableConverter.cxx:259)" % (passes, m, samples, dt, cores)}
-    emit(json.dumps(out))
+                               "sample": "the first %d steps x %d photons of the same bunch (%d photons, %d path samples) in %.1f s, %d threads; the "
+                                         "reference runs this kernel as ONE work item (StepToTableConverter.cxx:259)"
+                                         % (m, photons_per_step, done, samples, dt, cores)}
+    return out
 
 
-def host_path_run(CV, args, steps_np, conv, bunches):
+def tabulator_bench(args, torch, device):
+    """`--workload tab | tab5`: the table maker's own line."""
+    bunch = 262144 if args.bunch == (1 << 20) else min(args.bunch, 1 << 19)
+    emit(json.dumps(tabulator_measure(args, device, args.workload, args.steps, args.warmup, 0.0 if args.no_cpu_baseline else 10.0,
+                                      photons_per_step=args.photons_per_step, bunch=bunch)))
+
+
+def host_path_run(CV, args, steps_np, conv, bunches, in_place=None):
     """The reference's own calling pattern (benchmark.py:300-360): a producer thread enqueues bunches, the consumer takes
     results; wall clock from the first enqueue to the last result -- host buffers, PCIe transfers, index->ID conversion."""
     import threading
     from clsim_amd.synthetic import PHOTON_DTYPE
+    in_place = args.consume_in_place if in_place is None else in_place
     conv.EnqueueSteps(steps_np, 0)          # warm-up bunch
     conv.GetConversionResult()
     before = conv.GetStatistics()
+    recycled = None if in_place else np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=PHOTON_DTYPE)     # (the copying consumer's buffer, reused per bunch)
     t0 = time.perf_counter()
     producer = threading.Thread(target=lambda: [conv.EnqueueSteps(steps_np, i) for i in range(bunches)])
     producer.start()
     hits = 0
-    recycled = None if args.consume_in_place else np.zeros(conv.GetMaxNumWorkitems() * 10, dtype=PHOTON_DTYPE)     # (the copying consumer's buffer, reused per bunch)
     for _ in range(bunches):
-        if args.consume_in_place:               # the records where the library left them (benchmark.py only counts a result's photons)
+        if in_place:               # the records where the library left them (benchmark.py only counts a result's photons)
             _, ph, release = conv.GetConversionResultInPlace()
             hits += len(ph)
             release()
@@ -258,7 +274,7 @@ def host_path_run(CV, args, steps_np, conv, bunches):
     return {"value": photons / elapsed, "unit": "photons/s", "bunches": bunches, "steps_per_bunch": len(steps_np), "hits": hits,
             "seconds": elapsed, "device_utilization": device_ns * 1e-9 / elapsed,
             "device_ns_per_photon": device_ns / photons, "double_buffering": True,
-            "consumer": "reads the records in the library's page-locked result buffer, then releases it" if args.consume_in_place else
+            "consumer": "reads the records in the library's page-locked result buffer, then releases it" if in_place else
                         "copies every result into a buffer of its own (--copy-results)",
             "definition": "sum(numPhotons) / wall clock from the first EnqueueSteps to the last GetConversionResult "
                           "(reference benchmark.py:335-340), outside the timed region of `value`"}
@@ -1064,10 +1080,23 @@ def main():
             torch.cuda.empty_cache()
             conv2 = CV.initializeHIP(local_rank, geom, medium, bias, gens, pancakeFactor=5.0, enableDoubleBuffering=True,
                                      approximateNumberOfWorkItems=n, seed=12345)
-            out["host_path"] = host_path_run(CV, args, steps_np, conv2, 8)
+            out["host_path"] = host_path_run(CV, args, steps_np, conv2, 8, in_place=True)
+            # the reference's own meaning of GetConversionResult() (I3CLSimStepToPhotonConverter.h:178-189): the caller receives a photon
+            # series of its own -- every record is copied out of the library's buffer (what the C++ adapter's GetConversionResult() does)
+            out["host_path_copy"] = host_path_run(CV, args, steps_np, conv2, 8, in_place=False)
             del conv2
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
+        if world == 1 and args.workload == "c2" and not args.no_table_maker:
+            # BASELINE configs[4]'s other half, bounded: one warm-up and two timed passes of the table maker's own
+            # bench bunch (262 144 steps x 200 photons, ~2 s a pass) after and outside the timed region of `value`, with its roofline
+            # and an oracle baseline of a few seconds -- the same record `--workload tab` prints, so that a driver-run line holds it
+            del d_steps
+            torch.cuda.empty_cache()
+            tm = tabulator_measure(args, local_rank, "tab", passes=2, warmup=1, cpu_seconds=(0.0 if args.no_cpu_baseline else 6.0))
+            tm["definition"] = ("tabulated photons / wall clock of 2 passes (EnqueueSteps ... Finish) on a converter of its own, after and outside "
+                                "the timed region of `value`; the at-size check (1.25e8 photons) is tests/test_production_size_gpu.py")
+            out["table_maker"] = tm
         emit(json.dumps(out))
     fell_back = use_gather and gatherer is None
     if gatherer is not None:

@@ -510,6 +510,36 @@ def tabulate(tables, steps, x, a, reference, threads=8):
     return entries, num, left, x
 
 
+def tabulate_accumulate(tables, steps, x, a, reference, bins=None, photons_per_call=8, threads=8):
+    """The table maker's host loop around the kernel (oracle_tabulate_accumulate; StepToTableConverter.cxx:399-460,
+    495-507) for bunches whose entries would not fit in memory: every step runs `photons_per_call` photons per kernel
+    call, the calls' entries are added to `bins` (float64 array of n_bins, in place; None: not kept).  Returns
+    (per-step sum of weights [n] float64, per-step number of entries [n] uint64, x_after).  Raises if a call runs out of
+    entry space (tables.t.tab_entries_per_stream slots for photons_per_call photons)."""
+    L = lib()
+    steps = np.ascontiguousarray(steps, dtype=STEP_DTYPE)
+    n = len(steps)
+    x = np.array(x[:n], dtype=np.uint64, copy=True)
+    a = np.ascontiguousarray(a[:n], dtype=np.uint32)
+    ref = np.ascontiguousarray(reference, dtype=np.float32)
+    assert ref.shape == (12,)
+    if bins is not None:
+        n_bins = int(tables.t.tab_stride[0]) * (int(tables.t.tab_nbins[0]) + 2)            # Axes.cxx:51-64
+        assert bins.dtype == np.float64 and bins.flags["C_CONTIGUOUS"] and bins.size == n_bins
+    sums = np.zeros(n, dtype=np.float64)
+    counts = np.zeros(n, dtype=np.uint64)
+    L.oracle_tabulate_accumulate.restype = C.c_int
+    rc = L.oracle_tabulate_accumulate(C.byref(tables.t), steps.ctypes.data_as(C.c_void_p), C.c_uint32(n), x.ctypes.data_as(C.c_void_p),
+                                      a.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p),
+                                      bins.ctypes.data_as(C.c_void_p) if bins is not None else None,
+                                      sums.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                      C.c_uint32(photons_per_call), C.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("oracle_tabulate_accumulate: %d (-1: %d photons did not fit into %d entries)"
+                           % (rc, photons_per_call, int(tables.t.tab_entries_per_stream)))
+    return sums, counts, x
+
+
 def accumulate_entries(entries, num, n_bins, dtype=np.float32):
     """The host loop of StepToTableConverter.cxx:495-507: binContent_[index] += weight, stream by stream in entry
     order (float accumulators in the reference; float64 gives the order-independent sum)."""

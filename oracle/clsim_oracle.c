@@ -1115,7 +1115,7 @@ void oracle_tabulate(const oracle_tables *T, const oracle_step *steps, uint32_t 
                      const oracle_reference *source, oracle_table_entry *entries, uint32_t *num_entries,
                      uint32_t *photons_left, int threads)
 {
-#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (uint32_t i = 0; i < n; ++i) {
         rng_t r = { x[i], a[i] };
         hit_sink sink = { NULL, 0, 0, NULL, NULL };
@@ -1126,6 +1126,70 @@ void oracle_tabulate(const oracle_tables *T, const oracle_step *steps, uint32_t 
         x[i] = r.x;
     }
 }
+
+#ifndef ORACLE_COUNT_OPS     /* (the counting build has no use for it) */
+/* The table maker's host loop around the kernel (tabulator/I3CLSimStepToTableConverter.cxx:399-460 FetchSteps, :495-507
+ * binContent_[index] += weight), for bunches whose entries would not fit in memory at once: every step is run as the
+ * reference re-runs an unfinished one -- `photons_per_call` photons of it per kernel call from the stream as the previous
+ * call left it (c.cl:770-776: numPhotons = what is left, stream at the next photon's start) -- into one thread-private entry
+ * buffer of TABLE_ENTRIES_PER_STREAM slots, and the call's entries are added to `bins` (binary64, shared: atomic adds;
+ * may be NULL), to the step's own sum and count.  A call that runs out of entry space returns -1 at once: the reference
+ * would count the interrupted photon's first segments twice (LABBOOK section 8, N3), which no comparison wants.
+ * x[] is updated in place.  Returns 0. */
+int oracle_tabulate_accumulate(const oracle_tables *T, const oracle_step *steps, uint32_t n, uint64_t *x, const uint32_t *a,
+                               const oracle_reference *source, double *bins, double *step_sum, uint64_t *step_entries,
+                               uint32_t photons_per_call, int threads)
+{
+    int failed = 0;
+    if (photons_per_call == 0) return -2;
+#pragma omp parallel num_threads(threads)
+    {
+        oracle_table_entry *buf = (oracle_table_entry *)malloc((size_t)T->tab_entries_per_stream * sizeof(oracle_table_entry));
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t i = 0; i < n; ++i) {
+            int stop;
+#pragma omp atomic read
+            stop = failed;
+            if (stop || !buf) { if (!buf) {
+#pragma omp atomic write
+                failed = 1;
+                } continue; }
+            rng_t r = { x[i], a[i] };
+            hit_sink sink = { NULL, 0, 0, NULL, NULL };
+            oracle_step s = steps[i];
+            uint32_t left = steps[i].numPhotons;
+            double sum = 0.0;
+            uint64_t count = 0;
+            while (left > 0) {
+                uint32_t filled = 0;
+                s.numPhotons = left < photons_per_call ? left : photons_per_call;
+                tab_ctx tc = { source, buf, &filled, 0 };
+                propagate_step(T, &s, &r, &sink, NULL, &tc);
+                if (tc.photons_left_out != 0) {
+#pragma omp atomic write
+                    failed = 1;
+                    break;
+                }
+                for (uint32_t k = 0; k < filled; ++k) {
+                    const double w = (double)buf[k].weight;
+                    sum += w;
+                    if (bins) {
+#pragma omp atomic
+                        bins[buf[k].index] += w;
+                    }
+                }
+                count += filled;
+                left -= s.numPhotons;
+            }
+            x[i] = r.x;
+            if (step_sum) step_sum[i] = sum;
+            if (step_entries) step_entries[i] = count;
+        }
+        free(buf);
+    }
+    return failed ? -1 : 0;
+}
+#endif
 void oracle_eval_tabulator(const oracle_tables *T, const oracle_reference *source, const float *pos_and_time, int n,
                            float *coords, uint32_t *index, int32_t *out_of_bounds)
 {

@@ -196,3 +196,105 @@ def test_c5_eight_gpu_split_shard_on_the_classic_kernel():
     steps = S.flasher_steps(312500, seed=1000, photons_per_step=400, position=(float(g["x"][k]), float(g["y"][k]), float(g["z"][k])), pad_to=512)
     assert len(steps) == 312832
     check_at_size(cfg, steps, capacity=8 << 20, hit_fraction_range=(5e-3, 5e-2), expect_kernel="classic")
+
+
+TAB_SUBSET = 65536
+
+
+@pytest.mark.timeout(1800)
+def test_c5_table_maker_one_gpu_share_of_a_billion_photons():
+    """BASELINE configs[4], table-maker half, at the size ONE of 8 GPUs sees: 10^9 / 8 = 1.25e8 photons = 625 000 cascade-like
+    steps x 200 photons at the origin (padded to 625 152 with empty steps) through I3CLSimStepToTableConverterHIP, the default
+    spherical axes of python/tablemaker/tabulator.py:621-641 (200 x 36 x 100 x 105 bins + under/overflow = 670 MB of binary64
+    sums), SPICE-Mie, 42 absorption lengths, one sample per metre -- what bench.py --workload tab runs, 2.4 times its bunch.
+    (reference: propagation_kernel.c.cl:755-785, I3CLSimStepToTableConverter.cxx:178-265.)
+
+    (i)   two converters fill equal tables: same occupied bins, every sum equal to 1e-12 (fp64 atomics: the order differs);
+    (ii)  every stream of a 2 048-step prefix AND of 65 536 step indices drawn over the WHOLE bunch (the last 512 real steps,
+          the first padding step and the last step always among them) ends bit-equal to the oracle's run of those steps alone,
+          each from its own (x, a) -- a stream's draws depend on its own step only, and with a fixed number of absorption lengths
+          every draw of a photon lies before a branch the table's arithmetic decides (leaving the table ends the photon);
+    (iii) the drawn steps' OWN table -- a third converter that is given those steps and their streams alone -- equals the
+          oracle's entries of those steps added up in binary64: same occupied bins, sums to 1e-12, same sum of weights;
+    (iv)  nothing is left over: the reference's kernel hands a stream back with `numPhotons` left when its entry buffer is full
+          (c.cl:770-776); this table maker has no entry buffers, so every photon of the bunch must be in the statistics, every
+          stream with photons must have advanced, every padding stream must be where it was -- and the oracle, run with the
+          reference's resume loop, reports no unfinished call either (capi.tabulate_accumulate raises if one occurs)."""
+    import math
+    import time
+    from clsim_amd import converter as CV
+    from clsim_amd import tabulator as TB
+    from oracle import builders as B
+    cfg = common.config("mie")
+    share = 10 ** 9 // 8 // 200
+    steps = S.cascade_steps(share, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=200, pad_to=256)
+    n = len(steps)
+    assert share == 625000 and n == 625152 and int(steps["num"].sum()) == 125000000
+    x, a = common.streams(n)
+    ang = [0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435]
+    area = math.pi * 0.16510 ** 2
+    ref7 = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+
+    def axes():
+        return TB.SphericalAxes([TB.PowerAxis(0, 580, 200, 2), TB.LinearAxis(0, 180, 36), TB.LinearAxis(-1, 1, 100), TB.PowerAxis(0, 7e3, 105, 2)])
+
+    def fill(streams, bunch):
+        tab = TB.I3CLSimStepToTableConverterHIP(0, axes(), False, cfg["med_p"], area, CV.GetIceCubeDOMAcceptance(),
+                                                TB.I3CLSimFunctionPolynomial(ang), streams)
+        tab.EnqueueSteps(bunch, ref7)
+        tab.Finish()
+        st = tab.GetStatistics()
+        return tab.GetBinSums(), tab.GetRNGState(len(bunch)), st
+
+    sums_a, x_a, st_a = fill((x, a), steps)
+    assert st_a["NumKernelCalls"] == 1 and st_a["NumPhotons"] == 125000000.0                                        # (iv)
+    assert abs(st_a["SumOfPhotonWeights"] - float((steps["num"] * steps["weight"].astype(np.float64)).sum())) < 1e-3
+    live = steps["num"] > 0
+    assert np.all(x_a[live] != x[live]) and np.array_equal(x_a[~live], x[~live])                                    # (iv)
+    total_a, occupied_a = float(sums_a.sum()), int((sums_a > 0).sum())
+    assert occupied_a > 0.6 * sums_a.size and np.all(sums_a >= 0)
+    # a photon leaves about 1 660 samples of weight <= acceptance x step weight behind: the table's total is of that order
+    assert 1e3 < total_a / 125000000.0 < 1660.0 * 1.5
+    sums_b, x_b, st_b = fill((x, a), steps)                                                                         # (i)
+    assert np.array_equal(x_a, x_b) and st_b["NumPhotons"] == st_a["NumPhotons"]
+    assert np.array_equal(sums_a > 0, sums_b > 0)
+    assert np.allclose(sums_a, sums_b, rtol=1e-12, atol=0)
+    assert abs(float(sums_b.sum()) / total_a - 1) < 1e-12
+    del sums_b
+    # ---- the oracle on the prefix and on the whole-bunch subset ----
+    o_axes = [B.power_axis(0, 580, 200, 2), B.linear_axis(0, 180, 36), B.linear_axis(-1, 1, 100), B.power_axis(0, 7e3, 105, 2)]
+    tb = B.tabulator_config("spherical", o_axes, cfg["med_o"], ang, entries_per_stream=65536)          # 16 photons of <= 2 200 samples a call
+    bias_o = B.icecube_dom_acceptance()
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias_o, cfg["med_o"])], bias_o, pancake=1.0, tabulator=tb)
+    ref_o = B.reference_particle(ref7[:3], ref7[3], ref7[4:])
+    threads = min(os.cpu_count() or 8, 256)
+    m = 2048
+    t0 = time.time()
+    _, cnt_p, x_p = capi.tabulate_accumulate(T, steps[:m], x[:m], a[:m], ref_o, bins=None, photons_per_call=16, threads=threads)
+    per_step = (time.time() - t0) / m
+    assert np.array_equal(x_a[:m], x_p)                                                                             # (ii) prefix
+    assert 1000.0 < cnt_p.sum() / float(steps["num"][:m].sum()) < 2200.0
+    # the subset: 65 536 steps if the host finishes them in about four minutes at the prefix's pace, never fewer than 8 192
+    size = int(min(TAB_SUBSET, max(8192, 240.0 / per_step)))
+    rng = np.random.default_rng(20261005)
+    pick = whole_bunch_subset(steps, rng, size=size)
+    # (a converter wants a multiple of 256 streams: the surplus is taken from the drawn indices in front of the forced ones)
+    pick = np.concatenate([pick[:1], pick[1 + len(pick) % 256:]])
+    assert len(pick) % 256 == 0 and len(pick) >= 8192 and pick[-1] == n - 1 and pick[0] == 0
+    assert np.isin(np.arange(share - 512, share + 1), pick).all()
+    bins_o = np.zeros(tb["n_bins"], dtype=np.float64)
+    sum_s, cnt_s, x_s = capi.tabulate_accumulate(T, steps[pick], x[pick], a[pick], ref_o, bins=bins_o, photons_per_call=16, threads=threads)
+    assert np.array_equal(x_a[pick], x_s)                                                                           # (ii) whole-bunch subset
+    assert np.all((cnt_s > 0) == (steps["num"][pick] > 0))
+    # (iii) the subset alone on the GPU, on streams of its own
+    sums_s, x_g, st_s = fill((x[pick].copy(), a[pick].copy()), steps[pick])
+    assert np.array_equal(x_g, x_s) and st_s["NumPhotons"] == float(steps["num"][pick].sum())
+    assert np.array_equal(sums_s > 0, bins_o > 0) and int((bins_o > 0).sum()) > 1000000
+    assert np.allclose(sums_s, bins_o, rtol=1e-12, atol=0)
+    assert abs(float(sums_s.sum()) / float(sum_s.sum()) - 1) < 1e-12
+    # and the subset is a part of the whole: bin by bin its sums do not exceed the big table's
+    assert np.all(sums_s <= sums_a * (1 + 1e-12))
+    print("table maker at size: %d photons, %d occupied bins of %d, sum of weights %.6e; oracle subset %d steps, %.0f samples/photon"
+          % (int(st_a["NumPhotons"]), occupied_a, sums_a.size, total_a, len(pick), cnt_s.sum() / float(steps["num"][pick].sum())))
