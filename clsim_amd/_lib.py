@@ -105,6 +105,7 @@ SYMBOLS = [
     "clsimhip_replace_indices_with_ids", "clsimhip_kernel_time_ms", "clsimhip_get_table", "clsimhip_get_rng_state",
     "clsimhip_eval_math", "clsimhip_check_math_exhaustive", "clsimhip_version",
     "clsimhip_eval_device_function", "clsimhip_eval_device_random", "clsimhip_get_option",
+    "clsimhip_set_tuning", "clsimhip_get_tuning", "clsimhip_tabulator_set_tuning",
     "clsimhip_count_generated_steps", "clsimhip_generate_steps_device", "clsimhip_generate_steps",
     "clsimhip_ppc_create", "clsimhip_ppc_destroy", "clsimhip_ppc_photons_per_meter", "clsimhip_ppc_enqueue", "clsimhip_shower_parameters",
     "clsimhip_flasher_correction_factor", "clsimhip_flasher_enqueue",
@@ -212,6 +213,9 @@ def load():
         "clsimhip_get_rng_state": (i32, [vp, vp, sz]),
         "clsimhip_eval_math": (i32, [i32, i32, vp, vp, sz, vp]),
         "clsimhip_get_option": (i32, [vp, i32, DP]),
+        "clsimhip_set_tuning": (i32, [vp, C.c_char_p, C.c_longlong]),
+        "clsimhip_get_tuning": (i32, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
+        "clsimhip_tabulator_set_tuning": (i32, [vp, C.c_char_p, C.c_longlong]),
         "clsimhip_eval_device_function": (i32, [vp, i32, i32, i32, vp, sz, vp]),
         "clsimhip_eval_device_random": (i32, [vp, i32, i32, i32, vp, vp, sz, sz, vp]),
         "clsimhip_check_math_exhaustive": (i32, [i32, i32, i32, i32, vp, sz]),

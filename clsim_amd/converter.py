@@ -478,6 +478,20 @@ class I3CLSimStepToPhotonConverterHIP:
     def GetTotalNumPhotonsGenerated(self): return int(self.GetStatistics()["TotalNumPhotonsGenerated"])
     def GetTotalNumPhotonsAtDOMs(self): return int(self.GetStatistics()["TotalNumPhotonsAtDOMs"])
 
+    # ---- tuning (include/clsimhip.h: clsimhip_set_tuning; no result depends on it) ----
+    _KERNELS = {"auto": 0, "pool": 1, "classic": 2}
+
+    def SetTuning(self, key, value):
+        """clsimhip_set_tuning(key, value); "kernel" also takes "auto" | "pool" | "classic"."""
+        if key == "kernel" and isinstance(value, str):
+            value = self._KERNELS[value]
+        self._call("clsimhip_set_tuning", key.encode(), int(value))
+
+    def GetTuning(self, key):
+        v = C.c_longlong()
+        self._call("clsimhip_get_tuning", key.encode(), C.byref(v))
+        return v.value
+
     def _option(self, which):
         v = C.c_double()
         self._call("clsimhip_get_option", int(which), C.byref(v))
@@ -570,10 +584,12 @@ def initializeHIP(device, geometry, medium, wavelengthGenerationBias, wavelength
                   enableDoubleBuffering=False, doublePrecision=False, stopDetectedPhotons=True, saveAllPhotons=False,
                   saveAllPhotonsPrescale=0.01, fixedNumberOfAbsorptionLengths=float("nan"), pancakeFactor=1.0,
                   photonHistoryEntries=0, limitWorkgroupSize=0, approximateNumberOfWorkItems=262144,
-                  seed=12345, streams=None):
+                  seed=12345, streams=None, tuning=None):
     """Canonical configuration sequence, I3CLSimModuleHelper::initializeOpenCL
-    (ModuleHelper.cxx:303-372)."""
+    (ModuleHelper.cxx:303-372).  tuning: {key: value} for clsimhip_set_tuning, applied before Compile()."""
     conv = I3CLSimStepToPhotonConverterHIP(device)
+    for key, value in (tuning or {}).items():
+        conv.SetTuning(key, value)
     conv.SetWlenGenerators(wavelengthGenerators)
     conv.SetWlenBias(wavelengthGenerationBias)
     conv.SetMediumProperties(medium)

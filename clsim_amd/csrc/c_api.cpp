@@ -553,6 +553,14 @@ int clsimhip_get_option(const clsimhip_converter *c, int option, double *out)
 {
     return guarded_const(c, [&] { need(c, "converter"); need(out, "out"); *out = c->impl.option(option); });
 }
+int clsimhip_set_tuning(clsimhip_converter *c, const char *key, long long value)
+{
+    return guarded(c, [&] { need(c, "converter"); need(key, "key"); c->impl.set_tuning(key, value); });
+}
+int clsimhip_get_tuning(const clsimhip_converter *c, const char *key, long long *value)
+{
+    return guarded_const(c, [&] { need(c, "converter"); need(key, "key"); need(value, "value"); *value = c->impl.get_tuning(key); });
+}
 int clsimhip_propagate_device(clsimhip_converter *c, const void *d_steps, size_t n, size_t rng_offset, void *d_photons,
                               size_t capacity, void *d_hit_count, void *stream)
 {
@@ -880,6 +888,10 @@ int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step 
     return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->enqueue_steps(steps, n, reference); });
 }
 int clsimhip_tabulator_finish(clsimhip_tabulator *t) { return guarded_tab(t, [&] { need(t, "tabulator"); t->impl->finish(); }); }
+int clsimhip_tabulator_set_tuning(clsimhip_tabulator *t, const char *key, long long value)
+{
+    return guarded_tab(t, [&] { need(t, "tabulator"); need(key, "key"); t->impl->set_tuning(key, value); });
+}
 int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t *n_dim, size_t shape[5])
 {
     return guarded_tab(const_cast<clsimhip_tabulator *>(t), [&] {

@@ -27,9 +27,87 @@ constexpr size_t kPooledKernelMinSteps = 524288;
 
 hipError_t Converter::launch(const KParams &P, hipStream_t stream) const
 {
-    if (tables_.variant.keep_detected)
-        return pooled_for(P.n_steps) ? launch_pool_keep_kernel(P, tables_.variant, stream) : launch_keep_kernel(P, tables_.variant, stream);
-    return pooled_for(P.n_steps) ? launch_pool_kernel(P, tables_.variant, stream) : launch_prop_kernel(P, tables_.variant, stream);
+    KVariant v = tables_.variant;
+    const bool pooled = pooled_for(P.n_steps);
+    {
+        std::lock_guard<std::mutex> lk(tuning_mutex_);
+        v.grid = grid_;
+        v.generic_only = generic_only_;
+    }
+    if (v.keep_detected) return pooled ? launch_pool_keep_kernel(P, v, stream) : launch_keep_kernel(P, v, stream);
+    return pooled ? launch_pool_kernel(P, v, stream) : launch_prop_kernel(P, v, stream);
+}
+
+// ---- tuning (include/clsimhip.h: clsimhip_set_tuning) -----------------------------------------------------------------
+void Converter::apply_kernel_choice()
+{
+    use_pool_ = pool_possible_ && kernel_choice_ != 2;
+    pool_min_steps_ = (kernel_choice_ != 0) ? 0 : kPooledKernelMinSteps;
+    if (tuned_pool_min_steps_ >= 0) pool_min_steps_ = static_cast<size_t>(tuned_pool_min_steps_);
+    pool_max_steps_ = pool_kernel_max_steps();
+    if (tuned_pool_max_steps_ >= 0) pool_max_steps_ = std::min(pool_max_steps_, static_cast<size_t>(tuned_pool_max_steps_));
+}
+
+namespace {
+struct TuningKey { const char *name; long long lo, hi; };
+// (the table of include/clsimhip.h, in its order)
+const TuningKey kTuningKeys[] = {
+    {"kernel", 0, 2}, {"pool_min_steps", -1, 1ll << 40}, {"pool_max_steps", -1, 1ll << 40}, {"pool_ring", 0, 4096},
+    {"k_new", 0, 4096}, {"k_search", 0, 64}, {"slices", 0, 65535}, {"k_pop", 0, 64}, {"k_wait", -1, 1 << 20}, {"k_aim", -1, 64},
+    {"grid", 0, 1 << 20}, {"generic_kernels", 0, 1}, {"result_min_records", 1, 1ll << 32},
+    {"string_map_cells", 8, 4096}, {"dom_map_cells", 4, 512}, {"named_search", 0, 1},
+};
+}
+
+void Converter::set_tuning(const std::string &key, long long value)
+{
+    const TuningKey *k = nullptr;
+    for (const TuningKey &t : kTuningKeys) if (key == t.name) k = &t;
+    if (!k) throw Error(CLSIMHIP_ERR_ARGUMENT, "no tuning key named " + key);
+    if (value < k->lo || value > k->hi)
+        throw Error(CLSIMHIP_ERR_ARGUMENT, "tuning " + key + ": " + std::to_string(value) + " is outside " + std::to_string(k->lo) + " ... " + std::to_string(k->hi));
+    const bool table_key = (key == "string_map_cells" || key == "dom_map_cells" || key == "named_search");
+    if (table_key && compiled_) throw Error(CLSIMHIP_ERR_STATE, "tuning " + key + " shapes a table of Compile(): set it before Compile()");
+    std::lock_guard<std::mutex> lk(tuning_mutex_);          // (a launch reads its parameters under the same lock)
+    const int v = static_cast<int>(value);
+    if (key == "kernel") kernel_choice_ = v;
+    else if (key == "pool_min_steps") tuned_pool_min_steps_ = value;
+    else if (key == "pool_max_steps") tuned_pool_max_steps_ = value;
+    else if (key == "pool_ring") pool_ready_ = v;
+    else if (key == "k_new") k_new_ = v;
+    else if (key == "k_search") k_search_ = v;
+    else if (key == "slices") k_slices_ = v;
+    else if (key == "k_pop") k_pop_ = v;
+    else if (key == "k_wait") k_wait_ = v;
+    else if (key == "k_aim") k_aim_ = v;
+    else if (key == "grid") grid_ = v;
+    else if (key == "generic_kernels") generic_only_ = (v != 0);
+    else if (key == "result_min_records") min_result_records_ = static_cast<size_t>(value);
+    else if (key == "string_map_cells") table_tuning_.string_map_cells = v;
+    else if (key == "dom_map_cells") table_tuning_.dom_map_cells = v;
+    else if (key == "named_search") table_tuning_.named_search = (v != 0);
+    if (initialized_) apply_kernel_choice();
+}
+
+long long Converter::get_tuning(const std::string &key) const
+{
+    if (key == "kernel") return kernel_choice_;
+    if (key == "pool_min_steps") return initialized_ ? static_cast<long long>(pool_min_steps_) : tuned_pool_min_steps_;
+    if (key == "pool_max_steps") return initialized_ ? static_cast<long long>(pool_max_steps_) : tuned_pool_max_steps_;
+    if (key == "pool_ring") return pool_ready_;
+    if (key == "k_new") return k_new_;
+    if (key == "k_search") return k_search_;
+    if (key == "slices") return k_slices_;
+    if (key == "k_pop") return k_pop_;
+    if (key == "k_wait") return k_wait_;
+    if (key == "k_aim") return k_aim_;
+    if (key == "grid") return grid_;
+    if (key == "generic_kernels") return generic_only_ ? 1 : 0;
+    if (key == "result_min_records") return static_cast<long long>(min_result_records_);
+    if (key == "string_map_cells") return table_tuning_.string_map_cells;
+    if (key == "dom_map_cells") return table_tuning_.dom_map_cells;
+    if (key == "named_search") return table_tuning_.named_search ? 1 : 0;
+    throw Error(CLSIMHIP_ERR_ARGUMENT, "no tuning key named " + key);
 }
 
 void Converter::set_concurrent_device_launches(int k)
@@ -196,7 +274,13 @@ void Converter::compile()
     // kernel text compiled for x86-64 does (tools/verbatim_cl_check.py clear_keep).
     if (save_all_) throw Error(CLSIMHIP_ERR_CONFIG, "SaveAllPhotons is not available in the HIP propagator");
     if (history_entries_ > 1024) throw Error(CLSIMHIP_ERR_CONFIG, "PhotonHistoryEntries > 1024 is not supported");
-    tables_ = compile_tables(medium_, geometry_, generators_, bias_, pancake_);
+#ifdef CLSIMHIP_DEVELOPER
+    // (developer build only: the round 1-5 environment names of the three table keys)
+    if (const char *e = std::getenv("CLSIMHIP_PROX_N")) set_tuning("string_map_cells", std::max(8, std::min(4096, std::atoi(e))));
+    if (const char *e = std::getenv("CLSIMHIP_DOM_PROX_N")) set_tuning("dom_map_cells", std::max(4, std::min(512, std::atoi(e))));
+    if (const char *e = std::getenv("CLSIMHIP_NO_NAMED_SEARCH")) set_tuning("named_search", e[0] == '1' ? 0 : 1);
+#endif
+    tables_ = compile_tables(medium_, geometry_, generators_, bias_, pancake_, table_tuning_);
     if (!std::isnan(fixed_abs_lengths_)) {                      // OpenCL.cxx:425-431
         tables_.params.has_fixed_abs = 1;
         tables_.params.fixed_abs = to_float_literal(fixed_abs_lengths_);
@@ -372,29 +456,26 @@ void Converter::setup_device_buffers()
     }
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_queue_), static_cast<size_t>(kQueueWords) * kQueueSlots * sizeof(uint32_t)), "step queue");
     hip_check(hipMalloc(reinterpret_cast<void **>(&d_work_), max_workitems_ * sizeof(WorkRecord)), "work records");
-    if (const char *e = std::getenv("CLSIMHIP_K_NEW")) k_new_ = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_SEARCH")) k_search_ = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_SLICES")) k_slices_ = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_POP")) k_pop_ = std::max(0, std::atoi(e));
-    // (pooled kernel only -- the classic kernels have no scalar register to spare for them; -1 or unset: automatic; 0: a parked lane
-    // never waits for company / the string-aimed filter level is off, for A/B runs and the filter-off parity point)
-    if (const char *e = std::getenv("CLSIMHIP_K_WAIT")) k_wait_ = std::max(-1, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_K_AIM")) k_aim_ = std::max(-1, std::atoi(e));
-    if (const char *e = std::getenv("CLSIMHIP_RESULT_MIN_RECORDS")) min_result_records_ = static_cast<size_t>(std::max(1ll, std::atoll(e)));
-    if (const char *e = std::getenv("CLSIMHIP_POOL_R")) pool_ready_ = std::max(0, std::atoi(e));
-    use_pool_ = true;
-    pool_min_steps_ = kPooledKernelMinSteps;
-    pool_max_steps_ = pool_kernel_max_steps();
-    if (const char *e = std::getenv("CLSIMHIP_KERNEL")) {          // pool / classic: that kernel for every bunch size
-        use_pool_ = (std::strcmp(e, "pool") == 0);
-        pool_min_steps_ = 0;
+#ifdef CLSIMHIP_DEVELOPER
+    // DEVELOPER BUILD ONLY (make DEVELOPER=1; tools/build_variant.sh, tools/scan_env.sh): the round 1-5 environment names, through the
+    // same door as clsimhip_set_tuning.  The default build reads none of them.
+    {
+        static const char *const names[][2] = {
+            {"CLSIMHIP_K_NEW", "k_new"}, {"CLSIMHIP_K_SEARCH", "k_search"}, {"CLSIMHIP_SLICES", "slices"}, {"CLSIMHIP_K_POP", "k_pop"},
+            {"CLSIMHIP_K_WAIT", "k_wait"}, {"CLSIMHIP_K_AIM", "k_aim"}, {"CLSIMHIP_RESULT_MIN_RECORDS", "result_min_records"},
+            {"CLSIMHIP_POOL_R", "pool_ring"}, {"CLSIMHIP_POOL_MIN_STEPS", "pool_min_steps"}, {"CLSIMHIP_GRID", "grid"},
+            {"CLSIMHIP_NO_FAST", "generic_kernels"}};
+        for (const auto &n : names)
+            if (const char *e = std::getenv(n[0])) set_tuning(n[1], std::atoll(e));
+        if (const char *e = std::getenv("CLSIMHIP_KERNEL")) set_tuning("kernel", std::strcmp(e, "pool") == 0 ? 1 : 2);
+        if (const char *e = std::getenv("CLSIMHIP_POOL_INDEX_BITS")) set_tuning("pool_max_steps", (1ll << std::atoi(e)) - 1);
     }
-    if (const char *e = std::getenv("CLSIMHIP_POOL_MIN_STEPS")) pool_min_steps_ = static_cast<size_t>(std::max(0ll, std::atoll(e)));
+#endif
     // photon histories are kept per lane and the pooled kernel moves photons between lanes; a very large table image
     // leaves its pools no LDS
-    if (history_entries_ != 0 ||
-        !pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()), stop_detected_ ? 0u : static_cast<uint32_t>(tables_.params.num_strings), tables_.params.num_layers))
-        use_pool_ = false;
+    pool_possible_ = history_entries_ == 0 &&
+        pool_kernel_fits(static_cast<uint32_t>(tables_.lds_image.size()), stop_detected_ ? 0u : static_cast<uint32_t>(tables_.params.num_strings), tables_.params.num_layers);
+    apply_kernel_choice();
 }
 
 KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offset, void *d_photons, size_t capacity, void *d_hits, hipStream_t stream)
@@ -414,13 +495,16 @@ KParams Converter::launch_params(const void *d_steps, size_t n, size_t rng_offse
         last_queue_ = P.queue;
     }
     hip_check(hipMemsetAsync(P.queue, 0, kQueueWords * sizeof(uint32_t), stream), "reset step queue");
-    P.k_new = k_new_;
-    P.k_search = k_search_;
-    P.slices = k_slices_;
-    P.k_pop = k_pop_;
-    P.k_wait = k_wait_;
-    P.k_aim = k_aim_;
-    P.pool_ready = pool_ready_;
+    {
+        std::lock_guard<std::mutex> lk(tuning_mutex_);
+        P.k_new = k_new_;
+        P.k_search = k_search_;
+        P.slices = k_slices_;
+        P.k_pop = k_pop_;
+        P.k_wait = k_wait_;
+        P.k_aim = k_aim_;
+        P.pool_ready = pool_ready_;
+    }
     P.chip_share = concurrent_launches_;
 #ifdef CLSIMHIP_CENSUS
     if (!d_census_) hip_check(hipMalloc(reinterpret_cast<void **>(&d_census_), kCensusBytes), "census");

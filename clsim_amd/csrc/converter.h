@@ -65,9 +65,16 @@ struct CompiledTables {
     GeoTables geo;
     std::map<std::string, std::vector<double>> named;
 };
+// what Compile() may be told about the search filter's tables ("string_map_cells", "dom_map_cells", "named_search" of
+// clsimhip_set_tuning; measurement and the filter-off parity points of tests/): no result depends on it
+struct TableTuning {
+    int string_map_cells = 512;     // string proximity map: cells per axis (8 ... 4096)
+    int dom_map_cells = 256;        // DOM proximity map: at most this many cubic cells per axis (4 ... 512)
+    bool named_search = true;       // false: every DOM is marked "not nameable" and takes the full search
+};
 CompiledTables compile_tables(const MediumData &medium, const GeometryInput &geometry,
                               const std::vector<RandomValueData> &generators, const FunctionData &bias,
-                              double pancake_factor);
+                              double pancake_factor, const TableTuning &tuning = TableTuning());
 
 // bounded blocking queue (I3CLSimQueue.h:48-195).  Like the reference's, a consumer that waits in get() counts as
 // one free place: with capacity 0 the queue is a rendezvous -- put() returns only once a get() is there to take the
@@ -194,11 +201,16 @@ public:
     bool pooled_for(size_t n_steps) const
     {
         need_init();
+        std::lock_guard<std::mutex> lk(tuning_mutex_);
         return use_pool_ && n_steps <= pool_max_steps_ && n_steps * static_cast<size_t>(concurrent_launches_) >= pool_min_steps_;
     }
+    // clsimhip_set_tuning / clsimhip_get_tuning (include/clsimhip.h has the table of keys): launcher parameters, any time between
+    // launches; the three table keys before Compile().  The DEFAULT build reads no tuning from the environment.
+    void set_tuning(const std::string &key, long long value);
+    long long get_tuning(const std::string &key) const;
     void set_concurrent_device_launches(int k);
     int concurrent_device_launches() const { return concurrent_launches_; }
-    bool uses_pooled_kernel() const { need_init(); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
+    bool uses_pooled_kernel() const { need_init(); std::lock_guard<std::mutex> lk(tuning_mutex_); return use_pool_ && pool_min_steps_ == 0; }     // for every bunch size
 
 private:
     // A bunch on its way to the worker: the caller's steps are copied ONCE, in the caller's thread, into a page-locked buffer of the
@@ -295,7 +307,7 @@ private:
     // larger one.  (Rounds 3-4 kept buffers of max_output_photons_ records each -- 840 MB at a million work items, six of them.)
     struct PinnedBuffer { clsimhip_photon *p = nullptr; size_t capacity = 0; };
     static constexpr int kResultBuffers = 6;
-    size_t min_result_records_ = 65536;                 // (CLSIMHIP_RESULT_MIN_RECORDS: tests make the buffers grow with small bunches)
+    size_t min_result_records_ = 65536;                 // ("result_min_records": tests make the buffers grow with small bunches)
     std::vector<PinnedBuffer> free_result_buffers_;
     int result_buffers_made_ = 0;
     bool pinning_refused_ = false;                      // the host would not page-lock more: results are copied out from then on
@@ -326,14 +338,23 @@ private:
 #ifdef CLSIMHIP_CENSUS
     unsigned long long *d_census_ = nullptr;
 #endif
-    int k_wait_ = -1, k_aim_ = -1;               // -1 = automatic; CLSIMHIP_K_WAIT, CLSIMHIP_K_AIM (pooled kernel only: the classic and keep
+    int k_wait_ = -1, k_aim_ = -1;               // -1 = automatic; "k_wait", "k_aim" (pooled kernel only: the classic and keep
                                                  // kernels have them as constants); 0 is honoured: never wait / never ask
-    int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic (CLSIMHIP_K_SEARCH)
-    int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic (CLSIMHIP_K_NEW / CLSIMHIP_SLICES override)
-    int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic (CLSIMHIP_K_POP / CLSIMHIP_POOL_R)
-    bool use_pool_ = false;                      // pooled kernel allowed (CLSIMHIP_KERNEL=pool|classic forces one)
+    int k_search_ = 0;                           // lanes parked before a wave searches for DOMs, 0 = automatic ("k_search")
+    int k_new_ = 0, k_slices_ = 0;               // creation threshold; slices per step, 0 = automatic ("k_new", "slices")
+    int k_pop_ = 0, pool_ready_ = 0;             // pooled kernel: lanes serviced at once, ring entries per wave, 0 = automatic ("k_pop", "pool_ring")
+    bool use_pool_ = false;                      // pooled kernel allowed (derived by apply_kernel_choice())
     size_t pool_min_steps_ = 0;                  // ... for bunches of at least this many steps
     size_t pool_max_steps_ = 0;                  // ... and at most this many (pool_kernel_max_steps(): the pending entries' 23-bit step index)
+    int kernel_choice_ = 0;                      // "kernel": 0 automatic (by bunch size), 1 pooled, 2 classic for every bunch size
+    long long tuned_pool_min_steps_ = -1;        // "pool_min_steps": -1 = the default threshold
+    long long tuned_pool_max_steps_ = -1;        // "pool_max_steps": -1 = what the pending entries' step index can address; only ever lowers it
+    int grid_ = 0;                               // "grid"
+    bool generic_only_ = false;                  // "generic_kernels"
+    TableTuning table_tuning_;
+    bool pool_possible_ = false;                 // set by Initialize(): no photon histories, the table image leaves the pools their LDS
+    void apply_kernel_choice();
+    mutable std::mutex tuning_mutex_;            // the tuning members above: set_tuning() against the launches that read them
     hipError_t launch(const KParams &P, hipStream_t stream) const;
     hipStream_t stream_ = nullptr;           // upload + kernels (bunches serialise here: they share the RNG streams)
     hipStream_t copy_stream_ = nullptr;      // photon download

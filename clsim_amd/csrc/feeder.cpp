@@ -258,7 +258,11 @@ void Feeder::worker()
             flush(it.barrier);                              // :355-361
             if (it.barrier) continue;
             if (it.has_particle) {
-                static const bool trace = std::getenv("CLSIMHIP_FEEDER_TRACE") != nullptr;      // analysis: where a light source's time goes
+#ifdef CLSIMHIP_DEVELOPER
+                static const bool trace = std::getenv("CLSIMHIP_FEEDER_TRACE") != nullptr;      // analysis (developer build): where a light source's time goes
+#else
+                constexpr bool trace = false;
+#endif
                 const auto t_a = std::chrono::steady_clock::now();
                 std::vector<clsimhip_step_request> requests;
                 ppc_->enqueue(it.particle, requests);

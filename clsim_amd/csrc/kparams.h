@@ -223,6 +223,10 @@ struct KVariant {
     bool keep_detected = false;     // no STOP_PHOTONS_ON_DETECTION: every DOM on a segment's way is saved, the photon travels on
     bool fast = false;      // standard configuration, every proof in hand (prop_device.hip.h: FAST): the pooled kernel runs the
                             // instantiation without the wave-uniform tests of those facts
+    // launch tuning (clsimhip_set_tuning / clsimhip_tabulator_set_tuning; 0 / false = automatic).  Never part of a result.
+    int grid = 0;                   // workgroups of the propagation launch ("grid")
+    bool generic_only = false;      // the generic instantiation also where Compile() found every proof ("generic_kernels")
+    bool tab_fast = false;          // table maker: the FAST instantiation (measured slower, prop_kernel.hip: launch_tab_kernel) ("fast_kernels")
 };
 
 } // namespace clsimhip

@@ -9,6 +9,7 @@
 #include "detmath.hip.h"
 #include "../../include/clsimhip.h"
 #include "kparams.h"
+#include "instrument.hip.h"
 
 namespace clsimhip {
 
@@ -56,23 +57,9 @@ DM uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 struct Rec4 { float a, b, c, d; };
 
-// Analysis build (make EXTRA=-DCLSIMHIP_CENSUS, tools/exp_pool_census.py): one visit of a divergent region and the lanes that
-// are active in it, per wave, in the census buffer behind the per-wave records (word 32768 + 32 x wave + 2 x region).
+// the divergent regions the census build counts visits and active lanes of (instrument.hip.h: CENSUS_REGION)
 enum CensusRegion { kCensusCrossing = 0, kCensusFilter = 1, kCensusLiu = 2, kCensusHG = 3, kCensusSearchFull = 4, kCensusSearchNamed = 5,
                     kCensusCreation = 6, kCensusService = 7, kCensusScatter = 8, kCensusWalk = 9, kCensusAim = 10, kCensusRegions = 16 };
-#ifdef CLSIMHIP_CENSUS
-#define CENSUS_REGION(P, region)                                                                                                 \
-    do {                                                                                                                          \
-        const uint64_t census_m = __builtin_amdgcn_ballot_w64(true);                                                              \
-        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(census_m)) {                                                         \
-            unsigned long long *census_d = (P)->census + 32768u + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32u + 2u * (uint32_t)(region); \
-            census_d[0] += 1ull;                                                                                                  \
-            census_d[1] += (unsigned long long)__builtin_popcountll(census_m);                                                    \
-        }                                                                                                                         \
-    } while (0)
-#else
-#define CENSUS_REGION(P, region) ((void)0)
-#endif
 
 // The math tables of detmath.hip.h are the first dm::kMathTableWords words of every LDS image (tables.cpp puts them there): fixed
 // addresses, so the row loads are ds_read_b128 / ds_read_b64 with the table's offset as an immediate.
@@ -439,11 +426,7 @@ DM void scatter_direction(float cosa, float sina, Vec3 &d, float u)
     // a rotated unit vector: its squared length is one to within a few ulps -- the integer form of the reciprocal root (detmath.hip.h:
     // rsqrt_unit_) when every lane's is within 1023, the general one for the whole wave otherwise
     const float len2 = sqr(d.x) + sqr(d.y) + sqr(d.z);
-#ifdef CLSIMHIP_NO_RSQRT_UNIT      // (A/B builds, profiles/r04/ab_quarter_rate.txt)
-    const float recip_length = dm::rsqrt_near_(len2);
-#else
     const float recip_length = __builtin_expect(ballot(!dm::rsqrt_unit_ok_(len2)) == 0ull, 1) ? dm::rsqrt_unit_(len2) : dm::rsqrt_near_(len2);
-#endif
     d.x *= recip_length; d.y *= recip_length; d.z *= recip_length;
 }
 

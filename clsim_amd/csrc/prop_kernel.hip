@@ -269,9 +269,7 @@ DM T here_(T v)
 template <bool ANGLE>
 DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight,
                        float length, float &remainder, float depth, float this_depth, uint64_t &rx, uint32_t ra
-#ifdef CLSIMHIP_TAB_TIMERS
-                       , uint64_t &t_list, uint64_t &t_last
-#endif
+                       TAB_TIMED(, uint64_t &t_list, uint64_t &t_last)
                        )
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -319,18 +317,6 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
     bool stop = false;
     if (total == 0u) {
         // nothing to record
-#ifdef CLSIMHIP_EXP_TAB_NOSAMPLES   // experiment (profiles/r05/ab_tab_bound.txt): propagation alone; a segment's last sample is still looked at, so that photons leave the table where they do
-    } else if (true) {
-        const TabK K = tab_constants<ANGLE>(P);
-        double *const bins = P->tab_bins;
-        if (active && n > 0u) {
-            const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, ph.tab_wlen};
-            uint32_t index;
-            bool ok_ = true;
-            if (sample_bin<ANGLE, false>(K, g, d_end - vstep, rx, ra, index, ok_)) stop = true;
-            if (index == 0xfffffff0u) unsafeAtomicAdd(bins + index, 1.0);
-        }
-#endif
     } else if (total > slots) {
         const TabK K = tab_constants<ANGLE>(P);
         double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
@@ -369,9 +355,7 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CLSIMHIP_TAB_TIMERS
-        { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; }
-#endif
+        TAB_TIMED({ const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; })
         // Out of bounds (isOutOfBounds ends the walk: c.cl:781-784) is rare -- once in a photon's life -- and is kept in
         // registers: `dead`, the wave-uniform mask of lanes whose segment has left the table at an earlier sample, and per
         // lane the index of its own segment's first such sample.
@@ -458,11 +442,7 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
             segmented_step_<0x118, 0xf>(sum, sum_sq, flag, squares);
             segmented_step_<0x142, 0xa>(sum, sum_sq, flag, squares);
             segmented_step_<0x143, 0xc>(sum, sum_sq, flag, squares);
-#ifdef CLSIMHIP_EXP_TAB_NOATOMIC // experiment (profiles/r05/ab_tab_bound.txt): the kernel's arithmetic alone; a condition no sample meets keeps it alive
-            if (commit && (next_key != key) && (sum < -1.0e300)) {
-#else
             if (commit && (next_key != key)) {
-#endif
                 unsafeAtomicAdd(bins + index, sum);
                 if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
             }
@@ -502,9 +482,7 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
 // `carry`, `parity`: wave-uniform state across trips; flush: work off everything (after the wave's last trip).
 DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight, float length, float &remainder,
                              float depth, float this_depth, uint32_t &carry, uint32_t &parity, bool flush
-#ifdef CLSIMHIP_TAB_TIMERS
-                             , uint64_t &t_list, uint64_t &t_last, uint64_t &t_add
-#endif
+                             TAB_TIMED(, uint64_t &t_list, uint64_t &t_last, uint64_t &t_add)
                              )
 {
     typedef float row_t __attribute__((ext_vector_type(4)));
@@ -584,9 +562,7 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CLSIMHIP_TAB_TIMERS
-    { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; }
-#endif
+    TAB_TIMED({ const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; })
     const uint32_t pooled = walk_alone ? carry : total;                             // samples in the pool
     const uint32_t work = everything ? pooled : (pooled & ~63u);                    // ... and how many of them this trip works off
     uint64_t dead = 0ull;
@@ -649,41 +625,22 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
         // equal-bin neighbours are summed within rows of 16 lanes (row_shr / row_shl 1: the lane at a row's end keeps a key that is
         // not its own, so a run ends there; four DPP steps instead of six, and what a run loses at a row's end -- a second atomic into
         // the same sector from the same instruction -- the memory side merges)
-#ifdef CLSIMHIP_EXP_TAB_SCAN_ROWS
-        const uint32_t prev_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xf, 0xf, false);
-        const uint32_t next_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x101, 0xf, 0xf, false);
-#else
         const uint32_t prev_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138, 0xf, 0xf, false);
         const uint32_t next_key = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x130, 0xf, 0xf, false);
-#endif
         int flag = ((prev_key != key) || !commit) ? 1 : 0;     // first lane of its run
         double sum = (double)w, sum_sq = (double)w * (double)w;
         segmented_step_<0x111, 0xf>(sum, sum_sq, flag, squares);
         segmented_step_<0x112, 0xf>(sum, sum_sq, flag, squares);
         segmented_step_<0x114, 0xf>(sum, sum_sq, flag, squares);
         segmented_step_<0x118, 0xf>(sum, sum_sq, flag, squares);
-#ifndef CLSIMHIP_EXP_TAB_SCAN_ROWS
         segmented_step_<0x142, 0xa>(sum, sum_sq, flag, squares);
         segmented_step_<0x143, 0xc>(sum, sum_sq, flag, squares);
-#endif
-#ifdef CLSIMHIP_TAB_TIMERS
-        const uint64_t t_before_add = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef CLSIMHIP_EXP_TAB_NOATOMIC
-        if (commit && (next_key != key) && (sum < -1.0e300)) {
-#else
+        TAB_TIMED(const uint64_t t_before_add = __builtin_amdgcn_s_memtime();)
         if (commit && (next_key != key)) {
-#endif
-#ifdef CLSIMHIP_EXP_TAB_F32      // experiment (profiles/r05/ab_tab_bound.txt): binary32 atomics into the same sectors; the table's contents are meaningless in this build
-            unsafeAtomicAdd(reinterpret_cast<float *>(bins + index), (float)sum);
-#else
             unsafeAtomicAdd(bins + index, sum);
-#endif
             if (squares) unsafeAtomicAdd(sq_bins + index, sum_sq);
         }
-#ifdef CLSIMHIP_TAB_TIMERS
-        t_add += __builtin_amdgcn_s_memtime() - t_before_add;
-#endif
+        TAB_TIMED(t_add += __builtin_amdgcn_s_memtime() - t_before_add;)
     }
     if (walk_alone) {
         if (active) {
@@ -799,21 +756,17 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     // slice hand-offs and hold the last units of the bunch long after the queue is dry.  Each wave therefore takes
     // turns at the four issue priorities, offset by its wave slot.
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
-#ifdef CLSIMHIP_CENSUS
+    CENSUS(
     const unsigned long long t_start = wall_clock64();
     if (lane == 0 && !TAB) atomicMin(fresh_params(P0)->census + 8, t_start);
     unsigned long long c_trips = 0, t_dry = 0, c_run = 0, c_need = 0, c_wait = 0, c_parked = 0, c_dead = 0, c_phases = 0, c_created = 0;
-#endif
+    )
     // which lanes need a photon and which hold one, taken at the end of a trip for the next one (and for the loop's exit, a
     // plain backward branch)
     bool need_next = true;
     uint64_t m_need = ~0ull, m_ready = 0ull;
-#ifdef CLSIMHIP_TAB_TIMERS      // analysis build of the table maker (tools/exp_tab_timers.py): shader-clock time per phase of a trip, summed per wave
-    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
-#define TAB_STAMP(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_acc[k] += now_ - t_last; t_last = now_; }
-#else
-#define TAB_STAMP(k)
-#endif
+    // (analysis build of the table maker, tools/exp_tab_timers.py: shader-clock time per phase of a trip, summed per wave -- TAB_STAMP)
+    TAB_TIMED(uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();)
     for (uint32_t trip = 0;; ++trip) {
         if (!TAB && ((trip & ((1u << kPrioShift) - 1u)) == 0u)) switch (((trip >> kPrioShift) + wave_slot) & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -822,14 +775,14 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             default: __builtin_amdgcn_s_setprio(3); break;
         }
         bool need = need_next;
-#ifdef CLSIMHIP_CENSUS
+        CENSUS(
         ++c_trips;
         if (t_dry == 0 && used_up > 0) t_dry = wall_clock64();
         c_need += __popcll(ballot(need && !waiting));
         c_wait += __popcll(ballot(need && waiting));
         c_parked += __popcll(ballot(parked));
         c_dead += __popcll(ballot(!alive));
-#endif
+        )
 
         // ---- new units / new photons, deferred until enough lanes wait for them ----
         // Photon creation is what is worth batching (k_new lanes), and taking new units goes with it (one atomic on the
@@ -900,9 +853,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             if (need && waiting) {
                 WorkRecord *rec = P->work + sidx;
                 const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&rec->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CLSIMHIP_DEBUG_COUNTERS
-                if (published < slice) atomicAdd(P->queue + 2, 1u);
-#endif
+                DEBUG_COUNTED(if (published < slice) atomicAdd(P->queue + 2, 1u);)
                 if (published >= slice) {
                     // c.cl:458-461; slice 0 reads the state left by the previous bunch
                     rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -912,22 +863,17 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                     waiting = false;
                 }
             }
-#ifdef CLSIMHIP_CENSUS
+            CENSUS(
             if (do_create) ++c_phases;
             c_created += __popcll(ballot(do_create && need && !waiting && (photons_left > 0)));
-#endif
+            )
             if (do_create && need && !waiting && (photons_left > 0)) {
                 create_photon<MED, TILT, FLASHER, TABULATE, FAST>(P, &P->work[sidx].step, step_dir, rx, ra, ph);
                 need = false;
             }
-#ifdef CLSIMHIP_EXP_TAB_LOADS_IN_BLOCK
-            if (TABULATE) asm volatile("" :: "v"(rx), "v"(ra), "v"(step_dir.x), "v"(step_dir.y), "v"(step_dir.z), "v"(unit_weight), "v"(photons_left), "v"(sidx), "v"(slice));
-#endif
             // nothing runnable in this wave: every lane waits for another wave's slice
             if ((m_ready == 0ull) && (ballot(alive && !need) == 0ull)) {
-#ifdef CLSIMHIP_DEBUG_COUNTERS
-                if (lane == 0) atomicAdd(P->queue + 3, 1u);
-#endif
+                DEBUG_COUNTED(if (lane == 0) atomicAdd(P->queue + 3, 1u);)
                 __builtin_amdgcn_s_sleep(16);
             }
         }
@@ -938,9 +884,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         // length until `k_search` lanes of the wave are parked (or nothing else can advance), and the DOM search runs
         // for all of them at once: the search costs the wave the same whether 1 or 12 lanes need it.
         const bool run = alive && !need && !parked;
-#ifdef CLSIMHIP_CENSUS
-        c_run += __popcll(ballot(run));
-#endif
+        CENSUS(c_run += __popcll(ballot(run));)
         float distance = 0.0f;
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
@@ -1014,15 +958,11 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
             bool left_table;
             if (TAB == 2) left_table = save_path_wave<true>(P, wave_lds, run, ph, weight, distance,
                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra
-#ifdef CLSIMHIP_TAB_TIMERS
-                                                            , t_acc[6], t_last
-#endif
+                                                            TAB_TIMED(, t_acc[6], t_last)
                                                             );
             else left_table = save_path_wave_carry(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
                                                    tab_carry, tab_parity, false
-#ifdef CLSIMHIP_TAB_TIMERS
-                                                   , t_acc[6], t_last, t_acc[7]
-#endif
+                                                   TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                                    );
             if (run) {
                 if (left_table) ph.abs_lens_left = 0.0f;
@@ -1101,10 +1041,10 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         m_need = ballot(need_next);
         m_ready = ballot(alive && !need_next);
         TAB_STAMP(3)        // advance, scattering
-#ifdef CLSIMHIP_TAB_TIMERS
+        TAB_TIMED(
         t_acc[4] += 1;      // trips
         t_acc[5] += (uint64_t)__popcll(ballot(run));
-#endif
+        )
         if ((m_need | m_ready) == 0ull) break;
     }
     if ((TAB == 1) && (tab_carry != 0u)) {
@@ -1113,20 +1053,18 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         uint32_t *wave_lds = lds_words + ((P->table_words + 16u + 3u) & ~3u) + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
         float no_remainder = 0.0f;
         (void)save_path_wave_carry(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true
-#ifdef CLSIMHIP_TAB_TIMERS
-                                   , t_acc[6], t_last, t_acc[7]
-#endif
+                                   TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                    );
     }
-#ifdef CLSIMHIP_TAB_TIMERS
+    TAB_TIMED(
     if (TABULATE && lane == 0) {
         // (the table's first words take the sums: its contents are meaningless in this build)
         double *out = fresh_params(P0)->tab_bins;
         for (int k = 0; k < 12; ++k) unsafeAtomicAdd(out + k, (double)t_acc[k]);
     }
-#endif
+    )
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
-#ifdef CLSIMHIP_CENSUS
+    CENSUS(
     if (lane == 0 && !TAB) {
         unsigned long long *d = fresh_params(P0)->census;
         const uint32_t w = blockIdx.x * (uint32_t)kWavesPerBlock + (threadIdx.x >> 6);
@@ -1136,7 +1074,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_need); atomicAdd(d + 3, c_wait);
         atomicAdd(d + 4, c_parked); atomicAdd(d + 5, c_dead); atomicAdd(d + 6, c_phases); atomicAdd(d + 7, c_created);
     }
-#endif
+    )
 }
 
 #ifndef CLSIMHIP_TAB_UNIT      // (prop_tab_kernel.hip compiles this file for the TABULATE instantiations only)
@@ -1386,7 +1324,7 @@ hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipS
 #endif
 
 template <int MED, bool TILT, bool ANISO, bool FLASHER, int TAB, bool FAST = false>
-static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
+static hipError_t launch_variant(const KParams &Pin, hipStream_t stream, int grid_wanted = 0)
 {
     KParams P = Pin;
     constexpr bool TABULATE = (TAB == 1) || (TAB == 2);
@@ -1452,10 +1390,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream)
             if ((double)P.n_steps / ((double)cus * k * kBlock) >= steps_per_lane_wanted) { chosen = k; break; }
         grid = (uint32_t)(cus * chosen);
     }
-    if (const char *e = getenv("CLSIMHIP_GRID")) {
-        const int g = atoi(e);
-        if (g >= 1 && g <= resident) grid = (uint32_t)g;
-    }
+    if (grid_wanted >= 1 && grid_wanted <= resident) grid = (uint32_t)grid_wanted;          // clsimhip_set_tuning("grid")
     if (needed < grid) grid = needed;
     {
         const double r = (double)P.n_steps / ((double)grid * kBlock);
@@ -1490,10 +1425,9 @@ hipError_t launch_prop_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
-    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
-    const bool fast = v.fast && P.history_n == 0 && !(no_fast && no_fast[0] == '1');
+    const bool fast = v.fast && P.history_n == 0 && !v.generic_only;
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 0, true>(P, stream) : launch_variant<a, b, c, d, 0, false>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 0, true>(P, stream, v.grid) : launch_variant<a, b, c, d, 0, false>(P, stream, v.grid);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
@@ -1515,10 +1449,9 @@ hipError_t launch_keep_kernel(const KParams &P, const KVariant &v, hipStream_t s
     if (v.lengths < CLSIMHIP_LENGTHS_CONSTANT || v.lengths > CLSIMHIP_LENGTHS_TABLE) return hipErrorInvalidValue;
     if (v.lengths == CLSIMHIP_LENGTHS_TABLE && (!P.len_table || P.len_tab_n < 2)) return hipErrorInvalidValue;
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
-    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
-    const bool fast = v.fast && P.history_n == 0 && !(no_fast && no_fast[0] == '1');       // (as launch_prop_kernel)
+    const bool fast = v.fast && P.history_n == 0 && !v.generic_only;       // (as launch_prop_kernel)
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 3, true>(P, stream) : launch_variant<a, b, c, d, 3, false>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_variant<a, b, c, d, 3, true>(P, stream, v.grid) : launch_variant<a, b, c, d, 3, false>(P, stream, v.grid);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
@@ -1545,12 +1478,11 @@ hipError_t launch_tab_kernel(const KParams &P, const KVariant &v, hipStream_t st
     // (tests/test_tabulator.py) and measured -- 200x36x100x105 table: 2.15e7 photons/s against 2.24e7 for the generic instantiation, the
     // impact-angle table 1.92e7 both (profiles/r04/tab_fast_vs_generic.txt): this kernel waits for its memory-side fp64 atomics in 55 % of
     // its wave cycles and issues vector instructions in 37 % of the slots, fewer scalar branches buy nothing and the other register
-    // allocation costs.  So the generic instantiation runs; CLSIMHIP_TAB_FAST=1 selects the other one.
-    const char *tab_fast = getenv("CLSIMHIP_TAB_FAST");
-    const bool fast = v.fast && tab_fast && tab_fast[0] == '1';
+    // allocation costs.  So the generic instantiation runs; clsimhip_tabulator_set_tuning("fast_kernels", 1) selects the other one.
+    const bool fast = v.fast && v.tab_fast;
     switch (key) {
-#define CASE(k, m, t, a) case k: return (P.tab_ndim > 4) ? (fast ? launch_variant<m, t, a, true, 2, true>(P, stream) : launch_variant<m, t, a, true, 2, false>(P, stream)) \
-                                                         : (fast ? launch_variant<m, t, a, true, 1, true>(P, stream) : launch_variant<m, t, a, true, 1, false>(P, stream));
+#define CASE(k, m, t, a) case k: return (P.tab_ndim > 4) ? (fast ? launch_variant<m, t, a, true, 2, true>(P, stream, v.grid) : launch_variant<m, t, a, true, 2, false>(P, stream, v.grid)) \
+                                                         : (fast ? launch_variant<m, t, a, true, 1, true>(P, stream, v.grid) : launch_variant<m, t, a, true, 1, false>(P, stream, v.grid));
 #define CASES(m) CASE(4 * m + 0, m, false, false) CASE(4 * m + 1, m, false, true) CASE(4 * m + 2, m, true, false) CASE(4 * m + 3, m, true, true)
     CASES(CLSIMHIP_LENGTHS_CONSTANT) CASES(CLSIMHIP_LENGTHS_ICECUBE) CASES(CLSIMHIP_LENGTHS_TABLE)
 #undef CASES

@@ -43,9 +43,6 @@ namespace clsimhip {
 #ifndef CLSIMHIP_POOL_GROUPS
 #define CLSIMHIP_POOL_GROUPS 2                  // workgroups per CU the LDS is shared between (experiments: 4 groups of 7 waves, profiles/r05/ab_seven_waves.txt)
 #endif
-#ifndef CLSIMHIP_NAMED_POLICY
-#define CLSIMHIP_NAMED_POLICY 4                 // which parked lanes take the search confined to one DOM (see the search block)
-#endif
 constexpr int kPoolBlock = CLSIMHIP_POOL_BLOCK;
 constexpr int kPoolWavesPerBlock = kPoolBlock / 64;
 constexpr int kPoolMinWaves = CLSIMHIP_POOL_WAVES;
@@ -148,7 +145,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     ph.layer = 0;
 
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
-#ifdef CLSIMHIP_CENSUS
+    CENSUS(
     if (lane == 0) atomicMin(fresh_params(P0)->census + 8, wall_clock64());
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
     // shader-clock cycles of the wave inside the service block, its publication of finished units, the unit take and the creation chunks
@@ -158,7 +155,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     // five 16-byte loads, unpacking, the wave barrier (t_hand_out, c_hand_outs blocks)
     unsigned long long t_ring_store = 0, c_ring_stores = 0, t_hand_out = 0, c_hand_outs = 0;
     const unsigned long long t_wave_start = __builtin_readcyclecounter();
-#endif
+    )
     // who holds what, as lane masks; taken at the end of a trip for the next one (and for the loop's exit, a plain backward branch)
     uint64_t m_spent = 0ull, m_vacant = ~0ull, m_live = 0ull;
     for (uint32_t trip = 0;; ++trip) {
@@ -170,16 +167,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
         }
-#ifdef CLSIMHIP_EXP_SALU        // experiment: marginal cost of scalar / vector instructions (tools/exp_issue_cost.sh)
-        { uint32_t dummy = trip; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_SALU) "\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : : "scc"); if (dummy == 0xdeadbeefu) --n_left; }
-#endif
-#ifdef CLSIMHIP_EXP_VALU
-        { uint32_t dummy = lane; asm volatile(".rept " CLSIMHIP_STR(CLSIMHIP_EXP_VALU) "\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(dummy)); if (dummy == 0xdeadbeefu) --n_left; }
-#endif
-#ifdef CLSIMHIP_CENSUS
+        CENSUS(
         ++c_trips;
         c_vacant += __popcll(m_vacant | m_spent);
-#endif
+        )
 
         // ---- service: retire the units of spent photons, create photons when the ring has room, hand out ready photons ----
         const uint32_t n_free = (uint32_t)__popcll(m_spent | m_vacant);
@@ -187,37 +178,23 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         if (n_free >= (uint32_t)fresh_params(P0)->k_pop) {
             const KP P = fresh_params(P0);
             WorkRecord *work = P->work;
-#ifdef CLSIMHIP_CENSUS
+            CENSUS(
             ++c_services;
             if (st != kLive) CENSUS_REGION(P, kCensusService);
             const unsigned long long t_s0 = __builtin_readcyclecounter();
-#endif
+            )
             if (m_spent != 0ull) {
                 const bool mine = (st == kSpent);
                 const bool finished = mine && (photons_left == 0u);
                 const bool next = mine && (photons_left != 0u);
                 const uint64_t m_finished = ballot(finished), m_next = ballot(next);
                 if (m_finished != 0ull) {
-#ifdef CLSIMHIP_CENSUS
-                    const unsigned long long t_p0 = __builtin_readcyclecounter();
-#endif
+                    CENSUS(const unsigned long long t_p0 = __builtin_readcyclecounter();)
                     // publish the finished unit (c.cl:911-912).  The last slice of a step leaves the stream's state in the
                     // converter's array for the next bunch; any other slice hands it to whoever takes the next slice:
                     // state first, then the slice counter, both write-through so that a lane on another XCD that sees
                     // the counter sees the state
                     const bool last = (uflags & kFlagLast) != 0u;
-#ifdef CLSIMHIP_EXP_PUBLISH16
-                    // experiment (profiles/r04/ab_service_latency.txt): state, multiplier and slice counter are the last 16 bytes of the work
-                    // record -- ONE write-through store instead of store, wait for its acknowledgement, store
-                    if (finished) {
-                        if (last) P->rng_x[sidx] = rx;
-                        else {
-                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                            const u32x4 tail = {(uint32_t)rx, (uint32_t)(rx >> 32), ra, (uflags & 0xffffu) + 1u};
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&work[sidx].x), "v"(tail) : "memory");
-                        }
-                    }
-#else
                     if (finished) {
                         if (last) P->rng_x[sidx] = rx;
                         else __hip_atomic_store(&work[sidx].x, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -225,20 +202,14 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (finished && !last)
                         __hip_atomic_store(&work[sidx].done, (uflags & 0xffffu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
                     n_empty += (uint32_t)__popcll(m_finished);
-#ifdef CLSIMHIP_CENSUS
+                    CENSUS(
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     t_publish += __builtin_readcyclecounter() - t_p0;
-#endif
+                    )
                 }
                 if (next) {     // the unit goes to `pending` with its stream where the photon left it
                     pend_store(pend, n_pend + (uint32_t)__popcll(m_next & lanes_below), sidx, rx, photons_left, uflags);
-#ifdef CLSIMHIP_EXP_PREFETCH
-                    // experiment (profiles/r04/ab_service_latency.txt): touch the unit's work record now, one or more services before the
-                    // creation of its next photon reads it
-                    { const volatile uint32_t *touch = &work[sidx].a; (void)*touch; }
-#endif
                 }
                 n_pend += (uint32_t)__popcll(m_next);
                 if (mine) st = kVacant;
@@ -257,10 +228,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             const bool starving = (n_ready < n_free);
             const bool look_again = starving && (n_wait != 0u) && (room != 0u) && (((trip & 3u) == 0u) || (m_live == 0ull));
             if (__builtin_expect(((batch != 0u) && ((batch >= (uint32_t)P->k_new) || starving)) || look_again, 0)) {
-#ifdef CLSIMHIP_CENSUS
+                CENSUS(
                 ++c_creations;
                 const unsigned long long t_a0 = __builtin_readcyclecounter();
-#endif
+                )
                 // (a) new units for the empty slots: one atomic per wave and round on the wave's sub-queue
                 for (uint32_t round = 0; (n_empty != 0u) && (used_up < (uint32_t)kSubQueues) && (round < (uint32_t)kSubQueues + 2u); ++round) {
                     const uint32_t n_sub = (n_steps + (uint32_t)kSubQueues - 1u - sub_queue) / (uint32_t)kSubQueues;   // its steps
@@ -302,43 +273,25 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-#ifdef CLSIMHIP_CENSUS
+                CENSUS(
                 const unsigned long long t_b0 = __builtin_readcyclecounter();
                 t_take += t_b0 - t_a0;
-#endif
+                )
                 // (b) the pending units, 64 at a time: look for the predecessor's state where needed, create the next
                 // photon while the ring has room; what stays is compacted to the front of the list in its order
                 uint32_t kept = 0, created = 0, still_waiting = 0;
                 for (uint32_t c = 0; c < n_pend; c += 64u) {
-#ifdef CLSIMHIP_CENSUS
-                    ++c_chunks;
-#endif
+                    CENSUS(++c_chunks;)
                     const bool have = (c + lane) < n_pend;
                     uint32_t e_sidx = 0, e_left = 0, e_flags = 0;
                     uint64_t e_rx = 0;
                     if (have) pend_load(pend, c + lane, e_sidx, e_rx, e_left, e_flags);
                     bool waiting = have && ((e_flags & kFlagWaiting) != 0u);
-#ifdef CLSIMHIP_EXP_PUBLISH16
-                    if (waiting) {
-                        WorkRecord *rec = work + e_sidx;
-                        const uint32_t slice = e_flags & 0xffffu;
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        u32x4 tail = {0u, 0u, 0u, 0u};
-                        if (slice != 0u) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tail) : "v"(&rec->x) : "memory");
-                        if (tail.w >= slice) {
-                            e_rx = (slice == 0u) ? rec->x : ((uint64_t)tail.x | ((uint64_t)tail.y << 32));
-                            e_flags &= ~kFlagWaiting;
-                            waiting = false;
-                        }
-                    }
-#else
                     if (waiting) {
                         WorkRecord *rec = work + e_sidx;
                         const uint32_t slice = e_flags & 0xffffu;
                         const uint32_t published = (slice == 0u) ? 0u : __hip_atomic_load(&rec->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CLSIMHIP_CENSUS
-                        ++c_polls;
-#endif
+                        CENSUS(++c_polls;)
                         if (published >= slice) {
                             // c.cl:458-461; slice 0 reads the state left by the previous bunch
                             e_rx = (slice == 0u) ? rec->x : __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -346,15 +299,12 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                             waiting = false;
                         }
                     }
-#endif
                     still_waiting += (uint32_t)__popcll(ballot(waiting));
                     const bool can = have && !waiting;
                     const uint64_t m_can = ballot(can);
                     const uint32_t slot = created + (uint32_t)__popcll(m_can & lanes_below);
                     const bool make = can && (slot < (R - n_ready));
-#ifdef CLSIMHIP_CENSUS
-                    unsigned long long t_q0 = 0;
-#endif
+                    CENSUS(unsigned long long t_q0 = 0;)
                     if (make) {
                         const WorkRecord *rec = work + e_sidx;
                         const uint32_t e_ra = rec->a;
@@ -362,10 +312,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         Photon born;
                         born.layer = 0;
                         create_photon<MED, TILT, FLASHER, false, FAST>(P, &rec->step, step_dir, e_rx, e_ra, born);
-#ifdef CLSIMHIP_CENSUS
+                        CENSUS(
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         t_q0 = __builtin_readcyclecounter();
-#endif
+                        )
                         uint32_t pos = ready_head + n_ready + slot;
                         if (pos >= R) pos -= R;
                         if (pos >= R) pos -= R;
@@ -375,13 +325,9 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                         q[2] = pend_entry{dm::f2u(born.abs_lens_left), dm::f2u(born.ice.sca_pow), dm::f2u(born.ice.abs_pow), dm::f2u(born.ice.abs_exp)};
                         q[3] = pend_entry{(uint32_t)born.rx_start, (uint32_t)(born.rx_start >> 32), e_sidx, e_ra};
                         q[4] = pend_entry{(uint32_t)e_rx, (uint32_t)(e_rx >> 32), e_left, e_flags | ((uint32_t)born.layer << 18)};       // (flags: 18 bits; layers < 2^14, checked by the launcher)
-#ifdef CLSIMHIP_CENSUS
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+                        CENSUS(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");)
                     }
-#ifdef CLSIMHIP_CENSUS
-                    if (t_q0 != 0) { t_ring_store += __builtin_readcyclecounter() - t_q0; ++c_ring_stores; }
-#endif
+                    CENSUS(if (t_q0 != 0) { t_ring_store += __builtin_readcyclecounter() - t_q0; ++c_ring_stores; })
                     const bool keep = have && !make;
                     const uint64_t m_keep = ballot(keep);
                     // (every lane has read its entry above; the compacted entries land at or before the ones read)
@@ -398,17 +344,15 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 n_pend = kept;
                 n_wait = still_waiting;
                 n_ready += created;
-#ifdef CLSIMHIP_CENSUS
+                CENSUS(
                 c_created += created;
                 t_create += __builtin_readcyclecounter() - t_b0;
-#endif
+                )
             }
 
             // ready photons for the lanes without one, oldest first
             if (n_ready != 0u) {
-#ifdef CLSIMHIP_CENSUS
-                const unsigned long long t_h0 = __builtin_readcyclecounter();
-#endif
+                CENSUS(const unsigned long long t_h0 = __builtin_readcyclecounter();)
                 const bool want = (st == kVacant);
                 const uint64_t m_want = ballot(want);
                 const uint32_t rank = (uint32_t)__popcll(m_want & lanes_below);
@@ -436,25 +380,23 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CLSIMHIP_CENSUS
+                CENSUS(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (taken != 0u) { t_hand_out += __builtin_readcyclecounter() - t_h0; ++c_hand_outs; }
-#endif
+                )
             }
             // nothing runnable in this wave: every unit it holds waits for another wave's slice
             if (ballot(st != kVacant) == 0ull) __builtin_amdgcn_s_sleep(16);
-#ifdef CLSIMHIP_CENSUS
-            t_service += __builtin_readcyclecounter() - t_s0;
-#endif
+            CENSUS(t_service += __builtin_readcyclecounter() - t_s0;)
         }
 
         // ---- one reference loop iteration for the lanes that hold a live photon ----
         const bool run = (st == kLive);
-#ifdef CLSIMHIP_CENSUS
+        CENSUS(
         c_run += __popcll(ballot(run));
         c_parked += __popcll(ballot(st >= kParked));
         if (n_ready == 0u) ++c_empty_ring;
-#endif
+        )
         float distance = 0.0f;
         bool hit = false;
         uint32_t hit_string = 0, hit_dom = 0;
@@ -491,9 +433,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             if (!FLASHER) parked_trips = (n_parked != 0u) ? parked_trips + 1u : 0u;
             if (__builtin_expect((n_parked >= enough) || (!FLASHER && (parked_trips > (uint32_t)fresh_params(P0)->k_wait)), 0)) {
                 if (!FLASHER) parked_trips = 0u;
-#ifdef CLSIMHIP_CENSUS
-                ++c_searches;
-#endif
+                CENSUS(++c_searches;)
                 if (KEEP && (st >= kParked)) {
                     // without STOP_PHOTONS_ON_DETECTION (c.cl:704-750): the search saves what it finds, nothing is shortened or absorbed.
                     // The lane's string mask: one word per 64 strings in the wave's LDS region.
@@ -522,16 +462,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
                     // 3.553 / 3.050 / 2.886 / 2.042.  Cascade photons that reach a string mostly arrive with steps longer than
                     // the distance to the second-nearest DOM, so their waves run the full search anyway and only pay for the
                     // second code path; photons born at a DOM live within metres of it.
-                    bool full = (st == kParked);
-#if CLSIMHIP_NAMED_POLICY == 0
-                    full = true;
-#elif CLSIMHIP_NAMED_POLICY == 2
-                    full = (ballot(full) != 0ull);
-#elif CLSIMHIP_NAMED_POLICY == 3
-                    if (!FLASHER) full = true;
-#elif CLSIMHIP_NAMED_POLICY == 4
-                    full = FLASHER ? (ballot(full) != 0ull) : true;
-#endif
+                    // (the other policies: tools/experiments/named_policy.patch)
+                    bool full = FLASHER ? (ballot(st == kParked) != 0ull) : true;
                     if (!full) {
                         const uint32_t id = st - (kParked + 1u);
                         const uint4 named = fresh_params(P0)->dom_named[id];
@@ -602,7 +534,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         if (__builtin_expect((m_live | m_spent | (uint64_t)n_left) == 0ull, 0)) break;                // every unit slot has been retired (one test: the loop is scalar-issue bound)
     }
     if (n_staged != 0u) flush_hit_stubs(fresh_params(P0), stage, n_staged, lane);
-#ifdef CLSIMHIP_CENSUS
+    CENSUS(
     if (lane == 0) {
         unsigned long long *d = fresh_params(P0)->census;
         atomicAdd(d + 0, c_trips); atomicAdd(d + 1, c_run); atomicAdd(d + 2, c_services); atomicAdd(d + 3, c_creations);
@@ -616,7 +548,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         d[16 + 3 * w + 1] = 0;
         d[16 + 3 * w + 2] = c_trips;
     }
-#endif
+    )
 }
 
 // ring entries per wave that fit beside a table image of `table_words` words (two workgroups per CU share 160 KB; the image is per
@@ -633,7 +565,7 @@ hipError_t launch_scan_steps(const KParams &P, hipStream_t stream);
 hipError_t launch_assemble_hits(const KParams &P, bool flasher, int device, hipStream_t stream);
 
 template <int MED, bool TILT, bool ANISO, bool FLASHER, bool FAST, bool KEEP>
-static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
+static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream, int grid_wanted = 0)
 {
     KParams P = Pin;
     int dev = 0;
@@ -680,10 +612,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream)
     }
     uint32_t grid = (uint32_t)plan.resident;
     if (P.chip_share > 1) grid = (grid / (uint32_t)P.chip_share > 0u) ? grid / (uint32_t)P.chip_share : 1u;      // concurrent launches share the chip
-    if (const char *e = getenv("CLSIMHIP_GRID")) {
-        const int g = atoi(e);
-        if (g >= 1 && g <= plan.resident) grid = (uint32_t)g;
-    }
+    if (grid_wanted >= 1 && grid_wanted <= plan.resident) grid = (uint32_t)grid_wanted;      // clsimhip_set_tuning("grid")
     // Fewer steps than the grid has unit slots: smaller rings on every CU rather than full rings on fewer CUs (round 4: with the ring of 45 a
     // bunch of 625 000 flasher steps filled 478 of the 512 workgroups; a ring entry is worth 0.28 %, a workgroup 0.2 %) -- unless the ring
     // was asked for (CLSIMHIP_POOL_R) or would fall below the size from which the pooled kernel pays
@@ -759,11 +688,10 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
     if (P.num_layers >= (1 << 14)) return hipErrorInvalidValue;          // (a ring entry keeps the carried layer index in 14 bits: pool_kernel_fits() says so first)
     if (P.n_steps > kPoolIndexMask) return hipErrorInvalidValue;          // (a pending entry keeps the step index in 23 bits: Converter::pooled_for() says so first)
     const int key = 8 * v.lengths + (v.tilt ? 4 : 0) + (v.aniso ? 2 : 0) + (v.flasher ? 1 : 0);
-    // CLSIMHIP_NO_FAST=1: the generic instantiation also where Compile() found every proof (tests compare the two)
-    const char *no_fast = getenv("CLSIMHIP_NO_FAST");
-    const bool fast = v.fast && !(no_fast && no_fast[0] == '1');
+    // clsimhip_set_tuning("generic_kernels", 1): the generic instantiation also where Compile() found every proof (tests compare the two)
+    const bool fast = v.fast && !v.generic_only;
     switch (key) {
-#define CASE(k, a, b, c, d) case k: return fast ? launch_pool_variant<a, b, c, d, true, CLSIMHIP_POOL_KEEP>(P, stream) : launch_pool_variant<a, b, c, d, false, CLSIMHIP_POOL_KEEP>(P, stream);
+#define CASE(k, a, b, c, d) case k: return fast ? launch_pool_variant<a, b, c, d, true, CLSIMHIP_POOL_KEEP>(P, stream, v.grid) : launch_pool_variant<a, b, c, d, false, CLSIMHIP_POOL_KEEP>(P, stream, v.grid);
 #define CASES(m) \
     CASE(8 * m + 0, m, false, false, false) CASE(8 * m + 1, m, false, false, true) \
     CASE(8 * m + 2, m, false, true, false)  CASE(8 * m + 3, m, false, true, true)  \
@@ -777,17 +705,9 @@ hipError_t CLSIMHIP_POOL_LAUNCHER(const KParams &P, const KVariant &v, hipStream
 }
 
 #ifndef CLSIMHIP_POOL_KEEP_UNIT
-// the largest bunch the pooled kernel's 23-bit step index can address (CLSIMHIP_POOL_INDEX_BITS lowers the GUARD for tests: bunches
-// beyond 2^bits - 1 steps then take the classic kernel, exactly what a bunch beyond 2^23 - 1 does)
-size_t pool_kernel_max_steps()
-{
-    uint32_t bits = kPoolIndexBits;
-    if (const char *e = getenv("CLSIMHIP_POOL_INDEX_BITS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v < (int)kPoolIndexBits) bits = (uint32_t)v;
-    }
-    return (size_t{1} << bits) - 1;
-}
+// the largest bunch the pooled kernel's 23-bit step index can address (clsimhip_set_tuning("pool_max_steps") lowers the GUARD for tests:
+// larger bunches then take the classic kernel, exactly what a bunch beyond 2^23 - 1 does)
+size_t pool_kernel_max_steps() { return (size_t{1} << kPoolIndexBits) - 1; }
 // does the pooled kernel pay for this table image (its waves need at least kPoolWorthwhileReady ring entries)?  keep_strings: the
 // number of strings when the converter runs without STOP_PHOTONS_ON_DETECTION (the search's string masks share the pool's LDS), else 0
 bool pool_kernel_fits(uint32_t table_words, uint32_t keep_strings, int num_layers)

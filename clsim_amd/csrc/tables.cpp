@@ -76,7 +76,8 @@ std::vector<float> literals(const std::vector<double> &v)
 } // namespace
 
 CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry,
-                              const std::vector<RandomValueData> &generators, const FunctionData &bias, double pancake)
+                              const std::vector<RandomValueData> &generators, const FunctionData &bias, double pancake,
+                              const TableTuning &tuning)
 {
     m.validate();
     CompiledTables C;
@@ -521,8 +522,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         // 1M cascade steps 64^2 3.60e9 photons/s, 128^2 3.70, 256^2 3.73, 512^2 3.77, 768^2 3.78, 1024^2 3.78, 2048^2 (16 MB) 3.42;
         // SPICE-Lea 3.09 / 3.15 / 3.19 / 3.21 / - / 3.22.  512^2 words = 1 MB, L2 resident.  (A 64^2 copy in LDS was 1.5 % SLOWER
         // than the L2-resident map: the load is issued before the layer walk and is long back when it is needed.)
-        int n = 512;
-        if (const char *e = std::getenv("CLSIMHIP_PROX_N")) n = std::max(8, std::min(4096, std::atoi(e)));
+        const int n = std::max(8, std::min(4096, tuning.string_map_cells));         // 512 unless clsimhip_set_tuning("string_map_cells") said otherwise
         double x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY, reach = 0.;
         for (int s = 0; s < G.num_strings; ++s) {
             x_lo = std::min<double>(x_lo, G.str_x[s]); x_hi = std::max<double>(x_hi, G.str_x[s]);
@@ -581,8 +581,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
     }
     {   // DOM proximity map (kparams.h), the second level of the search filter.  Everything in double, rounded towards
         // "search anyway".  Cubic cells; at most 256 per axis (64 MB); border cells reach to infinity.
-        int n_max = 256;
-        if (const char *e = std::getenv("CLSIMHIP_DOM_PROX_N")) n_max = std::max(4, std::min(512, std::atoi(e)));
+        const int n_max = std::max(4, std::min(512, tuning.dom_map_cells));         // 256 unless clsimhip_set_tuning("dom_map_cells") said otherwise
         // DOM numbers of the maps: strings in index order, each with its DOMs in order (NOT the template index: strings with
         // equal DOM offsets share a template, GeometrySource.cxx:449-495)
         std::vector<size_t> first_dom(static_cast<size_t>(G.num_strings) + 1, 0);
@@ -659,9 +658,8 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         // subdetector's grid, or whose layers are not one contiguous run, is marked 0xffffffff and always takes the full search.
         C.dom_named.assign(4 * n_doms, 0u);
         {
-            // CLSIMHIP_NO_NAMED_SEARCH=1: every DOM takes the full search (tests compare the two on whole bunches)
-            const char *env = std::getenv("CLSIMHIP_NO_NAMED_SEARCH");
-            const bool no_named = env && env[0] == '1';
+            // clsimhip_set_tuning("named_search", 0): every DOM takes the full search (tests compare the two on whole bunches)
+            const bool no_named = !tuning.named_search;
             // a string lies in every cell its bounding square overlaps (GeometrySource.cxx:135-271): a rectangle of cells
             struct Rect { int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1, count = 0, sd = -1; bool bad = false; };
             std::vector<Rect> rect(static_cast<size_t>(G.num_strings));

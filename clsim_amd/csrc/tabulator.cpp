@@ -86,16 +86,21 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     // 64-byte sector; azimuth (axis 1) stays whole.  The table's sums are memory-side atomic requests of one sector each, and a path's
     // consecutive samples then meet fewer sectors than with eight time bins to a sector: the distance and polar-angle bins are the
     // ones a path crosses (profiles/r05/tab_tile_scan.txt: 2 x 2 x 2 1.5 % behind, eight time bins 14 %).  bin_content_double() puts the
-    // sums into the reference's order (Axes.cxx:51-64).  CLSIMHIP_TAB_LAYOUT=linear keeps the reference's order on the device too
-    // (measurement; five-axis tables always).
+    // sums into the reference's order (Axes.cxx:51-64).  (Developer build: CLSIMHIP_TAB_LAYOUT=linear keeps the reference's order on the
+    // device too, CLSIMHIP_TAB_TILE=e0e2e3 another tile shape -- the measurements behind profiles/r05/tab_tile_scan.txt; five-axis tables
+    // are always linear.)
     tiled_ = (nd == 4);
-    if (const char *e = std::getenv("CLSIMHIP_TAB_LAYOUT")) tiled_ = tiled_ && (std::strcmp(e, "linear") != 0);
     n_device_bins_ = n_bins_;
+#ifdef CLSIMHIP_DEVELOPER
+    if (const char *e = std::getenv("CLSIMHIP_TAB_LAYOUT")) tiled_ = tiled_ && (std::strcmp(e, "linear") != 0);
     if (const char *e = std::getenv("CLSIMHIP_TAB_TILE")) {
-        // (measurement: the tile's shape as three digits e0 e2 e3 with e0 + e2 + e3 = 3, e.g. 210 = 4 x 2 x 1 bins of distance, polar angle, time)
+        // (the tile's shape as three digits e0 e2 e3 with e0 + e2 + e3 = 3, e.g. 210 = 4 x 2 x 1 bins of distance, polar angle, time)
         if (std::strlen(e) == 3 && e[0] >= '0' && e[1] >= '0' && e[2] >= '0' && (e[0] - '0') + (e[1] - '0') + (e[2] - '0') == 3)
             for (int k = 0; k < 3; ++k) tile_bits_[k] = static_cast<unsigned>(e[k] - '0');
     }
+    if (const char *e = std::getenv("CLSIMHIP_TAB_FAST")) fast_kernels_ = (e[0] == '1');
+    if (const char *e = std::getenv("CLSIMHIP_GRID")) grid_ = std::atoi(e);
+#endif
     if (tiled_) {
         const size_t t0 = size_t(1) << tile_bits_[0], t2 = size_t(1) << tile_bits_[1], t3 = size_t(1) << tile_bits_[2];
         const size_t h0 = (shape_[0] + t0 - 1) / t0, h2 = (shape_[2] + t2 - 1) / t2, h3 = (shape_[3] + t3 - 1) / t3;
@@ -270,10 +275,22 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
         for (int k = 0; k < 12; ++k) P.tab_ref[k] = static_cast<float>(v[k]);
     }
     hip_check(hipEventRecord(ev_start_, stream_), "event");
-    hip_check(launch_tab_kernel(P, tables_.variant, stream_), "tabulation kernel launch");
+    KVariant variant = tables_.variant;
+    variant.tab_fast = fast_kernels_;
+    variant.grid = grid_;
+    hip_check(launch_tab_kernel(P, variant, stream_), "tabulation kernel launch");
     hip_check(hipEventRecord(ev_stop_, stream_), "event");
     pending_event_ = true;
     ++launches_;
+}
+
+// clsimhip_tabulator_set_tuning (include/clsimhip.h)
+void Tabulator::set_tuning(const std::string &key, long long value)
+{
+    std::lock_guard<std::mutex> lk(mutex_);
+    if (key == "fast_kernels" && (value == 0 || value == 1)) fast_kernels_ = (value != 0);
+    else if (key == "grid" && value >= 0 && value <= (1 << 20)) grid_ = static_cast<int>(value);
+    else throw Error(CLSIMHIP_ERR_ARGUMENT, "table maker tuning: no key " + key + " with the value " + std::to_string(value));
 }
 
 void Tabulator::finish()

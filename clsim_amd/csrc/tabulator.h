@@ -35,6 +35,7 @@ public:
 
     void enqueue_steps(const clsimhip_step *steps, size_t n, const double reference[7]);
     void finish();
+    void set_tuning(const std::string &key, long long value);
     size_t n_bins() const { return n_bins_; }
     const std::vector<size_t> &shape() const { return shape_; }
     const std::vector<AxisData> &axes() const { return axes_; }
@@ -60,6 +61,8 @@ private:
     size_t n_bins_ = 0;
     bool tiled_ = false;                     // the device keeps the bins in tiles of eight of axes 0, 2, 3 (tabulator.cpp)
     size_t n_device_bins_ = 0, tile_stride_[3] = {0, 0, 0};
+    bool fast_kernels_ = false;              // "fast_kernels" (set_tuning): the FAST instantiation, measured slower (prop_kernel.hip: launch_tab_kernel)
+    int grid_ = 0;                           // "grid": workgroups of the launch, 0 = automatic
     unsigned tile_bits_[3] = {2, 1, 0};      // bins per sector along axes 0, 2, 3 as powers of two (sum 3): 4 x 2 x 1 (tabulator.cpp)
     bool squared_;
     double reference_area_, step_length_;

@@ -116,6 +116,10 @@ class I3CLSimStepToTableConverterHIP:
         ref = (C.c_double * 7)(*[float(v) for v in reference])
         self._call("clsimhip_tabulator_enqueue_steps", steps.ctypes.data_as(C.c_void_p), len(steps), ref)
 
+    def SetTuning(self, key, value):
+        """clsimhip_tabulator_set_tuning: "fast_kernels" 0 | 1, "grid" (no result depends on either)"""
+        self._call("clsimhip_tabulator_set_tuning", key.encode(), int(value))
+
     def Finish(self):
         self._call("clsimhip_tabulator_finish")
 

@@ -262,6 +262,40 @@ int clsimhip_get_statistics(const clsimhip_converter *c, double out[8]);
 #define CLSIMHIP_OPTION_PHOTON_HISTORY_ENTRIES 7
 int clsimhip_get_option(const clsimhip_converter *c, int option, double *out);
 
+/* ---- tuning (no reference counterpart; the reference's one launch parameter is the work-group size it takes from
+ * the device, OpenCL.cxx:520-560) ----
+ * The launcher's parameters have defaults found by measurement; a caller who knows its bunches better
+ * sets them here.  NO RESULT DEPENDS ON ANY OF THEM: every schedule gives the same photon records and the same final
+ * RNG states (tests/test_stress_schedules_gpu.py).  The library reads NO tuning from the environment (a build with
+ * -DCLSIMHIP_DEVELOPER, `make DEVELOPER=1`, honours the round 1-5 variable names for the measurement tools under
+ * tools/); the only environment variables of the default build are CLSIMHIP_SAFEPRIMES_FILE (a file of multipliers
+ * in the reference's format, mwcrng_init.h:44-82) and CLSIMHIP_RCCL_LIBRARY (which RCCL to dlopen).
+ *
+ *   key                  values           meaning (default)
+ *   "kernel"             0 | 1 | 2        0: pooled kernel for bunches of at least "pool_min_steps" steps, classic below; 1: pooled,
+ *                                         2: classic, for every bunch size (0)
+ *   "pool_min_steps"     -1 | >= 0        smallest bunch the pooled kernel takes; -1: 524 288, or 0 when "kernel" is 1 (-1)
+ *   "pool_max_steps"     -1 | >= 1        largest bunch the pooled kernel takes; can only lower the limit of its 23-bit step index (-1)
+ *   "pool_ring"          0 ... 4096       pooled kernel: created photons a wave keeps ready; 0: what the LDS holds, 45 for IceCube (0)
+ *   "k_new"              0 ... 4096       lanes / ring entries waiting before a wave creates photons; 0: automatic (0)
+ *   "k_search"           0 ... 64         lanes parked before a wave searches for DOMs; 0: automatic (0)
+ *   "slices"             0 ... 65535      work units a step is cut into; 0: 16, or 1 for bunches smaller than the grid (0)
+ *   "k_pop"              0 ... 64         pooled kernel: free lanes before a wave hands out ready photons; 0: 4 (0)
+ *   "k_wait"             -1 | >= 0        pooled kernel: trips a parked lane waits for company; -1: 16; 0: never (-1)
+ *   "k_aim"              -1 ... 64        pooled kernel: lanes at a string up to which the "aimed at the string?" level is asked;
+ *                                         -1: 8; 0: the level is off (-1)
+ *   "grid"               0 ... 2^20       workgroups of the propagation launch; 0: what the chip holds, cut to the work (0)
+ *   "generic_kernels"    0 | 1            1: the generic instantiation also where Compile() found every proof of the fast one (0)
+ *   "result_min_records" >= 1             smallest page-locked result buffer, in photon records (65 536)
+ *   -- the three below shape tables of Compile(): CLSIMHIP_ERR_STATE after Compile() --
+ *   "string_map_cells"   8 ... 4096       string proximity map, cells per axis (512)
+ *   "dom_map_cells"      4 ... 512        DOM proximity map, largest number of cubic cells per axis (256)
+ *   "named_search"       0 | 1            0: every DOM takes the full search instead of the one confined to the named DOM (1)
+ * Any other key or value: CLSIMHIP_ERR_ARGUMENT.  May be called between bunches at any time; a launch reads the values
+ * when it is queued. */
+int clsimhip_set_tuning(clsimhip_converter *c, const char *key, long long value);
+int clsimhip_get_tuning(const clsimhip_converter *c, const char *key, long long *value);
+
 /* ---- device-resident path (no reference counterpart: the reference always
  * stages through host memory, OpenCL.cxx:824-911, 994-1086) ----
  * Propagates n steps that already live in HBM, on the caller's HIP stream
@@ -637,6 +671,9 @@ const char *clsimhip_tabulator_last_error(const clsimhip_tabulator *t);
 int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step *steps, size_t n, const double reference[7]);
 /* Finish() (:287-295): waits until every enqueued bunch is in the table */
 int clsimhip_tabulator_finish(clsimhip_tabulator *t);
+/* table maker tuning (see clsimhip_set_tuning; no result depends on it): "fast_kernels" 0 | 1 -- the instantiation with the
+ * medium's proofs compiled in, measured slower for this kernel (0); "grid" -- workgroups of the launch, 0: automatic (0) */
+int clsimhip_tabulator_set_tuning(clsimhip_tabulator *t, const char *key, long long value);
 /* number of bins including under-/overflow bins, number of axes (4, or 5 with the impact angle), and the shape
  * (n_bins + 2 per axis; unused entries 0) */
 int clsimhip_tabulator_get_shape(const clsimhip_tabulator *t, size_t *n_bins, size_t *n_dim, size_t shape[5]);

@@ -173,3 +173,52 @@ def test_option_getters_and_the_class_defaults():
     assert conv.GetFixedNumberOfAbsorptionLengths() == 46.0 and conv.GetDOMPancakeFactor() == 5.0
     assert conv.GetPhotonHistoryEntries() == 3 and conv.GetSaveAllPhotonsPrescale() == 0.25
     assert conv.GetNumKernelCalls() == 0 and conv.GetTotalNumPhotonsGenerated() == 0 and conv.GetTotalNumPhotonsAtDOMs() == 0
+
+
+def test_tuning_goes_through_the_c_abi_and_not_through_the_environment():
+    """launcher parameters are set with clsimhip_set_tuning (keys and ranges: include/clsimhip.h); the default
+    build of the library reads NO tuning from the environment -- the only variable names in the shared object are the two the
+    header documents -- and the sources call getenv outside `#ifdef CLSIMHIP_DEVELOPER` three times at most."""
+    import re
+    import subprocess
+    names = set(re.findall(rb"CLSIMHIP_[A-Z0-9_]{3,}", open(os.path.join(common.ROOT, "clsim_amd", "libclsimhip.so"), "rb").read()))
+    env_like = {n.decode() for n in names if not n.startswith((b"CLSIMHIP_ERR", b"CLSIMHIP_LENGTHS", b"CLSIMHIP_FUNCTION", b"CLSIMHIP_AX"))}
+    assert env_like <= {"CLSIMHIP_SAFEPRIMES_FILE", "CLSIMHIP_RCCL_LIBRARY"}, env_like
+    src = os.path.join(common.ROOT, "clsim_amd", "csrc")
+    calls = 0
+    for name in sorted(os.listdir(src)):
+        if not name.endswith((".cpp", ".hip", ".h")):
+            continue
+        text = subprocess.run(["g++", "-fpreprocessed", "-dD", "-E", "-P", "-x", "c++", os.path.join(src, name)], capture_output=True, text=True).stdout
+        depth_dev, stack = 0, []
+        for line in text.splitlines():
+            t = line.strip()
+            if t.startswith(("#if", "#ifdef", "#ifndef")):
+                stack.append("CLSIMHIP_DEVELOPER" in t and t.startswith("#ifdef"))
+            elif t.startswith("#else") and stack:
+                stack[-1] = False
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            elif "getenv(" in t and not any(stack):
+                calls += 1
+    assert 1 <= calls <= 3, calls
+    # the API itself (host side: no GPU needed before Initialize)
+    conv = CV.I3CLSimStepToPhotonConverterHIP(0)
+    assert conv.GetTuning("kernel") == 0 and conv.GetTuning("k_wait") == -1 and conv.GetTuning("string_map_cells") == 512
+    conv.SetTuning("kernel", "pool"); conv.SetTuning("slices", 5); conv.SetTuning("named_search", 0)
+    assert conv.GetTuning("kernel") == 1 and conv.GetTuning("slices") == 5 and conv.GetTuning("named_search") == 0
+    for key, value in (("no_such_key", 1), ("kernel", 3), ("k_pop", 65), ("string_map_cells", 4), ("slices", -1)):
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception) as err:
+            conv.SetTuning(key, value)
+        assert err.value.code == _lib.ERR_ARGUMENT
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
+        conv.GetTuning("no_such_key")
+    # the three table keys shape Compile()'s tables: afterwards they are refused, the launcher's keys are not
+    conv = common.product_converter(common.config("c1"), 512, initialize=False)
+    conv.SetTuning("dom_map_cells", 64)
+    conv.Compile()
+    with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception) as err:
+        conv.SetTuning("dom_map_cells", 128)
+    assert err.value.code == _lib.ERR_STATE
+    conv.SetTuning("k_new", 3)
+    assert conv.GetTuning("k_new") == 3

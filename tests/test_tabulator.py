@@ -118,14 +118,13 @@ def test_table_matches_the_oracle(kind, ice, step_length):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,ice", [("spherical", "mie"), ("cylindrical5", "lea")])
-def test_fast_table_instantiations_match_the_oracle_too(monkeypatch, kind, ice):
+def test_fast_table_instantiations_match_the_oracle_too(kind, ice):
     """round 4: the TABULATE kernels have FAST instantiations (the medium's proofs compiled in, as in the propagation kernels);
-    measured slower than the generic ones, so they run only with CLSIMHIP_TAB_FAST=1 -- under the same check"""
-    monkeypatch.setenv("CLSIMHIP_TAB_FAST", "1")
-    check_table_against_the_oracle(kind, ice, 1.0)
+    measured slower than the generic ones, so they run only after clsimhip_tabulator_set_tuning("fast_kernels", 1) -- under the same check"""
+    check_table_against_the_oracle(kind, ice, 1.0, fast_kernels=True)
 
 
-def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by medium"):
+def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by medium", fast_kernels=False):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
     the reference's in-order float accumulation to float accuracy.  step_length 0.2 m makes most waves exceed the
@@ -163,6 +162,10 @@ def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by mediu
     tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=step_length)
     assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
+    if fast_kernels:
+        tab.SetTuning("fast_kernels", 1)
+        with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
+            tab.SetTuning("no_such_key", 1)
     if expect_fast == "by medium":
         assert int(tab.GetTable("fast_variant")[0]) == (0 if ice.startswith("photonics") else 1)
     for k in range(len(o)):

@@ -7,6 +7,7 @@ usage: exp_census.py n:grid:slices ...      (grid in workgroups, 0 = automatic)
 Prints, per configuration: kernel time; fractions of lane trips spent running / waiting for a creation batch / waiting for
 a predecessor slice / parked for the DOM search / without work; photon creation batches; when the waves first found a
 sub-queue used up and when they ended; trips per wave."""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

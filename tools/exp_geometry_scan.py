@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: launch geometry scan (workgroups per CU x slices x k_search) per bunch size.  ANALYSIS TOOL.
 usage: exp_geometry_scan.py n [n ...]"""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: kernel time per bunch size / grid / slices with the product library.  ANALYSIS TOOL.
 usage: exp_grid_scan.py n:grid:slices ...   (0 = automatic)"""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """Census of the pooled kernel (GPU).  ANALYSIS TOOL.  Needs the analysis build:
     make -C clsim_amd/csrc clean && make -C clsim_amd/csrc -j EXTRA=-DCLSIMHIP_CENSUS
 usage: exp_pool_census.py spec ...   (spec as in exp_pool_scan.py)"""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

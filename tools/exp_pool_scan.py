@@ -2,6 +2,7 @@
 """Scan of the pooled kernel's scheduling parameters (GPU).  ANALYSIS TOOL.
 usage: exp_pool_scan.py [workload] spec ...   with spec = key=value,key=value  (keys: kernel R pop new slices search grid n)
 Prints kernel time and photons/s per spec."""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

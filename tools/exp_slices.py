@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: work-unit slicing -- kernel time and wait counters per slice count.  ANALYSIS TOOL
 (needs a library built with -DCLSIMHIP_DEBUG_COUNTERS, CLSIMHIP_LIB=...)."""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,7 @@
 slice counts and batching thresholds; every case is compared with the same bunch run as whole steps on a small grid
 (hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases] [keep]
 (keep: the instantiations without STOP_PHOTONS_ON_DETECTION, classic and pooled kernel; `clear` ice among the configurations)"""
+import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
