@@ -493,13 +493,13 @@ VALU_PEAK_LANE_OPS = 256 * 4 * 2.4e9 * 32       # MI355X_MICROARCH.md: 256 CUs x
 def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, kernel_ms=None):
     """The operative roofline (the kernel is vector-issue bound, not HBM bound).  USEFUL work: the reference's arithmetic per photon,
     counted by the instrumented oracle on a sample of this very bunch and priced in gfx950 vector instructions
-    (tools/count_reference_ops.py -> profiles/r05/reference_ops.json: `as_written` = every operation of the reference's
+    (tools/count_reference_ops.py -> profiles/r06/reference_ops.json: `as_written` = every operation of the reference's
     expressions at the device's generic sequences, search arithmetic on every trip included; `transformed` = the same photon
     histories after the bit-preserving transformations of DESIGN.md section 2, every division and root at the cheapest form proven
     exact for its site, no search arithmetic: the floor) x the measured photons per second, against the chip's vector peak.
     ISSUED work (only where a rocprofv3 --pmc pass of this workload is stored): SQ_INSTS_VALU per launch -> issue slots and
     lanes, whose ratio to the floor is the overhead (filter, searches, scheduling, creation bookkeeping, idle lanes)."""
-    path = os.path.join(ROOT, "profiles", "r05", "reference_ops.json")
+    path = os.path.join(ROOT, "profiles", "r06", "reference_ops.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -513,7 +513,7 @@ def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, ke
                                         "as_written_without_search": w["valu_per_photon"]["as_written_without_search"],
                                         "transformed": floor, "unit": "gfx950 vector instructions per lane",
                                         "transformed_issue_slots": slots,
-                                        "source": "profiles/r05/reference_ops.json (oracle %s, %s)" % (stored["oracle_sha16"], w["sample"])},
+                                        "source": "profiles/r06/reference_ops.json (oracle %s, %s)" % (stored["oracle_sha16"], w["sample"])},
            "trips_per_photon": w["events_per_photon"]["trips"],
            "useful_lane_slots_per_s": slots * photons_per_s, "peak_lane_slots_per_s": VALU_PEAK_LANE_OPS,
            "useful_frac": slots * photons_per_s / VALU_PEAK_LANE_OPS,

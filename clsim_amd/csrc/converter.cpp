@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 
@@ -53,7 +54,7 @@ struct TuningKey { const char *name; long long lo, hi; };
 // (the table of include/clsimhip.h, in its order)
 const TuningKey kTuningKeys[] = {
     {"kernel", 0, 2}, {"pool_min_steps", -1, 1ll << 40}, {"pool_max_steps", -1, 1ll << 40}, {"pool_ring", 0, 4096},
-    {"k_new", 0, 4096}, {"k_search", 0, 64}, {"slices", 0, 65535}, {"k_pop", 0, 64}, {"k_wait", -1, 1 << 20}, {"k_aim", -1, 64},
+    {"k_new", 0, 4096}, {"k_search", 0, 64}, {"slices", 0, 65535}, {"k_pop", 0, 64}, {"k_wait", -1, 255}, {"k_aim", -1, 64},
     {"grid", 0, 1 << 20}, {"generic_kernels", 0, 1}, {"result_min_records", 1, 1ll << 32},
     {"string_map_cells", 8, 4096}, {"dom_map_cells", 4, 512}, {"named_search", 0, 1},
 };
@@ -165,7 +166,7 @@ void Converter::release_device()
         sl = Slot();
     }
     for (const StepBuffer &b : free_step_buffers_) (void)hipHostFree(b.p);
-    free_step_buffers_.clear(); step_buffers_made_ = 0; step_pool_bytes_ = 0; step_pinning_refused_ = false;
+    free_step_buffers_.clear(); step_buffers_made_ = 0; step_pool_bytes_ = 0; step_pinning_refused_ = false; step_fallback_logged_ = false;
     (void)hipFree(d_tables_); (void)hipFree(d_dom_tx_); (void)hipFree(d_dom_ty_); (void)hipFree(d_dom_tz_); (void)hipFree(d_len_table_); (void)hipFree(d_prox_map_); (void)hipFree(d_dom_prox_); (void)hipFree(d_dom_centres_); (void)hipFree(d_dom_named_); (void)hipFree(d_id_strings_); (void)hipFree(d_id_doms_); (void)hipFree(d_id_dom_start_);
     for (const PinnedBuffer &b : free_result_buffers_) (void)hipHostFree(b.p);
     free_result_buffers_.clear(); result_buffers_made_ = 0; pinning_refused_ = false;
@@ -394,16 +395,23 @@ void Converter::setup_device_buffers()
     upload(reinterpret_cast<void **>(&d_tables_), tables_.lds_image.data(), tables_.lds_image.size() * 4, "tables");
     upload(reinterpret_cast<void **>(&d_len_table_), tables_.len_table.data(), tables_.len_table.size() * 4, "length tables");
     upload(reinterpret_cast<void **>(&d_prox_map_), tables_.prox_map.data(), tables_.prox_map.size() * sizeof(uint32_t), "string proximity map");
-    {   // the DOM proximity map as the kernels read it: every cell with the centre of the DOM it names (kparams.h: dom_cells)
+    {   // the DOM proximity map as the kernels read it: every cell with the centre of the DOM it names (kparams.h: dom_cells).  Built and
+        // uploaded in pieces of a million cells: the whole image is up to 256 MB, which the host need not hold beside the words
         const size_t cells = tables_.dom_prox.size();
-        std::vector<uint32_t> fused(4 * cells, 0u);
-        for (size_t c = 0; c < cells; ++c) {
-            const uint32_t w = tables_.dom_prox[c], id = w & 0xffffu;
-            fused[4 * c] = w;
-            if (id != 0xffffu && 4 * static_cast<size_t>(id) + 2 < tables_.dom_centres.size())
-                std::memcpy(&fused[4 * c + 1], &tables_.dom_centres[4 * static_cast<size_t>(id)], 12);
+        hip_check(hipMalloc(reinterpret_cast<void **>(&d_dom_prox_), std::max<size_t>(cells * 16, 16)), "DOM proximity map");
+        constexpr size_t kPiece = size_t{1} << 20;
+        std::vector<uint32_t> fused(4 * std::min(cells, kPiece));
+        for (size_t first = 0; first < cells; first += kPiece) {
+            const size_t count = std::min(kPiece, cells - first);
+            std::fill(fused.begin(), fused.begin() + static_cast<std::ptrdiff_t>(4 * count), 0u);
+            for (size_t k = 0; k < count; ++k) {
+                const uint32_t w = tables_.dom_prox[first + k], id = w & 0xffffu;
+                fused[4 * k] = w;
+                if (id != 0xffffu && 4 * static_cast<size_t>(id) + 2 < tables_.dom_centres.size())
+                    std::memcpy(&fused[4 * k + 1], &tables_.dom_centres[4 * static_cast<size_t>(id)], 12);
+            }
+            hip_check(hipMemcpy(d_dom_prox_ + 4 * first, fused.data(), count * 16, hipMemcpyHostToDevice), "DOM proximity map");
         }
-        upload(reinterpret_cast<void **>(&d_dom_prox_), fused.data(), fused.size() * 4, "DOM proximity map");
     }
     upload(reinterpret_cast<void **>(&d_dom_centres_), tables_.dom_centres.data(), tables_.dom_centres.size() * 4, "DOM centres");
     upload(reinterpret_cast<void **>(&d_dom_named_), tables_.dom_named.data(), tables_.dom_named.size() * 4, "named-DOM records");
@@ -547,29 +555,56 @@ void Converter::enqueue_steps(const clsimhip_step *steps, size_t n, uint32_t ide
 
 Converter::StepBuffer Converter::take_step_buffer(size_t steps)
 {
+    StepBuffer b;
+    b.capacity = std::min(max_workitems_, steps + steps / 4);
+    if (b.capacity < steps) b.capacity = steps;
+    const size_t bytes = b.capacity * sizeof(clsimhip_step);
+    StepBuffer retired;                 // a free buffer that is too small, given up for one of the size that is needed
     {
+        // one lock scope for "is there a buffer, may another be made, is one to be replaced" and the count (check and
+        // increment were in two scopes, so callers side by side could exceed kStepBuffers)
         std::lock_guard<std::mutex> lk(step_pool_mutex_);
         size_t best = free_step_buffers_.size();
         for (size_t i = 0; i < free_step_buffers_.size(); ++i)
             if (free_step_buffers_[i].capacity >= steps && (best == free_step_buffers_.size() || free_step_buffers_[i].capacity < free_step_buffers_[best].capacity)) best = i;
         if (best != free_step_buffers_.size()) {
-            const StepBuffer b = free_step_buffers_[best];
+            const StepBuffer found = free_step_buffers_[best];
             free_step_buffers_.erase(free_step_buffers_.begin() + static_cast<std::ptrdiff_t>(best));
-            return b;
+            return found;
         }
-        if (step_pinning_refused_ || step_buffers_made_ >= kStepBuffers) return StepBuffer();
-    }
-    StepBuffer b;
-    b.capacity = std::min(max_workitems_, steps + steps / 4);
-    if (b.capacity < steps) b.capacity = steps;
-    const size_t bytes = b.capacity * sizeof(clsimhip_step);
-    {
-        std::lock_guard<std::mutex> lk(step_pool_mutex_);
-        if (step_pool_bytes_ + bytes > kStepPoolBytes && step_buffers_made_ >= 3) return StepBuffer();
+        if (step_pinning_refused_) return StepBuffer();
+        const bool full = step_buffers_made_ >= kStepBuffers || (step_pool_bytes_ + bytes > kStepPoolBytes && step_buffers_made_ >= 3);
+        if (full) {
+            // A pool whose buffers were sized by small first bunches (warm-up, tests) must not stay too small for production bunches:
+            // the smallest FREE buffer goes and one of the needed size takes its place.  With none free every buffer is in flight:
+            // the steps travel in a vector this once.
+            if (free_step_buffers_.empty()) {
+                if (!step_fallback_logged_) {
+                    step_fallback_logged_ = true;
+                    std::fprintf(stderr, "clsimhip: all %d page-locked step buffers are in flight; this bunch of %zu steps is staged through pageable memory\n",
+                                 step_buffers_made_, steps);
+                }
+                return StepBuffer();
+            }
+            size_t smallest = 0;
+            for (size_t i = 1; i < free_step_buffers_.size(); ++i)
+                if (free_step_buffers_[i].capacity < free_step_buffers_[smallest].capacity) smallest = i;
+            retired = free_step_buffers_[smallest];
+            free_step_buffers_.erase(free_step_buffers_.begin() + static_cast<std::ptrdiff_t>(smallest));
+            step_pool_bytes_ -= retired.capacity * sizeof(clsimhip_step);
+            --step_buffers_made_;
+            if (step_pool_bytes_ + bytes > kStepPoolBytes && step_buffers_made_ >= 3) {     // (still over the byte budget: the pool shrinks by one)
+                free_step_buffers_.push_back(retired);
+                step_pool_bytes_ += retired.capacity * sizeof(clsimhip_step);
+                ++step_buffers_made_;
+                return StepBuffer();
+            }
+        }
         ++step_buffers_made_;
         step_pool_bytes_ += bytes;
     }
     DeviceGuard on_device(device_);
+    if (retired.p) (void)hipHostFree(retired.p);
     if (hipHostMalloc(reinterpret_cast<void **>(&b.p), bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(step_pool_mutex_);

@@ -314,13 +314,14 @@ private:
     std::mutex result_pool_mutex_;
     PinnedBuffer take_result_buffer(size_t records);    // {nullptr, 0} when every buffer is with the caller (or the host refuses)
     // Page-locked step buffers (see Job): input queue depth + one per slot + the one being filled, each sized by the bunch it first
-    // carried (a quarter more), at most kStepPoolBytes in all
+    // carried (a quarter more) and replaced by a larger one when a later bunch needs it, at most kStepPoolBytes in all
     static constexpr int kStepBuffers = 8;
     static constexpr size_t kStepPoolBytes = size_t{1} << 30;
     std::vector<StepBuffer> free_step_buffers_;
     int step_buffers_made_ = 0;
     size_t step_pool_bytes_ = 0;
     bool step_pinning_refused_ = false;
+    bool step_fallback_logged_ = false;                 // the pageable fallback is reported once (like finish() does for result buffers)
     std::mutex step_pool_mutex_;
     StepBuffer take_step_buffer(size_t steps);
     void give_step_buffer(StepBuffer b);

@@ -131,7 +131,9 @@ Feeder::Feeder(const PPCConverter *ppc, int device, uint64_t seed, size_t max_bu
         // the step producer's stream and buffers now (Initialize() of the Python / C++ classes), sized for a light source of three
         // bunches (a 40 TeV cascade is 2.4 bunches of a million steps); a larger one grows them when it comes
         producer_.reset(new StepProducer(device_));
-        producer_->reserve(3 * max_bunch_, 4096);
+        // (capped: at the 6.1M-stream limit three bunches would page-lock and device-allocate 1.1 GB each for a feeder that may never be
+        // fed -- ADVICE r5; 2.5M steps cover a 40 TeV cascade at the usual bunch of a million)
+        producer_->reserve(std::min<size_t>(3 * max_bunch_, 2500000), 4096);
     }
     thread_ = std::thread([this] { worker(); });
 }

@@ -102,7 +102,8 @@ struct KParams {
     // in the cell to the sphere of any OTHER DOM.  A step shorter than that bound can only touch the named DOM, and does
     // so only if the segment comes within its radius (prop_device.hip.h: dom_search_needed).  Consulted only by lanes whose step reaches a
     // string cylinder: most of them pass between two DOMs of the string (17 m apart, 0.8 m radius), and photons born
-    // at a DOM (flashers) spend their lives within metres of it.  <= 64 MB in HBM, the words in use L2 / MALL resident.
+    // at a DOM (flashers) spend their lives within metres of it.  <= 256^3 cells: 64 MB as host words, 256 MB as the 16-byte device cells
+    // below; the cells in use (the columns around the strings, a few MB) are L2 / MALL resident.
     // (round 5) On the device a cell is 16 bytes: {that word, x, y, z of the named DOM's centre} -- one load where rounds 2-4 made two
     // dependent ones (the word, then dom_centres[id]); 4 x the bytes, of which the columns around the strings (a few MB) are ever read.
     const uint4 *dom_cells;
@@ -210,6 +211,9 @@ struct KParams {
     // cell index (uint16 pairs), unused -- lanes sit in different subdetectors, so this is indexed per lane
     uint32_t off_subdet;
     float dom_mul_x, dom_mul_y;
+    // pooled kernel: the four thresholds a loop trip consults, in ONE word read once before the loop (round 6: each was a scalar load
+    // with its own wait in every trip): k_pop | k_search << 8 | k_aim << 16 | k_wait << 24, every field below 256 (the launcher packs them)
+    uint32_t k_packed;
 };
 
 // kernel variants (the reference's #ifdef switches, OpenCL.cxx:390-442 and the

@@ -145,6 +145,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     ph.layer = 0;
 
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID.wave_id
+    // k_pop, k_search, k_aim, k_wait: one scalar register for the whole loop (kparams.h: k_packed)
+    const uint32_t k_packed = P0->k_packed;
     CENSUS(
     if (lane == 0) atomicMin(fresh_params(P0)->census + 8, wall_clock64());
     unsigned long long c_trips = 0, c_run = 0, c_services = 0, c_creations = 0, c_created = 0, c_vacant = 0, c_polls = 0, c_parked = 0, c_searches = 0, c_chunks = 0, c_empty_ring = 0, c_hits = 0;
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         // ---- service: retire the units of spent photons, create photons when the ring has room, hand out ready photons ----
         const uint32_t n_free = (uint32_t)__popcll(m_spent | m_vacant);
         // (1 <= k_pop <= 64, so this also covers "no lane holds a live photon": then all 64 are free)
-        if (n_free >= (uint32_t)fresh_params(P0)->k_pop) {
+        if (n_free >= (k_packed & 0xffu)) {
             const KP P = fresh_params(P0);
             WorkRecord *work = P->work;
             CENSUS(
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             // whatever the others are told.  Not asked when any lane lies in a cylinder's cell: C2 -2.0 % -- a 2 m cell that touches a cylinder
             // is mostly outside it, 34 % of C2's wave trips hold such a lane, and it can very well be sent back.)
             bool at_string = !(distance < free_flight_of(near_string));
-            if (!FLASHER && (uint32_t)__popcll(ballot(at_string)) <= (uint32_t)fresh_params(P0)->k_aim)
+            if (!FLASHER && (uint32_t)__popcll(ballot(at_string)) <= ((k_packed >> 16) & 0xffu))
                 at_string = at_string && !segment_misses_string(fresh_params(P0), ph, distance, near_string);
             if (at_string) {
                 const uint32_t need = dom_search_needed<FLASHER>(fresh_params(P0), ph, distance);
@@ -428,10 +430,10 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
         {
             // the DOM search runs when k_search lanes are parked, or for any parked lane when nothing else can advance
             const uint32_t n_parked = (uint32_t)__popcll(ballot(st >= kParked));
-            const uint32_t enough = (ballot(advance) == 0ull) ? 1u : (uint32_t)fresh_params(P0)->k_search;
+            const uint32_t enough = (ballot(advance) == 0ull) ? 1u : ((k_packed >> 8) & 0xffu);
             // (flasher instantiations search for the first parked lane: nothing to count)
             if (!FLASHER) parked_trips = (n_parked != 0u) ? parked_trips + 1u : 0u;
-            if (__builtin_expect((n_parked >= enough) || (!FLASHER && (parked_trips > (uint32_t)fresh_params(P0)->k_wait)), 0)) {
+            if (__builtin_expect((n_parked >= enough) || (!FLASHER && (parked_trips > (k_packed >> 24))), 0)) {
                 if (!FLASHER) parked_trips = 0u;
                 CENSUS(++c_searches;)
                 if (KEEP && (st >= kParked)) {
@@ -661,6 +663,10 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream, in
         // create when the ring is down to its last entry: the batches are what makes creation cheap per photon
         // (ring of 34: threshold 20 2.76e9 photons/s, 26: 2.81, 30: 2.84, 33: 2.85)
         if (P.k_new <= 0 || P.k_new > R) P.k_new = (R > 8) ? R - 1 : R;
+        if (P.k_wait > 255) P.k_wait = 255;
+        if (P.k_search > 64) P.k_search = 64;
+        if (P.k_aim > 64) P.k_aim = 64;
+        P.k_packed = (uint32_t)P.k_pop | ((uint32_t)P.k_search << 8) | ((uint32_t)P.k_aim << 16) | ((uint32_t)P.k_wait << 24);
         if (P.slices > 0xffff) P.slices = 0xffff;
         if ((uint64_t)P.n_steps * (uint64_t)P.slices >= 0x7fffffffull) P.slices = 1;    // 32-bit unit counters
     }

@@ -580,7 +580,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
         name("STRING_PROXIMITY_GRID", {double(n), P.prox_x0, P.prox_y0, P.prox_inv_cell, reach, double(P.prox_reach)});
     }
     {   // DOM proximity map (kparams.h), the second level of the search filter.  Everything in double, rounded towards
-        // "search anyway".  Cubic cells; at most 256 per axis (64 MB); border cells reach to infinity.
+        // "search anyway".  Cubic cells; at most 256 per axis (64 MB of words here, 256 MB as the device's 16-byte cells); border cells reach to infinity.
         const int n_max = std::max(4, std::min(512, tuning.dom_map_cells));         // 256 unless clsimhip_set_tuning("dom_map_cells") said otherwise
         // DOM numbers of the maps: strings in index order, each with its DOMs in order (NOT the template index: strings with
         // equal DOM offsets share a template, GeometrySource.cxx:449-495)

@@ -97,16 +97,20 @@ public:
     explicit I3CLSimStepToPhotonConverterHIP(I3RandomServicePtr randomService, int device = 0) : handle_(nullptr), seed_(12345), randomService_(randomService)
     {
         if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
+        owner_.reset(handle_, [](clsimhip_converter *h) { clsimhip_destroy(h); });
     }
 #else
     explicit I3CLSimStepToPhotonConverterHIP(int device = 0, uint64_t seed = 12345) : handle_(nullptr), seed_(seed)
     {
         if (clsimhip_create(device, &handle_) != CLSIMHIP_OK) throw I3CLSimStepToPhotonConverter_exception(clsimhip_last_error(nullptr));
+        owner_.reset(handle_, [](clsimhip_converter *h) { clsimhip_destroy(h); });
     }
 #endif
     // the reference interface declares no virtual destructor (I3CLSimStepToPhotonConverter.h:88 has it commented out):
     // converters live in shared_ptrs made from the concrete type, as I3CLSimStepToPhotonConverterOpenCLPtr does
-    virtual ~I3CLSimStepToPhotonConverterHIP() { clsimhip_destroy(handle_); }
+    // (the library's converter goes when this object AND every ConversionResultView handed out by GetConversionResultInPlace() are
+    // gone: a view keeps the converter it must return its buffer to alive -- ADVICE r5)
+    virtual ~I3CLSimStepToPhotonConverterHIP() {}
     I3CLSimStepToPhotonConverterHIP(const I3CLSimStepToPhotonConverterHIP &) = delete;
     I3CLSimStepToPhotonConverterHIP &operator=(const I3CLSimStepToPhotonConverterHIP &) = delete;
 
@@ -229,8 +233,10 @@ public:
     }
     // Extension (no reference counterpart): the result where the library left it -- the page-locked buffer the device's records were
     // downloaded into -- for a caller that consumes the records in place (a server that serialises them, a hit maker that walks
-    // them once): no I3CLSimPhotonSeries is allocated, nothing is copied.  `photons` stays valid while `hold` (or a copy of it) lives;
-    // the buffer goes back to the converter's pool when the last copy is dropped.  Photon histories, if recorded, are not part
+    // them once): no I3CLSimPhotonSeries is allocated, nothing is copied.  `photons` stays valid while `hold` (or a copy of it) lives
+    // -- also beyond this adapter's own lifetime: `hold` shares ownership of the library's converter, which is destroyed (and its
+    // page-locked buffers freed) only after the adapter and the last view are gone.  The buffer goes back to the converter's pool
+    // when the last copy is dropped.  Photon histories, if recorded, are not part
     // of the view: use GetConversionResult().  GetConversionResult() copies because its interface type owns a std::vector.
     struct ConversionResultView {
         uint32_t identifier = 0;
@@ -247,8 +253,8 @@ public:
         check(clsimhip_get_conversion_result(handle_, &v.identifier, &p, &v.size));
         v.photons = reinterpret_cast<const I3CLSimPhoton *>(p);
         if (p) {
-            clsimhip_converter *h = handle_;
-            v.hold = std::shared_ptr<const void>(static_cast<const void *>(p), [h](const void *q) { (void)clsimhip_release_result(h, static_cast<const clsimhip_photon *>(q)); });
+            std::shared_ptr<clsimhip_converter> keep = owner_;
+            v.hold = std::shared_ptr<const void>(static_cast<const void *>(p), [keep](const void *q) { (void)clsimhip_release_result(keep.get(), static_cast<const clsimhip_photon *>(q)); });
         }
         return v;
     }
@@ -308,6 +314,7 @@ private:
     double stat(int i) const { double v[8]; check(clsimhip_get_statistics(handle_, v)); return v[i]; }
     double option(int which) const { double v = 0.; check(clsimhip_get_option(handle_, which, &v)); return v; }
     clsimhip_converter *handle_;
+    std::shared_ptr<clsimhip_converter> owner_;      // owns handle_ (deleter: clsimhip_destroy); shared with the in-place result views
     uint64_t seed_;
 #ifdef CLSIMHIP_WITH_ICETRAY
     I3RandomServicePtr randomService_;

@@ -18,9 +18,8 @@
         if (!thrown) { std::printf("FAILED: %s did not throw '%s'\n", #stmt, text); return 1; }    \
     } while (0)
 
-int main(int argc, char **argv)
+static int exercise(bool run, I3CLSimStepToPhotonConverterHIP::ConversionResultView *survivor)
 {
-    const bool run = argc > 1 && std::strcmp(argv[1], "run") == 0;
     I3CLSimStepToPhotonConverterHIP conv(0);
     EXPECT_THROW(conv.Compile(), "WlenGenerators");
     EXPECT_THROW(conv.EnqueueSteps(I3CLSimStepSeriesConstPtr(), 0), "not initialized");
@@ -93,5 +92,23 @@ int main(int argc, char **argv)
             if (p.string_id != 1 || p.om_id < 1 || p.om_id > 60) { std::printf("FAILED: bad IDs in the view\n"); return 1; }
         std::printf("view %d: identifier %u photons %zu\n", k, v.identifier, v.size);
     }
-    return (r.identifier == 42 && !r.photons->empty() && conv.GetStatistics().at("TotalNumPhotonsGenerated") == 600000.) ? 0 : 1;
+    // one more view, handed to the caller: it outlives `conv` (a view keeps the library's converter alive)
+    conv.EnqueueSteps(steps, 99);
+    *survivor = conv.GetConversionResultInPlace();
+    return (r.identifier == 42 && !r.photons->empty() && conv.GetStatistics().at("TotalNumPhotonsGenerated") == 800000.) ? 0 : 1;
+}
+
+int main(int argc, char **argv)
+{
+    const bool run = argc > 1 && std::strcmp(argv[1], "run") == 0;
+    I3CLSimStepToPhotonConverterHIP::ConversionResultView survivor;
+    const int rc = exercise(run, &survivor);
+    if (rc != 0 || !run) return rc;
+    // the adapter is gone; the view's records are still there and its buffer can still be given back
+    if (survivor.identifier != 99u || survivor.size == 0 || !survivor.hold) { std::printf("FAILED: the surviving view\n"); return 1; }
+    for (const I3CLSimPhoton &p : survivor)
+        if (p.string_id != 1 || p.om_id < 1 || p.om_id > 60) { std::printf("FAILED: bad IDs in the surviving view\n"); return 1; }
+    std::printf("view that outlived its adapter: identifier %u photons %zu\n", survivor.identifier, survivor.size);
+    survivor = I3CLSimStepToPhotonConverterHIP::ConversionResultView();        // releases the buffer, then the converter
+    return 0;
 }

@@ -281,7 +281,7 @@ int clsimhip_get_option(const clsimhip_converter *c, int option, double *out);
  *   "k_search"           0 ... 64         lanes parked before a wave searches for DOMs; 0: automatic (0)
  *   "slices"             0 ... 65535      work units a step is cut into; 0: 16, or 1 for bunches smaller than the grid (0)
  *   "k_pop"              0 ... 64         pooled kernel: free lanes before a wave hands out ready photons; 0: 4 (0)
- *   "k_wait"             -1 | >= 0        pooled kernel: trips a parked lane waits for company; -1: 16; 0: never (-1)
+ *   "k_wait"             -1 ... 255       pooled kernel: trips a parked lane waits for company; -1: 16; 0: never (-1)
  *   "k_aim"              -1 ... 64        pooled kernel: lanes at a string up to which the "aimed at the string?" level is asked;
  *                                         -1: 8; 0: the level is off (-1)
  *   "grid"               0 ... 2^20       workgroups of the propagation launch; 0: what the chip holds, cut to the work (0)

@@ -1,7 +1,7 @@
 """The counting build of the oracle (oracle/count_ops.hpp, `make -C oracle liboracle_count.so`): the restatement compiled as C++ with
 float operators that count themselves.  It must BE the oracle -- same records, same streams, bit for bit -- and its counters must
 satisfy the identities the reference's draw order implies.  The stored figures bench.py quotes
-(profiles/r05/reference_ops.json) must come from the oracle sources as they are now."""
+(profiles/r06/reference_ops.json) must come from the oracle sources as they are now."""
 import hashlib
 import json
 import os
@@ -48,7 +48,7 @@ def test_counting_build_is_the_oracle_and_counts_every_draw(name, stop, births):
 
 
 def test_stored_reference_ops_are_current():
-    path = os.path.join(ROOT, "profiles", "r05", "reference_ops.json")
+    path = os.path.join(ROOT, "profiles", "r06", "reference_ops.json")
     with open(path) as f:
         stored = json.load(f)
     src = b"".join(open(os.path.join(ROOT, "oracle", f), "rb").read() for f in ("clsim_oracle.c", "oracle_math.h", "count_ops.hpp", "count_ops_calls.hpp"))

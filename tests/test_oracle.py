@@ -225,6 +225,9 @@ def test_product_and_oracle_math_tables_are_the_same_text():
         return re.sub(r"^#ifndef \w+\n#define \w+\n", "", t)
     a, b = body("clsim_amd/csrc/math_tables.h"), body("oracle/math_tables.h")
     assert a == b and "MT_LOG_TABLE" in a and "MT_SC_TABLE" in a
-    before = open(os.path.join(root, "oracle", "math_tables.h")).read()
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_math_tables.py")], stdout=subprocess.DEVNULL)
-    assert open(os.path.join(root, "oracle", "math_tables.h")).read() == before
+    # the generator in its --check mode: compares what it would write with the checked-in headers and touches nothing (the headers are
+    # Makefile dependencies of every kernel)
+    pytest.importorskip("mpmath")
+    stamp = os.path.getmtime(os.path.join(root, "oracle", "math_tables.h"))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_math_tables.py"), "--check"], stdout=subprocess.DEVNULL)
+    assert os.path.getmtime(os.path.join(root, "oracle", "math_tables.h")) == stamp

@@ -30,7 +30,7 @@ with open(os.path.join(root, args.out), "a") as log:
             for lib in args.libs:
                 env = dict(os.environ, CLSIMHIP_LIB=os.path.abspath(lib))
                 cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--warmup", "2",
-                       "--no-cpu-baseline", "--no-host-path"]
+                       "--no-cpu-baseline", "--no-host-path", "--no-table-maker"]
                 if args.bunch:
                     cmd += ["--bunch", str(args.bunch)]
                 p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

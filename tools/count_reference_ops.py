@@ -16,7 +16,7 @@ prices what was counted in vector instructions of gfx950, two ways:
                remaining searches cost is the kernel's overhead, not the reference's arithmetic).  This is the floor the
                kernel's issued lane operations are compared with (roofline.valu.overhead_ratio).
 
-usage: tools/count_reference_ops.py [c2 c3 c5 ...] [--steps N] [--out profiles/r05/reference_ops.json]"""
+usage: tools/count_reference_ops.py [c2 c3 c5 ...] [--steps N] [--out profiles/r06/reference_ops.json]"""
 import argparse, hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -133,7 +133,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workloads", nargs="*", default=["c2", "c3", "c5"])
     ap.add_argument("--steps", type=int, default=16384)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05", "reference_ops.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06", "reference_ops.json"))
     args = ap.parse_args()
     cost, proven = unit_costs()
     cost_c, proven_c = unit_costs(cycles=True)

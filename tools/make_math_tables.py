@@ -7,6 +7,7 @@ Every value is computed with mpmath at 200 bits and printed as a C99 hexadecimal
 read identical bit patterns.  What the constants mean is documented where they are used (oracle/oracle_math.h: om_log, om_sincos_2pi;
 clsim_amd/csrc/detmath.hip.h: log_, sincos_2pi_).  usage: tools/make_math_tables.py  (build container; needs mpmath)"""
 import os
+import sys
 import struct
 
 import mpmath as mp
@@ -147,11 +148,30 @@ def main():
         body.append("    %s, %s, \\" % (hexf(S), hexf(C)))
     body.append("}")
     text = "\n".join(body) + "\n"
+    # --check: compare with the checked-in headers and write nothing (what tests/test_oracle.py runs: a test must not touch the tree --
+    # the headers are in both Makefiles' dependencies, a rewrite would rebuild every kernel); --output-dir DIR: write the two
+    # headers there instead of into the tree
+    check = "--check" in sys.argv[1:]
+    out_dir = sys.argv[sys.argv.index("--output-dir") + 1] if "--output-dir" in sys.argv[1:] else None
+    stale = []
     for path, guard in ((os.path.join(ROOT, "clsim_amd", "csrc", "math_tables.h"), "CLSIMHIP_MATH_TABLES_H"),
                         (os.path.join(ROOT, "oracle", "math_tables.h"), "CLSIM_ORACLE_MATH_TABLES_H")):
+        content = "#ifndef %s\n#define %s\n%s#endif\n" % (guard, guard, text)
+        if check:
+            with open(path) as f:
+                if f.read() != content:
+                    stale.append(path)
+            continue
+        if out_dir is not None:
+            path = os.path.join(out_dir, os.path.basename(os.path.dirname(path)) + "_" + os.path.basename(path))
         with open(path, "w") as f:
-            f.write("#ifndef %s\n#define %s\n%s#endif\n" % (guard, guard, text))
+            f.write(content)
         print("wrote", path)
+    if check:
+        if stale:
+            raise SystemExit("stale (run tools/make_math_tables.py): " + ", ".join(stale))
+        print("the checked-in math tables are what the generator writes")
+        return
     print("LOG_P", LOG_P, "SIN_P", SIN_P, "COS_P", COS_P, "H1", H1, "H2", H2)
 
 

@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path $*"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-table-maker $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kt.json 2> $OUT/kt.err; echo kt rc=$?
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/pmc1 -- $BENCH > $OUT/bench_pmc1.json 2> $OUT/pmc1.err; echo pmc1 rc=$?
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc2 -- $BENCH > /dev/null 2> $OUT/pmc2.err; echo pmc2 rc=$?
