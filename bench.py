@@ -66,6 +66,9 @@ def parse():
                     help="skip the host_path object (profile passes: counters then cover the timed launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-table-maker", action="store_true", help="skip the table_maker object of the default line")
+    ap.add_argument("--tab-generic-sampler", action="store_true",
+                    help="--workload tab: clsimhip_tabulator_set_tuning(\"standard_sampler\", 0) -- the generic path sampler instead of the one "
+                         "specialised for the reference's default table shape (an A/B measurement)")
     ap.add_argument("--gather-overlap", action="store_true",
                     help="N>1: gather the photons of launch k on a second stream while launch k+1 runs (two photon buffers). Default: "
                          "the gather runs between two launches on the launch stream -- the propagation kernel is a persistent grid "
@@ -148,6 +151,8 @@ def tabulator_measure(args, device, workload, passes, warmup, cpu_seconds, photo
     x = CV.seed_streams(a)
     tab = TB.I3CLSimStepToTableConverterHIP(device, axes, False, medium, math.pi * 0.16510 ** 2, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ang), (x, a))
+    if getattr(args, "tab_generic_sampler", False):
+        tab.SetTuning("standard_sampler", 0)
     steps = S.cascade_steps(n, seed=1000, vertex=(0.0, 0.0, 0.0), photons_per_step=photons_per_step)
     ref = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)
     for _ in range(warmup):
@@ -173,7 +178,9 @@ def tabulator_measure(args, device, workload, passes, warmup, cpu_seconds, photo
            "sum_of_weights_per_pass": (total - before) / passes,
            "config": {"workload": "%d steps x %d photons at the origin, spherical axes %s, spice_mie, 42 absorption lengths, "
                                   "1 m sampling; BASELINE.json configs[4] (tablemaker half)"
-                                  % (n, photons_per_step, "x".join(str(ax.n_bins) for ax in axis_list))}}
+                                  % (n, photons_per_step, "x".join(str(ax.n_bins) for ax in axis_list)),
+                      "sampler": "generic (standard_sampler = 0)" if getattr(args, "tab_generic_sampler", False) else
+                                 ("specialised for the default table shape" if workload == "tab" else "generic")}}
     # The table sums are fp64 atomic adds that execute at the memory side (MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s of added bytes
     # for 256-byte contiguous wave instructions = 2e10 sector requests per second; measured here for this kernel's shape, tools/micro/atomic_rate.hip:
     # 2.2e10 fp64 sector requests per second whatever the lanes per sector).  What the atomics cost the kernel is measured too

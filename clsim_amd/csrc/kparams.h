@@ -191,6 +191,9 @@ struct KParams {
     // the reference's order when the table is read.  tab_tiled = 0: the reference's order (five axes; CLSIMHIP_TAB_LAYOUT=linear).
     uint32_t tab_tiled, tab_tile_stride[3];     // strides of b0 >> e0, b1, b2 >> e2 (b3 >> e3 has stride 8)
     uint32_t tab_tile_bits[3];                  // e0, e2, e3: a sector holds 2^e0 x 2^e2 x 2^e3 bins of axes 0, 2, 3 (e0 + e2 + e3 = 3)
+    // (round 6) the standard table: spherical axes, folded azimuth, square-root axes 0 and 3, identity axes 1 and 2, tiled 4 x 2 x 1, no squared
+    // weights -- the four-axis kernel then runs the sampler specialised for it (prop_kernel.hip: sample_bin<..., STD>); set by tabulator.cpp
+    uint32_t tab_std;
     float tab_max0, tab_max3, tab_min_inv_groupvel, tab_tan_thetac, tab_volume_step;
     int32_t ang_n;                      // getAngularAcceptance polynomial (coefficients in the LDS image)
     uint32_t off_ang;

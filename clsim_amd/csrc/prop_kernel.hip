@@ -141,9 +141,18 @@ template <bool FASTMATH> DM float tab_div_(float a, float b, bool &ok)       // 
     return a / b;
 }
 // (x, a): the photon's stream before the two draws of this sample (ANGLE = TABULATE_IMPACT_ANGLE only)
-template <bool ANGLE, bool FASTMATH>
+// STD (round 6): the configuration python/tablemaker/tabulator.py:621-641 makes by default -- spherical axes, azimuth folded to 180 degrees,
+// square-root axes for distance and time, linear ones for the two angles, the tiled device order with 4 x 2 x 1 bins to a sector (KParams::tab_std,
+// set by tabulator.cpp).  The generic sampler asks about each of these once per batch of 64 samples -- wave-uniform, so every question is a scalar
+// compare and a branch, and the code of every answer (cube roots, fractional powers, the cylindrical formulas) sits in the loop: 95 branches and
+// 360 scalar instructions per batch next to 745 vector ones (profiles/r06/tab_scalar_summary.json), at three waves per SIMD.  With STD they are
+// constants and the other answers' code is gone.  Same arithmetic, same bins.
+template <bool ANGLE, bool FASTMATH, bool STD = false>
 DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_t a, uint32_t &index, bool &ok)
 {
+    static_assert(!(STD && ANGLE), "the standard configuration has four axes");
+    const int kind = STD ? 0 : K.kind;
+    const int full_azimuth = STD ? 0 : K.full_azimuth;
     auto R = [&](int k) { return K.ref[k]; };
     // spherical_coordinates.c.cl:39-81 / cylindrical_coordinates.c.cl:39-77
     const float ax = g.px + d * g.dx, ay = g.py + d * g.dy, az = g.pz + d * g.dz, aw = g.pt + d * g.igv;
@@ -156,7 +165,7 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
     constexpr int ndim = ANGLE ? 5 : 4;
     constexpr float kDegree = kPi / 180;
     float c0, c1, c2, c3, c4 = 0.0f;
-    if (K.kind == 0) {
+    if (kind == 0) {
         c0 = tab_sqrt_<FASTMATH>(px * px + py * py + pz * pz, ok);
         float azimuth = 0.0f;
         if (n_rho > 0.0f) {
@@ -164,7 +173,7 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
             if (FASTMATH) { ok = ok && dm::div_near_ok_(angle); azimuth = dm::div_near_with_(angle, kDegree, 1.0f / kDegree); }
             else azimuth = angle / kDegree;
         }
-        if (K.full_azimuth) {
+        if (full_azimuth) {
             const float cx = ry_ * qz - rz_ * qy, cy = rz_ * qx - rx_ * qz, cz = rx_ * qy - ry_ * qx;
             const float azisign = dot4(cx, cy, cz, 0.0f, ux, uy, uz, uw);
             c1 = (azisign > 0.0f) ? 360.f - azimuth : azimuth;
@@ -184,7 +193,7 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
         const float sina = dm::sqrt_(rng_co(x, a));
         Vec3 dd = {g.dx, g.dy, g.dz};
         scatter_direction(dm::sqrt_(1.0f - sina * sina), sina, dd, rng_co(x, a));
-        if (K.kind == 0) {
+        if (kind == 0) {
             c4 = (c0 > 0.0f) ? tab_div_<FASTMATH>(dot4(dd.x, dd.y, dd.z, g.wlen, px, py, pz, pw), c0, ok) : 1.0f;
         } else {
             // (l - rho*recip(tan_thetaC))*dir, component by component as OpenCL evaluates it
@@ -195,7 +204,7 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
             c4 = (cdist > 0.0f) ? (dot4(dd.x, dd.y, dd.z, g.wlen, kx, ky, kz, kw) / cdist) : 1.0f;
         }
     }
-    if (K.kind == 0) {
+    if (kind == 0) {
         if ((c3 > K.max3) || (c0 > K.max0)) return true;
     } else {
         if (c3 > K.max3) return true;
@@ -204,13 +213,13 @@ DM bool sample_bin(const TabK &K, const Segment &g, float d, uint64_t x, uint32_
     uint32_t bin[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < ndim; ++k) {
-        const int pw = K.inverse[k];                // wave-uniform
+        const int pw = STD ? ((k == 0 || k == 3) ? 2 : 1) : K.inverse[k];                // wave-uniform
         const float v = (pw <= 1) ? c[k] : (pw == 2) ? tab_sqrt_<FASTMATH>(c[k], ok) : (pw == 3) ? dm::cbrt_(c[k]) : dm::pow_frac_(c[k], K.inv_exp[k]);
         bin[k] = axis_bin_(K.scale[k] * v - K.offset[k], K.nbins[k]);
     }
-    if (!ANGLE && K.tiled) {
+    if (!ANGLE && (STD || K.tiled)) {
         // the device's own order (kparams.h: tab_tiled): 2^e0 x 2^e2 x 2^e3 = 8 bins of distance, polar angle and time in one 64-byte sector
-        const uint32_t e0 = K.tile_bits[0], e2 = K.tile_bits[1], e3 = K.tile_bits[2];
+        const uint32_t e0 = STD ? 2u : K.tile_bits[0], e2 = STD ? 1u : K.tile_bits[1], e3 = STD ? 0u : K.tile_bits[2];
         const uint32_t h0 = bin[0] >> e0, h2 = bin[2] >> e2, h3 = bin[3] >> e3;
         index = h0 * K.tile_stride[0] + bin[1] * K.tile_stride[1] + h2 * K.tile_stride[2] + (h3 << 3)
                 + (((bin[0] - (h0 << e0)) << (e2 + e3)) | ((bin[2] - (h2 << e2)) << e3) | (bin[3] - (h3 << e3)));
@@ -480,6 +489,7 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
 //   * samples carried once are in the next trip's first batch, or that trip works off everything (fewer than 64 in all), so a record
 //     is read in its own trip and the next one only.
 // `carry`, `parity`: wave-uniform state across trips; flush: work off everything (after the wave's last trip).
+template <bool STD>
 DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight, float length, float &remainder,
                              float depth, float this_depth, uint32_t &carry, uint32_t &parity, bool flush
                              TAB_TIMED(, uint64_t &t_list, uint64_t &t_last, uint64_t &t_add)
@@ -525,7 +535,7 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
     }
     const TabK K = tab_constants<false>(P);
     double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
-    const bool squares = (sq_bins != nullptr);
+    const bool squares = !STD && (sq_bins != nullptr);          // (STD: no squared weights, KParams::tab_std)
     uint32_t *pool_d = wave_lds, *pool_tag = wave_lds + kTabPool;
     uint32_t *records = wave_lds + 2 * kTabPool;
     const uint32_t my_record = (parity << 6) | lane;
@@ -548,7 +558,7 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
     // is every segment of this trip certainly inside the table?  (spherical axes; see above)
     if (!everything) {
         bool inside = false;
-        if (K.kind == 0) {
+        if (STD || K.kind == 0) {
             const float qx = ph.px - K.ref[0], qy = ph.py - K.ref[1], qz = ph.pz - K.ref[2];
             const float r0 = __builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz);
             const float far = (r0 + length) * 1.0001f + 0.01f;
@@ -590,14 +600,14 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
         bool ok = true;
         float along = 0.0f;
         if (have) {
-            oob = sample_bin<false, true>(K, g, d, 0ull, 0u, index, ok);
+            oob = sample_bin<false, true, STD>(K, g, d, 0ull, 0u, index, ok);
             along = tab_div_<true>(d, o_length, ok);
             ok = ok && (o_length <= 1.125899906842624e15f);       // (2^50; a segment is longer than its samples' d)
         }
         if (__builtin_expect(ballot(!ok) != 0ull, 0)) {
             // some lane's operand lies outside the exact forms' ranges: the IEEE sequences for the whole wave
             if (have) {
-                oob = sample_bin<false, false>(K, g, d, 0ull, 0u, index, ok);
+                oob = sample_bin<false, false, STD>(K, g, d, 0ull, 0u, index, ok);
                 along = d / o_length;
             }
         }
@@ -649,8 +659,8 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
             for (uint32_t taken = 0; (d < length) && (taken < n); d += vstep, ++taken) {
                 uint32_t index;
                 bool ok_ = true;
-                if (sample_bin<false, false>(K, g, d, 0ull, 0u, index, ok_)) { stop = true; break; }
-                add_to_bin(bins, sq_bins, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
+                if (sample_bin<false, false, STD>(K, g, d, 0ull, 0u, index, ok_)) { stop = true; break; }
+                add_to_bin(bins, STD ? nullptr : sq_bins, index, impact * dm::exp_(-(depth + (d / length) * this_depth)));
             }
             d_end = d;
         }
@@ -746,6 +756,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     bool alive = true;
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     float unit_weight = 0.0f;   // TABULATE: the step's weight (c.cl:246-251), read when the lane takes the unit
+    const bool tab_std = (TAB == 1) && (P0->tab_std != 0u);        // the table maker's standard configuration: the specialised sampler (sample_bin: STD)
     uint32_t tab_carry = 0u, tab_parity = 0u;      // TABULATE, four axes: samples carried into the next trip, generation of the segment records (save_path_wave_carry)
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
@@ -960,10 +971,14 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                                                             ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth, rx, ra
                                                             TAB_TIMED(, t_acc[6], t_last)
                                                             );
-            else left_table = save_path_wave_carry(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
-                                                   tab_carry, tab_parity, false
-                                                   TAB_TIMED(, t_acc[6], t_last, t_acc[7])
-                                                   );
+            else if (tab_std) left_table = save_path_wave_carry<true>(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
+                                                                      tab_carry, tab_parity, false
+                                                                      TAB_TIMED(, t_acc[6], t_last, t_acc[7])
+                                                                      );
+            else left_table = save_path_wave_carry<false>(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
+                                                          tab_carry, tab_parity, false
+                                                          TAB_TIMED(, t_acc[6], t_last, t_acc[7])
+                                                          );
             if (run) {
                 if (left_table) ph.abs_lens_left = 0.0f;
                 ph.tab_depth = P->fixed_abs - ph.abs_lens_left;
@@ -1052,7 +1067,7 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         const KP P = fresh_params(P0);
         uint32_t *wave_lds = lds_words + ((P->table_words + 16u + 3u) & ~3u) + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
         float no_remainder = 0.0f;
-        (void)save_path_wave_carry(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true
+        (void)save_path_wave_carry<false>(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true      // (once per wave: the generic sampler)
                                    TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                    );
     }

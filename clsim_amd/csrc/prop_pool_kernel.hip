@@ -162,6 +162,8 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
     uint64_t m_spent = 0ull, m_vacant = ~0ull, m_live = 0ull;
     for (uint32_t trip = 0;; ++trip) {
         if ((trip & ((1u << kPrioShift) - 1u)) == 0u) {            // the priority changes every 2^kPrioShift trips
+            // (round 6: written as two tests on the phase's bits it compiles to MORE scalar instructions -- the structuriser turns either
+            // form into chains of mask moves; the switch stays)
             switch (((trip >> kPrioShift) + wave_slot) & 3u) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -427,12 +429,17 @@ __global__ void __launch_bounds__(kPoolBlock, kPoolMinWaves) prop_pool_kernel(co
             }
         }
         bool advance = (st == kLive);
-        {
+        // (round 6) nobody parked -- three trips in four on cascade steps: one test instead of the count, the two thresholds and the
+        // waiting counter's update (the loop is scalar-issue bound)
+        const uint64_t m_parked = ballot(st >= kParked);
+        if (m_parked == 0ull) {
+            if (!FLASHER) parked_trips = 0u;
+        } else {
             // the DOM search runs when k_search lanes are parked, or for any parked lane when nothing else can advance
-            const uint32_t n_parked = (uint32_t)__popcll(ballot(st >= kParked));
+            const uint32_t n_parked = (uint32_t)__popcll(m_parked);
             const uint32_t enough = (ballot(advance) == 0ull) ? 1u : ((k_packed >> 8) & 0xffu);
             // (flasher instantiations search for the first parked lane: nothing to count)
-            if (!FLASHER) parked_trips = (n_parked != 0u) ? parked_trips + 1u : 0u;
+            if (!FLASHER) parked_trips = parked_trips + 1u;
             if (__builtin_expect((n_parked >= enough) || (!FLASHER && (parked_trips > (k_packed >> 24))), 0)) {
                 if (!FLASHER) parked_trips = 0u;
                 CENSUS(++c_searches;)

@@ -143,6 +143,10 @@ Tabulator::Tabulator(int device, int axes_kind, std::vector<AxisData> axes, bool
     P.tab_tiled = tiled_ ? 1u : 0u;
     for (int k = 0; k < 3; ++k) P.tab_tile_stride[k] = tiled_ ? static_cast<uint32_t>(tile_stride_[k]) : 0u;
     for (int k = 0; k < 3; ++k) P.tab_tile_bits[k] = tile_bits_[k];
+    // the reference's default table (python/tablemaker/tabulator.py:621-641) and every table of its shape: the specialised sampler (kparams.h: tab_std)
+    P.tab_std = (axes_kind_ == CLSIMHIP_AXES_SPHERICAL && nd == 4 && !P.tab_full_azimuth && tiled_ && tile_bits_[0] == 2 && tile_bits_[1] == 1 &&
+                 tile_bits_[2] == 0 && !squared_ && P.tab_inverse[0] == 2 && P.tab_inverse[1] <= 1 && P.tab_inverse[2] <= 1 && P.tab_inverse[3] == 2) ? 1u : 0u;
+    tables_.named["TABULATOR_STANDARD_SAMPLER"] = {double(P.tab_std)};
     P.tab_max0 = to_float_literal(axes_[0].max);
     P.tab_max3 = to_float_literal(axes_[3].max);
     const auto n_min = minimum_refractive_index(medium);
@@ -275,6 +279,7 @@ void Tabulator::enqueue_steps(const clsimhip_step *steps, size_t n, const double
         for (int k = 0; k < 12; ++k) P.tab_ref[k] = static_cast<float>(v[k]);
     }
     hip_check(hipEventRecord(ev_start_, stream_), "event");
+    if (!standard_sampler_) P.tab_std = 0u;          // ("standard_sampler" 0: the generic sampler also for the standard table; tests compare the two)
     KVariant variant = tables_.variant;
     variant.tab_fast = fast_kernels_;
     variant.grid = grid_;
@@ -289,6 +294,7 @@ void Tabulator::set_tuning(const std::string &key, long long value)
 {
     std::lock_guard<std::mutex> lk(mutex_);
     if (key == "fast_kernels" && (value == 0 || value == 1)) fast_kernels_ = (value != 0);
+    else if (key == "standard_sampler" && (value == 0 || value == 1)) standard_sampler_ = (value != 0);
     else if (key == "grid" && value >= 0 && value <= (1 << 20)) grid_ = static_cast<int>(value);
     else throw Error(CLSIMHIP_ERR_ARGUMENT, "table maker tuning: no key " + key + " with the value " + std::to_string(value));
 }

@@ -63,6 +63,7 @@ private:
     size_t n_device_bins_ = 0, tile_stride_[3] = {0, 0, 0};
     bool fast_kernels_ = false;              // "fast_kernels" (set_tuning): the FAST instantiation, measured slower (prop_kernel.hip: launch_tab_kernel)
     int grid_ = 0;                           // "grid": workgroups of the launch, 0 = automatic
+    bool standard_sampler_ = true;           // "standard_sampler": 0 keeps the generic sampler also for the standard table (KParams::tab_std)
     unsigned tile_bits_[3] = {2, 1, 0};      // bins per sector along axes 0, 2, 3 as powers of two (sum 3): 4 x 2 x 1 (tabulator.cpp)
     bool squared_;
     double reference_area_, step_length_;

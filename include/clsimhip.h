@@ -672,7 +672,9 @@ int clsimhip_tabulator_enqueue_steps(clsimhip_tabulator *t, const clsimhip_step 
 /* Finish() (:287-295): waits until every enqueued bunch is in the table */
 int clsimhip_tabulator_finish(clsimhip_tabulator *t);
 /* table maker tuning (see clsimhip_set_tuning; no result depends on it): "fast_kernels" 0 | 1 -- the instantiation with the
- * medium's proofs compiled in, measured slower for this kernel (0); "grid" -- workgroups of the launch, 0: automatic (0) */
+ * medium's proofs compiled in, measured slower for this kernel (0); "grid" -- workgroups of the launch, 0: automatic (0);
+ * "standard_sampler" 0 | 1 -- 0: the generic path sampler also for a table of the reference's default shape (spherical, folded
+ * azimuth, square-root distance and time axes, no squared weights), which otherwise runs the sampler specialised for it (1) */
 int clsimhip_tabulator_set_tuning(clsimhip_tabulator *t, const char *key, long long value);
 /* number of bins including under-/overflow bins, number of axes (4, or 5 with the impact angle), and the shape
  * (n_bins + 2 per axis; unused entries 0) */

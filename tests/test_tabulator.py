@@ -124,7 +124,18 @@ def test_fast_table_instantiations_match_the_oracle_too(kind, ice):
     check_table_against_the_oracle(kind, ice, 1.0, fast_kernels=True)
 
 
-def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by medium", fast_kernels=False):
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,ice,step_length,standard", [("spherical", "mie", 1.0, True), ("spherical", "mie", 1.0, False), ("spherical", "lea", 0.2, True),
+                                                           ("spherical", "mie", 0.3, True), ("spherical_small", "mie", 1.0, True), ("spherical_small", "lea", 0.5, True),
+                                                           ("spherical_small", "lea", 0.5, False)])
+def test_standard_table_sampler_matches_the_oracle(kind, ice, step_length, standard):
+    """round 6: a table of the reference's default shape (spherical, folded azimuth, square-root distance and time axes, no squared weights:
+    python/tablemaker/tabulator.py:621-641) runs the sampler specialised for it (prop_kernel.hip: sample_bin<..., STD>); with
+    clsimhip_tabulator_set_tuning("standard_sampler", 0) the generic one.  Both against the oracle, same bar as every other table."""
+    check_table_against_the_oracle(kind, ice, step_length, squared=False, standard_sampler=standard)
+
+
+def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by medium", fast_kernels=False, squared=True, standard_sampler=None):
     """prop_kernel<TAB> adds every path sample to its bin with an fp64 atomic; the oracle writes the reference's
     (bin, weight) entries.  Same samples <=> the double precision sums agree to rounding; the float image agrees with
     the reference's in-order float accumulation to float accuracy.  step_length 0.2 m makes most waves exceed the
@@ -159,9 +170,14 @@ def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by mediu
             np.add.at(bins64, ent["index"][i, :k], ent["weight"][i, :k].astype(np.float64))
             np.add.at(sq64, ent["index"][i, :k], ent["weight"][i, :k].astype(np.float64) ** 2)
             np.add.at(bins32, ent["index"][i, :k], ent["weight"][i, :k])
-    tab = TB.I3CLSimStepToTableConverterHIP(0, p, True, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
+    tab = TB.I3CLSimStepToTableConverterHIP(0, p, squared, cfg["med_p"], DOM_AREA, CV.GetIceCubeDOMAcceptance(),
                                             TB.I3CLSimFunctionPolynomial(ANGULAR), (x, a), stepLength=step_length)
     assert tab.n_bins == tb["n_bins"] and list(tab.shape) == tb["shape"]
+    # the specialised sampler is chosen for exactly one shape of table (kparams.h: tab_std)
+    is_standard = kind in ("spherical", "spherical_small") and not squared
+    assert int(tab.GetTable("TABULATOR_STANDARD_SAMPLER")[0]) == (1 if is_standard else 0)
+    if standard_sampler is not None:
+        tab.SetTuning("standard_sampler", 1 if standard_sampler else 0)
     if fast_kernels:
         tab.SetTuning("fast_kernels", 1)
         with pytest.raises(CV.I3CLSimStepToPhotonConverter_exception):
@@ -181,7 +197,8 @@ def check_table_against_the_oracle(kind, ice, step_length, expect_fast="by mediu
     assert bins64.sum() > 100 and (bins64 > 0).sum() > 1000
     assert (got > 0).sum() == (bins64 > 0).sum() and np.array_equal(got > 0, bins64 > 0)
     assert np.allclose(got, bins64, rtol=1e-12, atol=0)
-    assert np.allclose(tab.GetBinSums(squared=True), sq64, rtol=1e-12, atol=0)
+    if squared:
+        assert np.allclose(tab.GetBinSums(squared=True), sq64, rtol=1e-12, atol=0)
     assert np.array_equal(tab.GetRNGState(n), xo)
     raw = tab.GetBinContent().ravel()
     assert np.allclose(raw, bins32, rtol=2e-5, atol=1e-9)            # the reference's float accumulation, order dependent
