@@ -474,24 +474,31 @@ DM bool save_path_wave(KP P, uint32_t *wave_lds, bool active, const Photon &ph, 
     return stop;
 }
 
-// savePath for a whole wave, four-axis tables (round 5, second half).  As above, but the pool outlives the loop trip: a trip works its
-// samples off in FULL batches of 64 and carries the remainder (fewer than 64) into the next trip, where they are the front of the pool
-// -- a trip brings 117 samples on average, and two or three batches of which the last one is half empty were 24 % of this loop's
-// issue slots.  What makes that possible:
+// savePath for a whole wave, four-axis tables (round 5, second half; re-cut in round 6).  As above, but a segment's samples wait for the
+// samples of the SAME LANE's next segment and the two are worked off together, neighbours in the pool.
+//
+// Why (round 6, profiles/r06/tab_atomics_counters.json): the table maker sits on the memory side's atomic request rate -- the L2 hands every
+// one of the table's fp64 adds on (TCC_EA0_ATOMIC), one request per wave instruction and 64-byte sector, 4.4e10 per pass at 2.24e10 per
+// second, which IS what the memory side delivers (2.06e10 in tools/micro/atomic_rate.hip).  A batch of 64 samples held some thirty segments of
+// thirty different photons and met thirty sectors.  A photon's next segment starts where the last one ended: two segments in a row touch
+// 0.42 sectors per sample where one touches 0.61 (oracle, profiles/r06/tab_requests_per_sample.txt).  So: one trip only notes its segment
+// (record in LDS, first sample and count in two registers), the next trip lists the noted samples and its own, lane by lane, and works
+// off everything.  Round 5's version carried the samples a trip's last batch left empty into the next trip instead (full batches only);
+// full batches are worth less than fewer requests now that the requests are known to be the bound, and a carried rest would need the
+// records of four trips (12 KB of the 9.5 a wave has).
 //   * a sample names its segment by a record in LDS (two generations of 64 records, alternating per trip) instead of by its owner's
 //     registers, which have moved on by the next trip;
 //   * leaving the table must be known in the trip it happens (the photon is dropped and its stream is not drawn from again,
-//     c.cl:781-784), so a trip may only carry samples when every one of its segments is CERTAINLY inside the table: the far end of
+//     c.cl:781-784), so a trip may only note its samples when every one of its segments is CERTAINLY inside the table: the far end of
 //     the segment stays below the distance axis' end and its latest delay time below the time axis' end, each with a margin four
 //     orders of magnitude above the rounding of the sample's own arithmetic (conservative in one direction: a trip with a segment
-//     that fails the test -- the last trip or two of a photon's life, every trip of a cylindrical table -- works off everything it
-//     has, as before).  A carried sample is therefore never out of bounds;
-//   * samples carried once are in the next trip's first batch, or that trip works off everything (fewer than 64 in all), so a record
-//     is read in its own trip and the next one only.
-// `carry`, `parity`: wave-uniform state across trips; flush: work off everything (after the wave's last trip).
+//     that fails the test -- the last trip or two of a photon's life, every trip of a cylindrical table -- works off what it has at
+//     once).  A noted sample is therefore never out of bounds.
+// `held_n`, `held_d0`: the lane's noted segment (its record is in the other generation); `parity`: wave-uniform, the generation this trip's
+// records go to; flush: work off what is noted (after the wave's last trip).
 template <bool STD>
 DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon &ph, float weight, float length, float &remainder,
-                             float depth, float this_depth, uint32_t &carry, uint32_t &parity, bool flush
+                             float depth, float this_depth, uint32_t &held_n, float &held_d0, uint32_t &parity, bool flush
                              TAB_TIMED(, uint64_t &t_list, uint64_t &t_last, uint64_t &t_add)
                              )
 {
@@ -518,45 +525,14 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
     uint32_t n = 0;
     float d_end = remainder;
     if (active) for (; (d_end < length) && (n < (1u << 16)); d_end += vstep) ++n;
-    uint32_t incl = n;
-    incl += dpp_zero_<0x111, 0xf>(incl);
-    incl += dpp_zero_<0x112, 0xf>(incl);
-    incl += dpp_zero_<0x114, 0xf>(incl);
-    incl += dpp_zero_<0x118, 0xf>(incl);
-    incl += dpp_zero_<0x142, 0xa>(incl);
-    incl += dpp_zero_<0x143, 0xc>(incl);
-    const uint32_t fresh = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t first = carry + (incl - n);
-    const uint32_t total = carry + fresh;
-    bool stop = false;
-    if (total == 0u) {
-        if (active) remainder = d_end - length;      // (no lane's segment holds a sample)
-        return false;
-    }
     const TabK K = tab_constants<false>(P);
-    double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
-    const bool squares = !STD && (sq_bins != nullptr);          // (STD: no squared weights, KParams::tab_std)
     uint32_t *pool_d = wave_lds, *pool_tag = wave_lds + kTabPool;
     uint32_t *records = wave_lds + 2 * kTabPool;
-    const uint32_t my_record = (parity << 6) | lane;
-    bool everything = flush || (total < 64u);
-    if (__builtin_expect(total > (uint32_t)kTabPool, 0)) {
-        // (rare) more samples than the pool holds: this trip's segments are walked by their own lanes, after the carried samples
-        everything = true;
-    } else if (active && (n != 0u)) {
-        row_t *rec = reinterpret_cast<row_t *>(records + my_record * (uint32_t)kTabSegWords);
-        rec[0] = row_t{ph.px, ph.py, ph.pz, ph.pt};
-        rec[1] = row_t{ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
-        rec[2] = row_t{length, depth, this_depth, impact};
-        float d = remainder;
-        for (uint32_t j = 0; j < n; ++j, d += vstep) {
-            pool_d[first + j] = __builtin_bit_cast(uint32_t, d);
-            pool_tag[first + j] = my_record | (j << 8);
-        }
-    }
-    const bool walk_alone = total > (uint32_t)kTabPool;
+    const uint32_t my_record = (parity << 6) | lane, my_held_record = ((parity ^ 1u) << 6) | lane;
+    const bool held_any = ballot(held_n != 0u) != 0ull;
     // is every segment of this trip certainly inside the table?  (spherical axes; see above)
-    if (!everything) {
+    bool note = !flush && !held_any;
+    if (note) {
         bool inside = false;
         if (STD || K.kind == 0) {
             const float qx = ph.px - K.ref[0], qy = ph.py - K.ref[1], qz = ph.pz - K.ref[2];
@@ -567,14 +543,60 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
             const float latest = (t_end + 1.0e-4f * __builtin_fabsf(t_end) + 0.01f) - near * K.min_inv_groupvel * 0.9999f;
             inside = (far < K.max0) && (latest < K.max3 - 1.0e-4f * __builtin_fabsf(K.max3) - 0.01f);
         }
-        everything = ballot(active && (n != 0u) && !inside) != 0ull;
+        // (a segment longer than the pool could not be listed next to another one: worked off at once, by its own lane if need be)
+        note = ballot(active && (n != 0u) && (!inside || (n > (uint32_t)kTabPool / 2u))) == 0ull;
+    }
+    if (active && (n != 0u)) {
+        row_t *rec = reinterpret_cast<row_t *>(records + my_record * (uint32_t)kTabSegWords);
+        rec[0] = row_t{ph.px, ph.py, ph.pz, ph.pt};
+        rec[1] = row_t{ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel};
+        rec[2] = row_t{length, depth, this_depth, impact};
+    }
+    if (note) {
+        // this trip's samples wait for the lane's next segment
+        held_n = n;
+        held_d0 = remainder;
+        parity ^= 1u;
+        if (active) remainder = d_end - length;
+        return false;
+    }
+    const uint32_t both = held_n + n;
+    uint32_t incl = both;
+    incl += dpp_zero_<0x111, 0xf>(incl);
+    incl += dpp_zero_<0x112, 0xf>(incl);
+    incl += dpp_zero_<0x114, 0xf>(incl);
+    incl += dpp_zero_<0x118, 0xf>(incl);
+    incl += dpp_zero_<0x142, 0xa>(incl);
+    incl += dpp_zero_<0x143, 0xc>(incl);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t first = incl - both;              // the lane's noted samples, then its own
+    bool stop = false;
+    if (total == 0u) {
+        if (active) remainder = d_end - length;      // (no lane's segment holds a sample)
+        parity ^= 1u;
+        return false;
+    }
+    double *const bins = P->tab_bins, *const sq_bins = P->tab_sq_bins;
+    const bool squares = !STD && (sq_bins != nullptr);          // (STD: no squared weights, KParams::tab_std)
+    // (rare) more samples than the pool holds: every lane walks its own segments, the noted one first
+    const bool walk_alone = __builtin_expect(total > (uint32_t)kTabPool, 0);
+    if (!walk_alone) {
+        float d = held_d0;
+        for (uint32_t j = 0; j < held_n; ++j, d += vstep) {
+            pool_d[first + j] = __builtin_bit_cast(uint32_t, d);
+            pool_tag[first + j] = my_held_record | (j << 8);
+        }
+        d = remainder;
+        for (uint32_t j = 0; j < n; ++j, d += vstep) {
+            pool_d[first + held_n + j] = __builtin_bit_cast(uint32_t, d);
+            pool_tag[first + held_n + j] = my_record | (j << 8);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     TAB_TIMED({ const uint64_t now_ = __builtin_amdgcn_s_memtime(); t_list += now_ - t_last; t_last = now_; })
-    const uint32_t pooled = walk_alone ? carry : total;                             // samples in the pool
-    const uint32_t work = everything ? pooled : (pooled & ~63u);                    // ... and how many of them this trip works off
+    const uint32_t work = walk_alone ? 0u : total;                                  // samples in the pool: all of them are worked off
     uint64_t dead = 0ull;
     int my_first_oob = 0x7fffffff;
     uint32_t tag_next = (lane < work) ? pool_tag[lane] : 0u;
@@ -653,6 +675,19 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
         TAB_TIMED(t_add += __builtin_amdgcn_s_memtime() - t_before_add;)
     }
     if (walk_alone) {
+        // the noted segment (certainly inside the table), then this trip's
+        if (held_n != 0u) {
+            const row_t *rec = reinterpret_cast<const row_t *>(records + my_held_record * (uint32_t)kTabSegWords);
+            const row_t r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const Segment g = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, 0.0f};
+            float d = held_d0;
+            for (uint32_t taken = 0; taken < held_n; d += vstep, ++taken) {
+                uint32_t index;
+                bool ok_ = true;
+                if (sample_bin<false, false, STD>(K, g, d, 0ull, 0u, index, ok_)) break;        // (never: a noted sample is inside the table)
+                add_to_bin(bins, STD ? nullptr : sq_bins, index, r2.w * dm::exp_(-(r2.y + (d / r2.x) * r2.z)));
+            }
+        }
         if (active) {
             const Segment g = {ph.px, ph.py, ph.pz, ph.pt, ph.d.x, ph.d.y, ph.d.z, ph.inv_groupvel, 0.0f};
             float d = remainder;
@@ -664,21 +699,13 @@ DM bool save_path_wave_carry(KP P, uint32_t *wave_lds, bool active, const Photon
             }
             d_end = d;
         }
-        carry = 0u;
-    } else {
-        if (active && (my_first_oob != 0x7fffffff)) {
-            stop = true;
-            d_end = __builtin_bit_cast(float, pool_d[first + (uint32_t)my_first_oob]);
-        }
-        const uint32_t rest = pooled - work;
-        if (rest != 0u) {
-            // the remainder moves to the front of the pool (work is a multiple of 64 and at least 64 here)
-            const uint32_t t_ = (lane < rest) ? pool_tag[work + lane] : 0u, d_ = (lane < rest) ? pool_d[work + lane] : 0u;
-            if (lane < rest) { pool_tag[lane] = t_; pool_d[lane] = d_; }
-        }
-        carry = rest;
-        parity ^= 1u;
+    } else if (active && (my_first_oob != 0x7fffffff)) {
+        stop = true;
+        d_end = __builtin_bit_cast(float, pool_d[first + held_n + (uint32_t)my_first_oob]);
     }
+    held_n = 0u;
+    parity ^= 1u;
+    // (the lists are this wave's own and a later trip writes them again: the reads above have to be done first)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -757,7 +784,8 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
     Vec3 step_dir = {0.0f, 0.0f, 1.0f};
     float unit_weight = 0.0f;   // TABULATE: the step's weight (c.cl:246-251), read when the lane takes the unit
     const bool tab_std = (TAB == 1) && (P0->tab_std != 0u);        // the table maker's standard configuration: the specialised sampler (sample_bin: STD)
-    uint32_t tab_carry = 0u, tab_parity = 0u;      // TABULATE, four axes: samples carried into the next trip, generation of the segment records (save_path_wave_carry)
+    uint32_t tab_held_n = 0u, tab_parity = 0u;     // TABULATE, four axes: the lane's noted segment (samples, first sample) and the generation of this trip's
+    float tab_held_d0 = 0.0f;                      // segment records (save_path_wave_carry)
     Photon ph;
     ph.abs_lens_left = 0.0f;    // "< epsilon" == this lane needs a photon
     ph.layer = 0;
@@ -972,11 +1000,11 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
                                                             TAB_TIMED(, t_acc[6], t_last)
                                                             );
             else if (tab_std) left_table = save_path_wave_carry<true>(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
-                                                                      tab_carry, tab_parity, false
+                                                                      tab_held_n, tab_held_d0, tab_parity, false
                                                                       TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                                                       );
             else left_table = save_path_wave_carry<false>(P, wave_lds, run, ph, weight, distance, ph.tab_remainder, ph.tab_depth, travelled - ph.tab_depth,
-                                                          tab_carry, tab_parity, false
+                                                          tab_held_n, tab_held_d0, tab_parity, false
                                                           TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                                           );
             if (run) {
@@ -1062,12 +1090,12 @@ __global__ void __launch_bounds__(kBlock, TAB ? 4 : kMinWavesPerSimd) prop_kerne
         )
         if ((m_need | m_ready) == 0ull) break;
     }
-    if ((TAB == 1) && (tab_carry != 0u)) {
-        // the samples the last trip carried
+    if ((TAB == 1) && (ballot(tab_held_n != 0u) != 0ull)) {
+        // the samples the last trip noted
         const KP P = fresh_params(P0);
         uint32_t *wave_lds = lds_words + ((P->table_words + 16u + 3u) & ~3u) + (threadIdx.x >> 6) * (uint32_t)kTabWaveWords;
         float no_remainder = 0.0f;
-        (void)save_path_wave_carry<false>(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_carry, tab_parity, true      // (once per wave: the generic sampler)
+        (void)save_path_wave_carry<false>(P, wave_lds, false, ph, 0.0f, 0.0f, no_remainder, 0.0f, 0.0f, tab_held_n, tab_held_d0, tab_parity, true      // (once per wave: the generic sampler)
                                    TAB_TIMED(, t_acc[6], t_last, t_acc[7])
                                    );
     }

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""The "current numbers" table of DESIGN.md section 6, generated from the kept measurement files of the round (profiles/r05/final_*:
+"""The "current numbers" table of DESIGN.md section 6, generated from the kept measurement files of the round (profiles/r06/final_*:
 bench.py lines and rocprofv3 summaries taken at the shipped revision).  `--write` replaces the block between the numbers markers in
 DESIGN.md; tests/test_design_numbers.py fails when DESIGN.md and the files disagree."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r05")
+R = os.path.join(ROOT, "profiles", "r06")
 ROWS = [("C2 = configs[1] (the headline; `python bench.py`)", "final_bench_default_line.json", "final_c2_pmc_summary.json"),
         ("C3 = configs[2], 10 M steps in two bunches (`--workload c3`)", "final_bench_c3.json", "final_c3_pmc_summary.json"),
         ("C5 = configs[4], flasher half (`--workload c5`)", "final_bench_c5.json", "final_c5_pmc_summary.json"),
@@ -53,6 +53,9 @@ def table():
         extra = ""
         if b.get("host_path"):
             extra = "; through host buffers %s at %.0f %% device use" % (sci(b["host_path"]["value"]), 100 * b["host_path"]["device_utilization"])
+        if b.get("host_path_copy"):
+            extra += " (the caller's own copy of every result, the reference's `GetConversionResult()`: %s at %.0f %%)" % (
+                sci(b["host_path_copy"]["value"]), 100 * b["host_path_copy"]["device_utilization"])
         if b.get("reference_figures"):
             extra = "; device utilisation %.2f" % b["reference_figures"]["DeviceUtilization"]
         out.append("| %s | **%s**%s | %s | %s | %s |" % (label, sci(b["value"]), extra, ("%.1f" % ms) if ms else "", useful, counters))

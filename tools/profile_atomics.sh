@@ -11,19 +11,27 @@ export TMPDIR=/tmp
 TAB="python3 bench.py --workload tab --steps 2 --warmup 1 --no-cpu-baseline"
 [ -x tools/micro/atomic_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/micro/atomic_rate tools/micro/atomic_rate.hip
 MICRO="tools/micro/atomic_rate 670 3"
-P1="TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_RW_ATOMIC_REQ_sum TCP_TCC_UC_ATOMIC_REQ_sum TCP_TCC_NC_ATOMIC_REQ_sum TCP_TCC_CC_ATOMIC_REQ_sum TCP_ATOMIC_TAGCONFLICT_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"
-P2="TCC_ATOMIC_sum TCC_ATOMIC_SECTORS_sum TCC_EA0_ATOMIC_sum TCC_EA0_ATOMIC_LEVEL_sum TCC_EA0_WRREQ_ATOMIC_DRAM_sum TCC_BUSY_sum TCC_TAG_STALL_sum"
-P3="TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_LATENCY_FIFO_FULL_sum TCC_SRC_FIFO_FULL_sum TCC_IB_STALL_sum"
-P4="TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_ATOMIC_WAVEFRONTS_sum TA_TA_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
-P5="SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
-P6="TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_LFIFO_FULL_sum TCP_LFIFO_STALL_CYCLES_sum"
+# (at most four counters of a block per pass: more "exceeds the capabilities of the hardware to collect", and rocprofv3 then hangs in its
+# abort handler -- every pass runs under timeout)
+PASSES=(
+ "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_RW_ATOMIC_REQ_sum TCP_TCC_UC_ATOMIC_REQ_sum TCP_TCC_NC_ATOMIC_REQ_sum"
+ "TCP_TCC_CC_ATOMIC_REQ_sum TCP_ATOMIC_TAGCONFLICT_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
+ "TCC_ATOMIC_sum TCC_ATOMIC_SECTORS_sum TCC_EA0_ATOMIC_sum TCC_EA0_ATOMIC_LEVEL_sum"
+ "TCC_EA0_WRREQ_ATOMIC_DRAM_sum TCC_BUSY_sum TCC_TAG_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum"
+ "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_IB_STALL_sum"
+ "TCC_LATENCY_FIFO_FULL_sum TCC_SRC_FIFO_FULL_sum TCC_REQ_sum TCC_EA0_WRREQ_sum"
+ "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+ "TA_FLAT_ATOMIC_WAVEFRONTS_sum TA_TA_BUSY_sum"
+ "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+ "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_THRASHING_STALL_sum TCP_LFIFO_STALL_CYCLES_sum"
+)
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do
+for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/tab_p$i -- $TAB > /dev/null 2> $OUT/tab_p$i.err; echo tab p$i rc=$?
-  rocprofv3 --pmc $P --output-format csv -d $OUT/micro_p$i -- $MICRO > $OUT/micro_p$i.out 2> $OUT/micro_p$i.err; echo micro p$i rc=$?
+  timeout -k 10 150 rocprofv3 --pmc $P --output-format csv -d $OUT/tab_p$i -- $TAB > /dev/null 2> $OUT/tab_p$i.err; echo "tab p$i rc=$? ($P)"
+  timeout -k 10 150 rocprofv3 --pmc $P --output-format csv -d $OUT/micro_p$i -- $MICRO > $OUT/micro_p$i.out 2> $OUT/micro_p$i.err; echo "micro p$i rc=$?"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/micro_kt -- $MICRO > $OUT/micro_kt.out 2> $OUT/micro_kt.err; echo micro kt rc=$?
+timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/micro_kt -- $MICRO > $OUT/micro_kt.out 2> $OUT/micro_kt.err; echo micro kt rc=$?
 python3 - $OUT <<'PY' > $OUT/atomics_summary.json
 import csv, glob, json, os, sys
 from collections import defaultdict
