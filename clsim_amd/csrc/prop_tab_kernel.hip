@@ -3,4 +3,8 @@
 // loses 3 % under the settings that the propagation instantiations gain 8-12 % from (Makefile: KERNEL_CODEGEN) -- and in
 // parallel with them.
 #define CLSIMHIP_TAB_UNIT 1
+// (threads per workgroup of the table maker's kernels; the propagation kernels' 256 unless the build says otherwise)
+#ifdef CLSIMHIP_TAB_BLOCK
+#define CLSIMHIP_BLOCK CLSIMHIP_TAB_BLOCK
+#endif
 #include "prop_kernel.hip"
