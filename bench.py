@@ -1092,7 +1092,7 @@ def main():
             del conv2
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, steps_np, args.cpu_seconds)
-        if world == 1 and args.workload == "c2" and not args.no_table_maker:
+        if world == 1 and args.workload == "c2" and not args.no_table_maker and not args.keep_detected and args.shard_steps == 0:
             # BASELINE configs[4]'s other half, bounded: one warm-up and two timed passes of the table maker's own
             # bench bunch (262 144 steps x 200 photons, ~2 s a pass) after and outside the timed region of `value`, with its roofline
             # and an oracle baseline of a few seconds -- the same record `--workload tab` prints, so that a driver-run line holds it

@@ -30,7 +30,7 @@ constexpr int kTabSlots = 512;                   // TABULATE with the impact-ang
 #ifndef CLSIMHIP_TAB_POOL
 #define CLSIMHIP_TAB_POOL 448
 #endif
-constexpr int kTabPool = CLSIMHIP_TAB_POOL;                    // TABULATE, four axes: pooled path samples (d, tag) of a wave, some carried into the next trip
+constexpr int kTabPool = CLSIMHIP_TAB_POOL;                    // TABULATE, four axes: pooled path samples (d, tag) of a wave: two consecutive segments of every lane (save_path_wave_carry)
 constexpr int kTabSegWords = 12;                 // ... and a segment's record: position + time, direction + 1/v, length, depth, depth step, weight
 constexpr int kTabWaveWords = 2 * kTabPool + 2 * 64 * kTabSegWords;      // (two generations of segment records; 2432 words >= 2 * kTabSlots + 64)
 static_assert(kTabWaveWords >= 2 * kTabSlots + 64 && kTabWaveWords % 4 == 0, "table maker: a wave's LDS region");
