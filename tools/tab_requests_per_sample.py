@@ -23,15 +23,27 @@ ref_o = B.reference_particle((0,0,0), 0.0, (0,0,1.0))
 ent,num,left,xs = capi.tabulate(T, steps, x, a, ref_o, threads=8)
 shape=tb["shape"]; strides=tb["strides"]
 print("shape",shape)
-tot=0; res={}
-for chunk in (1,2,3,4,6,8,12,16,32):
-    req=0; n=0
-    for i in range(m):
-        k=int(num[i]); idx=ent["index"][i,:k].astype(np.int64)
-        b0=idx//strides[0]; r=idx%strides[0]; b1=r//strides[1]; r=r%strides[1]; b2=r//strides[2]; b3=r%strides[2]
-        sec=((b0>>2)*100000+b1)*100000*1000+(b2>>1)*1000+b3
-        for s in range(0,k,chunk):
-            req+=len(np.unique(sec[s:s+chunk])); 
-        n+=k
-    res[chunk]=req/n
-    print("consecutive samples of a photon per instruction: %2d -> %.3f requests per sample"%(chunk, req/n))
+import itertools
+decoded = []
+for i in range(m):
+    k = int(num[i]); idx = ent["index"][i, :k].astype(np.int64)
+    b0 = idx // strides[0]; r = idx % strides[0]; b1 = r // strides[1]; r = r % strides[1]; b2 = r // strides[2]; b3 = r % strides[2]
+    decoded.append((b0, b1, b2, b3))
+def requests_per_sample(bits, chunk):
+    """bits: (e0, e1, e2, e3) -- a sector holds 2^e0 x 2^e1 x 2^e2 x 2^e3 bins of distance, azimuth, polar angle, time"""
+    req = n = 0
+    for b0, b1, b2, b3 in decoded:
+        sec = (((b0 >> bits[0]) * 64 + (b1 >> bits[1])) * 128 + (b2 >> bits[2])) * 128 + (b3 >> bits[3])
+        k = len(sec)
+        for s_ in range(0, k, chunk):
+            req += len(np.unique(sec[s_:s_ + chunk]))
+        n += k
+    return req / n
+print("sectors per sample when an instruction holds k consecutive samples of a photon (a segment is 2.1 samples: k = 2 is round 5, k = 4 round 6)")
+print("%-28s %s" % ("tile (dist x azi x polar x time)", " ".join("k=%-5d" % c for c in (1, 2, 3, 4, 6, 8, 16))))
+shapes = [b for b in itertools.product(range(4), repeat=4) if sum(b) == 3]
+rows = []
+for bits in shapes:
+    rows.append((requests_per_sample(bits, 4), bits, [requests_per_sample(bits, c) for c in (1, 2, 3, 4, 6, 8, 16)]))
+for _, bits, vals in sorted(rows):
+    print("%-28s %s" % (" x ".join(str(1 << e) for e in bits) + ("   <- shipped" if bits == (2, 0, 1, 0) else ""), " ".join("%.3f " % v for v in vals)))
