@@ -277,6 +277,16 @@ public:
     uint64_t GetTotalNumPhotonsGenerated() const { return static_cast<uint64_t>(stat(3)); }
     uint64_t GetTotalNumPhotonsAtDOMs() const { return static_cast<uint64_t>(stat(4)); }
 
+    // ---- tuning (no reference counterpart; keys and ranges: include/clsimhip.h, clsimhip_set_tuning).  No result depends on it; the library
+    // reads none of it from the environment ----
+    void SetTuning(const std::string &key, long long value) { check(clsimhip_set_tuning(handle_, key.c_str(), value)); }
+    long long GetTuning(const std::string &key) const
+    {
+        long long v = 0;
+        check(clsimhip_get_tuning(handle_, key.c_str(), &v));
+        return v;
+    }
+
     // ---- concrete setters and getters of the OpenCL converter (OpenCL.h:78-258) ----
     bool GetEnableDoubleBuffering() const { return option(CLSIMHIP_OPTION_ENABLE_DOUBLE_BUFFERING) != 0.; }
     bool GetDoublePrecision() const { return option(CLSIMHIP_OPTION_DOUBLE_PRECISION) != 0.; }

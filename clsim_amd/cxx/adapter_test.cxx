@@ -57,6 +57,10 @@ static int exercise(bool run, I3CLSimStepToPhotonConverterHIP::ConversionResultV
     conv.SetSaveAllPhotons(false);
     conv.SetDOMPancakeFactor(5.);
     conv.SetPhotonHistoryEntries(0);
+    conv.SetTuning("slices", 8);
+    if (conv.GetTuning("slices") != 8 || conv.GetTuning("kernel") != 0) { std::printf("FAILED: tuning round trip\n"); return 1; }
+    EXPECT_THROW(conv.SetTuning("no_such_key", 1), "no tuning key");
+    conv.SetTuning("slices", 0);
     conv.Compile();
     const std::size_t wg = conv.GetMaxWorkgroupSize();
     conv.SetWorkgroupSize(wg);
