@@ -1415,7 +1415,7 @@ static hipError_t launch_variant(const KParams &Pin, hipStream_t stream, int gri
     //     holds: the largest grid (7, 6, 5 workgroups per CU) that leaves r >= 2 (0.5M steps: 5 per CU 1.81e9, 7: 1.53e9;
     //     1M steps: 7 per CU 2.06e9, 5: 1.99e9);
     //   * 16 slices (12 ... 24 are within 0.5 % of each other everywhere; 8 loses 1-2 %); whole steps for r < 1.
-    // CLSIMHIP_GRID / CLSIMHIP_SLICES (converter) override for tuning.
+    // clsimhip_set_tuning("grid" / "slices") overrides.
     const uint32_t needed = (P.n_steps + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)resident;
     {

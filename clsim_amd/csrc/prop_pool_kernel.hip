@@ -588,7 +588,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream, in
         const int fit = pool_ring_that_fits(P.table_words, KEEP ? (uint32_t)P.num_strings : 0u);
         if (R <= 0 || R > fit) R = fit;
         if (R > 64) R = 64;
-        // a ring the user asked for (CLSIMHIP_POOL_R) below the smallest one the kernel runs with is raised to it; an image
+        // a ring the caller asked for ("pool_ring") below the smallest one the kernel runs with is raised to it; an image
         // that leaves no room even for that never gets here: pool_kernel_fits() (below, the same arithmetic with the
         // larger threshold from which the pooled kernel pays) sends its bunches to the classic kernel
         if (R < kPoolMinReady) R = kPoolMinReady;
@@ -624,7 +624,7 @@ static hipError_t launch_pool_variant(const KParams &Pin, hipStream_t stream, in
     if (grid_wanted >= 1 && grid_wanted <= plan.resident) grid = (uint32_t)grid_wanted;      // clsimhip_set_tuning("grid")
     // Fewer steps than the grid has unit slots: smaller rings on every CU rather than full rings on fewer CUs (round 4: with the ring of 45 a
     // bunch of 625 000 flasher steps filled 478 of the 512 workgroups; a ring entry is worth 0.28 %, a workgroup 0.2 %) -- unless the ring
-    // was asked for (CLSIMHIP_POOL_R) or would fall below the size from which the pooled kernel pays
+    // was asked for ("pool_ring") or would fall below the size from which the pooled kernel pays
     size_t lds_launch = lds_bytes;
     if (Pin.pool_ready <= 0 && (uint64_t)grid * kPoolWavesPerBlock * (64u + (uint32_t)R) > (uint64_t)P.n_steps) {
         const int smaller = (int)((uint64_t)P.n_steps / ((uint64_t)grid * kPoolWavesPerBlock)) - 64;
