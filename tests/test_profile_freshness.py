@@ -1,5 +1,6 @@
 """profiles/latest_traffic.json -- the file bench.py quotes `roofline.traffic` and `roofline.valu` from -- must describe the
-kernels that ship: its git_revision has to be an ancestor of (or equal to) HEAD, and no kernel source may have changed since.
+kernels that ship: its git_revision has to be an ancestor of (or equal to) HEAD, and no kernel source may have changed since -- or, if
+one has, the in-tree library's machine code must still be what was profiled (the file's code_hashes; tools/code_hash.py).
 (Where there is no git history -- the GPU box gets a snapshot without .git -- the test has nothing to check and is skipped.)"""
 import json
 import os
@@ -28,5 +29,11 @@ def test_traffic_profile_was_taken_at_the_shipped_kernels():
     changed = git("diff", "--name-only", rev, "HEAD", "--", *KERNEL_FILES).stdout.split()
     # uncommitted edits count as well
     changed += git("diff", "--name-only", "HEAD", "--", *KERNEL_FILES).stdout.split()
+    if changed and prof.get("code_hashes"):
+        # the sources moved on, but did the machine code?  (comment edits, renames: tools/code_hash.py of the in-tree library)
+        out = subprocess.run(["python3", os.path.join(ROOT, "tools", "code_hash.py")], capture_output=True, text=True)
+        now = [line.split()[0] for line in out.stdout.splitlines() if line.strip()]
+        if out.returncode == 0 and now == prof["code_hashes"]:
+            changed = []
     assert not changed, "kernel sources changed since the profile of %s was taken: %s -- rerun tools/profile_round.sh + tools/make_latest_traffic.py" % (rev, sorted(set(changed)))
     assert "prop_pool_kernel<1, true, false, false, true, false>" in prof["kernel"]        # (MED, TILT, ANISO, FLASHER, FAST, KEEP)
