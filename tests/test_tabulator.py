@@ -105,6 +105,35 @@ def test_oracle_tabulator_entries_and_misses():
     assert left3.sum() == 0 and np.array_equal(x3, xo)
 
 
+def test_oracle_accumulate_mode_equals_the_entry_buffers():
+    """oracle_tabulate_accumulate (the table maker's host loop around the kernel: every step in calls of a few photons, entries added up and
+    dropped -- what the at-size GPU test checks against) gives the entry-buffer form's bins, counts and final streams; a call that runs out of
+    entry space is an error, not a silent double count (the reference counts an interrupted photon's first segments twice, c.cl:770-776)."""
+    cfg = common.config("mie")
+    o, _ = axes_pair("spherical")
+    bias = B.icecube_dom_acceptance()
+    g = cfg["geom"]
+    geo = B.build_geometry(g["string_ids"], g["dom_ids"], g["x"], g["y"], g["z"], g["subdetectors"], g["om_radius"])
+    tb = B.tabulator_config("spherical", o, cfg["med_o"], ANGULAR, entries_per_stream=40000)
+    T = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=1.0, tabulator=tb)
+    steps = S.cascade_steps(48, seed=5, vertex=(0.0, 0.0, 0.0), photons_per_step=12, pad_to=48)
+    steps["num"][7] = 0
+    x, a = common.streams(48)
+    ref = B.reference_particle((0., 0., 0.), 0.0, (0.0, 0.0, 1.0))
+    ent, num, left, xo = capi.tabulate(T, steps, x, a, ref)
+    assert left.sum() == 0
+    bins = np.zeros(tb["n_bins"], dtype=np.float64)
+    sums, counts, xa = capi.tabulate_accumulate(T, steps, x, a, ref, bins=bins, photons_per_call=5, threads=4)
+    assert np.array_equal(xa, xo) and np.array_equal(counts, num.astype(np.uint64)) and counts[7] == 0
+    expect = capi.accumulate_entries(ent, num, tb["n_bins"], dtype=np.float64)
+    assert np.array_equal(expect > 0, bins > 0) and np.allclose(expect, bins, rtol=1e-12, atol=0)
+    assert np.allclose(sums, [ent["weight"][i, :int(num[i])].astype(np.float64).sum() for i in range(48)], rtol=1e-12)
+    tiny = dict(tb, entries_per_stream=1500)
+    T2 = capi.make_tables(cfg["med_o"], geo, [B.cherenkov_wlen_generator(bias, cfg["med_o"])], bias, pancake=1.0, tabulator=tiny)
+    with pytest.raises(RuntimeError):
+        capi.tabulate_accumulate(T2, steps, x, a, ref, photons_per_call=5, threads=4)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,ice,step_length", [("spherical", "mie", 1.0), ("cylindrical", "lea", 1.0), ("spherical360", "photonics_mie", 1.0),
                                                   ("spherical", "lea", 0.2), ("spherical5", "mie", 1.0), ("cylindrical5", "lea", 1.0),
