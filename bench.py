@@ -25,7 +25,13 @@ Prints ONE JSON line on rank 0.  At N=1 the line also carries `host_path`: the
 reference's own calling pattern (a producer thread calls EnqueueSteps, the
 consumer GetConversionResult, double buffering on; benchmark.py:300-360) over 8
 bunches, PCIe transfers and index->ID conversion included -- measured after
-and outside the timed region of `value`.  `roofline` prices the propagation kernel's
+and outside the timed region of `value`; `host_path_copy`: the same with the
+caller's own copy of every result, which is what the reference's
+GetConversionResult() means (I3CLSimStepToPhotonConverter.h:178-189); and
+`table_maker`: two passes of `--workload tab` (BASELINE configs[4]'s table
+maker half, 262 144 steps x 200 photons) with its roofline -- memory-side
+atomic requests against the rate the memory side delivers -- and an oracle
+baseline.  `roofline` prices the propagation kernel's
 algorithmic HBM bytes against the 8 TB/s peak (the kernel is VALU-bound, so the
 fraction is tiny by construction -- see DESIGN.md); `cpu_baseline` times the CPU
 restatement of the reference kernel (oracle/, all host cores) on a bounded

@@ -227,21 +227,47 @@ DM void layer_lengths(uint32_t off_layers, const float *len_table, const IceFact
         abs_len = r.a;
     }
 }
+// The scattering angle's ten wave-uniform constants in ONE load group (round 6): read field by field the compiler sinks each scalar load
+// to its use, and the Liu / Henyey-Greenstein choice became four groups each with its own wait in every loop trip.  The fields sit next to
+// each other in KParams (static_asserts below), so two eight-dword loads cover them.
+struct ScatterK {
+    float mix_frac, mix_frac_rest, liu_beta, hg_g, hg_one_minus_g2, hg_one_plus_g2, hg_two_g;
+    float rcp_mix_frac, rcp_mix_frac_rest, rcp_hg_two_g;
+    uint32_t div_ok;
+};
+static_assert(offsetof(KParams, hg_two_g) - offsetof(KParams, mix_frac) == 24 && offsetof(KParams, liu_beta) - offsetof(KParams, mix_frac) == 8,
+              "mix_frac, mix_frac_rest, liu_beta, hg_g, hg_one_minus_g2, hg_one_plus_g2, hg_two_g are seven consecutive floats");
+static_assert(offsetof(KParams, div_ok) - offsetof(KParams, rcp_tilt_dz) == 20 && offsetof(KParams, rcp_mix_frac) - offsetof(KParams, rcp_tilt_dz) == 8,
+              "rcp_tilt_dz, rcp_layer_thickness, rcp_mix_frac, rcp_mix_frac_rest, rcp_hg_two_g, div_ok are six consecutive words");
+static_assert(sizeof(KParams) >= offsetof(KParams, rcp_tilt_dz) + 32 && sizeof(KParams) >= offsetof(KParams, mix_frac) + 32, "the two groups are read as eight words each");
+DM ScatterK scatter_constants(KP P)
+{
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) u32x8 *group_ptr;
+    const u32x8 a = *reinterpret_cast<group_ptr>(&P->mix_frac);
+    const u32x8 b = *reinterpret_cast<group_ptr>(&P->rcp_tilt_dz);
+    ScatterK K;
+    K.mix_frac = dm::u2f(a[0]); K.mix_frac_rest = dm::u2f(a[1]); K.liu_beta = dm::u2f(a[2]); K.hg_g = dm::u2f(a[3]);
+    K.hg_one_minus_g2 = dm::u2f(a[4]); K.hg_one_plus_g2 = dm::u2f(a[5]); K.hg_two_g = dm::u2f(a[6]);
+    K.rcp_mix_frac = dm::u2f(b[2]); K.rcp_mix_frac_rest = dm::u2f(b[3]); K.rcp_hg_two_g = dm::u2f(b[4]);
+    K.div_ok = b[5];
+    return K;
+}
 // HenyeyGreenstein.cxx:69-92
 template <bool FAST = false>
-DM float hg_cos(KP P, float u)
+DM float hg_cos(const ScatterK &K, float u)
 {
     const float s = 2.0f * u - 1.0f;
     // FAST: 1 - g^2 >= 2^-40 and 1 - g >= 2^-50 were checked at Compile() (tables.cpp), so the numerator and every divisor
     // 1 + g s, |s| <= 1, are inside div_near_'s range
-    const float ii = FAST ? dm::div_near_(P->hg_one_minus_g2, 1.0f + P->hg_g * s) : P->hg_one_minus_g2 / (1.0f + P->hg_g * s);
-    return clampf_ordered(div_by_t<FAST>(P->hg_one_plus_g2 - ii * ii, P->hg_two_g, P->rcp_hg_two_g, FAST || (P->div_ok & 16u) != 0), -1.0f, 1.0f);
+    const float ii = FAST ? dm::div_near_(K.hg_one_minus_g2, 1.0f + K.hg_g * s) : K.hg_one_minus_g2 / (1.0f + K.hg_g * s);
+    return clampf_ordered(div_by_t<FAST>(K.hg_one_plus_g2 - ii * ii, K.hg_two_g, K.rcp_hg_two_g, FAST || (K.div_ok & 16u) != 0), -1.0f, 1.0f);
 }
 // SimplifiedLiu.cxx:64-88
 template <bool FAST = false>
-DM float liu_cos(KP P, float u)
+DM float liu_cos(const ScatterK &K, float u)
 {
-    const float beta = P->liu_beta;
+    const float beta = K.liu_beta;
     // beta <= 0.09 (mean cosine >= 0.835, wave-uniform): beta |log u| <= 2 for u >= 2^-32, the single-word logarithm form
     const float p = (FAST || beta <= 0.09f) ? dm::powr_unit_from_log_(u, beta, lds_log(u)) : dm::powr_(u, beta);
     return clampf_ordered(2.0f * p - 1.0f, -1.0f, 1.0f);
@@ -250,20 +276,21 @@ DM float liu_cos(KP P, float u)
 template <bool FAST = false>
 DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
 {
+    const ScatterK K = scatter_constants(P);
     const float rr = rng_co(x, a);
     if (!FAST) {
         const int kind = P->scatter_kind;
-        if (kind == 0) return hg_cos(P, rr);
-        if (kind == 1) return liu_cos(P, rr);
+        if (kind == 0) return hg_cos(K, rr);
+        if (kind == 1) return liu_cos(K, rr);
     }
-    const uint32_t ok = FAST ? 0xffu : P->div_ok;
+    const uint32_t ok = FAST ? 0xffu : K.div_ok;
     CENSUS_REGION(P, kCensusScatter);
-    if (rr < P->mix_frac) {
+    if (rr < K.mix_frac) {
         CENSUS_REGION(P, kCensusLiu);
-        return liu_cos<FAST>(P, div_by_t<FAST>(rr, P->mix_frac, P->rcp_mix_frac, (ok & 4u) != 0));
+        return liu_cos<FAST>(K, div_by_t<FAST>(rr, K.mix_frac, K.rcp_mix_frac, (ok & 4u) != 0));
     }
     CENSUS_REGION(P, kCensusHG);
-    return hg_cos<FAST>(P, div_by_t<FAST>(1.0f - rr, P->mix_frac_rest, P->rcp_mix_frac_rest, (ok & 8u) != 0));
+    return hg_cos<FAST>(K, div_by_t<FAST>(1.0f - rr, K.mix_frac_rest, K.rcp_mix_frac_rest, (ok & 8u) != 0));
 }
 
 // ScalarFieldAnisotropyAbsLenScaling.cxx:92-140
