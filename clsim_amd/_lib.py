@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLSIMHIP_LIB", os.path.join(HERE, "libclsimhip.so"))
 
 OK, ERR_ARGUMENT, ERR_STATE, ERR_CONFIG, ERR_DEVICE, ERR_IO = 0, -1, -2, -3, -4, -5
+REFINDEX_ICECUBE, REFINDEX_TABLE, REFINDEX_DISPERSION = 0, 1, 2       # include/clsimhip.h: CLSIMHIP_REFINDEX_*
 
 DP = C.POINTER(C.c_double)
 

@@ -125,6 +125,13 @@ void MediumData::validate() const
         const int kind = which ? group_kind : phase_kind;
         const FunctionData &f = which ? group_table : phase_table;
         if (kind == CLSIMHIP_REFINDEX_ICECUBE) continue;
+        if (which == 1 && kind == CLSIMHIP_REFINDEX_DISPERSION) {
+            // no override: the group velocity comes from the phase index's derivative (MediumPropertiesSource.cxx:274-300), which
+            // FromTable does not have (FunctionFromTable.h:67; the reference's generated program would not compile)
+            if (phase_kind != CLSIMHIP_REFINDEX_ICECUBE)
+                throw Error(CLSIMHIP_ERR_ARGUMENT, "group velocity from dispersion needs a phase refractive index with a derivative (RefIndexIceCube)");
+            continue;
+        }
         if (kind != CLSIMHIP_REFINDEX_TABLE) throw Error(CLSIMHIP_ERR_ARGUMENT, "unknown refractive index kind");
         if (f.kind != CLSIMHIP_FUNCTION_TABLE || f.values.size() < 2 || !(f.step > 0.))
             throw Error(CLSIMHIP_ERR_ARGUMENT, "a tabulated refractive index needs at least 2 values and a positive step");

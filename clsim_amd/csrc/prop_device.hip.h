@@ -163,13 +163,21 @@ DM float phase_ref_index(KP P, float wlen)
     const float x = wlen / P->micrometer;
     return P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
 }
-// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163 or a FromTable override
+// MediumPropertiesSource.cxx:255-272 with the group index of RefIndexIceCube.cxx:158-163 or a FromTable override; without an override
+// (CLSIMHIP_REFINDEX_DISPERSION) from the phase index and its derivative, MediumPropertiesSource.cxx:274-300 with getDispersion =
+// RefIndexIceCube.cxx:205-215 (`x*4.f*n4` is (x*4.f)*n4).  FAST: Compile() has seen one of the first two (tables.cpp).
+template <bool FAST = false>
 DM float group_velocity(KP P, float wlen)
 {
     if (P->group_kind == CLSIMHIP_REFINDEX_TABLE)
         return P->c_light / table_value(P->off_group, P->group_start, P->group_step, P->group_n, wlen);
     const float x = wlen / P->micrometer;
     const float np = P->n[0] + x * (P->n[1] + x * (P->n[2] + x * (P->n[3] + x * P->n[4])));
+    if (!FAST && P->group_kind == CLSIMHIP_REFINDEX_DISPERSION) {
+        const float n_inv = 1.0f / np;
+        const float y = (P->n[1] + x * (2.0f * P->n[2] + x * (3.0f * P->n[3] + x * 4.0f * P->n[4]))) / P->micrometer;
+        return P->c_light * (1.0f + y * wlen * n_inv) * n_inv;
+    }
     const float np_corr = P->g[0] + x * (P->g[1] + x * (P->g[2] + x * (P->g[3] + x * P->g[4])));
     return P->c_light / (np * np_corr);
 }
@@ -564,7 +572,7 @@ DM void create_photon(KP P, const DevStep *step_ptr, const Vec3 &step_dir, uint6
     ph.num_scatters = 0;
     ph.total_path = 0.0f;
     if (!TILT) ph.layer = clamp_index((int)div_by_t<FAST>(ph.pz - P->layer_bottom, P->layer_thickness, P->rcp_layer_thickness, (P->div_ok & 2u) != 0), P->num_layers - 1);
-    ph.inv_groupvel = 1.0f / group_velocity(P, b.wlen);
+    ph.inv_groupvel = 1.0f / group_velocity<FAST>(P, b.wlen);
     ph.abs_lens_left = b.abs_lens_initial;
     ph.ice = ice_factors<MED>(P, b.wlen);
 }

@@ -421,7 +421,7 @@ CompiledTables compile_tables(const MediumData &m, const GeometryInput &geometry
 
     // KVariant::fast (prop_device.hip.h: FAST), the medium's part: the standard configuration with every proof in hand
     auto medium_proofs_complete = [&]() {
-        bool fast = (m.scatter_kind == CLSIMHIP_SCATTER_MIXED) && (P.liu_beta <= 0.09f) && ((P.div_ok & (2u | 4u | 8u | 16u | 32u | 64u)) == (2u | 4u | 8u | 16u | 32u | 64u));
+        bool fast = (m.scatter_kind == CLSIMHIP_SCATTER_MIXED) && (m.group_kind != CLSIMHIP_REFINDEX_DISPERSION) && (P.liu_beta <= 0.09f) && ((P.div_ok & (2u | 4u | 8u | 16u | 32u | 64u)) == (2u | 4u | 8u | 16u | 32u | 64u));
         if (m.has_aniso && !(P.div_ok & 128u)) fast = false;
         // hg_cos divides 1 - g^2 by 1 + g s, |s| <= 1, with dm::div_near_: numerator >= 2^-40, divisors in [2^-50, 2^50]
         if (!(P.hg_one_minus_g2 >= 9.094947017729282e-13f) || !(1.0f - std::abs(P.hg_g) >= 8.881784197001252e-16f) || !(std::abs(P.hg_g) <= 1.0f)) fast = false;

@@ -36,6 +36,8 @@ void Tabulator::hip_check(hipError_t e, const char *what) const
 static std::pair<double, double> minimum_refractive_index(const MediumData &m)
 {
     std::pair<double, double> best(INFINITY, INFINITY);
+    if (m.group_kind == CLSIMHIP_REFINDEX_DISPERSION)           // :103-104
+        throw Error(CLSIMHIP_ERR_CONFIG, "Medium properties don't know how to calculate group refractive indices");
     auto group = [&](double w) {
         if (m.group_kind == CLSIMHIP_REFINDEX_TABLE) return m.group_table.eval(w);
         const double x = w / units::micrometer;                 // RefIndexIceCube.cxx:84-101

@@ -257,7 +257,6 @@ inline void MakeHIPMedium(const I3CLSimMediumProperties &m, MediumHolder &out)
         if ((!g0) != (!gi) || (g0 && !gi->CompareTo(*g0))) log_fatal("HIP propagator: the group refractive index depends on the layer");
     }
     const I3CLSimFunctionConstPtr phase = m.GetPhaseRefractiveIndex(0), group = m.GetGroupRefractiveIndexOverride(0);
-    if (!group) log_fatal("HIP propagator: no group refractive index override is set (group velocity from dispersion is not implemented)");
     FunctionHolder phase_table, group_table;
     const boost::shared_ptr<const I3CLSimFunctionRefIndexIceCube> pr = boost::dynamic_pointer_cast<const I3CLSimFunctionRefIndexIceCube>(phase);
     const boost::shared_ptr<const I3CLSimFunctionRefIndexIceCube> gr = boost::dynamic_pointer_cast<const I3CLSimFunctionRefIndexIceCube>(group);
@@ -272,7 +271,11 @@ inline void MakeHIPMedium(const I3CLSimMediumProperties &m, MediumHolder &out)
         if (phase_table.f.kind != CLSIMHIP_FUNCTION_TABLE) log_fatal("HIP propagator: a constant phase refractive index is not implemented");
         d.phase_index_table = phase_table.f;
     }
-    if (gr) {
+    if (!group) {
+        // no override: group velocity from the phase index's dispersion (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300)
+        if (!pr) log_fatal("HIP propagator: no group refractive index override is set and the phase refractive index has no derivative");
+        d.group_index_kind = CLSIMHIP_REFINDEX_DISPERSION;
+    } else if (gr) {
         if (CLSIMHIP_PARAM(*gr, ref_mode, GetMode) != "group") log_fatal("HIP propagator: the group refractive index object is not in mode \"group\"");
         if (!pr) log_fatal("HIP propagator: I3CLSimFunctionRefIndexIceCube group index with a tabulated phase index is not implemented");
         // the group index of that class is n_phase(lambda) * correction(lambda) with its own copy of n0..n4 (RefIndexIceCube.cxx:158-163)

@@ -76,7 +76,7 @@ I3CLSimMediumPropertiesPtr MediumFromDescription(const clsimhip_medium_desc &d)
                 std::vector<double>(d.sca_length_table + i * nw, d.sca_length_table + (i + 1) * nw), d.table_store_as_16bit != 0)));
         }
         m->SetPhaseRefractiveIndex(i, phase);
-        m->SetGroupRefractiveIndexOverride(i, group);
+        if (d.group_index_kind != CLSIMHIP_REFINDEX_DISPERSION) m->SetGroupRefractiveIndexOverride(i, group);
     }
     if (d.scatter_kind == CLSIMHIP_SCATTER_MIXED)
         m->SetScatteringCosAngleDistribution(I3CLSimRandomValueConstPtr(new I3CLSimRandomValueMixed(
@@ -222,6 +222,14 @@ int Check(const char *ice_dir, const char *photonics_file)
         clsimhip_medium *tab = nullptr;
         REQUIRE(clsimhip_medium_create_from_photonics(photonics_file, 1948.07, &tab) == CLSIMHIP_OK);
         if (RoundTrip(tab, photonics_file) != 0) return 1;
+        {   // tabulated refractive indices without an override: FromTable has no derivative (I3CLSimFunctionFromTable.h:67)
+            clsimhip_medium_desc td;
+            REQUIRE(clsimhip_medium_describe(tab, &td) == CLSIMHIP_OK);
+            const I3CLSimMediumPropertiesPtr m = MediumFromDescription(td);
+            for (uint32_t i = 0; i < m->GetLayersNum(); ++i) m->SetGroupRefractiveIndexOverride(i, I3CLSimFunctionConstPtr());
+            clsimhip_glue::MediumHolder h;
+            REQUIRE(Fatal([&] { clsimhip_glue::MakeHIPMedium(*m, h); }, "has no derivative"));
+        }
         clsimhip_medium_destroy(tab);
     }
     {   // homogeneous medium with constant lengths (BASELINE config C1)
@@ -248,9 +256,23 @@ int Check(const char *ice_dir, const char *photonics_file)
     }
     {
         const I3CLSimMediumPropertiesPtr m = MediumFromDescription(d);
+        // (an override on some layers only: the group velocity would depend on the layer, propagation_kernel.c.cl:525-527)
         m->SetGroupRefractiveIndexOverride(0, I3CLSimFunctionConstPtr());
         clsimhip_glue::MediumHolder h;
-        REQUIRE(Fatal([&] { clsimhip_glue::MakeHIPMedium(*m, h); }, "group refractive index"));
+        REQUIRE(Fatal([&] { clsimhip_glue::MakeHIPMedium(*m, h); }, "the group refractive index depends on the layer"));
+    }
+    {
+        // no override on any layer: the group velocity comes from the phase index's dispersion
+        // (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300) -- CLSIMHIP_REFINDEX_DISPERSION, every other number as before
+        const I3CLSimMediumPropertiesPtr m = MediumFromDescription(d);
+        for (uint32_t i = 0; i < m->GetLayersNum(); ++i) m->SetGroupRefractiveIndexOverride(i, I3CLSimFunctionConstPtr());
+        clsimhip_glue::MediumHolder h;
+        clsimhip_glue::MakeHIPMedium(*m, h);
+        clsimhip_medium_desc got;
+        REQUIRE(clsimhip_medium_describe(h.m, &got) == CLSIMHIP_OK);
+        REQUIRE(got.group_index_kind == CLSIMHIP_REFINDEX_DISPERSION && got.phase_index_kind == CLSIMHIP_REFINDEX_ICECUBE);
+        for (int k = 0; k < 5; ++k) REQUIRE(got.n[k] == d.n[k]);
+        std::printf("medium without a group index override: group velocity from the dispersion\n");
     }
     {
         const I3CLSimMediumPropertiesPtr m = MediumFromDescription(d);

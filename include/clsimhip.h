@@ -105,6 +105,11 @@ typedef struct {
 #define CLSIMHIP_LENGTHS_TABLE 2    /* one I3CLSimFunctionFromTable per layer (photonics ice tables) */
 #define CLSIMHIP_REFINDEX_ICECUBE 0 /* I3CLSimFunctionRefIndexIceCube (n[] / g[])  */
 #define CLSIMHIP_REFINDEX_TABLE 1   /* I3CLSimFunctionFromTable, same function for every layer */
+#define CLSIMHIP_REFINDEX_DISPERSION 2 /* group_index_kind only: NO group refractive index override is set; the group velocity comes from the
+                                        * phase index and its derivative (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300,
+                                        * I3CLSimFunctionRefIndexIceCube.cxx:205-215).  Needs phase_index_kind ICECUBE: FromTable has no
+                                        * derivative (I3CLSimFunctionFromTable.h:67).  The table maker refuses it as the reference does
+                                        * (I3CLSimStepToTableConverter.cxx:103-104) */
 #define CLSIMHIP_SCATTER_HG 0
 #define CLSIMHIP_SCATTER_LIU 1
 #define CLSIMHIP_SCATTER_MIXED 2    /* Mixed(SimplifiedLiu, HenyeyGreenstein, f)   */

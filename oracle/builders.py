@@ -866,6 +866,8 @@ def minimum_refractive_index(medium):
     wmin + i*(wmax-wmin) for i = 0..999, NOT divided by the number of points; (n_group, n_phase) of the smallest
     group index above 1."""
     best = (float("inf"), float("inf"))
+    if medium.get("group_from_dispersion"):                 # :103-104
+        raise ValueError("Medium properties don't know how to calculate group refractive indices")
     tabulated = "group_table" in medium
     gmin = medium["group_table"]["start"] if tabulated else -float("inf")
     gmax = (medium["group_table"]["start"] + medium["group_table"]["step"] * float(len(medium["group_table"]["values"]) - 1)) if tabulated else float("inf")

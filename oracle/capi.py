@@ -231,6 +231,9 @@ def make_tables(medium, geometry, generators, bias, pancake=5.0, stop_detected=T
             setattr(t, key + "_start", fl(ft["start"]))
             setattr(t, key + "_step", fl(ft["step"]))
             setattr(t, key + "_data", O._ptr(key + "_data", fls(ft["values"]), C.c_float))
+    if m.get("group_from_dispersion"):                  # no group refractive index override (MediumPropertiesSource.cxx:274-300)
+        assert "phase_table" not in m and "group_table" not in m, "FromTable has no derivative"
+        t.group_mode = 2
     sc = m["scat"]
     g = sc["mean_cos"]
     t.liu_beta = fl((1.0 - g) / (1.0 + g))

@@ -148,7 +148,7 @@ typedef struct {
     const uint16_t *abs_q, *sca_q;      /* [layer][tab_n] */
     const float *abs_lo, *abs_hi, *sca_lo, *sca_hi;     /* per layer _SMALLEST_ENTRY / _LARGEST_ENTRY */
     const float *abs_f, *sca_f;         /* [layer][tab_n] float literals when not quantised */
-    int32_t phase_mode, group_mode;     /* 0 RefIndexIceCube, 1 FromTable (float data) */
+    int32_t phase_mode, group_mode;     /* 0 RefIndexIceCube, 1 FromTable (float data); group_mode 2: no override, from the dispersion */
     int32_t phase_n, group_n;
     float phase_start, phase_step, group_start, group_step;
     const float *phase_data, *group_data;
@@ -265,10 +265,22 @@ static inline float getGroupRefIndex(const oracle_tables *T, float wlen)
     const float np_corr = T->g[0] + x * (T->g[1] + x * (T->g[2] + x * (T->g[3] + x * T->g[4])));
     return np * np_corr;
 }
-/* MediumPropertiesSource.cxx:255-272 (group index override path) */
+/* RefIndexIceCube.cxx:205-215, the phase index's GetOpenCLFunctionDerivative (`x*4.f*n4` is (x*4.f)*n4) */
+static inline float getDispersion(const oracle_tables *T, float wlen)
+{
+    const float x = wlen / T->micrometer;
+    const float dnp = (T->n[1] + x * (2.f * T->n[2] + x * (3.f * T->n[3] + x * 4.f * T->n[4]))) / T->micrometer;
+    return dnp;
+}
+/* MediumPropertiesSource.cxx:255-272 (group index override path); group_mode 2 = no override, :274-300 (from the dispersion) */
 static inline float getGroupVelocity(const oracle_tables *T, float wlen)
 {
     REGION(OCR_MEDIUM_PER_PHOTON);
+    if (T->group_mode == 2) {
+        const float n_inv = 1.f / getPhaseRefIndex(T, wlen);
+        const float y = getDispersion(T, wlen);
+        return T->c_light * (1.0f + y * wlen * n_inv) * n_inv;
+    }
     return T->c_light / getGroupRefIndex(T, wlen);
 }
 /* _Optimizers.cxx:195-250 / FunctionConstant.cxx:81-100 */

@@ -48,6 +48,18 @@ def config(name):
     if name.endswith("_regular"):
         cfg = config(name[:-len("_regular")])
         return dict(cfg, name=name, geom=S.ic86_geometry(jitter=0.0))
+    if name.endswith("_dispersion"):
+        # the same medium WITHOUT a group refractive index override: the group velocity then comes from the phase index and its
+        # derivative (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300); CLSIMHIP_REFINDEX_DISPERSION in the C ABI
+        import ctypes as C
+        from clsim_amd import _lib
+        cfg = config(name[:-len("_dispersion")])
+        d = _lib.MediumDesc()
+        assert _lib.load().clsimhip_medium_describe(cfg["med_p"]._h, C.byref(d)) == 0
+        d.group_index_kind = 2
+        h = C.c_void_p()
+        assert _lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)) == 0
+        return dict(cfg, name=name, med_o=dict(cfg["med_o"], group_from_dispersion=True), med_p=CV.I3CLSimMediumProperties(h, keep=cfg["med_p"]))
     if name == "c1":
         geom = S.single_string_geometry()
         med_o = B.homogeneous_medium()

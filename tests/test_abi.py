@@ -75,6 +75,27 @@ def test_degenerate_medium_values_are_refused():
             CV.MakeHomogeneousMediumProperties(scaLen=bad)
 
 
+def test_group_velocity_from_dispersion_needs_a_phase_index_with_a_derivative():
+    """CLSIMHIP_REFINDEX_DISPERSION (no group refractive index override, MediumPropertiesSource.cxx:274-300): accepted with the
+    RefIndexIceCube phase index, refused with a tabulated one (FromTable has no derivative, I3CLSimFunctionFromTable.h:67); a
+    converter compiles with it on the generic kernels (no FAST instantiation: tables.cpp)."""
+    import ctypes as C
+    cfg = common.config("mie_dispersion")
+    assert cfg["med_p"].describe()["group_index_kind"] == _lib.REFINDEX_DISPERSION == 2
+    conv = common.product_converter(cfg, 512, initialize=False)
+    conv.Compile()
+    assert conv.GetTable("fast_variant")[0] == 0.0
+    tab = CV.MakeIceCubeMediumPropertiesPhotonics(common.PHOTONICS["photonics_mie"])
+    d = _lib.MediumDesc()
+    assert _lib.load().clsimhip_medium_describe(tab._h, C.byref(d)) == 0
+    d.group_index_kind = _lib.REFINDEX_DISPERSION
+    h = C.c_void_p()
+    assert _lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)) == _lib.ERR_ARGUMENT
+    assert b"derivative" in _lib.load().clsimhip_last_error(None)
+    d.group_index_kind = 7
+    assert _lib.load().clsimhip_medium_create(C.byref(d), C.byref(h)) == _lib.ERR_ARGUMENT
+
+
 def test_degenerate_wavelength_generators_are_refused():
     conv = CV.I3CLSimStepToPhotonConverterHIP(0)
     for gen in (CV.I3CLSimRandomValueConstant(0.0), CV.I3CLSimRandomValueConstant(float("nan")),

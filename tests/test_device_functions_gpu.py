@@ -55,6 +55,20 @@ def test_medium_functions_device_equals_oracle(setups, name):
         assert 1.30 < dev[:, 0].min() and dev[:, 0].max() < 1.40
 
 
+def test_group_velocity_from_the_dispersion_device_equals_oracle():
+    """no group refractive index override (CLSIMHIP_REFINDEX_DISPERSION; MediumPropertiesSource.cxx:274-300): device = oracle bit for
+    bit, and it is not the override's function"""
+    cfg = common.config("mie_dispersion")
+    T, conv = common.oracle_tables(cfg), common.product_converter(cfg, 1024)
+    wl = np.linspace(266e-9, 674e-9, 4001).astype(np.float32)
+    dev = conv.EvaluateOnDevice("refraction", wl)
+    assert np.array_equal(dev[:, 0].view(np.uint32), capi.eval_medium(T, 2, wl).view(np.uint32))
+    assert np.array_equal(dev[:, 1].view(np.uint32), capi.eval_medium(T, 3, wl).view(np.uint32))
+    override = capi.eval_medium(common.oracle_tables(common.config("mie")), 3, wl)
+    assert np.all(dev[:, 1] != override) and np.abs(dev[:, 1] / override - 1.0).max() < 0.011
+    assert conv.KernelForBunch(1 << 20) in ("pool", "classic") and conv.GetTable("fast_variant")[0] == 0.0
+
+
 def tilt_independent(medium, pos):
     """the tilt in double precision numpy, stated from ScalarFieldIceTiltZShift.cxx:145-213: bilinear between the dust-logger
     profiles along the tilt direction and in z, the outermost cells extended linearly beyond the table"""

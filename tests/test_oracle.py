@@ -97,6 +97,29 @@ def test_ice_functions_against_host_formulas(oracle_lib):
     assert np.allclose(capi.eval_medium(T, 3, wl), 0.299792458 / ngroup, rtol=1e-6)
 
 
+def test_group_velocity_from_the_dispersion_against_the_host_formula(oracle_lib):
+    """A medium WITHOUT a group refractive index override: getGroupVelocity = c (1 + y lambda / n) / n with y = dn/dlambda of the phase
+    index (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300, I3CLSimFunctionRefIndexIceCube.cxx:107-112 GetDerivative), here in
+    double; and what it is physically: within 1.1 % of the parameterised group index the IceCube media set as an override (the
+    `g` polynomial is a fit to this very derivative form, resources/plots/medium_properties_IceCube.py:68-80), never equal to it."""
+    T = common.oracle_tables(common.config("mie_dispersion"))
+    T_override = common.oracle_tables(common.config("mie"))
+    wl = np.linspace(265e-9, 675e-9, 411).astype(np.float32)
+    w = wl.astype(np.float64)
+    n = B.REFINDEX_N
+    x = w / 1e-6
+    n_phase = n[0] + x * (n[1] + x * (n[2] + x * (n[3] + x * n[4])))
+    dn = (n[1] + x * (2. * n[2] + x * (3. * n[3] + x * 4. * n[4]))) / 1e-6
+    v = capi.eval_medium(T, 3, wl)
+    assert np.allclose(v, 0.299792458 * (1.0 + dn * w / n_phase) / n_phase, rtol=1e-6)
+    assert np.array_equal(capi.eval_medium(T, 2, wl), capi.eval_medium(T_override, 2, wl))          # the phase index is the same function
+    rel = v / capi.eval_medium(T_override, 3, wl) - 1.0
+    assert 1e-4 < np.abs(rel).max() < 0.011 and np.all(v < 0.299792458 / 1.3)
+    # the table maker needs an override (I3CLSimStepToTableConverter.cxx:103-104)
+    with pytest.raises(ValueError, match="group refractive indices"):
+        B.minimum_refractive_index(common.config("mie_dispersion")["med_o"])
+
+
 def test_tilt_against_host_formula(oracle_lib):
     """resources/tests/testScalarFieldIceTiltZShift.py: device vs host GetValue(), <= 10 cm."""
     cfg = common.config("mie")

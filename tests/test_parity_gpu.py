@@ -159,7 +159,7 @@ def test_range_restricted_divides_fall_back_to_the_ieee_sequence():
 
 
 @pytest.mark.parametrize("kind", ["no_pancake", "no_tilt", "single_icecube_layer", "hg_only", "liu_only", "lea_no_tilt", "flasher_c1",
-                                  "table_float", "table_with_tilt_and_aniso", "no_dispersion_no_bias"])
+                                  "table_float", "table_with_tilt_and_aniso", "no_dispersion_no_bias", "group_velocity_from_dispersion"])
 def test_other_kernel_variants(kind):
     """Variants of the generated program: PANCAKE_FACTOR undefined (pancake = 1), getTiltZShift_IS_CONSTANT with
     layered ice (carried layer index), a one-layer IceCube medium (un-optimised per-function form, SURVEY 9.7 ii),
@@ -198,6 +198,20 @@ def test_other_kernel_variants(kind):
         med_o = B.load_ppc_ice(ice_dir("spice_lea"), use_tilt_if_available=False)
         med_p = product_medium(directory=ice_dir("spice_lea"), tilt=False)
         _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+    elif kind == "group_velocity_from_dispersion":
+        # no group refractive index override: getGroupVelocity from the phase index and its derivative
+        # (I3CLSimHelperGenerateMediumPropertiesSource.cxx:274-300); every arrival time moves by up to 1 %
+        cfg = common.config("lea_dispersion")
+        med_o, med_p = cfg["med_o"], cfg["med_p"]
+        _run_custom(med_o, med_p, geom, cher_o(med_o), lambda b: [CV.makeCherenkovWavelengthGenerator(b, med_p)], steps)
+        x, a = common.streams(len(steps))
+        with_override, _, _, _ = capi.propagate(common.oracle_tables(common.config("lea")), steps, x, a, threads=8)
+        from_dispersion, _, _, _ = capi.propagate(common.oracle_tables(cfg), steps, x, a, threads=8)
+        assert len(with_override) == len(from_dispersion) > 5                    # the same photons at the same DOMs ...
+        assert np.array_equal(with_override["wavelength"], from_dispersion["wavelength"])
+        rel = from_dispersion["groupVelocity"] / with_override["groupVelocity"] - 1.0
+        assert np.all(rel != 0.0) and np.abs(rel).max() < 0.011                  # ... at other times
+        assert np.any(with_override["time"] != from_dispersion["time"])
     elif kind == "no_dispersion_no_bias":
         # generateCherenkovPhotonsWithoutDispersion with a constant bias of 1 (ModuleHelper.cxx:265-275):
         # I3CLSimRandomValueWlenCherenkovNoDispersion over the medium's wavelength range, constant wavelength bias

@@ -1,6 +1,7 @@
 """profiles/latest_traffic.json -- the file bench.py quotes `roofline.traffic` and `roofline.valu` from -- must describe the
 kernels that ship: its git_revision has to be an ancestor of (or equal to) HEAD, and no kernel source may have changed since -- or, if
-one has, the in-tree library's machine code must still be what was profiled (the file's code_hashes; tools/code_hash.py).
+one has, the in-tree library's machine code must still be what was profiled (the file's code_hashes, or at least the profiled
+kernel's own instructions: kernel_hash; tools/code_hash.py).
 (Where there is no git history -- the GPU box gets a snapshot without .git -- the test has nothing to check and is skipped.)"""
 import json
 import os
@@ -35,5 +36,14 @@ def test_traffic_profile_was_taken_at_the_shipped_kernels():
         now = [line.split()[0] for line in out.stdout.splitlines() if line.strip()]
         if out.returncode == 0 and now == prof["code_hashes"]:
             changed = []
+    if changed and prof.get("kernel_hash"):
+        # other kernels of the library changed (the generic instantiations got a medium kind, say): is the PROFILED kernel still the
+        # same instructions?  (tools/code_hash.py --kernels: per kernel symbol, addresses and branch targets taken out)
+        out = subprocess.run(["python3", os.path.join(ROOT, "tools", "code_hash.py"), "--kernels"], capture_output=True, text=True)
+        want = prof["kernel_hash"]
+        for line in out.stdout.splitlines():
+            fields = line.split()
+            if len(fields) == 3 and fields[2] == want["symbol"] and fields[0] == want["sha16"] and int(fields[1]) == want["instructions"]:
+                changed = []
     assert not changed, "kernel sources changed since the profile of %s was taken: %s -- rerun tools/profile_round.sh + tools/make_latest_traffic.py" % (rev, sorted(set(changed)))
     assert "prop_pool_kernel<1, true, false, false, true, false>" in prof["kernel"]        # (MED, TILT, ANISO, FLASHER, FAST, KEEP)

@@ -331,3 +331,15 @@ def test_table_maker_refuses_an_acceptance_without_a_device_form():
         with pytest.raises(Exception) as err:
             TB.I3CLSimStepToTableConverterHIP(0, axes, False, medium, math.pi * 0.16510 ** 2, acceptance, ang, (x, a))
         assert "bias" in str(err.value) or "acceptance" in str(err.value)
+
+
+def test_table_maker_refuses_a_medium_without_a_group_index_override():
+    """GetMinimumRefractiveIndex (I3CLSimStepToTableConverter.cxx:103-104) log_fatal()s when a layer has no group refractive index
+    override; the propagator takes such a medium (group velocity from the dispersion), the table maker does not.  Host-only."""
+    medium = common.config("mie_dispersion")["med_p"]
+    axes = TB.SphericalAxes([TB.PowerAxis(0, 580, 20, 2), TB.LinearAxis(0, 180, 6), TB.LinearAxis(-1, 1, 10), TB.PowerAxis(0, 7e3, 15, 2)])
+    ang = TB.I3CLSimFunctionPolynomial([0.32813, 0.63899, 0.20049, -1.2250, -0.14470, 4.1695, 0.76898, -5.8690, -2.0939, 2.3834, 1.0435])
+    a = CV.mwc_multipliers(256)
+    x = CV.seed_streams(a)
+    with pytest.raises(Exception, match="group refractive indices"):
+        TB.I3CLSimStepToTableConverterHIP(0, axes, False, medium, math.pi * 0.16510 ** 2, CV.GetIceCubeDOMAcceptance(), ang, (x, a))

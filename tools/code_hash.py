@@ -4,7 +4,7 @@ hashes run the same machine code.  Used to check that a source clean-up (moving 
 no instruction of the shipped kernels.  BUILD CONTAINER TOOL.
    tools/code_hash.py [LIB]              one line per code object
    tools/code_hash.py [LIB] --kernels    one line per kernel symbol: sha256 of its instructions as the disassembler prints them, addresses
-                                         and branch targets taken out (a kernel keeps its hash when only its neighbours in the code
+                                         branch targets and pc-relative literals taken out (a kernel keeps its hash when only its neighbours in the code
                                          object change)"""
 import hashlib, os, re, shutil, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
@@ -32,7 +32,11 @@ with tempfile.TemporaryDirectory() as d:
                 elif name is not None and line.strip():
                     # (branch targets are printed as absolute addresses / symbol+offset: keep the mnemonic only)
                     t = line.split("//")[0].strip()
-                    body.append(re.sub(r"(s_c?branch\S*|s_call\S*)\s.*", r"\1", t))
+                    t = re.sub(r"(s_c?branch\S*|s_call\S*)\s.*", r"\1", t)
+                    # (and the pc-relative literal behind s_getpc_b64: the distance to the code object's constant data)
+                    if body and body[-1].startswith("s_getpc_b64") and t.startswith("s_add_u32"):
+                        t = re.sub(r"0x[0-9a-f]+$", "PCREL", t)
+                    body.append(t)
             flush()
             continue
         text = os.path.join(d, f + ".text")

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """profiles/latest_traffic.json from a tools/profile_round.sh summary (the file bench.py quotes `roofline.traffic` and
 `roofline.valu` from, with the kernel name and the git revision the counters were taken at).
-usage: make_latest_traffic.py gpurun_out/prof_<tag>/summary.json <git revision> [scalar-mix summary.json]"""
-import json, sys
+usage: make_latest_traffic.py gpurun_out/prof_<tag>/summary.json <git revision> [scalar-mix summary.json]
+The in-tree library has to be the build that was profiled: its code hashes go into the file (tests/test_profile_freshness.py)."""
+import json, os, subprocess, sys
 d = json.load(open(sys.argv[1]))
 rev = sys.argv[2]
 kernel = [k for k in d["kernels"] if "prop_pool_kernel" in k or "prop_kernel<" in k][0]
@@ -19,4 +20,15 @@ out = {
     "valu_lane_utilisation": d.get("valu_lane_utilisation"),
     "valu_note": "separate --pmc pass of the same command (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)); a wave64 VALU operation occupies a SIMD for 2 cycles, so the issue-slot fraction is insts x 2 / (1024 SIMDs x 2.4e9 Hz x kernel time); scalar instructions compete for issue with the same weight (profiles/r02/v15_issue_cost_experiment.txt)",
 }
+# what was profiled, as machine code (tools/code_hash.py): every code object of the library, and the profiled kernel's own instructions
+tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "code_hash.py")
+out["code_hashes"] = [l.split()[0] for l in subprocess.run([sys.executable, tool], capture_output=True, text=True, check=True).stdout.splitlines() if l.strip()]
+out["code_hashes_note"] = ("sha256[:16] of the .text of every gfx950 code object of clsim_amd/libclsimhip.so as profiled; tests/test_profile_freshness.py accepts "
+                           "later edits of the kernel SOURCES while the library's hashes are these, or while the profiled kernel's own hash (kernel_hash) is")
+rows = [l.split() for l in subprocess.run([sys.executable, tool, "--kernels"], capture_output=True, text=True, check=True).stdout.splitlines() if l.strip()]
+names = subprocess.run(["c++filt"], input="\n".join(r[2] for r in rows), capture_output=True, text=True, check=True).stdout.splitlines()
+for r, name in zip(rows, names):
+    if name.replace("void ", "").split("(")[0] == out["kernel"]:
+        out["kernel_hash"] = {"symbol": r[2], "sha16": r[0], "instructions": int(r[1]),
+                              "note": "tools/code_hash.py --kernels: the profiled kernel's own instructions (addresses and branch targets taken out)"}
 print(json.dumps(out, indent=1))
