@@ -92,6 +92,7 @@ void Converter::set_tuning(const std::string &key, long long value)
 
 long long Converter::get_tuning(const std::string &key) const
 {
+    std::lock_guard<std::mutex> lk(tuning_mutex_);
     if (key == "kernel") return kernel_choice_;
     if (key == "pool_min_steps") return initialized_ ? static_cast<long long>(pool_min_steps_) : tuned_pool_min_steps_;
     if (key == "pool_max_steps") return initialized_ ? static_cast<long long>(pool_max_steps_) : tuned_pool_max_steps_;
