@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # case -> (configuration, converter options)   [tools/verbatim_cl_check.py: CASES]
 CASES = {"c1": ("c1", {}), "mie": ("mie", {}), "lea": ("lea", {}), "flasher": ("flasher", {}), "photonics_mie": ("photonics_mie", {}),
          "mie_history": ("mie", dict(history=4)), "mie_fixed_abs": ("mie", dict(fixed_abs=1.5)), "lea_no_pancake": ("lea", dict(pancake=1.0)),
-         "flasher_led405": ("flasher_led405", {}),
+         "flasher_led405": ("flasher_led405", {}), "lea_dispersion": ("lea_dispersion", {}),
          "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
          "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
          "clear_keep": ("clear", dict(stop_detected=False)), "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4))}

@@ -196,6 +196,17 @@ def emit_refindex(name, n, g, mode):
     return s
 
 
+def emit_refindex_derivative(name, n):
+    """function/I3CLSimFunctionRefIndexIceCube.cxx:182-231, mode "phase": the text GetOpenCLFunctionDerivative prints"""
+    from oracle import builders as B
+    s = "inline float %s(float wlen);\ninline float %s(float wlen)\n{\n" % (name, name)
+    for i in range(1, 5):
+        s += "    const float n%d = %s;\n" % (i, fl(n[i]))
+    s += "    const float x = wlen/%s;\n" % fl(B.MICROMETER)
+    s += "    const float dnp = (n1 + x*(2.f*n2 + x*(3.f*n3 + x*4.f*n4)))/%s;\n    return dnp;\n}\n" % fl(B.MICROMETER)
+    return s
+
+
 def emit_single_layer_wrapper(name):
     """MediumPropertiesSource.cxx:91-125 when every layer has the same function object"""
     return ("#define FUNCTION_%s_DOES_NOT_DEPEND_ON_LAYER\n"
@@ -216,14 +227,29 @@ def emit_medium(m):
         s += emit_function_from_table("getPhaseRefIndex_func0", m["phase_table"]) + emit_single_layer_wrapper("getPhaseRefIndex")
     else:
         s += emit_refindex("getPhaseRefIndex_func0", m["n"], m["g"], "phase") + emit_single_layer_wrapper("getPhaseRefIndex")
-    if "group_table" in m:
+    if m.get("group_from_dispersion"):
+        # no group refractive index override: MediumPropertiesSource.cxx:274-308, with the derivative of the phase index
+        # (GenerateLayeredWlenDependentFunctions(..., "getPhaseRefIndex", "getDispersion"), :230-235)
+        s += emit_refindex_derivative("getDispersion_func0", m["n"]) + emit_single_layer_wrapper("getDispersion")
+        s += "#ifdef FUNCTION_getPhaseRefIndex_DOES_NOT_DEPEND_ON_LAYER\n#define FUNCTION_getGroupVelocity_DOES_NOT_DEPEND_ON_LAYER\n"
+        s += "#define FUNCTION_getGroupRefIndex_DOES_NOT_DEPEND_ON_LAYER\n#endif\n"
+        s += "inline float getGroupVelocity(unsigned int layer, float wavelength);\n"
+        s += "inline float getGroupVelocity(unsigned int layer, float wavelength)\n{\n    const float c_light = %s;\n" % fl(B.C_LIGHT)
+        s += "#ifdef USE_NATIVE_MATH\n    const float n_inv = native_recip(getPhaseRefIndex(layer, wavelength));\n#else\n"
+        s += "    const float n_inv = 1.f/getPhaseRefIndex(layer, wavelength);\n#endif\n"
+        s += "    const float y = getDispersion(layer, wavelength);\n    return c_light * (1.0f + y*wavelength*n_inv) * n_inv;\n}\n\n"
+        s += "inline float getGroupRefIndex(unsigned int layer, float wavelength);\n"
+        s += "inline float getGroupRefIndex(unsigned int layer, float wavelength)\n{\n    const float c_light = %s;\n" % fl(B.C_LIGHT)
+        s += "    const float groupvel = getGroupVelocity(layer, wavelength);\n    return c_light / groupvel;\n}\n\n"
+    elif "group_table" in m:
         s += emit_function_from_table("getGroupRefIndex_func0", m["group_table"]) + emit_single_layer_wrapper("getGroupRefIndex")
     else:
         s += emit_refindex("getGroupRefIndex_func0", m["n"], m["g"], "group") + emit_single_layer_wrapper("getGroupRefIndex")
-    s += "#ifdef FUNCTION_getGroupRefIndex_DOES_NOT_DEPEND_ON_LAYER\n#define FUNCTION_getGroupVelocity_DOES_NOT_DEPEND_ON_LAYER\n#endif\n"
-    s += "inline float getGroupVelocity(unsigned int layer, float wavelength);\n"
-    s += "inline float getGroupVelocity(unsigned int layer, float wavelength)\n{\n    const float c_light = %s;\n" % fl(B.C_LIGHT)
-    s += "    const float n_group = getGroupRefIndex(layer, wavelength);\n    return c_light / n_group;\n}\n\n"
+    if not m.get("group_from_dispersion"):
+        s += "#ifdef FUNCTION_getGroupRefIndex_DOES_NOT_DEPEND_ON_LAYER\n#define FUNCTION_getGroupVelocity_DOES_NOT_DEPEND_ON_LAYER\n#endif\n"
+        s += "inline float getGroupVelocity(unsigned int layer, float wavelength);\n"
+        s += "inline float getGroupVelocity(unsigned int layer, float wavelength)\n{\n    const float c_light = %s;\n" % fl(B.C_LIGHT)
+        s += "    const float n_group = getGroupRefIndex(layer, wavelength);\n    return c_light / n_group;\n}\n\n"
     if m["len_mode"] == "icecube":
         assert m["num_layers"] > 1
         nl = m["num_layers"]
@@ -533,6 +559,7 @@ CASES = {
     # and has (GEO_MAX_DOM_INDEX+63)/64 = 1 word here, so a 65th string makes it read and write past its array
     "c1_keep": ("c1", dict(stop_detected=False)), "mie_60_keep": ("mie_60", dict(stop_detected=False)),
     "flasher_60_keep": ("flasher_60", dict(stop_detected=False)), "clear_60_keep": ("clear_60", dict(stop_detected=False)),
+    "lea_dispersion": ("lea_dispersion", {}),                       # no group refractive index override: getGroupVelocity from getDispersion
     "flasher_led405": ("flasher_led405", {}),                       # the LED's measured spectrum: InterpolatedDistribution with its own x values
     "clear_keep": ("clear", dict(stop_detected=False)),             # 86 strings: strings 64-85 index the DOM mask out of bounds (informational)
     "lea_60_keep_history": ("lea_60", dict(stop_detected=False, history=4)),
