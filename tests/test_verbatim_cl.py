@@ -178,7 +178,7 @@ def test_hip_table_maker_equals_the_verbatim_kernel(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/resources/kernels"), reason="the reference tree is not on this machine")
 def test_fixture_is_what_the_reference_kernel_text_yields_today():
     """build container only: recompile the reference's .cl files and run the smallest configuration again (the tool exits
-    non-zero unless the verbatim kernel and the oracle agree bit for bit); `tools/verbatim_cl_check.py` runs all nineteen"""
+    non-zero unless the verbatim kernel and the oracle agree bit for bit); `tools/verbatim_cl_check.py` runs all twenty"""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verbatim_cl_check.py"), "--configs", "c1"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "hit records IDENTICAL | final RNG states IDENTICAL" in p.stdout
