@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stress test (GPU): the propagation result must not depend on the schedule.  Random bunch sizes, photon counts, grids,
 slice counts and batching thresholds; every case is compared with the same bunch run as whole steps on a small grid
-(hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases] [keep]
+(hit multiset and final RNG states, bit for bit).  A hang shows up as the caller's timeout.  usage: stress_schedules.py [cases] [keep|stop] [seed]
 (keep: the instantiations without STOP_PHOTONS_ON_DETECTION, classic and pooled kernel; `clear` ice among the configurations)"""
 import devlib  # noqa: F401  (the developer build of the library: this tool steers it through the environment)
 import os, sys
@@ -14,7 +14,8 @@ from tests import common
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 KEEP = len(sys.argv) > 2 and sys.argv[2] == "keep"
-rng = np.random.Generator(np.random.PCG64(2024))
+SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 2024
+rng = np.random.Generator(np.random.PCG64(SEED))
 dev = torch.device("cuda", 0)
 cap = 1 << 21
 out = torch.empty((cap, 80), dtype=torch.uint8, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -37,10 +38,11 @@ def run(cfg, steps, env):
 
 
 for case in range(cases):
-    name = (["mie", "lea", "clear", "flasher"] if KEEP else ["mie", "lea", "c1", "flasher"])[case % 4]
+    # (seeds other than the first: a medium without a group index override -- generic kernels only -- among the configurations)
+    name = (["mie", "lea", "clear", "flasher"] if KEEP else ["mie", "lea", "c1", "flasher"] if SEED == 2024 else ["mie", "lea_dispersion", "c1", "flasher"])[case % 4]
     cfg = common.config(name)
     n = 256 * int(rng.integers(1, [40, 400, 1200][case % 3]))
-    steps = common.steps_for(cfg, n, seed=100 + case)
+    steps = common.steps_for(cfg, n, seed=100 + case + (SEED - 2024) * 1000)
     mode = case % 5
     if mode == 0:
         steps["num"] = rng.choice([0, 1, 2, 7, 63, 64, 65, 200, 399, 1500], size=n).astype(np.uint32)
