@@ -293,19 +293,6 @@ DM float scattering_cos(KP P, uint64_t &x, uint32_t a)
     }
     const uint32_t ok = FAST ? 0xffu : K.div_ok;
     CENSUS_REGION(P, kCensusScatter);
-#ifdef CLSIMHIP_EXP_BOTH_SCATTER_BRANCHES
-    if (FAST) {
-        // Both distributions for every lane, the lane's own picked by a select: a wave visits both branches in 99.6 % of its trips anyway
-        // (27 + 33 lanes), so the instruction count is the same -- without the exec-mask bookkeeping, and the two dependent chains (a table
-        // logarithm from LDS; two divides) are in one block for the scheduler to interleave.  (A lane gets a harmless argument for the
-        // distribution it does not use: both forms are exact range-restricted ones.)
-        const bool is_liu = rr < K.mix_frac;
-        const float u_liu = is_liu ? div_by_t<true>(rr, K.mix_frac, K.rcp_mix_frac, true) : 0.5f;
-        const float u_hg = is_liu ? 0.5f : div_by_t<true>(1.0f - rr, K.mix_frac_rest, K.rcp_mix_frac_rest, true);
-        const float c_liu = liu_cos<true>(K, u_liu), c_hg = hg_cos<true>(K, u_hg);
-        return is_liu ? c_liu : c_hg;
-    }
-#endif
     if (rr < K.mix_frac) {
         CENSUS_REGION(P, kCensusLiu);
         return liu_cos<FAST>(K, div_by_t<FAST>(rr, K.mix_frac, K.rcp_mix_frac, (ok & 4u) != 0));
