@@ -537,6 +537,18 @@ def valu_roofline(workload, photons_per_s, pmc=None, photons_per_launch=None, ke
                     "issued_live_lane_ops_per_photon": (insts * 64.0 * lanes / photons_per_launch) if lanes else None,
                     "overhead_ratio": (insts * 64.0 * lanes / photons_per_launch / floor) if lanes else None,
                     "pmc_source": "rocprofv3 --pmc pass of this command (profiles/latest_traffic.json) x the live kernel time"})
+        # `issue_slot_frac` prices every vector instruction at the two cycles the guide's fp32 peak assumes.  What instructions cost THIS kernel was
+        # measured by adding 48 of a kind to its loop (profiles/r06/issue_cost_by_kind.txt): double-rate opcodes 2.1-2.6 cycles, the same with a
+        # scalar-register source 2.8, single-rate ones (compares, conversions, min / max, selects, shift-adds) 3.0-3.2, v_rcp_f32 / v_sqrt_f32 10.2.
+        # With the shipped C2 kernel's mix (profiles/r06/c2_valu_prices.json) a SIMD is busy issuing vector instructions for:
+        prices = os.path.join(ROOT, "profiles", "r06", "c2_valu_prices.json")
+        if workload == "c2" and os.path.exists(prices):
+            with open(prices) as f:
+                pr = json.load(f)
+            out["issue_busy_at_measured_prices"] = insts * pr["mean_cycles_per_instruction_in_kernel"] / (1024 * pr["shader_clock_ghz"] * 1e9 * kernel_ms * 1e-3)
+            out["issue_busy_note"] = ("SQ_INSTS_VALU x %.2f cycles (the kernel's instruction mix at marginal prices measured in this kernel) / (1024 SIMDs x %.2f GHz x kernel time); "
+                                      ">= 1: the vector pipe is full, marginal prices overstate averages by what exceeds 1 (%s)"
+                                      % (pr["mean_cycles_per_instruction_in_kernel"], pr["shader_clock_ghz"], "profiles/r06/issue_cost_by_kind.txt"))
     return out
 
 
@@ -1055,6 +1067,7 @@ def main():
         rf["valu_useful_frac"] = valu.get("useful_frac") if valu else None
         rf["valu_useful_frac_counting_instructions"] = valu.get("useful_frac_counting_instructions") if valu else None
         rf["valu_issue_slot_frac"] = valu.get("issue_slot_frac") if valu else None
+        rf["valu_issue_busy_at_measured_prices"] = valu.get("issue_busy_at_measured_prices") if valu else None
         rf["valu_lane_utilisation"] = valu.get("lane_utilisation") if valu else None
         rf["valu_overhead_ratio"] = valu.get("overhead_ratio") if valu else None
         rf["valu_floor_issue_slots_per_photon"] = valu["reference_ops_per_photon"]["transformed_issue_slots"] if valu else None

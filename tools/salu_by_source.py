@@ -19,11 +19,46 @@ ap.add_argument("--symbol", default="_ZN8clsimhip16prop_pool_kernelILi1ELb1ELb0E
 ap.add_argument("--measured", default=None, help="scalar_summary.json of tools/profile_scalar.sh (the check)")
 ap.add_argument("--trips-per-wave", type=float, default=15814.0, help="census: wave trips per wave (C2: p50 15 814)")
 ap.add_argument("--blocks", action="store_true", help="print every block with its region and weight")
+ap.add_argument("--valu-classes", action="store_true", help="split the vector instructions by issue cost class (tools/micro/valu_rates.hip)")
 args = ap.parse_args()
 
 # visits per wave trip (profiles/r05/census_hand_over_timers.txt, workload c2; the round-6 kernel's schedule is the same)
 FREQ = {"prologue": 0.0, "trip": 1.0, "prio": 0.25, "service": 0.450, "publish": 0.30, "creation": 0.0584, "hand_out": 0.42, "walk": 0.9998, "crossing": 1.3083,
         "aim": 0.5998, "filter23": 0.1564, "search": 0.0192, "hit": 0.0023, "scatter": 0.9996, "liu": 0.9963, "hg": 0.9971, "rare": 0.0005}
+
+# prop_device.hip.h: the region of a line is the region of the function it stands in (found by name, so that edits of the header do not move
+# the map); inside propagate_through_layers the layer-crossing loop is a region of its own
+FUNCTION_REGION = {
+    "phase_ref_index": "creation", "group_velocity": "creation", "ice_factors": "creation", "generate_wavelength": "creation", "wavelength_bias": "creation",
+    "step_direction": "creation", "work_direction": "creation", "photon_birth": "creation", "create_photon": "creation", "sph_dir_from_car": "creation",
+    "table_bin_fraction": "creation", "table_value": "creation",
+    "layer_lengths": None,                                    # walk or crossing -- by context
+    "hg_cos": "hg", "liu_cos": "liu", "scatter_constants": "scatter", "scattering_cos": "scatter", "scatter_direction": "scatter",
+    "abs_len_corr": "scatter", "apply_matrix": "scatter",
+    "tilt_z_shift": "walk", "propagate_through_layers": "walk", "free_flight_bound": "walk", "free_flight_of": "walk",
+    "dom_position": "search", "collide_with_string": "search", "find_collision_named": "search", "find_collision": "search",
+    "save_hit_now": "search", "collide_with_string_keep": "search", "find_collisions_keep": "search",
+    "segment_misses_string": "aim", "dom_search_needed": "filter23", "make_hit_record": "hit", "flush_hit_stubs": "hit"}
+def device_regions():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "clsim_amd", "csrc", "prop_device.hip.h")
+    out, current, in_walk, depth_at_loop = {}, "unmapped", False, None
+    for n, text in enumerate(open(path).read().split("\n"), 1):
+        m = re.match(r"^DM\s+[\w:<>\s\*&]+?\b(\w+)\(", text)
+        if m and not text.startswith(" "):
+            current = m.group(1)
+        region = FUNCTION_REGION.get(current, "unmapped")
+        if current == "propagate_through_layers":
+            if "kCensusCrossing" in text:
+                in_walk = True                                   # the loop's body: from its `while` line (one above) to its closing brace
+                out[n - 1] = "crossing"
+            if in_walk:
+                region = "crossing"
+                if text.strip() == "}":
+                    in_walk = False
+        if region != "unmapped" and region is not None:
+            out[n] = region
+    return out
+DEVICE_REGIONS = device_regions()
 
 def region_of(file, line):
     if line == 0:
@@ -42,25 +77,23 @@ def region_of(file, line):
         if line <= 535: return "trip"
         return "prologue"
     if file.startswith("prop_device"):
-        if 157 <= line <= 200: return "creation"            # group velocity, ice factors
-        if 203 <= line <= 226: return None                   # layer_lengths: walk or crossing -- by context
-        if 229 <= line <= 237: return "hg"
-        if 239 <= line <= 246: return "liu"
-        if 248 <= line <= 265: return "scatter"
-        if 297 <= line <= 328: return "walk"                 # tilt
-        if 331 <= line <= 375: return "creation"
-        if 376 <= line <= 396: return "search"
-        if 398 <= line <= 432: return "scatter"
-        if 471 <= line <= 541: return "creation"
-        if 596 <= line <= 604: return "crossing"
-        if 544 <= line <= 625: return "walk"
-        if 635 <= line <= 694: return "search"
-        if 696 <= line <= 705: return "walk"
-        if 717 <= line <= 746: return "aim"
-        if 749 <= line <= 798: return "filter23"
-        if 800 <= line <= 941: return "search"
-        if line >= 1060: return "hit"
+        return DEVICE_REGIONS.get(line)
     return None
+
+# vector instructions by issue cost (tools/micro/valu_rates.hip on this chip: cycles per wave64 instruction and SIMD in a stream of the same
+# opcode; in the real kernel the differences are smaller -- profiles/r06/issue_cost_by_kind.txt): "fast" = the double-rate ones (2.2-2.6) with
+# vector / literal / inline-constant sources, "sgpr" = the same with a scalar-register source (4.1), "slow" = everything else measured at 4.1-4.3
+# (compares, conversions, min / max / med3, ldexp, shift-add, DPP, integer multiplies; unmeasured opcodes are counted here), "trans" = 8.2
+FAST_OPS = ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mov_b32", "v_add_u32", "v_sub_u32",
+            "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32")
+def valu_class(op, text):
+    base = re.sub(r"_e(32|64)$", "", op)
+    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_", base): return "v_trans"
+    if base in FAST_OPS and "dpp" not in text and "sdwa" not in text:
+        operands = text.split(None, 1)[1] if " " in text else ""
+        srcs = operands.split(",")[1:]
+        return "v_sgpr" if any(re.match(r"\s*-?\|?(s\d+|s\[|vcc|exec|ttmp|m0)", o) for o in srcs) else "v_fast"
+    return "v_slow"
 
 def kind(op, text):
     if op.startswith("v_"): return "valu"
@@ -101,6 +134,8 @@ for l in asm[start + 1:end]:
     op = s.split()[0]
     k = kind(op, s.split(";")[0])
     cur["n"][k] += 1
+    if k == "valu":
+        cur["n"][valu_class(op, s.split(";")[0])] += 1
     r = region_of(*loc)
     if r:
         cur["votes"][r] += 1
@@ -140,7 +175,7 @@ for b in blocks:
     prev = b["region"]
     if b["cold"] and b["region"] not in ("hit", "prologue"):
         b["region"] = "rare"
-KINDS = ["valu", "salu", "exec", "branch", "smem", "wait", "nop", "lds", "vmem"]
+KINDS = ["valu", "salu", "exec", "branch", "smem", "wait", "nop", "lds", "vmem"] + (["v_fast", "v_sgpr", "v_slow", "v_trans"] if "--valu-classes" in sys.argv else [])
 by_region = collections.defaultdict(lambda: collections.Counter())
 for b in blocks:
     w = FREQ[b["region"]]
