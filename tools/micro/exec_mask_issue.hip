@@ -167,18 +167,20 @@ int main()
             printf("%d waves per SIMD  %-32s %8.3f ms  mix of mul / add / integer / select: %.2f ns per iteration of 88 vector instructions and SIMD\n", waves_per_simd, m.name, ms,
                    ms * 1e6 / ((double)waves_per_simd * iterations));
         }
-        for (int region = 0; region <= 32; region += 16) {
+        for (int region : {0, 16, 32, 64, 128, 256, 512}) {
             for (auto &m : masks) {
-                auto kernel = region == 0 ? region_in_loop<0> : region == 16 ? region_in_loop<16> : region_in_loop<32>;
+                auto kernel = region == 0 ? region_in_loop<0> : region == 16 ? region_in_loop<16> : region == 32 ? region_in_loop<32> : region == 64 ? region_in_loop<64> :
+                              region == 128 ? region_in_loop<128> : region == 256 ? region_in_loop<256> : region_in_loop<512>;
+                if (region > 32 && m.mask != ~0ull && m.mask != 0xffull && m.mask != 0xffffffffull) continue;          // (longer regions: all, 32 and 8 lanes only)
                 hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, m.mask, 100, 1.0000001f, 1e-9f);
                 CHECK(hipEventRecord(e0, 0));
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, m.mask, iterations, 1.0000001f, 1e-9f);
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, m.mask, region > 64 ? iterations / 4 : iterations, 1.0000001f, 1e-9f);
                 CHECK(hipEventRecord(e1, 0));
                 CHECK(hipEventSynchronize(e1));
                 float ms = 0.f;
                 CHECK(hipEventElapsedTime(&ms, e0, e1));
-                printf("%d waves per SIMD  %-32s %8.3f ms  64 full-lane instructions + a region of %2d under the mask: %.1f cycles per iteration and wave at 2.4 GHz\n", waves_per_simd, m.name, ms,
-                       region, ms * 1e-3 * 2.4e9 / ((double)waves_per_simd * iterations));
+                printf("%d waves per SIMD  %-32s %8.3f ms  64 full-lane instructions + a region of %3d under the mask: %.1f cycles per iteration and wave at 2.4 GHz\n", waves_per_simd, m.name, ms,
+                       region, ms * 1e-3 * 2.4e9 / ((double)waves_per_simd * (region > 64 ? iterations / 4 : iterations)));
                 if (region == 0) break;          // (no region: the mask does not matter)
             }
         }
